@@ -1,0 +1,134 @@
+// Internal declarations shared by the libfav translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/fav.h"
+
+namespace fav {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define FAV_HIP(expr)                                              \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) return ::fav::hip_fail(e__, #expr); \
+    } while (0)
+#define FAV_LAUNCH_CHECK(name)                                            \
+    do {                                                                  \
+        hipError_t e__ = hipGetLastError();                               \
+        if (e__ != hipSuccess) return ::fav::hip_fail(e__, "launch " name); \
+    } while (0)
+#define FAV_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::fav::set_error(__VA_ARGS__);     \
+            return FAV_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+int ensure_device();   // FAV_OK or FAV_ENODEVICE
+
+// ------------------------------------------------------------------------------------------------
+// host-side description of a parsed checkpoint (t7_reader.cpp)
+// ------------------------------------------------------------------------------------------------
+enum LayerType { L_PAD, L_CONV, L_IN, L_RELU, L_RES, L_UP, L_TANH, L_MUL, L_IDENTITY };
+
+struct Layer {
+    LayerType type = L_IDENTITY;
+    // pad
+    int pl = 0, pr = 0, pt = 0, pb = 0;
+    // conv
+    int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
+    std::vector<float> w, b;        // [cout][cin][k][k], [cout] (may be empty)
+    // instance norm
+    std::vector<float> gamma, beta;
+    float eps = 1e-5f;
+    // upsample / mul / shave
+    int scale = 1;
+    float mul = 1.f;
+    int shave = 0;
+    std::vector<Layer> block;       // residual branch
+};
+
+int t7_parse_model(const char* path, std::vector<Layer>& out);          // .t7 -> layer list
+int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob);
+int blob_unpack(const void* blob, size_t bytes, std::vector<Layer>& out);
+std::string describe_layers(const std::vector<Layer>& layers, int indent = 0);
+
+// ------------------------------------------------------------------------------------------------
+// device kernels: launch wrappers (each enqueues on `st` and does not synchronise)
+// ------------------------------------------------------------------------------------------------
+struct Affine {            // pending per-channel transform t(x) = relu?(x*scale+shift), up to two stages
+    const float* scale1 = nullptr; const float* shift1 = nullptr; int relu1 = 0;
+    const float* scale2 = nullptr; const float* shift2 = nullptr; int relu2 = 0;
+    int stages = 0;
+};
+
+struct ConvLaunch {
+    const float* in = nullptr;      // NHWC physical [IHp][IWp][CIN]
+    int IH = 0, IW = 0;             // logical input size (after `ups` nearest upsampling)
+    int IWp = 0;                    // physical row pitch in pixels
+    int ups = 0;                    // log2 of the nearest-upsample factor applied on load (0|1)
+    int CIN = 0;                    // physical channels (multiple of 4)
+    Affine pre;                     // applied on load (zero padding is applied AFTER it)
+    const float* wgt = nullptr;     // [COUTp][Kpad], k = tap*CIN + ci
+    const float* bias = nullptr;    // [COUTp]
+    int COUT = 0, COUTp = 0;        // valid / padded (multiple of the N tile) output channels
+    int KH = 0, KW = 0, stride = 1, pad = 0;
+    int Kpad = 0;                   // multiple of 32
+    int OH = 0, OW = 0;
+    float* out = nullptr;           // NHWC [OH][OW][COUT]   (mode 0)
+    float* partials = nullptr;      // [mblocks][COUTp] float2 (mean, M2) or null
+    // final-layer epilogue (mode 1): out_planar[2-c][m] = (tanh(v)*tanh_mul + mean[c]) / 255
+    int final_mode = 0;
+    float tanh_mul = 1.f;
+    float* out_planar = nullptr;    // [3][OH][OW] RGB  (deprocessed)   or null
+    float* out_raw_nchw = nullptr;  // [3][OH][OW] BGR  (150*tanh)      or null
+};
+constexpr int CONV_BM = 128;
+inline int conv_mblocks(int OH, int OW) { return (OH * OW + CONV_BM - 1) / CONV_BM; }
+int launch_conv(const ConvLaunch& p, hipStream_t st);
+
+// per-channel finalize of (mean, M2) partials -> scale/shift:  scale = gamma/sqrt(var+eps)
+int launch_in_finalize(const float* partials, int mblocks, int M, int block_pixels, int C, int Cpitch,
+                       const float* gamma, const float* beta, float eps,
+                       float* scale, float* shift, hipStream_t st);
+// statistics of t(x) over an NHWC tensor [M][C] -> partials [ceil(M/128)][C] float2
+int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st);
+// z[oy][ox][c] = y[oy][ox][c]*scale[c]+shift[c] + t(skip[oy+s][ox+s][c])
+int launch_res_add(const float* y, const float* scale, const float* shift,
+                   const float* skip, int SH, int SW, int shave, const Affine& skip_t,
+                   int C, float* z, hipStream_t st);
+// NCHW [C][H][W] -> NHWC [H+2p][W+2p][Cp] with reflection padding p and zero channels >= C
+int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int Cp, float* out, hipStream_t st);
+// NHWC [M][C] with transform -> NCHW [C][M]
+int launch_nhwc_to_nchw(const float* in, int M, int C, const Affine& t, float* out, hipStream_t st);
+
+// frame-level kernels (kernels_frame.hip / kernels_consistency.hip)
+int launch_warp(const float* img, const float* flow, float* out, int B, int C, int H, int W, int Ho, int Wo,
+                int border, hipStream_t st);
+int launch_min_filter_f32(const float* cert, float* out, int H, int W, int r, hipStream_t st);
+int launch_assemble(const float* frame, const float* warped, const float* cert, float* in7, int H, int W,
+                    hipStream_t st);
+// certainty preparation for the fused path: u8 mask (optionally inverted / multiplied by the
+// fix_occlusions term) -> min-filtered float certainty [H][W]
+int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int invert, int fix_occ, int border,
+                        int r, float* cert_tmp, float* cert, int H, int W, hipStream_t st);
+// fused A2+A6+A7+reflection pad: writes the padded NHWC8 network input
+int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo,
+                      const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st);
+int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
+
+size_t structure_workspace_bytes(int W, int H);
+int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes,
+                     const float** structure_out, const float** avg_out, hipStream_t st);
+int launch_consistency(const float* f1_flo, const float* f2_flo, const float* structure, const float* avg,
+                       uint8_t* out, int W, int H, hipStream_t st);
+
+}  // namespace fav

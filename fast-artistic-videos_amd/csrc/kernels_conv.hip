@@ -1,0 +1,511 @@
+// kernels_conv.hip -- the transformer network's device code for gfx950 (MI355X, CDNA4).
+//
+// nn.SpatialConvolution (models_video.lua:20,32,80,93) as an implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain), with
+//   * nn.InstanceNormalization + nn.ReLU of the PRODUCING layer applied on load (per-channel
+//     scale/shift [+ReLU], up to two stacked stages), zero padding applied after the transform,
+//   * nn.SpatialUpSamplingNearest(2) folded into the gather index map,
+//   * bias add, the raw NHWC store and the InstanceNorm statistics of the OUTPUT (per-tile mean and
+//     M2, merged later in fp64) in the epilogue,
+//   * for the last layer: nn.Tanh, nn.MulConstant and the VGG de-processing in the epilogue.
+// Activations are NHWC (channels-last) so that a K-slice (32 consecutive input channels of one
+// filter tap) is one contiguous 128-byte line.  GEMM view: M = output pixels, N = output channels,
+// K = taps * Cin.
+//
+// Tiling: 256 threads = 4 waves (64 lanes each).  Block tile 128 (M) x BN (N) x 32 (K), LDS
+// double-buffered [rows][36] (row stride 36 floats makes the 16-byte fragment reads conflict-free),
+// register-staged global->LDS copies issued one K-step ahead of the MFMAs.
+#include "fav_internal.h"
+
+namespace fav {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies lower to memcpy through scratch
+
+namespace {
+
+constexpr int BM = CONV_BM;   // 128 output pixels per block
+constexpr int BK = 32;        // K elements per step
+constexpr int LDSS = 36;      // LDS row stride in floats (144 B: 16-B aligned, conflict-free b128 reads)
+
+struct ConvArgs {
+    const float* in; const float* wgt; const float* bias;
+    const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+    float* out; float2* partials; float* out_planar; float* out_raw;
+    int IH, IW, IWp, ups, CIN;
+    int COUT, COUTp, KH, KW, stride, pad, Kpad, OH, OW;
+    int stages, relu1, relu2, final_mode;
+    float tanh_mul;
+};
+
+__device__ __forceinline__ float4 affine4(float4 v, const float* sc, const float* sh, int relu)
+{
+    const float4 s = *reinterpret_cast<const float4*>(sc);
+    const float4 b = *reinterpret_cast<const float4*>(sh);
+    v.x = fmaf(v.x, s.x, b.x); v.y = fmaf(v.y, s.y, b.y); v.z = fmaf(v.z, s.z, b.z); v.w = fmaf(v.w, s.w, b.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
+{
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [2][BM*LDSS]
+    float* Bs = smem + 2 * BM * LDSS;         // [2][BN*LDSS]
+    float* aff = Bs + 2 * BN * LDSS;          // [4][CIN]: scale1, shift1, scale2, shift2
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int mblock = blockIdx.x, nblock = blockIdx.y;
+    const int M = p.OH * p.OW;
+    const int CIN = p.CIN;
+
+    if (p.stages >= 1)
+        for (int i = t; i < CIN; i += 256) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
+    if (p.stages >= 2)
+        for (int i = t; i < CIN; i += 256) { aff[2 * CIN + i] = p.scale2[i]; aff[3 * CIN + i] = p.shift2[i]; }
+
+    // per-thread staging assignment: row r0 + 32*i of the tile, 16-byte chunk c4 of the 32-wide K slice
+    const int c4 = t & 7, r0 = t >> 3;
+    int iy0[AROWS], ix0[AROWS];
+    bool rv[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = mblock * BM + r0 + 32 * i;
+        rv[i] = m < M;
+        const int mm = rv[i] ? m : 0;
+        const int oy = mm / p.OW, ox = mm - oy * p.OW;
+        iy0[i] = oy * p.stride - p.pad;
+        ix0[i] = ox * p.stride - p.pad;
+    }
+    const int ntaps = p.KH * p.KW;
+    const int nsteps = p.Kpad / BK;
+    const float* wrow = p.wgt + (size_t)(nblock * BN + r0) * p.Kpad + c4 * 4;
+
+    float4 ra[AROWS];
+    v4f rb[BROWS];
+    bool va[AROWS];
+    int ci_cur = 0;
+
+// global -> registers for K-step s (raw values; the transform is applied when they are written to LDS)
+#define FAV_LOAD_STEP(s_)                                                                                   \
+    {                                                                                                       \
+        const int kb_ = (s_) * BK + c4 * 4;                                                                 \
+        const int tap_ = kb_ / CIN;                                                                         \
+        const int ci_ = kb_ - tap_ * CIN;                                                                   \
+        const int ky_ = tap_ / p.KW, kx_ = tap_ - ky_ * p.KW;                                               \
+        const bool tv_ = tap_ < ntaps;                                                                      \
+        ci_cur = ci_;                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < AROWS; ++i) {                                                 \
+            const int iy_ = iy0[i] + ky_, ix_ = ix0[i] + kx_;                                               \
+            va[i] = rv[i] && tv_ && (unsigned)iy_ < (unsigned)p.IH && (unsigned)ix_ < (unsigned)p.IW;       \
+            const size_t off_ = va[i] ? ((size_t)(iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci_ : 0;  \
+            ra[i] = *reinterpret_cast<const float4*>(p.in + off_);                                          \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < BROWS; ++j)                                                   \
+            rb[j] = *reinterpret_cast<const v4f*>(wrow + (size_t)(32 * j) * p.Kpad + (s_) * BK);            \
+    }
+
+// registers -> LDS buffer buf_: pending transform of the producer (IN scale/shift [+ReLU], up to two
+// stages), then zero for padding / out-of-range rows
+#define FAV_STORE_STEP(buf_)                                                                                \
+    {                                                                                                       \
+        float* a_ = As + (buf_) * BM * LDSS + r0 * LDSS + c4 * 4;                                           \
+        float* b_ = Bs + (buf_) * BN * LDSS + r0 * LDSS + c4 * 4;                                           \
+        _Pragma("unroll") for (int i = 0; i < AROWS; ++i) {                                                 \
+            float4 v_ = ra[i];                                                                              \
+            if (p.stages >= 1) {                                                                            \
+                v_ = affine4(v_, aff + ci_cur, aff + CIN + ci_cur, p.relu1);                                \
+                if (p.stages >= 2) v_ = affine4(v_, aff + 2 * CIN + ci_cur, aff + 3 * CIN + ci_cur, p.relu2); \
+            }                                                                                               \
+            if (!va[i]) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+            *reinterpret_cast<float4*>(a_ + 32 * i * LDSS) = v_;                                            \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(b_ + 32 * j * LDSS) = rb[j]; \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    FAV_LOAD_STEP(0);
+    __syncthreads();          // affine tables visible
+    FAV_STORE_STEP(0);
+    __syncthreads();
+
+    // fragment read bases: lane l supplies row (l&31) and the k pair {r, 4+r} selected by (l>>5)
+    const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
+    int cur = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) FAV_LOAD_STEP(s + 1);
+        const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;
+        const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) FAV_STORE_STEP(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#undef FAV_LOAD_STEP
+#undef FAV_STORE_STEP
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    const int m_wave = mblock * BM + wm * TM * 32;
+    const int n_wave = nblock * BN + wn * TN * 32;
+
+    if (p.final_mode) {
+        const float mean3[3] = {103.939f, 116.779f, 123.68f};   // preprocess.lua:48 (BGR)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_wave + j * 32 + col;
+            if (n >= p.COUT || n >= 3) continue;
+            const float bv = p.bias[n];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    if (m >= M) continue;
+                    const float v = tanhf(acc[i][j][r] + bv) * p.tanh_mul;           // models_video.lua:135-136
+                    if (p.out_raw) p.out_raw[(size_t)n * M + m] = v;
+                    if (p.out_planar) p.out_planar[(size_t)(2 - n) * M + m] = (v + mean3[n]) / 255.f;  // preprocess.lua:66-71
+                }
+        }
+        return;
+    }
+
+    float* red = smem;               // [WM][BN] (LDS is free again: the K loop ended on a barrier)
+    float* mean_s = smem + WM * BN;  // [BN]
+    const int cnt = min(BM, M - mblock * BM);
+    float lsum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_wave + j * 32 + col;
+        const float bv = p.bias[n];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                const float v = acc[i][j][r] + bv;
+                acc[i][j][r] = v;
+                if (m < M) {
+                    if (n < p.COUT) p.out[(size_t)m * p.COUT + n] = v;
+                    s += v;
+                }
+            }
+        lsum[j] = s;
+    }
+    if (p.partials == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s = lsum[j] + __shfl_xor(lsum[j], 32);
+        if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = s;
+    }
+    __syncthreads();
+    if (t < BN) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[w * BN + t];
+        mean_s[t] = s / (float)cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float mu = mean_s[(wn * TN + j) * 32 + col];
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                const float d = acc[i][j][r] - mu;
+                if (m < M) q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 32);
+        if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = q;
+    }
+    __syncthreads();
+    if (t < BN) {
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) q += red[w * BN + t];
+        p.partials[(size_t)mblock * p.COUTp + nblock * BN + t] = make_float2(mean_s[t], q);
+    }
+}
+
+template <int BN, int WM, int WN>
+int launch_conv_t(const ConvArgs& a, hipStream_t st)
+{
+    const int M = a.OH * a.OW;
+    const size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    dim3 grid((M + BM - 1) / BM, a.COUTp / BN);
+    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN>), grid, dim3(256), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_mfma_kernel");
+    return FAV_OK;
+}
+
+}  // namespace
+
+int launch_conv(const ConvLaunch& c, hipStream_t st)
+{
+    FAV_REQUIRE(c.CIN % 4 == 0 && c.CIN <= 1024, "conv: CIN=%d must be a multiple of 4 and <= 1024", c.CIN);
+    FAV_REQUIRE(c.COUTp % 32 == 0 && c.Kpad % BK == 0, "conv: COUTp=%d / Kpad=%d not tile aligned", c.COUTp, c.Kpad);
+    FAV_REQUIRE(c.Kpad >= c.KH * c.KW * c.CIN, "conv: Kpad too small");
+    FAV_REQUIRE(c.ups == 0 || c.ups == 1, "conv: upsample factor must be 1 or 2");
+    ConvArgs a;
+    a.in = c.in; a.wgt = c.wgt; a.bias = c.bias;
+    a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
+    a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
+    a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials);
+    a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN;
+    a.COUT = c.COUT; a.COUTp = c.COUTp; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
+    a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
+    if (c.COUTp % 128 == 0) return launch_conv_t<128, 2, 2>(a, st);
+    if (c.COUTp % 64 == 0) return launch_conv_t<64, 2, 2>(a, st);
+    return launch_conv_t<32, 4, 1>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm finalize: merge per-tile (mean, M2) in fp64 (Chan et al.), emit scale/shift.
+// InstanceNormalization.lua:33-53: biased variance, eps inside the sqrt.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ double block_sum_d(double v, double* sh)
+{
+    const int t = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((t & 63) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials, int mblocks, int M, int bp,
+                                                          int Cpitch, const float* gamma, const float* beta,
+                                                          float eps, float* scale, float* shift)
+{
+    __shared__ double sh[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0;
+    for (int b = t; b < mblocks; b += 256) {
+        const int nb = min(bp, M - b * bp);
+        s += (double)nb * (double)partials[(size_t)b * Cpitch + c].x;
+    }
+    const double mean = block_sum_d(s, sh) / (double)M;
+    double q = 0;
+    for (int b = t; b < mblocks; b += 256) {
+        const int nb = min(bp, M - b * bp);
+        const float2 pr = partials[(size_t)b * Cpitch + c];
+        const double d = (double)pr.x - mean;
+        q += (double)pr.y + (double)nb * d * d;
+    }
+    const double var = block_sum_d(q, sh) / (double)M;
+    if (t == 0) {
+        const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+        const double sc = g / sqrt(var + (double)eps);
+        scale[c] = (float)sc;
+        shift[c] = (float)(bt - mean * sc);
+    }
+}
+
+__device__ __forceinline__ float4 apply_affine_g(float4 v, const Affine& a, int c)
+{
+    if (a.stages >= 1) {
+        v = affine4(v, a.scale1 + c, a.shift1 + c, a.relu1);
+        if (a.stages >= 2) v = affine4(v, a.scale2 + c, a.shift2 + c, a.relu2);
+    }
+    return v;
+}
+
+// statistics of t(x) over [M][C]: one block per 128 pixels, two passes (mean, then M2) over the tile
+__global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C, const Affine a, float2* partials)
+{
+    __shared__ float red[1024];
+    __shared__ float mean_s[1024];
+    const int t = threadIdx.x;
+    const int groups = C >> 2;                 // float4 groups per pixel
+    const int nl = 256 / groups;               // pixel lanes
+    const int g = t % groups, pl = t / groups;
+    const int m0 = blockIdx.x * 128;
+    const int cnt = min(128, M - m0);
+    const bool active = pl < nl;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (active)
+        for (int pix = pl; pix < cnt; pix += nl) {
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
+            v = apply_affine_g(v, a, 4 * g);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    if (active) *reinterpret_cast<float4*>(red + pl * C + 4 * g) = s;
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float r = 0;
+        for (int i = 0; i < nl; ++i) r += red[i * C + c];
+        mean_s[c] = r / (float)cnt;
+    }
+    __syncthreads();
+    float4 q = make_float4(0, 0, 0, 0);
+    if (active) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean_s + 4 * g);
+        for (int pix = pl; pix < cnt; pix += nl) {
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
+            v = apply_affine_g(v, a, 4 * g);
+            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+        }
+        *reinterpret_cast<float4*>(red + pl * C + 4 * g) = q;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        float r = 0;
+        for (int i = 0; i < nl; ++i) r += red[i * C + c];
+        partials[(size_t)blockIdx.x * C + c] = make_float2(mean_s[c], r);
+    }
+}
+
+// residual join: nn.CAddTable of (IN(conv_b) , ShaveImage(skip))  -- models_video.lua:41-53
+__global__ __launch_bounds__(256) void res_add_kernel(const float* y, const float* scale, const float* shift,
+                                                      const float* skip, int SW, int shave, const Affine sa,
+                                                      int OH, int OW, int C, float* z)
+{
+    const int groups = C >> 2;
+    const size_t total = (size_t)OH * OW * groups;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int g = (int)(idx % groups);
+        const size_t pix = idx / groups;
+        const int oy = (int)(pix / OW), ox = (int)(pix - (size_t)oy * OW);
+        float4 v = *reinterpret_cast<const float4*>(y + pix * C + 4 * g);
+        v = affine4(v, scale + 4 * g, shift + 4 * g, 0);
+        float4 k = *reinterpret_cast<const float4*>(skip + ((size_t)(oy + shave) * SW + ox + shave) * C + 4 * g);
+        k = apply_affine_g(k, sa, 4 * g);
+        v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w;
+        *reinterpret_cast<float4*>(z + pix * C + 4 * g) = v;
+    }
+}
+
+__device__ __forceinline__ int reflect(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// NCHW -> reflection-padded NHWC with channel padding (nn.SpatialReflectionPadding, train_video.lua:319-325)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* in, int C, int H, int W, int pad, int Cp,
+                                                               float* out)
+{
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const size_t total = (size_t)Hp * Wp * Cp;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % Cp);
+        const size_t pix = idx / Cp;
+        const int y = (int)(pix / Wp), x = (int)(pix - (size_t)y * Wp);
+        float v = 0.f;
+        if (c < C) v = in[((size_t)c * H + reflect(y - pad, H)) * W + reflect(x - pad, W)];
+        out[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, int M, int C, const Affine a, float* out)
+{
+    const size_t total = (size_t)M * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx / M);
+        const size_t m = idx - (size_t)c * M;
+        float v = in[m * C + c];
+        if (a.stages >= 1) {
+            v = fmaf(v, a.scale1[c], a.shift1[c]); if (a.relu1) v = fmaxf(v, 0.f);
+            if (a.stages >= 2) { v = fmaf(v, a.scale2[c], a.shift2[c]); if (a.relu2) v = fmaxf(v, 0.f); }
+        }
+        out[idx] = v;
+    }
+}
+
+inline int grid_for(size_t total) { size_t b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b ? b : 1)); }
+
+}  // namespace
+
+int launch_in_finalize(const float* partials, int mblocks, int M, int block_pixels, int C, int Cpitch,
+                       const float* gamma, const float* beta, float eps, float* scale, float* shift, hipStream_t st)
+{
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(C), dim3(256), 0, st, reinterpret_cast<const float2*>(partials),
+                       mblocks, M, block_pixels, Cpitch, gamma, beta, eps, scale, shift);
+    FAV_LAUNCH_CHECK("in_finalize_kernel");
+    return FAV_OK;
+}
+
+int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st)
+{
+    FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "stats: unsupported channel count %d", C);
+    hipLaunchKernelGGL(stats_kernel, dim3((M + 127) / 128), dim3(256), 0, st, x, M, C, t,
+                       reinterpret_cast<float2*>(partials));
+    FAV_LAUNCH_CHECK("stats_kernel");
+    return FAV_OK;
+}
+
+int launch_res_add(const float* y, const float* scale, const float* shift, const float* skip, int SH, int SW,
+                   int shave, const Affine& skip_t, int C, float* z, hipStream_t st)
+{
+    const int OH = SH - 2 * shave, OW = SW - 2 * shave;
+    FAV_REQUIRE(C % 4 == 0 && OH > 0 && OW > 0, "res_add: bad shape");
+    hipLaunchKernelGGL(res_add_kernel, dim3(grid_for((size_t)OH * OW * (C / 4))), dim3(256), 0, st, y, scale, shift,
+                       skip, SW, shave, skip_t, OH, OW, C, z);
+    FAV_LAUNCH_CHECK("res_add_kernel");
+    return FAV_OK;
+}
+
+int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int Cp, float* out, hipStream_t st)
+{
+    FAV_REQUIRE(pad < H && pad < W, "reflection pad %d must be smaller than the image (%dx%d)", pad, W, H);
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((size_t)(H + 2 * pad) * (W + 2 * pad) * Cp)), dim3(256), 0,
+                       st, in, C, H, W, pad, Cp, out);
+    FAV_LAUNCH_CHECK("nchw_to_nhwc_pad_kernel");
+    return FAV_OK;
+}
+
+int launch_nhwc_to_nchw(const float* in, int M, int C, const Affine& t, float* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((size_t)M * C)), dim3(256), 0, st, in, M, C, t, out);
+    FAV_LAUNCH_CHECK("nhwc_to_nchw_kernel");
+    return FAV_OK;
+}
+
+}  // namespace fav

@@ -1,0 +1,255 @@
+// kernels_frame.hip -- per-frame gather / elementwise kernels for gfx950 (HBM-bound work):
+//   A2  optical-flow warp            (stnbdhw/BilinearSamplerBDHW.cu:48-109, utils.lua:141-149)
+//   A5  certainty erosion            (utils.lua:161-169)
+//   A6  VGG pre-processing           (preprocess.lua:48,57-62)
+//   A7  7-channel input assembly     (fast_artistic_video_core.lua:133-138,161-171)
+//   A9  image.save quantisation      (fast_artistic_video.lua:160-170)
+// plus the fused form used by the per-frame pipeline: warp + preprocess + mask + concat +
+// nn.SpatialReflectionPadding written straight into the network's padded NHWC8 input.
+// One lane per output pixel, consecutive lanes on consecutive x => coalesced streams for every
+// dense operand; the bilinear taps are gathers served by L2 (the flow is locally smooth).
+// Compiled with -ffp-contract=off so the fp32 expressions round like the CPU restatement.
+#include "fav_internal.h"
+
+namespace fav {
+namespace {
+
+__device__ __forceinline__ int reflect(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// bilinear weights/taps shared by all channels of one output pixel
+struct Taps {
+    int o00, o01, o10, o11;     // linear offsets y*W+x (clamped so they are always addressable)
+    float w00, w01, w10, w11;   // already zeroed for invalid taps
+};
+
+// FAV_BORDER_STN: BilinearSamplerBDHW.cu:13-23,72-73,92-106.  yf = dy + y, xf = dx + x.
+__device__ __forceinline__ Taps taps_stn(float yf, float xf, int H, int W)
+{
+    Taps t;
+    const int x0 = (int)floorf(xf), y0 = (int)floorf(yf);
+    const float wx = 1.f - (xf - (float)x0), wy = 1.f - (yf - (float)y0);
+    const bool xi0 = x0 >= 0 && x0 <= W - 1, xi1 = x0 + 1 >= 0 && x0 + 1 <= W - 1;
+    const bool yi0 = y0 >= 0 && y0 <= H - 1, yi1 = y0 + 1 >= 0 && y0 + 1 <= H - 1;
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    t.o00 = yc0 * W + xc0; t.o01 = yc0 * W + xc1; t.o10 = yc1 * W + xc0; t.o11 = yc1 * W + xc1;
+    t.w00 = (xi0 && yi0) ? wx * wy : 0.f;
+    t.w01 = (xi1 && yi0) ? (1.f - wx) * wy : 0.f;
+    t.w10 = (xi0 && yi1) ? wx * (1.f - wy) : 0.f;
+    t.w11 = (xi1 && yi1) ? (1.f - wx) * (1.f - wy) : 0.f;
+    return t;
+}
+
+// FAV_BORDER_CPU: image.warp(..., 'bilinear', true, 'pad', 0) [Torch7 `image`, recalled]
+__device__ __forceinline__ Taps taps_cpu(float iy, float ix, int H, int W)
+{
+    Taps t;
+    if (iy < 0.f || iy > (float)(H - 1) || ix < 0.f || ix > (float)(W - 1)) {
+        t.o00 = t.o01 = t.o10 = t.o11 = 0;
+        t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+        return t;
+    }
+    const int xw = (int)floorf(ix), yn = (int)floorf(iy);
+    const int xe = xw + 1, ys = yn + 1;
+    t.w00 = ((float)xe - ix) * ((float)ys - iy);
+    t.w01 = (ix - (float)xw) * ((float)ys - iy);
+    t.w10 = ((float)xe - ix) * (iy - (float)yn);
+    t.w11 = (ix - (float)xw) * (iy - (float)yn);
+    const int xec = min(xe, W - 1), ysc = min(ys, H - 1);
+    t.o00 = yn * W + xw; t.o01 = yn * W + xec; t.o10 = ysc * W + xw; t.o11 = ysc * W + xec;
+    return t;
+}
+
+__device__ __forceinline__ Taps make_taps(int border, float yf, float xf, int H, int W)
+{
+    return border == FAV_BORDER_CPU ? taps_cpu(yf, xf, H, W) : taps_stn(yf, xf, H, W);
+}
+
+__device__ __forceinline__ float sample(const float* plane, const Taps& t)
+{
+    // summation order of BilinearSamplerBDHW.cu:103-106
+    return t.w00 * plane[t.o00] + t.w01 * plane[t.o01] + t.w10 * plane[t.o10] + t.w11 * plane[t.o11];
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const float* img, const float* flow, float* out, int C, int H, int W,
+                                                   int Ho, int Wo, int border)
+{
+    const int b = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= Wo) return;
+    const size_t on = (size_t)Ho * Wo;
+    const float* fl = flow + (size_t)b * 2 * on;
+    const float yf = fl[(size_t)y * Wo + x] + (float)y;        // flow[:,0] = dy  (BilinearSamplerBDHW.cu:72)
+    const float xf = fl[on + (size_t)y * Wo + x] + (float)x;   // flow[:,1] = dx  (:73)
+    const Taps t = make_taps(border, yf, xf, H, W);
+    const float* ib = img + (size_t)b * C * H * W;
+    float* ob = out + (size_t)b * C * on + (size_t)y * Wo + x;
+    for (int c = 0; c < C; ++c) ob[(size_t)c * on] = sample(ib + (size_t)c * H * W, t);
+}
+
+__global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, float* out, int H, int W, int r)
+{
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int p = r / 2;
+    float m = -INFINITY;
+    for (int dy = -p; dy < r - p; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -p; dx < r - p; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const float v = cert[(size_t)yy * W + xx] * -1.f + 1.f;     // MulConstant(-1), AddConstant(1)
+            m = fmaxf(m, v);
+        }
+    }
+    out[(size_t)y * W + x] = m * -1.f + 1.f;
+}
+
+__device__ __forceinline__ float vgg_mean(int c) { return c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f); }
+
+__global__ __launch_bounds__(256) void assemble_kernel(const float* frame, const float* warped, const float* cert,
+                                                       float* in7, int H, int W)
+{
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float cv = (warped != nullptr) ? cert[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        in7[c * n + i] = frame[(2 - c) * n + i] * 255.f - vgg_mean(c);                // preprocess.lua:57-62
+        float pr = 0.f;
+        if (warped != nullptr) pr = (warped[(2 - c) * n + i] * 255.f - vgg_mean(c)) * cv + 0.f;   // core:166-170
+        in7[(3 + c) * n + i] = pr;
+    }
+    in7[6 * n + i] = cv;                                                             // core:171 / :136
+}
+
+// certainty from the checker's PGM byte: image.load(...,1) = byte/255; -invert_occlusion and
+// -fix_occlusions of fast_artistic_video.lua:79-86,99-112
+__global__ __launch_bounds__(256) void cert_raw_kernel(const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ,
+                                                       int border, float* cert, int H, int W)
+{
+    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const size_t i = (size_t)y * W + x;
+    float c = (float)mask[i] / 255.f;
+    if (invert) c = (c + -1.f) * -1.f;
+    if (fix_occ) {
+        const float2 f = bw_flo[i];
+        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
+        float ones = t.w00 + t.w01 + t.w10 + t.w11;         // warp of an all-ones image
+        ones = ones + -0.5f;
+        const float sg = ones > 0.f ? 1.f : (ones < 0.f ? -1.f : 0.f);
+        c *= fmaxf(sg, 0.f);
+    }
+    cert[i] = c;
+}
+
+// Fused A2 + A6 + A7 + reflection pad -> padded NHWC8 network input [H+2p][W+2p][8]
+//   ch 0..2 content (BGR, mean-subtracted), ch 3..5 masked warped prior, ch 6 certainty, ch 7 zero
+__global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb,
+                                                         const float2* bw_flo, const float* cert, int border, int H,
+                                                         int W, int pad, float* in8)
+{
+    const int Wp = W + 2 * pad;
+    const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
+    if (xp >= Wp) return;
+    const int y = reflect(yp - pad, H), x = reflect(xp - pad, W);
+    const size_t i = (size_t)y * W + x, n = (size_t)H * W;
+    const uint8_t* px = frame_hwc + i * 3;
+    const float rgb[3] = {(float)px[0] / 255.f, (float)px[1] / 255.f, (float)px[2] / 255.f};   // image.load: byte/255
+    float4 lo, hi;
+    lo.x = rgb[2] * 255.f - 103.939f;
+    lo.y = rgb[1] * 255.f - 116.779f;
+    lo.z = rgb[0] * 255.f - 123.68f;
+    if (prev_rgb != nullptr) {
+        const float2 f = bw_flo[i];                                     // .flo payload: (u, v) = (dx, dy)
+        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
+        const float cv = cert[i];
+        const float wr = sample(prev_rgb, t), wg = sample(prev_rgb + n, t), wb = sample(prev_rgb + 2 * n, t);
+        lo.w = (wb * 255.f - 103.939f) * cv + 0.f;
+        hi.x = (wg * 255.f - 116.779f) * cv + 0.f;
+        hi.y = (wr * 255.f - 123.68f) * cv + 0.f;
+        hi.z = cv;
+    } else {
+        lo.w = 0.f; hi.x = 0.f; hi.y = 0.f; hi.z = 0.f;                 // core:133-138: zero prior, zero mask
+    }
+    hi.w = 0.f;
+    float4* o = reinterpret_cast<float4*>(in8 + ((size_t)yp * Wp + xp) * 8);
+    o[0] = lo; o[1] = hi;
+}
+
+// image.save: clamp to [0,1], *255, truncate [Torch7 `image`, recalled]; planar float RGB -> HWC u8
+__global__ __launch_bounds__(256) void quantize_kernel(const float* rgb, uint8_t* out, int H, int W)
+{
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = rgb[c * n + i];
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i * 3 + c] = (uint8_t)(v * 255.f);
+    }
+}
+
+}  // namespace
+
+int launch_warp(const float* img, const float* flow, float* out, int B, int C, int H, int W, int Ho, int Wo, int border,
+                hipStream_t st)
+{
+    hipLaunchKernelGGL(warp_kernel, dim3((Wo + 255) / 256, Ho, B), dim3(256), 0, st, img, flow, out, C, H, W, Ho, Wo,
+                       border);
+    FAV_LAUNCH_CHECK("warp_kernel");
+    return FAV_OK;
+}
+
+int launch_min_filter_f32(const float* cert, float* out, int H, int W, int r, hipStream_t st)
+{
+    hipLaunchKernelGGL(min_filter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, cert, out, H, W, r);
+    FAV_LAUNCH_CHECK("min_filter_kernel");
+    return FAV_OK;
+}
+
+int launch_assemble(const float* frame, const float* warped, const float* cert, float* in7, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st, frame, warped,
+                       cert, in7, H, W);
+    FAV_LAUNCH_CHECK("assemble_kernel");
+    return FAV_OK;
+}
+
+int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int invert, int fix_occ, int border, int r,
+                        float* cert_tmp, float* cert, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(cert_raw_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, mask,
+                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert_tmp, H, W);
+    FAV_LAUNCH_CHECK("cert_raw_kernel");
+    return launch_min_filter_f32(cert_tmp, cert, H, W, r, st);
+}
+
+int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo, const float* cert,
+                      int border, int H, int W, int pad, float* in8, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
+                       prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8);
+    FAV_LAUNCH_CHECK("prep_input_kernel");
+    return FAV_OK;
+}
+
+int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st, rgb_planar,
+                       out_hwc, H, W);
+    FAV_LAUNCH_CHECK("quantize_kernel");
+    return FAV_OK;
+}
+
+}  // namespace fav

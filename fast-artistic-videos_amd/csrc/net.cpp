@@ -1,0 +1,630 @@
+// net.cpp -- host side of the transformer network (A8) and of the fused per-frame pipeline.
+//
+// fav_net  : replaces `checkpoint.model` + `model:forward(input)` (fast_artistic_video_core.lua:38-57,172).
+// fav_stream: replaces one iteration of run_fast_neural_video's loop (core.lua:194-211) with the video
+//             CLI's callbacks (fast_artistic_video.lua:93-172), keeping last_frame_stylized on the device.
+//
+// Execution model ("lazy activations"): every activation lives in HBM exactly once, as the RAW output
+// of the kernel that produced it (NHWC fp32).  nn.InstanceNormalization / nn.ReLU /
+// nn.SpatialUpSamplingNearest never run as kernels of their own: they become a pending per-channel
+// transform + index map attached to the tensor and are applied by the NEXT convolution while it
+// stages its operand into LDS.  The InstanceNorm statistics come from the producing convolution's
+// epilogue (per-tile mean/M2, merged in fp64), or -- when the normalised tensor is itself a pending
+// transform of another tensor (the IN that follows an upsample of an already normalised+rectified
+// tensor, models_video.lua:94-98,121-130) -- from one read-only reduction pass.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "fav_internal.h"
+
+using namespace fav;
+
+namespace {
+
+struct DevBuf { void* p = nullptr; size_t bytes = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
+
+struct Act {
+    float* data = nullptr;
+    int Hp = 0, Wp = 0;          // physical size
+    int C = 0;                   // channel pitch
+    int ups = 0;                 // pending nearest upsample (log2)
+    Affine pre;                  // pending per-channel transform
+    float* partials = nullptr;   // (mean, M2) tiles of the raw tensor from the producing conv, or null
+    int mblocks = 0, ppitch = 0;
+    int H() const { return Hp << ups; }
+    int W() const { return Wp << ups; }
+};
+
+int dev_upload(const std::vector<float>& h, size_t pad_to, float** out)
+{
+    const size_t n = std::max(pad_to, h.size());
+    std::vector<float> tmp(n, 0.f);
+    std::copy(h.begin(), h.end(), tmp.begin());
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(out), (n ? n : 1) * sizeof(float)));
+    if (n) FAV_HIP(hipMemcpy(*out, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return FAV_OK;
+}
+
+// repack [cout][cin][k][k] -> [coutp][kpad] with k-index = (ky*k + kx)*cinp + ci (channels-last taps)
+void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<float>& out)
+{
+    out.assign((size_t)coutp * kpad, 0.f);
+    for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < L.cin; ++ci)
+            for (int ky = 0; ky < L.k; ++ky)
+                for (int kx = 0; kx < L.k; ++kx)
+                    out[(size_t)co * kpad + (size_t)(ky * L.k + kx) * cinp + ci] =
+                        L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+}
+
+bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul)
+{
+    has_tanh = false; mul = 1.f;
+    for (size_t i = from; i < ls.size(); ++i) {
+        if (ls[i].type == L_TANH) { if (has_tanh) return false; has_tanh = true; }
+        else if (ls[i].type == L_MUL) { if (!has_tanh) return false; mul *= ls[i].mul; }
+        else if (ls[i].type != L_IDENTITY) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct fav_net {
+    int device = 0;
+    std::vector<Layer> layers;
+    int pad = 0;                  // leading nn.SpatialReflectionPadding (train_video.lua:319-325)
+    int in_channels = 0;
+    long long params = 0;
+    std::vector<DevConvW> convs;  // traversal order
+    std::vector<DevIN> ins;
+    float* ones = nullptr; float* zeros = nullptr;
+    // activation arena: buffers are created on the first forward for a given (H, W) and reused after
+    int curH = 0, curW = 0;
+    std::vector<DevBuf> bufs;
+    size_t cursor = 0, conv_cursor = 0, in_cursor = 0;
+    hipStream_t st = nullptr;
+    float* stage = nullptr; size_t stage_bytes = 0;   // NCHW-boundary staging (fav_net_forward)
+    // optional per-convolution event timing (bench.py roofline)
+    bool profiling = false;
+    struct ProfRec { hipEvent_t a, b; int conv; };
+    std::vector<ProfRec> prof_pending;
+    std::vector<double> prof_ms, prof_macs; std::vector<int> prof_n, prof_tile;
+
+    ~fav_net()
+    {
+        (void)hipSetDevice(device);
+        (void)hipFree(stage);
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); }
+        for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
+        for (auto& b : bufs) (void)hipFree(b.p);
+        (void)hipFree(ones); (void)hipFree(zeros);
+    }
+    int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
+    int upload();
+    int alloc(size_t bytes, float** out);
+    int timed_conv(const ConvLaunch& c, int conv_index, const Layer& L);
+    int run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw);
+    int forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
+    void out_size(int H, int W, int* Ho, int* Wo) const;
+};
+
+int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
+{
+    for (Layer& L : ls) {
+        if (L.type == L_CONV) {
+            DevConvW d;
+            d.cinp = chan_pitch;
+            if (L.cin > chan_pitch || (chan_pitch != 8 && L.cin != chan_pitch)) {
+                set_error("network: conv expects %d input channels, producer has %d", L.cin, chan_pitch); return FAV_EFORMAT; }
+            if (L.k < 1 || L.stride < 1 || L.pad < 0) { set_error("network: bad convolution geometry"); return FAV_EFORMAT; }
+            d.coutp = (L.cout + 31) / 32 * 32;
+            d.kpad = (L.k * L.k * d.cinp + 31) / 32 * 32;
+            std::vector<float> w;
+            repack_weights(L, d.cinp, d.coutp, d.kpad, w);
+            int rc = dev_upload(w, 0, &d.wgt); if (rc) return rc;
+            rc = dev_upload(L.b, (size_t)d.coutp, &d.bias); if (rc) return rc;
+            convs.push_back(d);
+            params += (long long)L.w.size() + (long long)L.b.size();
+            chan_pitch = L.cout;
+            maxc = std::max(maxc, std::max(d.coutp, d.cinp));
+        } else if (L.type == L_IN) {
+            if ((int)L.gamma.size() != chan_pitch) { set_error("network: InstanceNormalization(%zu) after %d channels", L.gamma.size(), chan_pitch); return FAV_EFORMAT; }
+            DevIN d;
+            int rc = dev_upload(L.gamma, 0, &d.gamma); if (rc) return rc;
+            rc = dev_upload(L.beta, 0, &d.beta); if (rc) return rc;
+            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.scale), L.gamma.size() * sizeof(float)));
+            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
+            ins.push_back(d);
+            params += 2 * (long long)L.gamma.size();
+        } else if (L.type == L_RES) {
+            int cp = chan_pitch;
+            int rc = upload_layers(L.block, cp, maxc); if (rc) return rc;
+            if (cp != chan_pitch) { set_error("network: residual branch changes the channel count"); return FAV_EUNSUPPORTED; }
+        }
+    }
+    return FAV_OK;
+}
+
+int fav_net::upload()
+{
+    FAV_HIP(hipSetDevice(device));
+    if (layers.empty()) { set_error("network: empty model"); return FAV_EFORMAT; }
+    size_t first = 0;
+    if (layers[0].type == L_PAD) {
+        const Layer& P = layers[0];
+        if (P.pl != P.pr || P.pl != P.pt || P.pl != P.pb || P.pl < 0) { set_error("network: asymmetric reflection padding is unsupported"); return FAV_EUNSUPPORTED; }
+        pad = P.pl; first = 1;
+    }
+    for (size_t i = first; i < layers.size(); ++i)
+        if (layers[i].type == L_PAD) { set_error("network: reflection padding is only supported as the first layer (padding_type reflect-start)"); return FAV_EUNSUPPORTED; }
+    in_channels = 0;
+    for (const Layer& L : layers) if (L.type == L_CONV) { in_channels = L.cin; break; }
+    if (in_channels != 7) { set_error("network: first convolution has %d input channels; the video hot path needs 7 (models_video.lua:57)", in_channels); return FAV_EUNSUPPORTED; }
+    int chan = 8, maxc = 8;
+    int rc = upload_layers(layers, chan, maxc); if (rc) return rc;
+    std::vector<float> o((size_t)maxc, 1.f), z((size_t)maxc, 0.f);
+    rc = dev_upload(o, 0, &ones); if (rc) return rc;
+    return dev_upload(z, 0, &zeros);
+}
+
+int fav_net::alloc(size_t bytes, float** out)
+{
+    bytes = (bytes + 255) / 256 * 256;
+    if (cursor < bufs.size()) {
+        if (bufs[cursor].bytes < bytes) { set_error("internal: activation arena mismatch"); return FAV_EINVAL; }
+        *out = static_cast<float*>(bufs[cursor++].p);
+        return FAV_OK;
+    }
+    DevBuf b; b.bytes = bytes;
+    FAV_HIP(hipMalloc(&b.p, bytes));
+    bufs.push_back(b); ++cursor;
+    *out = static_cast<float*>(b.p);
+    return FAV_OK;
+}
+
+int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
+{
+    if (!profiling) return launch_conv(c, st);
+    ProfRec r; r.conv = conv_index;
+    FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
+    FAV_HIP(hipEventRecord(r.a, st));
+    int rc = launch_conv(c, st);
+    FAV_HIP(hipEventRecord(r.b, st));
+    prof_pending.push_back(r);
+    if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
+    prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
+    prof_tile[conv_index] = c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32);
+    return rc;
+}
+
+int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw)
+{
+    for (size_t li = 0; li < ls.size(); ++li) {
+        Layer& L = ls[li];
+        switch (L.type) {
+        case L_PAD: break;   // folded into the input conversion (leading layer only, checked in upload())
+        case L_CONV: {
+            const DevConvW& d = convs[conv_cursor++];
+            if (cur.C != d.cinp) { set_error("internal: channel pitch mismatch (%d vs %d)", cur.C, d.cinp); return FAV_EINVAL; }
+            ConvLaunch c;
+            c.in = cur.data; c.IH = cur.H(); c.IW = cur.W(); c.IWp = cur.Wp; c.ups = cur.ups; c.CIN = d.cinp;
+            c.pre = cur.pre;
+            c.wgt = d.wgt; c.bias = d.bias; c.COUT = L.cout; c.COUTp = d.coutp; c.KH = c.KW = L.k; c.stride = L.stride;
+            c.pad = L.pad; c.Kpad = d.kpad;
+            c.OH = (c.IH + 2 * L.pad - L.k) / L.stride + 1;
+            c.OW = (c.IW + 2 * L.pad - L.k) / L.stride + 1;
+            if (c.IH + 2 * L.pad < L.k || c.IW + 2 * L.pad < L.k) { set_error("network: input too small for the architecture"); return FAV_EINVAL; }
+            bool has_tanh = false; float mul = 1.f;
+            const bool is_final = top && only_tail(ls, li + 1, has_tanh, mul) && has_tanh && L.cout == 3;
+            Act nxt;
+            nxt.Hp = c.OH; nxt.Wp = c.OW; nxt.C = L.cout;
+            if (is_final) {
+                c.final_mode = 1; c.tanh_mul = mul; c.out_planar = out_planar; c.out_raw_nchw = out_raw;
+                int rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
+                cur = nxt;
+                return FAV_OK;        // Tanh / MulConstant / TotalVariation are folded into the epilogue
+            }
+            if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
+            int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
+            const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
+            nxt.mblocks = conv_mblocks(c.OH, c.OW); nxt.ppitch = d.coutp;
+            if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
+            c.out = nxt.data; c.partials = nxt.partials;
+            rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
+            cur = nxt;
+            break;
+        }
+        case L_IN: {
+            const DevIN& d = ins[in_cursor++];
+            const int C = (int)L.gamma.size();
+            const int M = cur.Hp * cur.Wp;
+            if (cur.data == nullptr || C != cur.C) { set_error("network: misplaced InstanceNormalization"); return FAV_EUNSUPPORTED; }
+            if (cur.partials != nullptr && cur.pre.stages == 0) {
+                int rc = launch_in_finalize(cur.partials, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
+                                            d.scale, d.shift, st);
+                if (rc) return rc;
+                cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1;
+            } else {
+                if (cur.pre.stages >= 2) { set_error("network: more than two stacked normalisations on one tensor are unsupported"); return FAV_EUNSUPPORTED; }
+                // statistics of the pending-transformed tensor (nearest upsampling replicates every
+                // element s*s times and leaves mean and biased variance unchanged)
+                float* part = nullptr;
+                const int mb = (M + 127) / 128;
+                int rc = alloc((size_t)mb * C * 2 * sizeof(float), &part); if (rc) return rc;
+                rc = launch_stats(cur.data, M, C, cur.pre, part, st); if (rc) return rc;
+                rc = launch_in_finalize(part, mb, M, 128, C, C, d.gamma, d.beta, L.eps, d.scale, d.shift, st); if (rc) return rc;
+                if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
+                else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
+            }
+            cur.partials = nullptr;
+            break;
+        }
+        case L_RELU:
+            if (cur.pre.stages == 0) { cur.pre.scale1 = ones; cur.pre.shift1 = zeros; cur.pre.relu1 = 1; cur.pre.stages = 1; }
+            else if (cur.pre.stages == 1) cur.pre.relu1 = 1;
+            else cur.pre.relu2 = 1;
+            cur.partials = nullptr;
+            break;
+        case L_UP:
+            if (L.scale != 2 || cur.ups != 0) { set_error("network: only a single x2 nearest upsampling per convolution is supported"); return FAV_EUNSUPPORTED; }
+            cur.ups = 1;
+            break;
+        case L_RES: {
+            if (cur.ups != 0) { set_error("network: residual block directly after an upsampling is unsupported"); return FAV_EUNSUPPORTED; }
+            Act skip = cur;
+            Act br = cur;
+            br.partials = nullptr;
+            int rc = run(L.block, br, false, nullptr, nullptr); if (rc) return rc;
+            if (br.pre.stages != 1 || br.pre.relu1 || br.ups != 0) { set_error("network: residual branch must end in conv + InstanceNormalization"); return FAV_EUNSUPPORTED; }
+            if (br.Hp != skip.Hp - 2 * L.shave || br.Wp != skip.Wp - 2 * L.shave || br.C != skip.C) {
+                set_error("network: residual branch output %dx%d does not match the shaved skip %dx%d", br.Wp, br.Hp,
+                          skip.Wp - 2 * L.shave, skip.Hp - 2 * L.shave);
+                return FAV_EUNSUPPORTED; }
+            Act z; z.Hp = br.Hp; z.Wp = br.Wp; z.C = br.C;
+            rc = alloc((size_t)z.Hp * z.Wp * z.C * sizeof(float), &z.data); if (rc) return rc;
+            rc = launch_res_add(br.data, br.pre.scale1, br.pre.shift1, skip.data, skip.Hp, skip.Wp, L.shave, skip.pre, z.C,
+                                z.data, st);
+            if (rc) return rc;
+            cur = z;
+            break;
+        }
+        case L_TANH: case L_MUL:
+            set_error("network: Tanh/MulConstant are only supported after the last convolution"); return FAV_EUNSUPPORTED;
+        case L_IDENTITY: break;
+        }
+    }
+    if (top) { set_error("network: the model does not end in a 3-channel convolution followed by Tanh"); return FAV_EUNSUPPORTED; }
+    return FAV_OK;
+}
+
+void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
+{
+    // shape walk (models_video.lua:55-140): convs floor((in+2p-k)/s)+1, residual blocks shave, upsampling doubles
+    int h = H + 2 * pad, w = W + 2 * pad;
+    std::function<void(const std::vector<Layer>&)> walk = [&](const std::vector<Layer>& ls) {
+        for (const Layer& L : ls) {
+            if (L.type == L_CONV) { h = (h + 2 * L.pad - L.k) / L.stride + 1; w = (w + 2 * L.pad - L.k) / L.stride + 1; }
+            else if (L.type == L_UP) { h *= L.scale; w *= L.scale; }
+            else if (L.type == L_RES) walk(L.block);
+        }
+    };
+    walk(layers);
+    *Ho = h; *Wo = w;
+}
+
+int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)
+{
+    FAV_HIP(hipSetDevice(device));
+    if (H != curH || W != curW) {
+        if (!bufs.empty()) {
+            FAV_HIP(hipDeviceSynchronize());
+            for (auto& b : bufs) (void)hipFree(b.p);
+            bufs.clear();
+        }
+        curH = H; curW = W;
+    }
+    st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0;
+    Act cur;
+    cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.C = 8;
+    return run(layers, cur, true, out_planar, out_raw);
+}
+
+// ================================================================================================
+// C ABI: network
+// ================================================================================================
+static int finish_create(fav_net* net, fav_net** out)
+{
+    int rc = net->upload();
+    if (rc) { delete net; return rc; }
+    *out = net;
+    return FAV_OK;
+}
+
+extern "C" int fav_net_create(const char* t7_path_host, int device, fav_net** out)
+{
+    FAV_REQUIRE(t7_path_host && out, "fav_net_create: null argument");
+    int rc = ensure_device(); if (rc) return rc;
+    fav_net* net = new fav_net();
+    net->device = device;
+    rc = t7_parse_model(t7_path_host, net->layers);
+    if (rc) { delete net; return rc; }
+    return finish_create(net, out);
+}
+
+extern "C" int fav_net_pack_host(const char* t7_path_host, void* blob_host, size_t capacity, size_t* bytes)
+{
+    FAV_REQUIRE(t7_path_host && bytes, "fav_net_pack_host: null argument");
+    std::vector<Layer> layers;
+    int rc = t7_parse_model(t7_path_host, layers); if (rc) return rc;
+    std::vector<uint8_t> blob;
+    rc = blob_pack(layers, blob); if (rc) return rc;
+    *bytes = blob.size();
+    if (blob_host) {
+        FAV_REQUIRE(capacity >= blob.size(), "fav_net_pack_host: capacity %zu < %zu", capacity, blob.size());
+        memcpy(blob_host, blob.data(), blob.size());
+    }
+    return FAV_OK;
+}
+
+extern "C" int fav_net_create_from_blob(const void* blob_host, size_t bytes, int device, fav_net** out)
+{
+    FAV_REQUIRE(blob_host && out, "fav_net_create_from_blob: null argument");
+    int rc = ensure_device(); if (rc) return rc;
+    fav_net* net = new fav_net();
+    net->device = device;
+    rc = blob_unpack(blob_host, bytes, net->layers);
+    if (rc) { delete net; return rc; }
+    return finish_create(net, out);
+}
+
+extern "C" void fav_net_destroy(fav_net* net) { delete net; }
+
+extern "C" int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity)
+{
+    FAV_REQUIRE(net && buf_host && capacity > 0, "fav_net_describe_host: null argument");
+    const std::string s = describe_layers(net->layers);
+    FAV_REQUIRE(s.size() + 1 <= capacity, "fav_net_describe_host: need %zu bytes", s.size() + 1);
+    memcpy(buf_host, s.c_str(), s.size() + 1);
+    return FAV_OK;
+}
+
+extern "C" int fav_net_profile_enable(fav_net* net, int on)
+{
+    FAV_REQUIRE(net, "fav_net_profile_enable: null net");
+    net->profiling = on != 0;
+    return FAV_OK;
+}
+
+extern "C" int fav_net_profile_read_host(fav_net* net, int capacity, int* count, double* ms_sum, int* launches,
+                                         double* macs_per_launch, int* ntile)
+{
+    FAV_REQUIRE(net && count && ms_sum && launches && macs_per_launch && ntile, "fav_net_profile_read_host: null argument");
+    FAV_HIP(hipSetDevice(net->device));
+    for (auto& r : net->prof_pending) {
+        FAV_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        FAV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        net->prof_ms[r.conv] += ms; net->prof_n[r.conv] += 1;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    net->prof_pending.clear();
+    const int n = (int)net->prof_ms.size();
+    FAV_REQUIRE(n <= capacity, "fav_net_profile_read_host: need capacity %d", n);
+    for (int i = 0; i < n; ++i) { ms_sum[i] = net->prof_ms[i]; launches[i] = net->prof_n[i]; macs_per_launch[i] = net->prof_macs[i]; ntile[i] = net->prof_tile[i]; }
+    *count = n;
+    std::fill(net->prof_ms.begin(), net->prof_ms.end(), 0.0); std::fill(net->prof_n.begin(), net->prof_n.end(), 0);
+    return FAV_OK;
+}
+
+extern "C" int fav_t7_describe_host(const char* t7_path_host, char* buf_host, size_t capacity)
+{
+    FAV_REQUIRE(t7_path_host && buf_host && capacity > 0, "fav_t7_describe_host: null argument");
+    std::vector<Layer> layers;
+    int rc = t7_parse_model(t7_path_host, layers); if (rc) return rc;
+    const std::string s = describe_layers(layers);
+    FAV_REQUIRE(s.size() + 1 <= capacity, "fav_t7_describe_host: need %zu bytes", s.size() + 1);
+    memcpy(buf_host, s.c_str(), s.size() + 1);
+    return FAV_OK;
+}
+
+extern "C" long long fav_net_param_count(const fav_net* net) { return net ? net->params : 0; }
+
+extern "C" int fav_net_output_size(const fav_net* net, int H, int W, int* Ho, int* Wo)
+{
+    FAV_REQUIRE(net && Ho && Wo && H > 0 && W > 0, "fav_net_output_size: bad argument");
+    net->out_size(H, W, Ho, Wo);
+    return FAV_OK;
+}
+
+extern "C" int fav_net_forward(fav_net* net, const float* in7, float* out3, int H, int W, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(net && in7 && out3 && H > 0 && W > 0, "fav_net_forward: bad argument");
+    FAV_REQUIRE(net->pad < H && net->pad < W, "fav_net_forward: %dx%d is smaller than the reflection padding %d", W, H, net->pad);
+    FAV_HIP(hipSetDevice(net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // boundary conversion: NCHW [7][H][W] -> reflection-padded NHWC8 (nn.SpatialReflectionPadding folded in)
+    const size_t bytes = (size_t)(H + 2 * net->pad) * (W + 2 * net->pad) * 8 * sizeof(float);
+    if (net->stage_bytes < bytes) {
+        FAV_HIP(hipDeviceSynchronize());
+        (void)hipFree(net->stage); net->stage = nullptr; net->stage_bytes = 0;
+        FAV_HIP(hipMalloc(reinterpret_cast<void**>(&net->stage), bytes));
+        net->stage_bytes = bytes;
+    }
+    float* in8 = net->stage;
+    int rc = launch_nchw_to_nhwc_pad(in7, 7, H, W, net->pad, 8, in8, st); if (rc) return rc;
+    return net->forward_padded(in8, H, W, nullptr, out3, st);
+}
+
+// nn.SpatialConvolution [+ nn.InstanceNormalization [+ nn.ReLU]] as a stand-alone operator (tests / ops)
+extern "C" int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                                   int k, int stride, int pad, const float* gamma, const float* beta, float eps, int relu,
+                                   float* out, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(in && weight && out && Cin > 0 && Cout > 0 && k > 0 && stride > 0 && pad >= 0, "fav_conv2d_nchw_f32: bad argument");
+    int rc = ensure_device(); if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cinp = (Cin + 3) / 4 * 4, coutp = (Cout + 31) / 32 * 32, kpad = (k * k * cinp + 31) / 32 * 32;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    FAV_REQUIRE(OH > 0 && OW > 0, "fav_conv2d_nchw_f32: empty output");
+    const int M = OH * OW, mb = conv_mblocks(OH, OW);
+    Layer L; L.cin = Cin; L.cout = Cout; L.k = k;
+    L.w.resize((size_t)Cin * Cout * k * k);
+    FAV_HIP(hipMemcpy(L.w.data(), weight, L.w.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> wre, hb((size_t)coutp, 0.f);
+    repack_weights(L, cinp, coutp, kpad, wre);
+    if (bias) FAV_HIP(hipMemcpy(hb.data(), bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToHost));
+    float *dw = nullptr, *db = nullptr, *din = nullptr, *dout = nullptr, *dpart = nullptr, *dsc = nullptr, *dsh = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dw); (void)hipFree(db); (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dpart); (void)hipFree(dsc); (void)hipFree(dsh); };
+    rc = dev_upload(wre, 0, &dw); if (rc) { cleanup(); return rc; }
+    rc = dev_upload(hb, 0, &db); if (rc) { cleanup(); return rc; }
+    if (hipMalloc(reinterpret_cast<void**>(&din), (size_t)H * W * cinp * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dout), (size_t)M * Cout * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dpart), (size_t)mb * coutp * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dsc), (size_t)coutp * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dsh), (size_t)coutp * 4) != hipSuccess) { cleanup(); return hip_fail(hipErrorOutOfMemory, "hipMalloc"); }
+    rc = launch_nchw_to_nhwc_pad(in, Cin, H, W, 0, cinp, din, st);
+    ConvLaunch c;
+    c.in = din; c.IH = H; c.IW = W; c.IWp = W; c.CIN = cinp; c.wgt = dw; c.bias = db; c.COUT = Cout; c.COUTp = coutp;
+    c.KH = c.KW = k; c.stride = stride; c.pad = pad; c.Kpad = kpad; c.OH = OH; c.OW = OW; c.out = dout;
+    c.partials = gamma ? dpart : nullptr;
+    if (!rc) rc = launch_conv(c, st);
+    Affine t;
+    if (!rc && gamma) {
+        rc = launch_in_finalize(dpart, mb, M, CONV_BM, Cout, coutp, gamma, beta, eps, dsc, dsh, st);
+        t.scale1 = dsc; t.shift1 = dsh; t.relu1 = relu; t.stages = 1;
+    }
+    if (!rc) rc = launch_nhwc_to_nchw(dout, M, Cout, t, out, st);
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = hip_fail(hipGetLastError(), "fav_conv2d_nchw_f32");
+    cleanup();
+    return rc;
+}
+
+// ================================================================================================
+// C ABI: fused per-frame pipeline
+// ================================================================================================
+struct fav_stream {
+    fav_net* net = nullptr;
+    int H = 0, W = 0;
+    fav_stream_opts opts{};
+    float* state = nullptr;      // last_frame_stylized: [3][H][W] float RGB, unclamped (fav.lua:169)
+    bool has_state = false;
+    float* in8 = nullptr;        // padded NHWC8 network input
+    float* cert_tmp = nullptr; float* cert = nullptr;
+    uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
+    void* ws = nullptr; size_t ws_bytes = 0;
+    ~fav_stream()
+    {
+        if (net) (void)hipSetDevice(net->device);
+        (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws);
+    }
+};
+
+extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* o, fav_stream** out)
+{
+    FAV_REQUIRE(net && out && H > 0 && W > 0, "fav_stream_create: bad argument");
+    FAV_REQUIRE(net->pad < H && net->pad < W, "fav_stream_create: %dx%d is smaller than the reflection padding %d", W, H, net->pad);
+    int Ho, Wo; net->out_size(H, W, &Ho, &Wo);
+    FAV_REQUIRE(Ho == H && Wo == W, "frame size %dx%d gives a %dx%d output: the recurrent pipeline needs width and height to be multiples of 4 (two stride-2 convolutions)", W, H, Wo, Ho);
+    FAV_HIP(hipSetDevice(net->device));
+    fav_stream* s = new fav_stream();
+    s->net = net; s->H = H; s->W = W;
+    if (o) s->opts = *o; else { s->opts.border_mode = FAV_BORDER_STN; s->opts.occlusions_min_filter = 7; s->opts.invert_occlusion = 0; s->opts.fix_occlusions = 0; }
+    if (s->opts.occlusions_min_filter < 1) s->opts.occlusions_min_filter = 1;
+    const size_t n = (size_t)H * W;
+    s->ws_bytes = structure_workspace_bytes(W, H);
+    if (hipMalloc(reinterpret_cast<void**>(&s->state), 3 * n * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->in8), (size_t)(H + 2 * net->pad) * (W + 2 * net->pad) * 32) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->cert_tmp), n * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->cert), n * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->mask), n) != hipSuccess ||
+        hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) { delete s; return hip_fail(hipErrorOutOfMemory, "hipMalloc(stream buffers)"); }
+    *out = s;
+    return FAV_OK;
+}
+
+extern "C" void fav_stream_destroy(fav_stream* s) { delete s; }
+
+static int stream_finish(fav_stream* s, float* out_rgb_f32, uint8_t* out_rgb8_hwc, hipStream_t st)
+{
+    const size_t n = (size_t)s->H * s->W;
+    s->has_state = true;
+    if (out_rgb_f32) FAV_HIP(hipMemcpyAsync(out_rgb_f32, s->state, 3 * n * 4, hipMemcpyDeviceToDevice, st));
+    if (out_rgb8_hwc) return launch_quantize_rgb8(s->state, out_rgb8_hwc, s->H, s->W, st);
+    return FAV_OK;
+}
+
+extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hwc, float* out_rgb_f32, uint8_t* out_rgb8_hwc,
+                                      fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && frame_rgb_hwc, "fav_stream_first_frame: null argument");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = launch_prep_input(frame_rgb_hwc, nullptr, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st);
+    if (rc) return rc;
+    rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
+    return stream_finish(s, out_rgb_f32, out_rgb8_hwc, st);
+}
+
+static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, const uint8_t* mask, float* out_f32, uint8_t* out_u8,
+                       hipStream_t st)
+{
+    FAV_REQUIRE(s->has_state, "fav_stream_next_frame: no previous stylised frame (call fav_stream_first_frame or fav_stream_set_state first)");
+    int rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+                                 s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
+    if (rc) return rc;
+    rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st);
+    if (rc) return rc;
+    rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
+    return stream_finish(s, out_f32, out_u8, st);
+}
+
+extern "C" int fav_stream_next_frame_cert(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                                          const uint8_t* cert_pgm, float* out_rgb_f32, uint8_t* out_rgb8_hwc,
+                                          fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && cert_pgm, "fav_stream_next_frame_cert: null argument");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FAV_HIP(hipMemcpyAsync(s->mask, cert_pgm, (size_t)s->H * s->W, hipMemcpyDeviceToDevice, st));
+    return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+}
+
+extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                                          const float* forward_flo, int use_structure, float* out_rgb_f32,
+                                          uint8_t* out_rgb8_hwc, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && forward_flo, "fav_stream_next_frame_flow: null argument");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // makeOptFlow_deepflow.sh:59: consistencyChecker backward_i_j.flo forward_j_i.flo reliable_i_j.pgm [frame_i.ppm]
+    const float* structure = nullptr; const float* avg = nullptr;
+    if (use_structure) {
+        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->ws, s->ws_bytes, &structure, &avg, st); if (rc) return rc;
+    }
+    int rc = launch_consistency(backward_flo, forward_flo, structure, avg, s->mask, s->W, s->H, st); if (rc) return rc;
+    return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+}
+
+extern "C" int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && state_rgb_f32 && s->has_state, "fav_stream_get_state: no state");
+    FAV_HIP(hipSetDevice(s->net->device));
+    FAV_HIP(hipMemcpyAsync(state_rgb_f32, s->state, (size_t)3 * s->H * s->W * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return FAV_OK;
+}
+
+extern "C" int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && state_rgb_f32, "fav_stream_set_state: null argument");
+    FAV_HIP(hipSetDevice(s->net->device));
+    FAV_HIP(hipMemcpyAsync(s->state, state_rgb_f32, (size_t)3 * s->H * s->W * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    s->has_state = true;
+    return FAV_OK;
+}
+
+extern "C" const uint8_t* fav_stream_last_mask(const fav_stream* s) { return s ? s->mask : nullptr; }

@@ -1,0 +1,59 @@
+// consistencyChecker -- drop-in for the reference's stand-alone executable
+//   consistencyChecker <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]
+// (consistencyChecker/consistencyChecker.cpp:136-171; called by makeOptFlow_deepflow.sh:59-60 and
+// video_dataset/make_occlusions.sh:31-36).  Same argv, same PGM bytes, exit code 0; the mask is computed
+// on the MI355X through libfav (fav_consistency_u8).  Deliberate deviations: the output is written
+// once, atomically (the reference first writes an all-255 placeholder, :152, which races with the
+// polling consumer), and failures return a non-zero exit code instead of asserting.
+// Device selection: environment variable FAV_GPU (default 0).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/fav.h"
+
+static int fail(const char* what)
+{
+    fprintf(stderr, "consistencyChecker: %s: %s\n", what, fav_last_error());
+    return 1;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) {
+        fprintf(stderr, "usage: consistencyChecker <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n");
+        return 2;
+    }
+    float *f1 = nullptr, *f2 = nullptr;
+    int w1, h1, w2, h2;
+    if (fav_read_flo_host(argv[1], &f1, &w1, &h1)) return fail(argv[1]);
+    if (fav_read_flo_host(argv[2], &f2, &w2, &h2)) return fail(argv[2]);
+    if (w1 != w2 || h1 != h2) { fprintf(stderr, "consistencyChecker: flow sizes differ\n"); return 1; }   // :144-145
+    uint8_t* img = nullptr;
+    if (argc >= 5) {
+        int wi, hi, ch;
+        if (fav_read_pnm_host(argv[4], &img, &wi, &hi, &ch)) return fail(argv[4]);
+        if (wi != w1 || hi != h1 || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); return 1; }
+    }
+    if (fav_device_count() <= 0) return fail("device");
+    const char* g = getenv("FAV_GPU");
+    if (hipSetDevice(g ? atoi(g) : 0) != hipSuccess) { fprintf(stderr, "consistencyChecker: cannot select GPU\n"); return 1; }
+    const size_t n = (size_t)w1 * h1;
+    float *d1 = nullptr, *d2 = nullptr; uint8_t *dimg = nullptr, *dout = nullptr; void* ws = nullptr;
+    const size_t wsb = fav_consistency_workspace_bytes(w1, h1, img != nullptr);
+    if (hipMalloc((void**)&d1, n * 8) || hipMalloc((void**)&d2, n * 8) || hipMalloc((void**)&dout, n) ||
+        (img && hipMalloc((void**)&dimg, n * 3)) || (wsb && hipMalloc(&ws, wsb))) { fprintf(stderr, "consistencyChecker: hipMalloc failed\n"); return 1; }
+    hipMemcpy(d1, f1, n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d2, f2, n * 8, hipMemcpyHostToDevice);
+    if (img) hipMemcpy(dimg, img, n * 3, hipMemcpyHostToDevice);
+    if (fav_consistency_u8(d1, d2, dimg, dout, w1, h1, ws, wsb, nullptr)) return fail("fav_consistency_u8");
+    std::vector<uint8_t> out(n);
+    if (hipMemcpy(out.data(), dout, n, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "consistencyChecker: device error\n"); return 1; }
+    if (fav_write_pgm_host(argv[3], out.data(), w1, h1)) return fail(argv[3]);
+    printf("%s", argv[3]);   // :166
+    fav_free_host(f1); fav_free_host(f2); fav_free_host(img);
+    hipFree(d1); hipFree(d2); hipFree(dimg); hipFree(dout); hipFree(ws);
+    return 0;
+}

@@ -1,0 +1,368 @@
+// fav_stylize -- drop-in for `th fast_artistic_video.lua ...` (fast_artistic_video.lua:21-67,174-189 +
+// fast_artistic_video_core.lua:34-229) on MI355X.  Same single-dash flags, same file-name patterns
+// ({..} = index i-1, [..] = index i; fast_artistic_video.lua:70-77), same 1-based frame loop that stops
+// at the first missing frame (core.lua:196-197), same "<prefix>-%05d.png" outputs (fav.lua:161).
+//
+// Host structure: a loader thread reads/decodes frame i+1 (PPM, .flo, .pgm) while the GPU works on
+// frame i; PNG deflate + file writes run on a small pool so they never stall the GPU.  All compute
+// goes through libfav's C ABI (fav_stream_*); there is no CPU backend (-gpu -1 is rejected).
+//
+// Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
+// GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
+// makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>,
+// -writers <n>, -timing <0|1>.
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fav.h"
+
+namespace {
+
+struct Opt {
+    std::map<std::string, std::string> v;
+    std::map<std::string, bool> b;
+    std::string s(const char* k) const { return v.at(k); }
+    int i(const char* k) const { return atoi(v.at(k).c_str()); }
+    double d(const char* k) const { return atof(v.at(k).c_str()); }
+    bool f(const char* k) const { return b.at(k); }
+};
+
+[[noreturn]] void die(const std::string& m)
+{
+    fprintf(stderr, "%s\n", m.c_str());
+    exit(1);
+}
+
+void check(int rc, const char* what)
+{
+    if (rc) die(std::string(what) + ": " + fav_last_error());
+}
+
+bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+std::string fmt_int(const std::string& pattern, int i)
+{
+    char buf[4096];
+    snprintf(buf, sizeof buf, pattern.c_str(), i);
+    return buf;
+}
+
+// getFormatedFlowFileName (fast_artistic_video.lua:70-77): {fmt} <- fromIndex, [fmt] <- toIndex
+std::string flow_name(const std::string& pattern, int from, int to)
+{
+    std::string out;
+    for (size_t p = 0; p < pattern.size();) {
+        const char c = pattern[p];
+        if (c == '{' || c == '[') {
+            const char close = c == '{' ? '}' : ']';
+            const size_t e = pattern.find(close, p + 1);
+            if (e != std::string::npos) {
+                out += fmt_int(pattern.substr(p + 1, e - p - 1), c == '{' ? from : to);
+                p = e + 1;
+                continue;
+            }
+        }
+        out += c; ++p;
+    }
+    return out;
+}
+
+// utils.wait_for_file (fast_artistic_video/utils.lua:74-80), bounded: poll until the file exists and its
+// size is stable (the reference sleeps one extra second instead)
+void wait_for_file(const std::string& path, double timeout_s)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    bool announced = false;
+    long long last = -1;
+    for (;;) {
+        struct stat st;
+        if (stat(path.c_str(), &st) == 0 && st.st_size > 0) {
+            if ((long long)st.st_size == last) return;
+            last = (long long)st.st_size;
+        } else if (!announced) {
+            printf("Waiting for file \"%s\"\n", path.c_str()); fflush(stdout); announced = true;
+        }
+        if (std::chrono::duration<double>(clk::now() - t0).count() > timeout_s)
+            die("timed out waiting for " + path);
+        usleep(last >= 0 && !announced ? 2000 : 50000);
+    }
+}
+
+void mkdirs_for(const std::string& path)
+{
+    for (size_t p = 1; p < path.size(); ++p)
+        if (path[p] == '/') mkdir(path.substr(0, p).c_str(), 0777);
+}
+
+// minimal PNG reader for -continue_with (8-bit RGB / RGBA / grey, non-interlaced)
+bool read_png_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& W, int& H)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    uint8_t buf[65536]; size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + got);
+    fclose(f);
+    if (d.size() < 33 || memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8)) return false;
+    auto be32 = [&](size_t p) { return (uint32_t)d[p] << 24 | (uint32_t)d[p + 1] << 16 | (uint32_t)d[p + 2] << 8 | d[p + 3]; };
+    size_t p = 8; int ctype = -1, depth = 0, interlace = 0; std::vector<uint8_t> idat;
+    while (p + 12 <= d.size()) {
+        const uint32_t len = be32(p); const char* ty = (const char*)&d[p + 4];
+        if (p + 12 + len > d.size()) return false;
+        if (!memcmp(ty, "IHDR", 4)) { W = (int)be32(p + 8); H = (int)be32(p + 12); depth = d[p + 16]; ctype = d[p + 17]; interlace = d[p + 20]; }
+        else if (!memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), d.begin() + p + 8, d.begin() + p + 8 + len);
+        else if (!memcmp(ty, "IEND", 4)) break;
+        p += 12 + len;
+    }
+    const int ch = ctype == 2 ? 3 : ctype == 6 ? 4 : ctype == 0 ? 1 : 0;
+    if (!ch || depth != 8 || interlace || W <= 0 || H <= 0) return false;
+    const size_t stride = (size_t)W * ch;
+    std::vector<uint8_t> raw((stride + 1) * H);
+    uLongf rl = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rl, idat.data(), (uLong)idat.size()) != Z_OK || rl != raw.size()) return false;
+    std::vector<uint8_t> img(stride * H);
+    for (int y = 0; y < H; ++y) {
+        const uint8_t ft = raw[(stride + 1) * y];
+        const uint8_t* s = &raw[(stride + 1) * y + 1];
+        uint8_t* o = &img[stride * y];
+        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t x = 0; x < stride; ++x) {
+            const int a = x >= (size_t)ch ? o[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int pr = 0;
+            if (ft == 1) pr = a; else if (ft == 2) pr = b; else if (ft == 3) pr = (a + b) / 2;
+            else if (ft == 4) { const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            o[x] = (uint8_t)(s[x] + pr);
+        }
+    }
+    rgb.resize((size_t)W * H * 3);
+    for (size_t i = 0; i < (size_t)W * H; ++i)
+        for (int c = 0; c < 3; ++c) rgb[i * 3 + c] = img[i * ch + (ch == 1 ? 0 : c)];
+    return true;
+}
+
+// tiny thread pool for PNG encode + write
+class Pool {
+public:
+    explicit Pool(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); }); }
+    ~Pool() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); ++pending_; } cv_.notify_one(); }
+    void wait_below(size_t n) { std::unique_lock<std::mutex> l(m_); done_.wait(l, [&] { return pending_ <= n; }); }
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return stop_ || !q_.empty(); }); if (q_.empty()) return; f = std::move(q_.front()); q_.pop_front(); }
+            f();
+            { std::lock_guard<std::mutex> l(m_); --pending_; }
+            done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_; std::deque<std::function<void()>> q_; std::mutex m_; std::condition_variable cv_, done_;
+    size_t pending_ = 0; bool stop_ = false;
+};
+
+struct FrameIn {           // everything frame i needs from disk
+    int index = 0; bool ok = false; bool single = false;
+    uint8_t* frame = nullptr; int W = 0, H = 0;
+    float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr;
+    void release() { fav_free_host(frame); fav_free_host(bw); fav_free_host(fw); fav_free_host(cert); frame = nullptr; bw = fw = nullptr; cert = nullptr; }
+};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Opt o;
+    // fast_artistic_video.lua:21-67 (defaults as there, except -gpu: the reference defaults to the CPU)
+    o.v = {{"model_img", "self"}, {"model_vid", "models/checkpoint-candy-video.t7"}, {"num_frames", "9999"}, {"continue_with", "1"},
+           {"input_pattern", ""}, {"output_prefix", "out"}, {"flow_pattern", ""}, {"occlusions_pattern", ""},
+           {"occlusions_min_filter", "7"}, {"fill_occlusions", "vgg-mean"}, {"median_filter", "3"}, {"scale_factor", "1"},
+           {"gpu", "0"}, {"backend", "cuda"}, {"use_cudnn", "1"}, {"cudnn_benchmark", "0"},
+           {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""}, {"evaluation_file", "evaluation.txt"},
+           {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"},
+           {"style_image", "images/styles/candy.jpg"}, {"style_image_size", "256"}, {"style_weights", "1.0"},
+           {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
+           // additive
+           {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
+           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}};
+    o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
+           {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
+    for (int a = 1; a < argc; ++a) {
+        if (argv[a][0] != '-') die(std::string("invalid argument: ") + argv[a]);
+        const std::string k = argv[a] + 1;
+        if (o.b.count(k)) { o.b[k] = true; continue; }
+        if (!o.v.count(k)) die("unknown option -" + k);
+        if (a + 1 >= argc) die("missing value for -" + k);
+        o.v[k] = argv[++a];
+    }
+    if (o.s("input_pattern").empty()) die("Must give -input_pattern");                                      // fav.lua:177-179
+    const bool fused_check = !o.s("forward_flow_pattern").empty();
+    if (!o.f("create_inconsistent") && (o.s("flow_pattern").empty() || (o.s("occlusions_pattern").empty() && !fused_check)))
+        die("Must give -flow_pattern and -occlusions_pattern");                                              // fav.lua:180-182
+    if (o.i("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement lives in oracle/ and is test infrastructure only)");
+    if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
+    if (o.s("model_img") != "self") die("-model_img <file>: image models (SpatialFullConvolution) are not supported yet; use -model_img self");
+    if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
+    if (o.s("fill_occlusions") != "vgg-mean") die("-fill_occlusions uniform-random is not supported (unseeded in the reference: core.lua:109)");
+    const int border = o.s("warp_border") == "cpu" ? FAV_BORDER_CPU : FAV_BORDER_STN;
+
+    if (fav_device_count() <= 0) die(std::string("ERROR: ") + fav_last_error());
+    if (hipSetDevice(o.i("gpu")) != hipSuccess) die("cannot select -gpu " + o.s("gpu"));
+    fav_net* net = nullptr;
+    if (fav_net_create(o.s("model_vid").c_str(), o.i("gpu"), &net)) die(fav_last_error());                   // core.lua:39-43
+    printf("Model loaded.\n");
+
+    const int num_frames = o.i("num_frames");
+    const bool backward = o.f("backward");
+    const int start = backward ? num_frames - 1 : o.i("continue_with"), end = backward ? 1 : num_frames, inc = backward ? -1 : 1;   // core:189-191
+    const double poll = o.d("poll_timeout");
+
+    auto load = [&](int i, bool first_of_run) {
+        FrameIn in; in.index = i;
+        const std::string fp = fmt_int(o.s("input_pattern"), i);
+        if (!file_exists(fp)) return in;                                                                     // fav.lua:93-97 -> nil -> break
+        int ch;
+        check(fav_read_pnm_host(fp.c_str(), &in.frame, &in.W, &in.H, &ch), fp.c_str());
+        if (ch != 3) die(fp + ": expected a colour (P6) frame");
+        in.single = (i == 1) || o.f("create_inconsistent") || first_of_run;                                 // fav.lua:172
+        if (!in.single) {
+            const std::string fl = flow_name(o.s("flow_pattern"), i - 1, i);                               // fav.lua:100,154
+            int w, h;
+            if (fused_check) {
+                const std::string ff = flow_name(o.s("forward_flow_pattern"), i - 1, i);
+                wait_for_file(fl, poll); wait_for_file(ff, poll);
+                check(fav_read_flo_host(ff.c_str(), &in.fw, &w, &h), ff.c_str());
+                if (w != in.W || h != in.H) die(ff + ": size differs from the frame");
+            } else {
+                const std::string cp = flow_name(o.s("occlusions_pattern"), i - 1, i);
+                wait_for_file(cp, poll);                                                                     // fav.lua:102
+                int cch;
+                check(fav_read_pnm_host(cp.c_str(), &in.cert, &w, &h, &cch), cp.c_str());
+                if (cch != 1 || w != in.W || h != in.H) die(cp + ": expected a P5 mask of the frame's size");
+                wait_for_file(fl, poll);
+            }
+            check(fav_read_flo_host(fl.c_str(), &in.bw, &w, &h), fl.c_str());
+            if (w != in.W || h != in.H) die(fl + ": size differs from the frame");
+        }
+        in.ok = true;
+        return in;
+    };
+
+    Pool writers(std::max(1, o.i("writers")));
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess) die("hipStreamCreate failed");
+    fav_stream* fs = nullptr;
+    int W = 0, H = 0;
+    uint8_t *d_frame = nullptr, *d_cert = nullptr, *d_out8 = nullptr; float *d_bw = nullptr, *d_fw = nullptr;
+    const int nslots = 4;
+    std::vector<uint8_t*> h_out(nslots, nullptr);
+    int slot = 0;
+
+    // continue_with > 1: reload the previous stylised PNG as the recurrent state (8-bit; the reference's
+    // video CLI does not reload anything and fails, fast_artistic_video.lua:89,153-156)
+    std::vector<float> resume_state;
+    bool have_resume = false;
+    if (!backward && start > 1 && !o.f("create_inconsistent")) {
+        std::vector<uint8_t> prev; int pw, ph;
+        char nm[4096]; snprintf(nm, sizeof nm, "%s-%05d.png", o.s("output_prefix").c_str(), start - 1);
+        if (read_png_rgb8(nm, prev, pw, ph)) {
+            resume_state.resize((size_t)pw * ph * 3);
+            for (size_t i = 0; i < (size_t)pw * ph; ++i)
+                for (int c = 0; c < 3; ++c) resume_state[(size_t)c * pw * ph + i] = prev[i * 3 + c] / 255.0f;
+            W = -pw; H = -ph; have_resume = true;    // validated against the first frame below
+        } else {
+            fprintf(stderr, "warning: %s not found; frame %d is stylised without a prior\n", nm, start);
+        }
+    }
+
+    std::thread loader;
+    FrameIn next = load(start, !have_resume && start != 1);
+    bool first = true;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int done = 0;
+    for (int i = start; backward ? i >= end : i <= end; i += inc) {
+        FrameIn cur = next;
+        if (!cur.ok) break;                                                                                   // core:196-197
+        const int ni = i + inc;
+        const bool has_next = backward ? ni >= end : ni <= end;
+        next = FrameIn();
+        if (has_next) loader = std::thread([&, ni] { next = load(ni, false); });
+        if (first) {
+            if (have_resume && (-W != cur.W || -H != cur.H)) die("-continue_with: previous PNG size differs from the frames");
+            W = cur.W; H = cur.H;
+            fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0};
+            check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
+            const size_t n = (size_t)W * H;
+            if (hipMalloc((void**)&d_frame, n * 3) || hipMalloc((void**)&d_cert, n) || hipMalloc((void**)&d_out8, n * 3) ||
+                hipMalloc((void**)&d_bw, n * 8) || hipMalloc((void**)&d_fw, n * 8)) die("hipMalloc failed");
+            for (auto& p : h_out) if (hipHostMalloc((void**)&p, n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+            if (have_resume) {
+                float* d_state = nullptr;
+                if (hipMalloc((void**)&d_state, n * 12) != hipSuccess) die("hipMalloc failed");
+                hipMemcpy(d_state, resume_state.data(), n * 12, hipMemcpyHostToDevice);
+                check(fav_stream_set_state(fs, d_state, st), "fav_stream_set_state");
+                hipStreamSynchronize(st); hipFree(d_state);
+            }
+            first = false;
+        } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
+        const size_t n = (size_t)W * H;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipMemcpyAsync(d_frame, cur.frame, n * 3, hipMemcpyHostToDevice, st);
+        if (cur.single) {
+            check(fav_stream_first_frame(fs, d_frame, nullptr, d_out8, st), "fav_stream_first_frame");        // core:203-204
+        } else {
+            hipMemcpyAsync(d_bw, cur.bw, n * 8, hipMemcpyHostToDevice, st);
+            if (fused_check) {
+                hipMemcpyAsync(d_fw, cur.fw, n * 8, hipMemcpyHostToDevice, st);
+                check(fav_stream_next_frame_flow(fs, d_frame, d_bw, d_fw, o.i("structure"), nullptr, d_out8, st), "fav_stream_next_frame_flow");
+            } else {
+                hipMemcpyAsync(d_cert, cur.cert, n, hipMemcpyHostToDevice, st);
+                check(fav_stream_next_frame_cert(fs, d_frame, d_bw, d_cert, nullptr, d_out8, st), "fav_stream_next_frame_cert");   // core:206-208
+            }
+        }
+        writers.wait_below((size_t)nslots - 1);          // a free pinned slot
+        uint8_t* hb = h_out[slot]; slot = (slot + 1) % nslots;
+        hipMemcpyAsync(hb, d_out8, n * 3, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) die("GPU error while stylising a frame");
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (cur.single) printf("Elapsed time for stylizing frame independently:%g\n", ms / 1000.0);           // core:155
+        else printf("Elapsed time for stylizing frame:%g\n", ms / 1000.0);                                   // core:177
+        char nm[4096]; snprintf(nm, sizeof nm, "%s-%05d.png", o.s("output_prefix").c_str(), i);              // fav.lua:161
+        printf("Writing output image to %s\n", nm); fflush(stdout);
+        mkdirs_for(nm);
+        const int lvl = o.i("png_level");
+        const std::string path = nm;
+        writers.submit([hb, path, W, H, lvl] { if (fav_write_png_rgb8_host(path.c_str(), hb, W, H, lvl)) fprintf(stderr, "%s\n", fav_last_error()); });
+        cur.release();
+        ++done;
+        if (loader.joinable()) loader.join();
+    }
+    if (loader.joinable()) loader.join();
+    next.release();
+    writers.wait_below(0);
+    if (o.i("timing")) {
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f}\n", done, s, done / s);
+    }
+    fav_stream_destroy(fs); fav_net_destroy(net);
+    hipFree(d_frame); hipFree(d_cert); hipFree(d_out8); hipFree(d_bw); hipFree(d_fw);
+    for (auto p : h_out) hipHostFree(p);
+    return 0;
+}

@@ -1,0 +1,343 @@
+"""ctypes binding of libfav (include/fav.h) -- thin plumbing for the tests and bench.py.
+
+The product is the C-ABI shared library ``fast-artistic-videos_amd/libfav.so`` (hand-written HIP for
+gfx950 + C++ host code).  This module only moves pointers: device buffers are torch CUDA(=HIP)
+tensors, ``tensor.data_ptr()`` and the current torch stream are handed to the C entry points.  There
+is NO Python/CPU fallback: if the library is missing, or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # fast-artistic-videos_amd/
+LIB_PATH = os.path.join(_PKG, "libfav.so")
+BORDER_STN, BORDER_CPU = 0, 1
+
+_lib = None
+
+
+class FavError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libfav.so and the drop-in executables for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", _PKG, "-j8", "all"], stdout=None if verbose else subprocess.DEVNULL)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FavError(f"{LIB_PATH} is missing: build it with `make -C {_PKG}` "
+                       "(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    L.fav_last_error.restype = C.c_char_p
+    L.fav_consistency_workspace_bytes.restype = C.c_size_t
+    L.fav_consistency_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.fav_net_param_count.restype = C.c_longlong
+    L.fav_net_param_count.argtypes = [C.c_void_p]
+    L.fav_stream_last_mask.restype = C.c_void_p
+    L.fav_stream_last_mask.argtypes = [C.c_void_p]
+    L.fav_net_destroy.argtypes = [C.c_void_p]; L.fav_net_destroy.restype = None
+    L.fav_stream_destroy.argtypes = [C.c_void_p]; L.fav_stream_destroy.restype = None
+    L.fav_free_host.argtypes = [C.c_void_p]; L.fav_free_host.restype = None
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "fav_last_error", "fav_version", "fav_device_count", "fav_warp_bdhw_f32", "fav_consistency_workspace_bytes",
+    "fav_consistency_u8", "fav_min_filter_f32", "fav_assemble_input_f32", "fav_net_create", "fav_net_pack_host",
+    "fav_net_create_from_blob", "fav_net_destroy", "fav_net_describe_host", "fav_t7_describe_host", "fav_net_param_count",
+    "fav_net_output_size", "fav_net_forward", "fav_net_profile_enable", "fav_net_profile_read_host",
+    "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
+    "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_get_state",
+    "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
+    "fav_write_png_rgb8_host", "fav_free_host",
+]
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise FavError(f"libfav error {rc}: {lib().fav_last_error().decode(errors='replace')}")
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise FavError("no HIP device visible to torch: libfav has no CPU fallback")
+    return torch
+
+
+def _p(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _chk_f32(t, name):
+    torch = _torch()
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise FavError(f"{name} must be a contiguous float32 CUDA tensor")   # BilinearSamplerBDHW.lua:26-42
+
+
+def device_count() -> int:
+    n = lib().fav_device_count()
+    if n < 0:
+        _check(n)
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ ops
+def warp(img, flow, border: int = BORDER_STN):
+    """nn.BilinearSamplerBDHW():forward({img, flow}) (stnbdhw/BilinearSamplerBDHW.lua:54-82): 3-D inputs get a
+    batch dimension added and removed."""
+    torch = _torch(); _chk_f32(img, "img"); _chk_f32(flow, "flow")
+    squeeze = img.dim() == 3
+    if squeeze:
+        img, flow = img[None], flow[None]
+    b, c, h, w = img.shape
+    assert flow.shape[0] == b and flow.shape[1] == 2
+    ho, wo = flow.shape[2], flow.shape[3]
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=img.device)
+    _check(lib().fav_warp_bdhw_f32(_p(img), _p(flow), _p(out), b, c, h, w, ho, wo, border, _stream()))
+    return out[0] if squeeze else out
+
+
+def consistency(flow1_flo, flow2_flo, rgb_hwc=None):
+    """consistencyChecker flow1.flo flow2.flo out.pgm [img.ppm]: inputs are the .flo payloads [H][W][2]."""
+    torch = _torch(); _chk_f32(flow1_flo, "flow1"); _chk_f32(flow2_flo, "flow2")
+    h, w, _ = flow1_flo.shape
+    out = torch.empty((h, w), dtype=torch.uint8, device=flow1_flo.device)
+    ws_bytes = lib().fav_consistency_workspace_bytes(w, h, 1 if rgb_hwc is not None else 0)
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=flow1_flo.device)
+    _check(lib().fav_consistency_u8(_p(flow1_flo), _p(flow2_flo), _p(rgb_hwc), _p(out), w, h, _p(ws),
+                                    C.c_size_t(ws_bytes), _stream()))
+    return out
+
+
+def min_filter(cert, r: int = 7):
+    torch = _torch(); _chk_f32(cert, "cert")
+    out = torch.empty_like(cert)
+    _check(lib().fav_min_filter_f32(_p(cert), _p(out), cert.shape[-2], cert.shape[-1], r, _stream()))
+    return out
+
+
+def assemble(frame_rgb, warped_rgb=None, cert=None):
+    torch = _torch(); _chk_f32(frame_rgb, "frame")
+    _, h, w = frame_rgb.shape
+    out = torch.empty((7, h, w), dtype=torch.float32, device=frame_rgb.device)
+    _check(lib().fav_assemble_input_f32(_p(frame_rgb), _p(warped_rgb), _p(cert), _p(out), h, w, _stream()))
+    return out
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, gamma=None, beta=None, eps=1e-5, relu=False):
+    torch = _torch(); _chk_f32(x, "x"); _chk_f32(weight, "weight")
+    cin, h, w = x.shape; cout, _, k, _ = weight.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((cout, oh, ow), dtype=torch.float32, device=x.device)
+    _check(lib().fav_conv2d_nchw_f32(_p(x), cin, h, w, _p(weight), _p(bias), cout, k, stride, pad, _p(gamma), _p(beta),
+                                     C.c_float(eps), 1 if relu else 0, _p(out), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ network
+class Net:
+    def __init__(self, t7_path: Optional[str] = None, device: int = 0, blob: Optional[bytes] = None):
+        h = C.c_void_p()
+        if blob is not None:
+            _check(lib().fav_net_create_from_blob(blob, C.c_size_t(len(blob)), device, C.byref(h)))
+        else:
+            _check(lib().fav_net_create(t7_path.encode(), device, C.byref(h)))
+        self.h, self.device = h, device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fav_net_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().fav_net_describe_host(self.h, buf, C.c_size_t(len(buf))))
+        return buf.value.decode()
+
+    def param_count(self) -> int:
+        return int(lib().fav_net_param_count(self.h))
+
+    def output_size(self, h: int, w: int) -> Tuple[int, int]:
+        ho, wo = C.c_int(), C.c_int()
+        _check(lib().fav_net_output_size(self.h, h, w, C.byref(ho), C.byref(wo)))
+        return ho.value, wo.value
+
+    def profile_enable(self, on: bool = True):
+        _check(lib().fav_net_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """[(ms_sum, launches, useful_macs_per_launch, n_tile)] per convolution, network order"""
+        cap = 256
+        cnt = C.c_int(); ms = (C.c_double * cap)(); n = (C.c_int * cap)(); macs = (C.c_double * cap)(); tile = (C.c_int * cap)()
+        _check(lib().fav_net_profile_read_host(self.h, cap, C.byref(cnt), ms, n, macs, tile))
+        return [(ms[i], n[i], macs[i], tile[i]) for i in range(cnt.value)]
+
+    def forward(self, in7):
+        torch = _torch(); _chk_f32(in7, "in7")
+        x = in7[0] if in7.dim() == 4 else in7
+        _, h, w = x.shape
+        ho, wo = self.output_size(h, w)
+        out = torch.empty((3, ho, wo), dtype=torch.float32, device=x.device)
+        _check(lib().fav_net_forward(self.h, _p(x), _p(out), h, w, _stream()))
+        return out[None] if in7.dim() == 4 else out
+
+
+def describe_t7(t7_path: str) -> str:
+    """host-only: layer list as parsed by the product's C++ .t7 reader"""
+    buf = C.create_string_buffer(1 << 16)
+    _check(lib().fav_t7_describe_host(t7_path.encode(), buf, C.c_size_t(len(buf))))
+    return buf.value.decode()
+
+
+def describe_layers(layers, indent: int = 0) -> str:
+    """the same text from the Python reader's layer list (fav_amd.t7.extract_layers)"""
+    out = []
+    pad = "  " * indent
+    for L in layers:
+        t = L["type"]
+        if t == "pad": out.append(f"{pad}pad {L['l']} {L['r']} {L['t']} {L['b']}")
+        elif t == "conv":
+            co, ci, k, _ = L["w"].shape
+            out.append(f"{pad}conv {ci} {co} {k} {L['stride']} {L['pad']} bias={0 if L['b'] is None else 1}")
+        elif t == "in": out.append(f"{pad}in {len(L['gamma'])}")
+        elif t == "relu": out.append(f"{pad}relu")
+        elif t == "res":
+            out.append(f"{pad}res shave={L['shave']}"); out.append(describe_layers(L["block"], indent + 1).rstrip("\n"))
+        elif t == "up": out.append(f"{pad}up {L['s']}")
+        elif t == "tanh": out.append(f"{pad}tanh")
+        elif t == "mul": out.append(f"{pad}mul {L['k']:g}")
+        else: out.append(f"{pad}identity")
+    return "\n".join(out) + "\n"
+
+
+def pack_checkpoint(t7_path: str) -> bytes:
+    n = C.c_size_t()
+    _check(lib().fav_net_pack_host(t7_path.encode(), None, C.c_size_t(0), C.byref(n)))
+    buf = C.create_string_buffer(n.value)
+    _check(lib().fav_net_pack_host(t7_path.encode(), buf, C.c_size_t(n.value), C.byref(n)))
+    return buf.raw[:n.value]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("border_mode", C.c_int), ("occlusions_min_filter", C.c_int), ("invert_occlusion", C.c_int),
+                ("fix_occlusions", C.c_int)]
+
+
+class Stream:
+    """One video stream: the recurrent per-frame pipeline (fast_artistic_video_core.lua:194-211)."""
+
+    def __init__(self, net: Net, h: int, w: int, border: int = BORDER_STN, min_filter_r: int = 7,
+                 invert_occlusion: bool = False, fix_occlusions: bool = False):
+        self.net, self.H, self.W = net, h, w
+        o = _Opts(border, min_filter_r, int(invert_occlusion), int(fix_occlusions))
+        hd = C.c_void_p()
+        _check(lib().fav_stream_create(net.h, h, w, C.byref(o), C.byref(hd)))
+        self.h = hd
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fav_stream_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def _outs(self, dev, want_f32, want_u8):
+        torch = _torch()
+        f = torch.empty((3, self.H, self.W), dtype=torch.float32, device=dev) if want_f32 else None
+        u = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+        return f, u
+
+    def first_frame(self, frame_u8_hwc, want_f32=True, want_u8=False, out_f32=None, out_u8=None):
+        f, u = self._outs(frame_u8_hwc.device, want_f32 and out_f32 is None, want_u8 and out_u8 is None)
+        f = out_f32 if out_f32 is not None else f; u = out_u8 if out_u8 is not None else u
+        _check(lib().fav_stream_first_frame(self.h, _p(frame_u8_hwc), _p(f), _p(u), _stream()))
+        return f, u
+
+    def next_frame_cert(self, frame_u8_hwc, backward_flo, cert_u8, want_f32=True, want_u8=False, out_f32=None, out_u8=None):
+        f, u = self._outs(frame_u8_hwc.device, want_f32 and out_f32 is None, want_u8 and out_u8 is None)
+        f = out_f32 if out_f32 is not None else f; u = out_u8 if out_u8 is not None else u
+        _check(lib().fav_stream_next_frame_cert(self.h, _p(frame_u8_hwc), _p(backward_flo), _p(cert_u8), _p(f), _p(u), _stream()))
+        return f, u
+
+    def next_frame_flow(self, frame_u8_hwc, backward_flo, forward_flo, use_structure=False, want_f32=True, want_u8=False,
+                        out_f32=None, out_u8=None):
+        f, u = self._outs(frame_u8_hwc.device, want_f32 and out_f32 is None, want_u8 and out_u8 is None)
+        f = out_f32 if out_f32 is not None else f; u = out_u8 if out_u8 is not None else u
+        _check(lib().fav_stream_next_frame_flow(self.h, _p(frame_u8_hwc), _p(backward_flo), _p(forward_flo),
+                                                1 if use_structure else 0, _p(f), _p(u), _stream()))
+        return f, u
+
+    def state(self):
+        torch = _torch()
+        out = torch.empty((3, self.H, self.W), dtype=torch.float32, device=f"cuda:{self.net.device}")
+        _check(lib().fav_stream_get_state(self.h, _p(out), _stream()))
+        return out
+
+    def set_state(self, t):
+        _chk_f32(t, "state")
+        _check(lib().fav_stream_set_state(self.h, _p(t), _stream()))
+
+    def last_mask(self):
+        """copy of the u8 certainty mask used for the last frame (before the min filter)"""
+        torch = _torch()
+        ptr = lib().fav_stream_last_mask(self.h)
+        out = torch.empty((self.H, self.W), dtype=torch.uint8, device=f"cuda:{self.net.device}")
+        # device-to-device copy through torch's runtime (same HIP context)
+        src = _from_ptr_u8(ptr, self.H * self.W, self.net.device)
+        out.view(-1).copy_(src)
+        return out
+
+
+def _from_ptr_u8(ptr: int, n: int, device: int):
+    """wrap a raw device pointer as a torch uint8 tensor (no ownership) via __cuda_array_interface__"""
+    torch = _torch()
+
+    class _W:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_W(), device=f"cuda:{device}")
+
+
+# ------------------------------------------------------------------------------------------------ host formats
+def read_flo(path: str) -> np.ndarray:
+    d = C.POINTER(C.c_float)(); w, h = C.c_int(), C.c_int()
+    _check(lib().fav_read_flo_host(path.encode(), C.byref(d), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(d, shape=(h.value, w.value, 2)).copy()
+    finally:
+        lib().fav_free_host(d)
+
+
+def read_pnm(path: str) -> np.ndarray:
+    d = C.POINTER(C.c_uint8)(); w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().fav_read_pnm_host(path.encode(), C.byref(d), C.byref(w), C.byref(h), C.byref(ch)))
+    try:
+        a = np.ctypeslib.as_array(d, shape=(h.value, w.value, ch.value)).copy()
+        return a if ch.value == 3 else a[..., 0]
+    finally:
+        lib().fav_free_host(d)
+
+
+def write_pgm(path: str, a: np.ndarray) -> None:
+    a = np.ascontiguousarray(a, np.uint8)
+    _check(lib().fav_write_pgm_host(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
+
+
+def write_png(path: str, rgb_hwc: np.ndarray, level: int = 1) -> None:
+    a = np.ascontiguousarray(rgb_hwc, np.uint8)
+    _check(lib().fav_write_png_rgb8_host(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], level))

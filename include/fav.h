@@ -1,0 +1,181 @@
+/*
+ * fav.h -- C ABI of libfav: the MI355X-native (gfx950, hand-written HIP) implementation of the
+ * per-frame hot path of manuelruder/fast-artistic-videos:
+ *
+ *   frames + backward .flo (+ forward .flo | .pgm certainty) + .t7 weights
+ *     -> warp previous stylised frame -> occlusion/consistency mask -> 7-channel assembly
+ *     -> conv-InstanceNorm-ReLU residual transformer network -> deprocess -> stylised frame
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the reference
+ * tree).  Conventions:
+ *   - plain C, no exceptions / longjmp across the boundary; return 0 (FAV_OK) or a negative
+ *     fav_status; fav_last_error() gives a thread-local message.
+ *   - all data pointers are DEVICE pointers unless the parameter name ends in `_host`;
+ *     the caller owns every buffer it passes.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns
+ *     without synchronising (NULL = the default stream).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     FAV_ENODEVICE.
+ */
+#ifndef FAV_H
+#define FAV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fav_hipstream_t;
+
+enum fav_status {
+    FAV_OK = 0,
+    FAV_EINVAL = -1,       /* bad argument (shape, null pointer, ...) */
+    FAV_EIO = -2,          /* file could not be opened / read / written */
+    FAV_EFORMAT = -3,      /* malformed .t7 / .flo / pnm */
+    FAV_EUNSUPPORTED = -4, /* valid input, but outside the hot-path scope (e.g. SpatialFullConvolution) */
+    FAV_EHIP = -5,         /* HIP runtime error */
+    FAV_ENODEVICE = -6     /* no HIP device: the product path has no CPU fallback */
+};
+
+/* border policy of the warp: the reference has two (fast_artistic_video/utils.lua:141-149) */
+enum fav_border {
+    FAV_BORDER_STN = 0, /* GPU path: stnbdhw/BilinearSamplerBDHW.cu:48-109, each tap zeroed individually */
+    FAV_BORDER_CPU = 1  /* CPU path: image.warp(img, flow, 'bilinear', true, 'pad', 0) */
+};
+
+const char* fav_last_error(void);
+int fav_version(void);
+/* number of HIP devices, or FAV_ENODEVICE */
+int fav_device_count(void);
+
+/* ---- A2: optical-flow warp -------------------------------------------------------------------
+ * Replaces nn.BilinearSamplerBDHW():forward({img, flow}) (stnbdhw/BilinearSamplerBDHW.lua:54-82,
+ * native cunn_BilinearSamplerBDHW_updateOutput, stnbdhw/BilinearSamplerBDHW.cu:111-152) and the
+ * CPU branch of utils.warp_image (fast_artistic_video/utils.lua:147).
+ * img [B][C][H][W], flow [B][2][Ho][Wo] with flow[:,0]=dy, flow[:,1]=dx (pixel offsets),
+ * out [B][C][Ho][Wo]; all contiguous fp32. */
+int fav_warp_bdhw_f32(const float* img, const float* flow, float* out,
+                      int B, int C, int H, int W, int Ho, int Wo,
+                      int border_mode, fav_hipstream_t stream);
+
+/* ---- A3/A4: forward-backward consistency mask ------------------------------------------------
+ * Replaces the process `consistencyChecker flow1.flo flow2.flo out.pgm [image.ppm]`
+ * (consistencyChecker/consistencyChecker.cpp:136-171; checkConsistency :80-134, computeCorners
+ * :39-78).  flow1_flo / flow2_flo are the .flo payloads: [H][W][2] interleaved (u,v) fp32.
+ * rgb_hwc is the P6 payload [H][W][3] u8, or NULL for the 3-argument mode.  out is the PGM
+ * payload: [H][W] u8 in {0,255}, bit-exact with the reference binary.
+ * workspace: fav_consistency_workspace_bytes(W,H,with_structure) bytes of device memory (may be
+ * NULL when that returns 0). */
+size_t fav_consistency_workspace_bytes(int W, int H, int with_structure);
+int fav_consistency_u8(const float* flow1_flo, const float* flow2_flo, const uint8_t* rgb_hwc,
+                       uint8_t* out, int W, int H, void* workspace, size_t workspace_bytes,
+                       fav_hipstream_t stream);
+
+/* ---- A5: certainty erosion -------------------------------------------------------------------
+ * Replaces utils.min_filter(cert, r) (fast_artistic_video/utils.lua:161-169):
+ * 1 - maxpool_{r x r, stride 1, pad r/2}(1 - cert), window truncated at the borders. cert [H][W]. */
+int fav_min_filter_f32(const float* cert, float* out, int H, int W, int r, fav_hipstream_t stream);
+
+/* ---- A6/A7: VGG preprocessing + 7-channel input assembly --------------------------------------
+ * Replaces run_next_image's input construction (fast_artistic_video_core.lua:161-171) and the first
+ * frame's (:133-138) with fill_occlusions = vgg-mean; preprocess.lua:57-62.
+ * frame_rgb [3][H][W] RGB in [0,1]; warped_rgb [3][H][W] or NULL (first frame);
+ * cert [H][W] (already min-filtered) or NULL; in7 [7][H][W]. */
+int fav_assemble_input_f32(const float* frame_rgb, const float* warped_rgb, const float* cert,
+                           float* in7, int H, int W, fav_hipstream_t stream);
+
+/* ---- A8: the transformer network ---------------------------------------------------------------
+ * Replaces torch.load(path).model + model:forward(input) (fast_artistic_video_core.lua:38-57,172);
+ * layer semantics of fast_artistic_video/models_video.lua:10-140, InstanceNormalization.lua:33-53,
+ * ShaveImage.lua:9-16, train_video.lua:319-325. */
+typedef struct fav_net fav_net;
+
+/* parse a Torch7 .t7 checkpoint on the host and upload the weights to `device` */
+int fav_net_create(const char* t7_path_host, int device, fav_net** out);
+/* host-side: flatten a .t7 checkpoint into a self-describing blob (what rank 0 broadcasts over
+ * RCCL in the multi-GPU launcher).  Call with blob_host=NULL to query the size. */
+int fav_net_pack_host(const char* t7_path_host, void* blob_host, size_t capacity, size_t* bytes);
+/* create a net from a packed blob (host memory) */
+int fav_net_create_from_blob(const void* blob_host, size_t bytes, int device, fav_net** out);
+void fav_net_destroy(fav_net* net);
+/* human-readable layer list (one line per layer) -- used to cross-check the .t7 reader */
+int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity);
+/* host-only (no device needed): parse a .t7 checkpoint and write the same layer list text */
+int fav_t7_describe_host(const char* t7_path_host, char* buf_host, size_t capacity);
+/* number of fp32 parameters (conv weights+biases+IN gamma/beta) */
+long long fav_net_param_count(const fav_net* net);
+/* output size for an H x W input (equals H x W when H, W are multiples of 4) */
+int fav_net_output_size(const fav_net* net, int H, int W, int* Ho, int* Wo);
+/* in7 [1][7][H][W] -> out3 [1][3][Ho][Wo] (150*tanh(...), BGR mean-subtracted space), fp32 NCHW.
+ * Internal buffers are (re)sized on first use for a given H x W (allocation happens outside the
+ * stream order only then). */
+int fav_net_forward(fav_net* net, const float* in7, float* out3, int H, int W, fav_hipstream_t stream);
+
+/* per-convolution timing with HIP events recorded on the forward's stream (bench / roofline use).
+ * enable: every later forward records one event pair per convolution launch.  read: synchronises the
+ * recorded events and returns, per convolution in network order, the summed milliseconds, the number of
+ * launches, the useful MACs of one launch (no padding) and the N-tile width of the kernel instance that
+ * ran it (128, 64 or 32); then clears the accumulators.  Arrays hold up to `capacity` entries. */
+int fav_net_profile_enable(fav_net* net, int on);
+int fav_net_profile_read_host(fav_net* net, int capacity, int* count, double* ms_sum, int* launches,
+                              double* macs_per_launch, int* ntile);
+
+/* operator-level entry (nn.SpatialConvolution [+ nn.InstanceNormalization [+ nn.ReLU]]), NCHW fp32;
+ * weight [Cout][Cin][k][k], bias [Cout] or NULL, gamma/beta [Cout] or NULL (no IN).
+ * Runs the same MFMA implicit-GEMM kernel the network uses.  Allocates temporaries: test/ops use. */
+int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W,
+                        const float* weight, const float* bias, int Cout, int k, int stride, int pad,
+                        const float* gamma, const float* beta, float eps, int relu,
+                        float* out, fav_hipstream_t stream);
+
+/* ---- the fused per-frame pipeline (A1..A10 minus file I/O) -------------------------------------
+ * Replaces one iteration of run_fast_neural_video's loop (fast_artistic_video_core.lua:194-211)
+ * with the video CLI's callbacks (fast_artistic_video.lua:93-172).  Holds the recurrent state
+ * last_frame_stylized (float, unclamped: fast_artistic_video.lua:169) on the device. */
+typedef struct fav_stream fav_stream;
+
+typedef struct fav_stream_opts {
+    int border_mode;           /* enum fav_border */
+    int occlusions_min_filter; /* -occlusions_min_filter (default 7) */
+    int invert_occlusion;      /* -invert_occlusion */
+    int fix_occlusions;        /* -fix_occlusions */
+} fav_stream_opts;
+
+int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* opts_host, fav_stream** out);
+void fav_stream_destroy(fav_stream* s);
+/* first frame / -create_inconsistent: core.lua:121-158 with model_img == 'self'.
+ * frame_rgb_hwc: P6 payload [H][W][3] u8.  out_rgb_f32 [3][H][W] float RGB (deprocessed, unclamped)
+ * and/or out_rgb8_hwc [H][W][3] u8 (image.save quantisation); either may be NULL. */
+int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hwc,
+                           float* out_rgb_f32, uint8_t* out_rgb8_hwc, fav_hipstream_t stream);
+/* next frame with a precomputed certainty map (the .pgm written by consistencyChecker):
+ * backward_flo [H][W][2] (u,v) payload of backward_[i]_{i-1}.flo, cert_pgm [H][W] u8. */
+int fav_stream_next_frame_cert(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                               const uint8_t* cert_pgm, float* out_rgb_f32, uint8_t* out_rgb8_hwc,
+                               fav_hipstream_t stream);
+/* next frame with the consistency check fused on the GPU: forward_flo = forward_{i-1}_[i].flo.
+ * use_structure != 0 selects the 4-argument (image-structure) mode of the checker. */
+int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                               const float* forward_flo, int use_structure,
+                               float* out_rgb_f32, uint8_t* out_rgb8_hwc, fav_hipstream_t stream);
+/* read / overwrite the recurrent state ([3][H][W] float RGB) -- for -continue_with */
+int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
+int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream);
+/* device pointer of the last certainty mask used (u8 [H][W], before the min filter) -- tests */
+const uint8_t* fav_stream_last_mask(const fav_stream* s);
+
+/* ---- host-side formats (A1, A9) ----------------------------------------------------------------
+ * .flo: flowFileLoader.lua:14-34 / consistencyChecker.cpp:16-36 (tag read, not validated);
+ * P6/P5 8-bit binary PNM; PNG writer (RGB8, zlib).  Buffers are malloc'ed; free with fav_free_host. */
+int fav_read_flo_host(const char* path, float** uv_out, int* W, int* H);
+int fav_read_pnm_host(const char* path, uint8_t** data_out, int* W, int* H, int* channels);
+int fav_write_pgm_host(const char* path, const uint8_t* data, int W, int H);
+int fav_write_png_rgb8_host(const char* path, const uint8_t* rgb_hwc, int W, int H, int zlib_level);
+void fav_free_host(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAV_H */

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fast-artistic-videos_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def favlib():
+    """libfav must exist (built by __graft_entry__.build()); there is no fallback."""
+    import fav_amd
+    if not os.path.exists(fav_amd.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return fav_amd
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    return torch.device("cuda:0")

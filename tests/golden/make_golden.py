@@ -1,0 +1,72 @@
+"""Generate the committed golden fixtures.  Run in the build container (needs /root/reference for the
+mask fixtures: they are outputs of the reference's OWN consistencyChecker, compiled by oracle/Makefile
+into oracle/_ref/, on seeded synthetic inputs).  The network fixture comes from a PyTorch-CPU fp64
+restatement (the reference's Lua/Torch7 stack cannot run offline) -- it cross-checks the C oracle, it
+is not a reference output.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "fast-artistic-videos_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as O          # noqa: E402
+from fav_amd import synth, t7   # noqa: E402
+
+
+def mask_fixture(name, h, w, kind, seed):
+    if kind == "smooth":
+        bw = synth.backward_flow(h, w, seed); fw = synth.forward_flow_from_backward(bw, seed + 1)
+    else:
+        bw = synth.random_flow(h, w, seed); fw = synth.random_flow(h, w, seed + 1)
+    img = synth.smooth_frame(h, w, seed + 2)
+    d = tempfile.mkdtemp()
+    O.write_flo(d + "/a.flo", bw); O.write_flo(d + "/b.flo", fw); O.write_pnm(d + "/i.ppm", img)
+    subprocess.check_call([O.REF_CHECKER, d + "/a.flo", d + "/b.flo", d + "/o3.pgm"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([O.REF_CHECKER, d + "/a.flo", d + "/b.flo", d + "/o4.pgm", d + "/i.ppm"], stdout=subprocess.DEVNULL)
+    m3, m4 = O.read_pnm(d + "/o3.pgm"), O.read_pnm(d + "/o4.pgm")
+    np.savez_compressed(os.path.join(HERE, name), bw=bw, fw=fw, img=img, mask3=m3, mask4=m4)
+    print(name, "reliable% 3-arg", (m3 == 255).mean() * 100, "4-arg", (m4 == 255).mean() * 100, "flips", int((m3 != m4).sum()))
+
+
+def net_fixture():
+    import torch
+    import torch.nn.functional as F
+    path = os.path.join(HERE, "tiny_model.t7")
+    t7.make_synthetic_checkpoint(path, arch="c9s1-8,d16,d32,R32,R32,U2,c3s1-16,U2,c9s1-3", seed=7)
+    layers = t7.extract_layers(t7.load(path)["model"])
+
+    def tnet(layers, x):
+        for L in layers:
+            t = L["type"]
+            if t == "pad": x = F.pad(x, (L["l"], L["r"], L["t"], L["b"]), mode="reflect")
+            elif t == "conv": x = F.conv2d(x, torch.from_numpy(L["w"]).double(), torch.from_numpy(L["b"]).double(), L["stride"], L["pad"])
+            elif t == "in": x = F.instance_norm(x, weight=torch.from_numpy(L["gamma"]).double(), bias=torch.from_numpy(L["beta"]).double(), eps=L["eps"])
+            elif t == "relu": x = F.relu(x)
+            elif t == "res":
+                y = tnet(L["block"], x); s = L["shave"]; x = y + x[:, :, s:x.shape[2] - s, s:x.shape[3] - s]
+            elif t == "up": x = F.interpolate(x, scale_factor=L["s"], mode="nearest")
+            elif t == "tanh": x = torch.tanh(x)
+            elif t == "mul": x = x * L["k"]
+        return x
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((7, 40, 56)) * 50).astype(np.float32)
+    y = tnet(layers, torch.from_numpy(x)[None].double())[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_net_io.npz"), x=x, y=y)
+    print("tiny net", y.shape, float(np.abs(y).max()))
+
+
+if __name__ == "__main__":
+    O.build()
+    assert os.path.exists(O.REF_CHECKER), "oracle/_ref/consistencyChecker missing (needs /root/reference)"
+    mask_fixture("mask_smooth_64x96.npz", 64, 96, "smooth", 100)
+    mask_fixture("mask_rand_120x160.npz", 120, 160, "rand", 200)
+    mask_fixture("mask_smooth_180x320.npz", 180, 320, "smooth", 300)
+    net_fixture()

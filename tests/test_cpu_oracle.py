@@ -1,0 +1,219 @@
+"""CPU suite (-m "not gpu"): pins the oracle against the committed golden vectors (outputs of the
+reference's own consistencyChecker), cross-checks the [recalled] Torch7 semantics against PyTorch-CPU,
+and checks the host-side pieces of libfav (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from fav_amd import synth, t7
+
+
+# ---------------------------------------------------------------------------------------------- mask
+@pytest.mark.parametrize("name", ["mask_smooth_64x96.npz", "mask_rand_120x160.npz", "mask_smooth_180x320.npz"])
+def test_oracle_mask_matches_reference_golden(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    m3 = oracle.consistency(g["bw"], g["fw"])
+    m4 = oracle.consistency(g["bw"], g["fw"], g["img"])
+    assert np.array_equal(m3, g["mask3"]), "3-argument mode must be bit-exact with the reference binary"
+    assert np.array_equal(m4, g["mask4"]), "4-argument mode must be bit-exact with the reference binary"
+    assert set(np.unique(m3)) <= {0, 255}
+    assert (g["mask3"] != g["mask4"]).sum() > 0     # the structure term is exercised
+
+
+def test_oracle_mask_vs_live_reference_binary(oracle, tmp_path):
+    if not os.path.exists(oracle.REF_CHECKER):
+        pytest.skip("oracle/_ref/consistencyChecker not built (reference tree absent)")
+    for seed, (h, w) in enumerate([(33, 47), (72, 128), (2, 9)]):
+        bw = synth.random_flow(h, w, 50 + seed, 2.0); fw = synth.random_flow(h, w, 60 + seed, 2.0)
+        img = synth.random_frame(h, w, 70 + seed)
+        a, b, i, o = (str(tmp_path / n) for n in ("a.flo", "b.flo", "i.ppm", "o.pgm"))
+        oracle.write_flo(a, bw); oracle.write_flo(b, fw); oracle.write_pnm(i, img)
+        subprocess.check_call([oracle.REF_CHECKER, a, b, o], stdout=subprocess.DEVNULL)
+        assert np.array_equal(oracle.read_pnm(o), oracle.consistency(bw, fw))
+        subprocess.check_call([oracle.REF_CHECKER, a, b, o, i], stdout=subprocess.DEVNULL)
+        assert np.array_equal(oracle.read_pnm(o), oracle.consistency(bw, fw, img))
+
+
+def test_mask_edge_cases(oracle):
+    h, w = 8, 12
+    z = np.zeros((h, w, 2), np.float32)
+    m = oracle.consistency(z, z)
+    assert (m[:-1, :-1] == 255).all() and (m[-1, :] == 0).all() and (m[:, -1] == 0).all()   # x2>=W / y2>=H -> 0
+    far = np.full((h, w, 2), 100.0, np.float32)
+    assert (oracle.consistency(far, z) == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------- warp & co
+def _warp_numpy(img, flow, mode):
+    c, h, w = img.shape
+    out = np.zeros((c, flow.shape[1], flow.shape[2]), np.float64)
+    for y in range(flow.shape[1]):
+        for x in range(flow.shape[2]):
+            yf = np.float32(y) + flow[0, y, x]; xf = np.float32(x) + flow[1, y, x]
+            if mode == "cpu" and (yf < 0 or yf > h - 1 or xf < 0 or xf > w - 1):
+                continue
+            x0, y0 = int(np.floor(xf)), int(np.floor(yf))
+            ax, ay = float(xf) - x0, float(yf) - y0
+            for dy, wy in ((0, 1 - ay), (1, ay)):
+                for dx, wx in ((0, 1 - ax), (1, ax)):
+                    yy, xx = y0 + dy, x0 + dx
+                    if mode == "cpu":
+                        yy, xx = min(yy, h - 1), min(xx, w - 1)
+                    elif not (0 <= yy < h and 0 <= xx < w):
+                        continue
+                    out[:, y, x] += wy * wx * img[:, yy, xx]
+    return out
+
+
+@pytest.mark.parametrize("mode", ["stn", "cpu"])
+def test_oracle_warp(oracle, mode):
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((3, 17, 23)).astype(np.float32)
+    flow = (rng.standard_normal((2, 17, 23)) * 4).astype(np.float32)
+    flow[:, 0, 0] = 0; flow[:, 1, 1] = (-1.5, -0.25); flow[:, 2, 2] = (30, 30)
+    got = oracle.warp(img, flow, mode)
+    assert np.abs(got - _warp_numpy(img, flow, mode)).max() < 1e-5
+    ident = oracle.warp(img, np.zeros_like(flow), mode)
+    assert np.array_equal(ident, img)
+
+
+def test_oracle_min_filter_matches_maxpool(oracle):
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(4)
+    cert = (rng.random((31, 45)) > 0.2).astype(np.float32)
+    got = oracle.min_filter(cert, 7)
+    ref = 1 - F.max_pool2d(1 - torch.from_numpy(cert)[None, None], 7, 1, 3)[0, 0].numpy()
+    assert np.array_equal(got, ref)
+    grey = rng.random((9, 9)).astype(np.float32)
+    ref = 1 - F.max_pool2d(1 - torch.from_numpy(grey)[None, None], 7, 1, 3)[0, 0].numpy()
+    assert np.abs(oracle.min_filter(grey, 7) - ref).max() < 2e-7
+
+
+def test_oracle_assemble_and_preprocess(oracle):
+    rng = np.random.default_rng(5)
+    fr = rng.random((3, 6, 7)).astype(np.float32); wp = rng.random((3, 6, 7)).astype(np.float32)
+    ce = (rng.random((6, 7)) > 0.5).astype(np.float32)
+    mean = np.array([103.939, 116.779, 123.68], np.float32)[:, None, None]
+    pre = lambda a: a[::-1] * np.float32(255) - mean                  # preprocess.lua:57-62
+    x = oracle.assemble(fr, wp, ce)
+    assert np.allclose(x[:3], pre(fr), atol=1e-4) and np.allclose(x[3:6], pre(wp) * ce, atol=1e-4) and np.array_equal(x[6], ce)
+    x0 = oracle.assemble(fr, None, None)
+    assert np.allclose(x0[:3], pre(fr), atol=1e-4) and (x0[3:] == 0).all()
+    assert np.allclose(oracle.deprocess(oracle.preprocess(fr)), fr, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- network
+def test_oracle_net_matches_torch_golden(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_net_io.npz"))
+    layers = t7.extract_layers(t7.load(os.path.join(golden_dir, "tiny_model.t7"))["model"])
+    y = oracle.net_forward(layers, g["x"])
+    assert y.shape == g["y"].shape
+    assert np.abs(y - g["y"]).max() < 2e-3          # fp32 storage between layers vs the fp64 restatement
+
+
+def test_oracle_layers_vs_torch(oracle):
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((5, 13, 18)).astype(np.float32)
+    for k, s, p, co in [(3, 1, 0, 8), (3, 2, 1, 4), (9, 1, 4, 3), (1, 1, 0, 2)]:
+        w = rng.standard_normal((co, 5, k, k)).astype(np.float32); b = rng.standard_normal(co).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), s, p)[0]
+        assert np.abs(oracle.conv2d(x, w, b, s, p) - ref.numpy()).max() < 1e-4
+    g = rng.random(5).astype(np.float32); bt = rng.standard_normal(5).astype(np.float32)
+    ref = F.instance_norm(torch.from_numpy(x)[None].double(), weight=torch.from_numpy(g).double(), bias=torch.from_numpy(bt).double(), eps=1e-5)[0]
+    assert np.abs(oracle.instnorm_(x.copy(), g, bt, 1e-5) - ref.numpy()).max() < 1e-5
+    assert np.array_equal(oracle.reflect_pad(x, 3, 3, 3, 3), F.pad(torch.from_numpy(x)[None], (3, 3, 3, 3), mode="reflect")[0].numpy())
+    assert np.array_equal(oracle.upsample(x, 2), F.interpolate(torch.from_numpy(x)[None], scale_factor=2, mode="nearest")[0].numpy())
+    blk = rng.standard_normal((5, 9, 14)).astype(np.float32)
+    assert np.array_equal(oracle.shave_add(blk, x, 2), blk + x[:, 2:-2, 2:-2])
+
+
+def _convs(ls):
+    for L in ls:
+        if L["type"] == "conv": yield L
+        if L["type"] == "res": yield from _convs(L["block"])
+
+
+def _ins(ls):
+    for L in ls:
+        if L["type"] == "in": yield L
+        if L["type"] == "res": yield from _ins(L["block"])
+
+
+def test_canonical_architecture_shapes(tmp_path):
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, seed=1)
+    layers = t7.extract_layers(t7.load(p)["model"])
+    assert layers[0] == {"type": "pad", "l": 40, "r": 40, "t": 40, "b": 40}        # train_video.lua:319-325
+    n = sum(L["w"].size + L["b"].size for L in _convs(layers)) + sum(2 * len(L["gamma"]) for L in _ins(layers))
+    assert n == 1679235                                                              # 6.72 MB
+
+
+# ---------------------------------------------------------------------------------------------- libfav host side
+def test_c_abi_exports_every_declared_symbol(favlib):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "fav.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fav_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    L = favlib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libfav.so does not export {name}"
+    assert declared == set(favlib.EXPORTS)
+
+
+def test_no_gpu_means_loud_failure(favlib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = favlib.lib()
+    assert L.fav_device_count() == -6                      # FAV_ENODEVICE
+    assert b"no CPU fallback" in L.fav_last_error()
+    h = C.c_void_p()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert L.fav_net_create(os.path.join(root, "tests/golden/tiny_model.t7").encode(), 0, C.byref(h)) == -6
+    with pytest.raises(favlib.FavError):
+        favlib.warp(None, None)
+
+
+def test_cpp_t7_reader_matches_python_reader(favlib, golden_dir, tmp_path):
+    path = os.path.join(golden_dir, "tiny_model.t7")
+    assert favlib.describe_t7(path) == favlib.describe_layers(t7.extract_layers(t7.load(path)["model"]))
+    p = str(tmp_path / "canon.t7")
+    t7.make_synthetic_checkpoint(p, seed=3)
+    assert favlib.describe_t7(p) == favlib.describe_layers(t7.extract_layers(t7.load(p)["model"]))
+    blob = favlib.pack_checkpoint(p)
+    assert blob[:4] == b"FAVB" and len(blob) > 1679235 * 4
+    # malformed inputs fail with a status, never crash
+    bad = str(tmp_path / "bad.t7")
+    with open(bad, "wb") as f:
+        f.write(open(p, "rb").read()[:1000])
+    with pytest.raises(favlib.FavError):
+        favlib.describe_t7(bad)
+    with pytest.raises(favlib.FavError):
+        favlib.describe_t7(str(tmp_path / "missing.t7"))
+
+
+def test_host_formats_roundtrip(favlib, oracle, tmp_path):
+    from PIL import Image
+    uv = synth.random_flow(11, 7, 1)
+    p = str(tmp_path / "f.flo"); oracle.write_flo(p, uv)
+    assert np.array_equal(favlib.read_flo(p), uv)
+    img = synth.random_frame(9, 13, 2)
+    pp = str(tmp_path / "i.ppm"); oracle.write_pnm(pp, img)
+    assert np.array_equal(favlib.read_pnm(pp), img)
+    with open(pp, "wb") as f:
+        f.write(b"P6\n# a comment\n13 9\n255\n" + img.tobytes())
+    assert np.array_equal(favlib.read_pnm(pp), img)
+    pg = str(tmp_path / "m.pgm"); favlib.write_pgm(pg, img[..., 0])
+    assert open(pg, "rb").read() == b"P5\n13 9\n255\n" + img[..., 0].tobytes()      # CMatrix.h:1064
+    png = str(tmp_path / "o.png"); favlib.write_png(png, img)
+    assert np.array_equal(np.asarray(Image.open(png)), img)
+    with pytest.raises(favlib.FavError):
+        favlib.read_flo(str(tmp_path / "nope.flo"))
