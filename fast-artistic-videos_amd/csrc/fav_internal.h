@@ -94,6 +94,9 @@ struct ConvLaunch {
 constexpr int CONV_BM = 128;
 inline int conv_mblocks(int OH, int OW) { return (OH * OW + CONV_BM - 1) / CONV_BM; }
 int launch_conv(const ConvLaunch& p, hipStream_t st);
+// last layer with few output channels: kx taps folded into N (see kernels_conv.hip); wfold = [KH][32][CIN]
+bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride);
+int launch_conv_fold(const ConvLaunch& p, const float* wfold, hipStream_t st);
 
 // per-channel finalize of (mean, M2) partials -> scale/shift:  scale = gamma/sqrt(var+eps)
 int launch_in_finalize(const float* partials, int mblocks, int M, int block_pixels, int C, int Cpitch,

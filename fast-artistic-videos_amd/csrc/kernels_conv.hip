@@ -280,6 +280,205 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Last layer (c9s1-3: 64 -> 3 channels, 9x9): "row-folded" implicit GEMM.
+// With only 3 output channels a pixels x channels GEMM would waste 29/32 of every MFMA.  Instead the
+// kx taps are folded into the N dimension: for one output row y
+//     D[x'][(c,kx)] = sum_{ky,ci} in[y+ky-p][x'][ci] * w[c][ci][ky][kx]        (M = 128 input columns x',
+//                                                                               N = 3*9 = 27 -> 32,
+//                                                                               K = 9*64 = 576)
+//     out[y][x][c]  = sum_kx D[x+kx-p][(c,kx)]                                  (diagonal sum, done in LDS)
+// MFMA utilisation = 27/32 * 120/128 = 79 % instead of 9 %.  A block owns R = 8 output rows x 120 output
+// columns: every staged (transformed, nearest-upsampled) input row feeds up to 8 output rows with 8
+// different ky weight slices, all 9 slices stay resident in LDS, and with x2 upsampling each physical
+// input row is staged once for its two logical rows.  Epilogue: bias, Tanh, MulConstant, VGG de-process.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int FOLD_R = 8;        // output rows per block
+constexpr int FOLD_M = 128;      // input columns per block
+
+struct FoldArgs {
+    const float* in; const float* wfold; const float* bias;
+    const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+    float* out_planar; float* out_raw;
+    int IH, IW, IWp, ups, COUT, KH, KW, pad, OH, OW;
+    int stages, relu1, relu2;
+    float tanh_mul;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
+{
+    constexpr int S = CIN + 4;                 // LDS row stride (floats): odd multiple of 16 B -> conflict-free b128
+    constexpr int NV = CIN / 8;                // float4 per thread per staged row (2 threads per column)
+    constexpr int KK = CIN / 8;                // fragment steps per row (8 k values each)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bs = smem;                          // [KH][32][S]
+    float* As = Bs + p.KH * 32 * S;            // [2][FOLD_M][S]
+    float* aff = As + 2 * FOLD_M * S;          // [4][CIN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int XO = FOLD_M - (p.KW - 1);        // output columns per block
+    const int ox0 = blockIdx.x * XO, oy0 = blockIdx.y * FOLD_R;
+    const int xs = ox0 - p.pad;                // first input column of the tile (may be negative)
+
+    if (p.stages >= 1)
+        for (int i = t; i < CIN; i += 256) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
+    if (p.stages >= 2)
+        for (int i = t; i < CIN; i += 256) { aff[2 * CIN + i] = p.scale2[i]; aff[3 * CIN + i] = p.shift2[i]; }
+    // all ky weight slices -> LDS (wfold is [KH][32][CIN], zero rows for n >= COUT*KW)
+    for (int e = t; e < p.KH * 32 * (CIN / 4); e += 256) {
+        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+        *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(p.wfold + (size_t)row * CIN + c4 * 4);
+    }
+
+    const int iy_lo = max(0, oy0 - p.pad), iy_hi = min(p.IH - 1, oy0 + FOLD_R - 1 + p.KH - 1 - p.pad);
+    const int pr_lo = iy_lo >> p.ups, pr_hi = iy_hi >> p.ups;
+
+    // staging assignment: column xl = t>>1 of the tile, channel half (t&1)
+    const int xl = t >> 1, ch0 = (t & 1) * (CIN / 2);
+    const int ix = xs + xl;
+    const bool colv = ix >= 0 && ix < p.IW;
+    const size_t coloff = colv ? (size_t)(ix >> p.ups) * CIN + ch0 : 0;
+    float4 ra[NV];
+
+#define FOLD_LOAD(pr_)                                                                              \
+    {                                                                                               \
+        const float* src_ = p.in + (size_t)(pr_) * p.IWp * CIN + coloff;                            \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) ra[i] = *reinterpret_cast<const float4*>(src_ + 4 * i); \
+    }
+#define FOLD_STORE(buf_)                                                                            \
+    {                                                                                               \
+        float* dst_ = As + (buf_) * FOLD_M * S + xl * S + ch0;                                      \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                            \
+            float4 v_ = ra[i];                                                                      \
+            if (p.stages >= 1) {                                                                    \
+                v_ = affine4(v_, aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, p.relu1);              \
+                if (p.stages >= 2) v_ = affine4(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, p.relu2); \
+            }                                                                                       \
+            if (!colv) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+            *reinterpret_cast<float4*>(dst_ + 4 * i) = v_;                                          \
+        }                                                                                           \
+    }
+
+    f32x16 acc[FOLD_R];
+#pragma unroll
+    for (int y = 0; y < FOLD_R; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+
+    FOLD_LOAD(pr_lo);
+    __syncthreads();               // affine tables + weights visible
+    FOLD_STORE(0);
+    __syncthreads();
+
+    const int frag = (lane & 31) * S + (lane >> 5) * 4;
+    int cur = 0;
+    for (int pr = pr_lo; pr <= pr_hi; ++pr) {
+        const bool more = pr < pr_hi;
+        if (more) FOLD_LOAD(pr + 1);
+        const float* a_base = As + cur * FOLD_M * S + wave * 32 * S + frag;
+        const int iy_first = max(iy_lo, pr << p.ups), iy_last = min(iy_hi, ((pr + 1) << p.ups) - 1);
+        for (int iy = iy_first; iy <= iy_last; ++iy) {
+            const int kyb = iy - oy0 + p.pad;          // ky for output row yy is kyb - yy
+#pragma unroll 2
+            for (int kk = 0; kk < KK; ++kk) {
+                const float4 af = *reinterpret_cast<const float4*>(a_base + kk * 8);
+#pragma unroll
+                for (int yy = 0; yy < FOLD_R; ++yy) {
+                    const int ky = kyb - yy;
+                    if (ky >= 0 && ky < p.KH) {        // block-uniform
+                        const float4 bf = *reinterpret_cast<const float4*>(Bs + ky * 32 * S + frag + kk * 8);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[yy], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) FOLD_STORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef FOLD_LOAD
+#undef FOLD_STORE
+
+    // ---- epilogue: D tiles -> LDS [R][128][33], then the diagonal sum over kx
+    float* D = smem;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+    for (int yy = 0; yy < FOLD_R; ++yy)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int xr = wave * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            D[(yy * FOLD_M + xr) * 33 + col] = acc[yy][r];
+        }
+    __syncthreads();
+    const size_t MO = (size_t)p.OH * p.OW;
+    const int per_row = XO * p.COUT;
+    for (int e = t; e < FOLD_R * per_row; e += 256) {
+        const int yy = e / per_row, rem = e - yy * per_row;
+        const int c = rem / XO, xo = rem - c * XO;
+        const int oy = oy0 + yy, ox = ox0 + xo;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        float v = p.bias[c];
+        const float* d = D + (yy * FOLD_M + xo) * 33 + c * p.KW;
+        for (int kx = 0; kx < p.KW; ++kx) v += d[kx * 33 + kx];
+        v = tanhf(v) * p.tanh_mul;                                              // models_video.lua:135-136
+        const size_t o = (size_t)oy * p.OW + ox;
+        if (p.out_raw) p.out_raw[(size_t)c * MO + o] = v;
+        if (p.out_planar) {
+            const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+            p.out_planar[(size_t)(2 - c) * MO + o] = (v + mean) / 255.f;          // preprocess.lua:66-71
+        }
+    }
+}
+
+template <int CIN>
+int launch_fold_t(const FoldArgs& a, hipStream_t st)
+{
+    const int S = CIN + 4;
+    size_t lds = (size_t)(a.KH * 32 * S + 2 * FOLD_M * S + 4 * CIN) * sizeof(float);
+    const size_t epi = (size_t)FOLD_R * FOLD_M * 33 * sizeof(float);
+    if (epi > lds) lds = epi;
+    if (lds > 160 * 1024) { set_error("row-folded conv: %zu bytes of LDS needed", lds); return FAV_EUNSUPPORTED; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_kernel<CIN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int XO = FOLD_M - (a.KW - 1);
+    dim3 grid((a.OW + XO - 1) / XO, (a.OH + FOLD_R - 1) / FOLD_R);
+    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), grid, dim3(256), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_rowfold_kernel");
+    return FAV_OK;
+}
+
+}  // namespace
+
+bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride)
+{
+    return stride == 1 && cout * k <= 32 && k <= 9 && (cin_pitch == 16 || cin_pitch == 32 || cin_pitch == 64);
+}
+
+int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
+{
+    FAV_REQUIRE(conv_fold_eligible(c.CIN, c.COUT, c.KW, c.stride) && c.KH == c.KW && c.final_mode, "row-folded conv: not eligible");
+    FoldArgs a;
+    a.in = c.in; a.wfold = wfold; a.bias = c.bias;
+    a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
+    a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
+    a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.COUT = c.COUT; a.KH = c.KH; a.KW = c.KW; a.pad = c.pad;
+    a.OH = c.OH; a.OW = c.OW; a.tanh_mul = c.tanh_mul;
+    if (c.CIN == 64) return launch_fold_t<64>(a, st);
+    if (c.CIN == 32) return launch_fold_t<32>(a, st);
+    return launch_fold_t<16>(a, st);
+}
+
 int launch_conv(const ConvLaunch& c, hipStream_t st)
 {
     FAV_REQUIRE(c.CIN % 4 == 0 && c.CIN <= 1024, "conv: CIN=%d must be a multiple of 4 and <= 1024", c.CIN);

@@ -14,6 +14,7 @@
 // tensor, models_video.lua:94-98,121-130) -- from one read-only reduction pass.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -24,7 +25,7 @@ using namespace fav;
 namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
-struct DevConvW { float* wgt = nullptr; float* bias = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
 struct Act {
@@ -99,7 +100,7 @@ struct fav_net {
     {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
-        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); }
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
         (void)hipFree(ones); (void)hipFree(zeros);
@@ -128,6 +129,16 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             repack_weights(L, d.cinp, d.coutp, d.kpad, w);
             int rc = dev_upload(w, 0, &d.wgt); if (rc) return rc;
             rc = dev_upload(L.b, (size_t)d.coutp, &d.bias); if (rc) return rc;
+            if (conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
+                // [ky][n = c*k + kx][ci] for the row-folded last-layer kernel
+                std::vector<float> wf((size_t)L.k * 32 * d.cinp, 0.f);
+                for (int co = 0; co < L.cout; ++co)
+                    for (int ci = 0; ci < L.cin; ++ci)
+                        for (int ky = 0; ky < L.k; ++ky)
+                            for (int kx = 0; kx < L.k; ++kx)
+                                wf[((size_t)ky * 32 + co * L.k + kx) * d.cinp + ci] = L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+                rc = dev_upload(wf, 0, &d.wfold); if (rc) return rc;
+            }
             convs.push_back(d);
             params += (long long)L.w.size() + (long long)L.b.size();
             chan_pitch = L.cout;
@@ -189,16 +200,18 @@ int fav_net::alloc(size_t bytes, float** out)
 
 int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
-    if (!profiling) return launch_conv(c, st);
+    const float* wfold = (c.final_mode && !getenv("FAV_NO_FOLD")) ? convs[conv_index].wfold : nullptr;
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : launch_conv(c, st); };
+    if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
     FAV_HIP(hipEventRecord(r.a, st));
-    int rc = launch_conv(c, st);
+    int rc = go();
     FAV_HIP(hipEventRecord(r.b, st));
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    prof_tile[conv_index] = c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32);
+    prof_tile[conv_index] = wfold ? 1 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32));
     return rc;
 }
 
