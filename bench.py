@@ -80,17 +80,12 @@ def main():
 
     # ---- weights: rank 0 parses the (synthetic, canonical-architecture) .t7 and broadcasts the packed blob
     ckpt = os.path.join(tempfile.gettempdir(), f"fav_bench_canonical_{os.getpid()}.t7")
+    from fav_amd import shard
+    blob = None
     if rank == 0:
         t7.make_synthetic_checkpoint(ckpt, seed=1234)
         blob = fav_amd.pack_checkpoint(ckpt)
-        n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
-    else:
-        blob, n = None, torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(n, 0)
-        buf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev) if rank == 0 else torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(buf, 0)                         # RCCL over xGMI: 6.7 MB, once
-        blob = buf.cpu().numpy().tobytes()
+    blob = shard.broadcast_blob(blob, dev)             # RCCL over xGMI: 6.7 MB, once, before the timed region
     net = fav_amd.Net(blob=blob, device=local)
     stream = fav_amd.Stream(net, H, W)
 
@@ -125,10 +120,7 @@ def main():
     dt = time.perf_counter() - t0
     net.profile_enable(False)
     prof = net.profile_read()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = shard.max_over_ranks(dt, dev)
 
     if rank == 0:
         fps = world * args.steps / dt

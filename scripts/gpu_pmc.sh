@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC passes (each counter set in its own run, --kernel-trace only): HBM bytes and MFMA busy for the bench kernels.
+TAG=${1:-x}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $O/counters_list.txt 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"; do
+  N=$(echo $C | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${TAG}_$N -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_$N.log 2>&1
+done
+cd $R
+python - <<PY
+import csv, glob, collections, json, re
+out = {}
+for f in sorted(glob.glob("$O/pmc_${TAG}_*/*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+        if "conv_mfma" in k or "rowfold" in k: k += " grid=%s" % r.get("Grid_Size", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        for c, v in d.items():
+            out.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
+json.dump(out, open("$O/pmc_$TAG.json", "w"), indent=1, sort_keys=True)
+for k in sorted(out):
+    print(k[:80], {c: round(v["mean"], 1) for c, v in out[k].items()})
+PY
+grep -i -E "mfma|FETCH_SIZE|WRITE_SIZE" $O/counters_list.txt | head -30

@@ -1,0 +1,96 @@
+"""Drop-in executables on the GPU: `consistencyChecker` (same argv / same PGM bytes as the reference's)
+and `fav_stylize` (the flag contract of fast_artistic_video.lua, file-name patterns of
+stylizeVideo_deepflow.sh:87-96).  Outputs are compared with the oracle's per-frame loop."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fav_amd import synth, t7
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "fast-artistic-videos_amd", "bin")
+
+
+def _write_clip(oracle, d, h, w, n, seed):
+    frames, bws, fws = [], [None], [None]
+    os.makedirs(d / "flow", exist_ok=True)
+    for i in range(1, n + 1):
+        f = synth.smooth_frame(h, w, seed + i); frames.append(f)
+        oracle.write_pnm(str(d / f"frame_{i:05d}.ppm"), f)
+        if i > 1:
+            bw = synth.backward_flow(h, w, seed + 100 + i); fw = synth.forward_flow_from_backward(bw, seed + 200 + i)
+            bws.append(bw); fws.append(fw)
+            oracle.write_flo(str(d / "flow" / f"backward_{i}_{i-1}.flo"), bw)
+            oracle.write_flo(str(d / "flow" / f"forward_{i-1}_{i}.flo"), fw)
+    return frames, bws, fws
+
+
+def test_consistency_checker_binary(oracle, favlib, tmp_path):
+    h, w = 90, 130
+    bw = synth.backward_flow(h, w, 1); fw = synth.forward_flow_from_backward(bw, 2); img = synth.smooth_frame(h, w, 3)
+    a, b, i, o = (str(tmp_path / n) for n in ("a.flo", "b.flo", "i.ppm", "o.pgm"))
+    oracle.write_flo(a, bw); oracle.write_flo(b, fw); oracle.write_pnm(i, img)
+    exe = os.path.join(BIN, "consistencyChecker")
+    r = subprocess.run([exe, a, b, o], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == o                       # consistencyChecker.cpp:166 prints the output path
+    assert open(o, "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw).tobytes()
+    r = subprocess.run([exe, a, b, o, i], capture_output=True, text=True)
+    assert r.returncode == 0
+    assert open(o, "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw, img).tobytes()
+    assert subprocess.run([exe, a, str(tmp_path / "missing.flo"), o]).returncode != 0
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_fav_stylize_matches_oracle_loop(oracle, favlib, tmp_path, golden_dir, fused):
+    from PIL import Image
+    h, w, n = 48, 64, 4
+    frames, bws, fws = _write_clip(oracle, tmp_path, h, w, n, 40)
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    checker = os.path.join(BIN, "consistencyChecker")
+    masks = [None, None]
+    for i in range(2, n + 1):     # makeOptFlow_deepflow.sh:59
+        if not fused:
+            subprocess.check_call([checker, str(tmp_path / "flow" / f"backward_{i}_{i-1}.flo"), str(tmp_path / "flow" / f"forward_{i-1}_{i}.flo"),
+                                   str(tmp_path / "flow" / f"reliable_{i}_{i-1}.pgm"), str(tmp_path / f"frame_{i:05d}.ppm")], stdout=subprocess.DEVNULL)
+        masks.append(oracle.consistency(bws[i - 1], fws[i - 1], frames[i - 1]))
+    cmd = [os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"),
+           "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
+           "-occlusions_pattern", str(tmp_path / "flow" / "reliable_[%d]_{%d}.pgm"),
+           "-output_prefix", str(tmp_path / "out" / "out"), "-backend", "cuda", "-use_cudnn", "1", "-gpu", "0",
+           "-model_vid", model, "-model_img", "self"]
+    if fused:
+        cmd += ["-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Model loaded." in r.stdout and r.stdout.count("Writing output image to") == n
+    ref = oracle.Stylizer(t7.extract_layers(t7.load(model)["model"]))
+    for i in range(1, n + 1):
+        f01 = np.transpose(frames[i - 1], (2, 0, 1)).astype(np.float32) / np.float32(255)
+        out = ref.first(f01) if i == 1 else ref.next(f01, bws[i - 1], masks[i].astype(np.float32) / np.float32(255))
+        png = np.asarray(Image.open(str(tmp_path / "out" / f"out-{i:05d}.png")))
+        want = oracle.to_u8_hwc(out)
+        assert png.shape == want.shape
+        assert np.abs(png.astype(int) - want.astype(int)).max() <= 1, f"frame {i}"
+    assert not os.path.exists(str(tmp_path / "out" / f"out-{n+1:05d}.png"))     # loop stops at the first missing frame
+
+
+def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
+    exe = os.path.join(BIN, "fav_stylize")
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "Must give -input_pattern" in r.stderr                       # fast_artistic_video.lua:177-179
+    r = subprocess.run([exe, "-input_pattern", "x_%05d.ppm"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Must give -flow_pattern and -occlusions_pattern" in r.stderr  # :180-182
+    r = subprocess.run([exe, "-input_pattern", "x", "-flow_pattern", "a", "-occlusions_pattern", "b", "-gpu", "-1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU backend" in r.stderr
+    r = subprocess.run([exe, "-input_pattern", "x", "-flow_pattern", "a", "-occlusions_pattern", "b", "-model_vid", str(tmp_path / "none.t7")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not load model" in r.stderr                             # core.lua:41
+    # th shim used by the unmodified shell drivers
+    shim = os.path.join(ROOT, "fast-artistic-videos_amd", "host", "th")
+    r = subprocess.run([shim, "fast_artistic_video.lua", "-input_pattern", str(tmp_path / "no_%05d.ppm"), "-create_inconsistent",
+                        "-model_vid", model, "-gpu", "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Model loaded." in r.stdout
