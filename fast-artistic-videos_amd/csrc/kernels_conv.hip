@@ -38,6 +38,16 @@ struct ConvArgs {
     float tanh_mul;
 };
 
+// branch-free form used inside the MFMA loop: lo = 0 for ReLU, -inf for none; identity = scale 1, shift 0
+__device__ __forceinline__ float4 affine4_lo(float4 v, const float* sc, const float* sh, float lo)
+{
+    const float4 s = *reinterpret_cast<const float4*>(sc);
+    const float4 b = *reinterpret_cast<const float4*>(sh);
+    v.x = fmaxf(fmaf(v.x, s.x, b.x), lo); v.y = fmaxf(fmaf(v.y, s.y, b.y), lo);
+    v.z = fmaxf(fmaf(v.z, s.z, b.z), lo); v.w = fmaxf(fmaf(v.w, s.w, b.w), lo);
+    return v;
+}
+
 __device__ __forceinline__ float4 affine4(float4 v, const float* sc, const float* sh, int relu)
 {
     const float4 s = *reinterpret_cast<const float4*>(sc);
@@ -60,14 +70,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int mblock = blockIdx.x, nblock = blockIdx.y;
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (observed; used for L2 locality only).
+    // Give every XCD a contiguous range of M tiles so the 3x3/9x9 halo rows of neighbouring tiles hit its L2.
+    int mblock;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nblock = blockIdx.y;
     const int M = p.OH * p.OW;
     const int CIN = p.CIN;
 
-    if (p.stages >= 1)
-        for (int i = t; i < CIN; i += 256) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
-    if (p.stages >= 2)
-        for (int i = t; i < CIN; i += 256) { aff[2 * CIN + i] = p.scale2[i]; aff[3 * CIN + i] = p.shift2[i]; }
+    // transform tables: always two stages in the loop (identity = scale 1, shift 0, no ReLU floor), so the
+    // K loop carries no data-dependent or uniform branches and the scheduler can interleave it with the MFMAs
+    for (int i = t; i < CIN; i += 256) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
 
     // per-thread staging assignment: row r0 + 32*i of the tile, 16-byte chunk c4 of the 32-wide K slice
     const int c4 = t & 7, r0 = t >> 3;
@@ -86,47 +107,79 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     const int nsteps = p.Kpad / BK;
     const float* wrow = p.wgt + (size_t)(nblock * BN + r0) * p.Kpad + c4 * 4;
 
-    float4 ra[AROWS];
-    v4f rb[BROWS];
-    bool va[AROWS];
-    int ci_cur = 0;
+    // Two register sets: while the MFMAs of step s run, the global loads of step s+2 are in flight (set L)
+    // and the data of step s+1 (set S, loaded one step earlier) is transformed and written to the other
+    // LDS buffer in four chunks interleaved with the four MFMA groups, so that VALU / LDS-store work
+    // executes in the shadow of the 64-cycle matrix instructions instead of in a phase of its own.
+    float4 ra0[AROWS], ra1[AROWS];
+    v4f rb0[BROWS], rb1[BROWS];
+    bool va0[AROWS], va1[AROWS];
+    int ci0 = 0, ci1 = 0;
 
-// global -> registers for K-step s (raw values; the transform is applied when they are written to LDS)
-#define FAV_LOAD_STEP(s_)                                                                                   \
+// global -> registers (set X) for K-step s_: raw values, transform applied when they are written to LDS
+#define FAV_LOAD_STEP(X, s_)                                                                                \
     {                                                                                                       \
         const int kb_ = (s_) * BK + c4 * 4;                                                                 \
         const int tap_ = kb_ / CIN;                                                                         \
         const int ci_ = kb_ - tap_ * CIN;                                                                   \
         const int ky_ = tap_ / p.KW, kx_ = tap_ - ky_ * p.KW;                                               \
         const bool tv_ = tap_ < ntaps;                                                                      \
-        ci_cur = ci_;                                                                                       \
+        ci##X = ci_;                                                                                        \
         _Pragma("unroll") for (int i = 0; i < AROWS; ++i) {                                                 \
             const int iy_ = iy0[i] + ky_, ix_ = ix0[i] + kx_;                                               \
-            va[i] = rv[i] && tv_ && (unsigned)iy_ < (unsigned)p.IH && (unsigned)ix_ < (unsigned)p.IW;       \
-            const size_t off_ = va[i] ? ((size_t)(iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci_ : 0;  \
-            ra[i] = *reinterpret_cast<const float4*>(p.in + off_);                                          \
+            va##X[i] = rv[i] & tv_ & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW);   \
+            const int off_ = va##X[i] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci_ : 0;          \
+            ra##X[i] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */          \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < BROWS; ++j)                                                   \
-            rb[j] = *reinterpret_cast<const v4f*>(wrow + (size_t)(32 * j) * p.Kpad + (s_) * BK);            \
+            rb##X[j] = *reinterpret_cast<const v4f*>(wrow + (32 * j) * p.Kpad + (s_) * BK);                 \
     }
 
-// registers -> LDS buffer buf_: pending transform of the producer (IN scale/shift [+ReLU], up to two
-// stages), then zero for padding / out-of-range rows
-#define FAV_STORE_STEP(buf_)                                                                                \
+// registers (set X) -> LDS buffer buf_, chunk q_ of 4: A row q_ (pending transform of the producer: IN
+// scale/shift [+ReLU], up to two stages; then zero for padding / out-of-range rows) and B row q_
+#define FAV_STORE_CHUNK(X, buf_, q_)                                                                        \
     {                                                                                                       \
-        float* a_ = As + (buf_) * BM * LDSS + r0 * LDSS + c4 * 4;                                           \
-        float* b_ = Bs + (buf_) * BN * LDSS + r0 * LDSS + c4 * 4;                                           \
-        _Pragma("unroll") for (int i = 0; i < AROWS; ++i) {                                                 \
-            float4 v_ = ra[i];                                                                              \
-            if (p.stages >= 1) {                                                                            \
-                v_ = affine4(v_, aff + ci_cur, aff + CIN + ci_cur, p.relu1);                                \
-                if (p.stages >= 2) v_ = affine4(v_, aff + 2 * CIN + ci_cur, aff + 3 * CIN + ci_cur, p.relu2); \
-            }                                                                                               \
-            if (!va[i]) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
-            *reinterpret_cast<float4*>(a_ + 32 * i * LDSS) = v_;                                            \
+        if ((q_) < AROWS) {                                                                                 \
+            float4 v_ = ra##X[(q_) < AROWS ? (q_) : 0];                                                     \
+            v_ = affine4_lo(v_, aff + ci##X, aff + CIN + ci##X, lo1);                                       \
+            v_ = affine4_lo(v_, aff + 2 * CIN + ci##X, aff + 3 * CIN + ci##X, lo2);                         \
+            const float m_ = va##X[(q_) < AROWS ? (q_) : 0] ? 1.f : 0.f;                                    \
+            v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_;                                                 \
+            *reinterpret_cast<float4*>(As + (buf_) * BM * LDSS + (r0 + 32 * (q_)) * LDSS + c4 * 4) = v_;    \
         }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(b_ + 32 * j * LDSS) = rb[j]; \
+        if ((q_) < BROWS)                                                                                   \
+            *reinterpret_cast<v4f*>(Bs + (buf_) * BN * LDSS + (r0 + 32 * (q_)) * LDSS + c4 * 4) = rb##X[(q_) < BROWS ? (q_) : 0]; \
     }
+
+// one group of MFMAs: fragment step kk_ of the current LDS buffer
+#define FAV_MFMA_GROUP(kk_)                                                                                 \
+    {                                                                                                       \
+        float4 af[TM], bf[TN];                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);     \
+            }                                                                                               \
+    }
+
+// one K-step: LDS[cur] holds step s, set S holds step s+1 (raw), set L is free.
+#define FAV_STEP(L, S, do_load_, do_store_)                                                                 \
+    {                                                                                                       \
+        const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;                      \
+        const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;                      \
+        if (do_load_) FAV_LOAD_STEP(L, s + 2);                                                              \
+        FAV_MFMA_GROUP(0); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 0);                                   \
+        FAV_MFMA_GROUP(1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1);                                   \
+        FAV_MFMA_GROUP(2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2);                                   \
+        FAV_MFMA_GROUP(3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3);                                   \
+        __syncthreads();                                                                                    \
+        cur ^= 1; ++s;                                                                                      \
+    }
+    static_assert(AROWS == 4 && BROWS <= 4 && BK == 32, "store chunks are tied to the 4 MFMA groups of a K-step");
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -136,43 +189,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    FAV_LOAD_STEP(0);
-    __syncthreads();          // affine tables visible
-    FAV_STORE_STEP(0);
-    __syncthreads();
-
     // fragment read bases: lane l supplies row (l&31) and the k pair {r, 4+r} selected by (l>>5)
     const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
-    int cur = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) FAV_LOAD_STEP(s + 1);
-        const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;
-        const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + kk * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more) FAV_STORE_STEP(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    int cur = 0, s = 0;
+
+    FAV_LOAD_STEP(0, 0);
+    __syncthreads();          // affine tables visible
+    FAV_STORE_CHUNK(0, 0, 0); FAV_STORE_CHUNK(0, 0, 1); FAV_STORE_CHUNK(0, 0, 2); FAV_STORE_CHUNK(0, 0, 3);
+    if (nsteps > 1) FAV_LOAD_STEP(1, 1);
+    __syncthreads();
+
+    while (s + 3 < nsteps) {          // steady state: no guards, two steps per trip (register sets swap roles)
+        FAV_STEP(0, 1, true, true);
+        FAV_STEP(1, 0, true, true);
     }
+    if (s < nsteps) FAV_STEP(0, 1, s + 2 < nsteps, s + 1 < nsteps);
+    if (s < nsteps) FAV_STEP(1, 0, s + 2 < nsteps, s + 1 < nsteps);
+    if (s < nsteps) FAV_STEP(0, 1, s + 2 < nsteps, s + 1 < nsteps);
 
 #undef FAV_LOAD_STEP
-#undef FAV_STORE_STEP
+#undef FAV_STORE_CHUNK
+#undef FAV_MFMA_GROUP
+#undef FAV_STEP
     // ---------------------------------------------------------------- epilogue
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col = lane & 31, rbase = 4 * (lane >> 5);
@@ -485,6 +523,8 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     FAV_REQUIRE(c.COUTp % 32 == 0 && c.Kpad % BK == 0, "conv: COUTp=%d / Kpad=%d not tile aligned", c.COUTp, c.Kpad);
     FAV_REQUIRE(c.Kpad >= c.KH * c.KW * c.CIN, "conv: Kpad too small");
     FAV_REQUIRE(c.ups == 0 || c.ups == 1, "conv: upsample factor must be 1 or 2");
+    FAV_REQUIRE((long long)((c.IH >> c.ups) + 1) * c.IWp * c.CIN < (1ll << 31) && (long long)c.COUTp * c.Kpad < (1ll << 31),
+                "conv: tensor too large for 32-bit element offsets");
     ConvArgs a;
     a.in = c.in; a.wgt = c.wgt; a.bias = c.bias;
     a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
