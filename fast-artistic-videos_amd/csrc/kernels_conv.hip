@@ -12,9 +12,11 @@
 // filter tap) is one contiguous 128-byte line.  GEMM view: M = output pixels, N = output channels,
 // K = taps * Cin.
 //
-// Tiling: 256 threads = 4 waves (64 lanes each).  Block tile 128 (M) x BN (N) x 32 (K), LDS
-// double-buffered [rows][36] (row stride 36 floats makes the 16-byte fragment reads conflict-free),
-// register-staged global->LDS copies issued one K-step ahead of the MFMAs.
+// Tiling: 4 or 8 waves of 64 lanes.  Block tile 128 (M) x BN (N) x 32 (K), LDS double-buffered
+// [rows][36] (row stride 36 floats makes the 16-byte fragment reads conflict-free), register-staged
+// global->LDS copies issued two K-steps ahead and written to LDS in chunks interleaved with the MFMAs.
+#include <cstdlib>
+
 #include "fav_internal.h"
 
 namespace fav {
@@ -35,6 +37,7 @@ struct ConvArgs {
     int IH, IW, IWp, ups, CIN;
     int COUT, COUTp, KH, KW, stride, pad, Kpad, OH, OW;
     int stages, relu1, relu2, final_mode;
+    int cin_shift, kw_magic;
     float tanh_mul;
 };
 
@@ -57,12 +60,14 @@ __device__ __forceinline__ float4 affine4(float4 v, const float* sc, const float
     return v;
 }
 
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
+template <int BN, int WM, int WN, int ABL = 0>   // ABL: ablation variants for tuning (FAV_ABL env), 0 = product kernel
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs p)
 {
+    constexpr int NT = 64 * WM * WN;           // threads per block (4 or 8 waves)
+    constexpr int RP = NT / 8;                 // tile rows staged per pass (8 threads x 16 B per 32-wide K slice)
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;
-    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int AROWS = BM / RP, BROWS = (BN + RP - 1) / RP;
+    static_assert(BM % RP == 0 && (BN % RP == 0 || BN < RP), "staging layout");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][BM*LDSS]
     float* Bs = smem + 2 * BM * LDSS;         // [2][BN*LDSS]
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
 
     // transform tables: always two stages in the loop (identity = scale 1, shift 0, no ReLU floor), so the
     // K loop carries no data-dependent or uniform branches and the scheduler can interleave it with the MFMAs
-    for (int i = t; i < CIN; i += 256) {
+    for (int i = t; i < CIN; i += NT) {
         aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
         aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
     }
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     bool rv[AROWS];
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = mblock * BM + r0 + 32 * i;
+        const int m = mblock * BM + r0 + RP * i;
         rv[i] = m < M;
         const int mm = rv[i] ? m : 0;
         const int oy = mm / p.OW, ox = mm - oy * p.OW;
@@ -116,47 +121,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     bool va0[AROWS], va1[AROWS];
     int ci0 = 0, ci1 = 0;
 
-// global -> registers (set X) for K-step s_: raw values, transform applied when they are written to LDS
-#define FAV_LOAD_STEP(X, s_)                                                                                \
+// tap decomposition for K-step s_ and this thread's 16-byte chunk.  CIN is a power of two (checked on the
+// host), so k -> (tap, ci) is a shift; when CIN >= 32 the tap is the same for the whole K slice and the
+// compiler keeps it in scalar registers.  tap -> (ky, kx) uses a 16.16 reciprocal of KW (exact for tap < 4096).
+#define FAV_TAP_SETUP(X, s_)                                                                                \
+    int ky##X, kx##X; bool tv##X;                                                                           \
     {                                                                                                       \
-        const int kb_ = (s_) * BK + c4 * 4;                                                                 \
-        const int tap_ = kb_ / CIN;                                                                         \
-        const int ci_ = kb_ - tap_ * CIN;                                                                   \
-        const int ky_ = tap_ / p.KW, kx_ = tap_ - ky_ * p.KW;                                               \
-        const bool tv_ = tap_ < ntaps;                                                                      \
-        ci##X = ci_;                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < AROWS; ++i) {                                                 \
-            const int iy_ = iy0[i] + ky_, ix_ = ix0[i] + kx_;                                               \
-            va##X[i] = rv[i] & tv_ & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW);   \
-            const int off_ = va##X[i] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci_ : 0;          \
-            ra##X[i] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */          \
-        }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < BROWS; ++j)                                                   \
-            rb##X[j] = *reinterpret_cast<const v4f*>(wrow + (32 * j) * p.Kpad + (s_) * BK);                 \
+        const int kb_ = (s_) * BK + (p.cin_shift >= 5 ? 0 : c4 * 4);                                        \
+        const int tap_ = kb_ >> p.cin_shift;                                                                \
+        ci##X = ((s_) * BK + c4 * 4) & (CIN - 1);                                                           \
+        ky##X = (tap_ * p.kw_magic) >> 16; kx##X = tap_ - ky##X * p.KW;                                     \
+        tv##X = tap_ < ntaps;                                                                               \
     }
+// global -> registers (set X), chunk q_ of 4: A row q_ and B row q_ of K-step s_ (raw values; the transform
+// is applied when they are written to LDS)
+#define FAV_LOAD_CHUNK(X, s_, q_)                                                                           \
+    if (ABL != 1 && ABL != 2 && ABL != 3) {                                                                 \
+        if ((q_) < AROWS) {                                                                                 \
+            constexpr int i_ = (q_) < AROWS ? (q_) : 0;                                                     \
+            const int iy_ = iy0[i_] + ky##X, ix_ = ix0[i_] + kx##X;                                         \
+            va##X[i_] = rv[i_] & tv##X & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+            const int off_ = (ABL == 6 || ABL == 7) ? (lane & 7) * 4 : (va##X[i_] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci##X : 0); \
+            ra##X[i_] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */         \
+        }                                                                                                   \
+        if ((q_) < BROWS) {                                                                                 \
+            constexpr int j_ = (q_) < BROWS ? (q_) : 0;                                                     \
+            if (BN >= RP || r0 < BN) rb##X[j_] = *reinterpret_cast<const v4f*>((ABL == 6 || ABL == 8) ? p.wgt + (lane & 7) * 4 : wrow + (RP * j_) * p.Kpad + (s_) * BK); \
+        }                                                                                                   \
+    }
+#define FAV_LOAD_STEP(X, s_)                                                                                \
+    { FAV_TAP_SETUP(X, s_); FAV_LOAD_CHUNK(X, s_, 0); FAV_LOAD_CHUNK(X, s_, 1); FAV_LOAD_CHUNK(X, s_, 2); FAV_LOAD_CHUNK(X, s_, 3); }
 
 // registers (set X) -> LDS buffer buf_, chunk q_ of 4: A row q_ (pending transform of the producer: IN
 // scale/shift [+ReLU], up to two stages; then zero for padding / out-of-range rows) and B row q_
 #define FAV_STORE_CHUNK(X, buf_, q_)                                                                        \
-    {                                                                                                       \
+    if (ABL != 2 && ABL != 3) {                                                                             \
         if ((q_) < AROWS) {                                                                                 \
             float4 v_ = ra##X[(q_) < AROWS ? (q_) : 0];                                                     \
             v_ = affine4_lo(v_, aff + ci##X, aff + CIN + ci##X, lo1);                                       \
             v_ = affine4_lo(v_, aff + 2 * CIN + ci##X, aff + 3 * CIN + ci##X, lo2);                         \
             const float m_ = va##X[(q_) < AROWS ? (q_) : 0] ? 1.f : 0.f;                                    \
             v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_;                                                 \
-            *reinterpret_cast<float4*>(As + (buf_) * BM * LDSS + (r0 + 32 * (q_)) * LDSS + c4 * 4) = v_;    \
+            *reinterpret_cast<float4*>(As + (buf_) * BM * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = v_;    \
         }                                                                                                   \
-        if ((q_) < BROWS)                                                                                   \
-            *reinterpret_cast<v4f*>(Bs + (buf_) * BN * LDSS + (r0 + 32 * (q_)) * LDSS + c4 * 4) = rb##X[(q_) < BROWS ? (q_) : 0]; \
+        if ((q_) < BROWS && (BN >= RP || r0 < BN))                                                          \
+            *reinterpret_cast<v4f*>(Bs + (buf_) * BN * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = rb##X[(q_) < BROWS ? (q_) : 0]; \
     }
 
 // one group of MFMAs: fragment step kk_ of the current LDS buffer
 #define FAV_MFMA_GROUP(kk_)                                                                                 \
     {                                                                                                       \
         float4 af[TM], bf[TN];                                                                              \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = ABL == 3 ? make_float4(1.f + i, 2.f, 3.f, 4.f + (kk_)) : *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = ABL == 3 ? make_float4(1.f, 2.f + j, 3.f, 4.f) : *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);     \
@@ -171,15 +188,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     {                                                                                                       \
         const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;                      \
         const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;                      \
-        if (do_load_) FAV_LOAD_STEP(L, s + 2);                                                              \
-        FAV_MFMA_GROUP(0); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 0);                                   \
-        FAV_MFMA_GROUP(1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1);                                   \
-        FAV_MFMA_GROUP(2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2);                                   \
-        FAV_MFMA_GROUP(3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3);                                   \
-        __syncthreads();                                                                                    \
+        FAV_TAP_SETUP(L, s + 2);                                                                            \
+        FAV_MFMA_GROUP(0); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 0); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 0); \
+        FAV_MFMA_GROUP(1); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1); \
+        FAV_MFMA_GROUP(2); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2); \
+        FAV_MFMA_GROUP(3); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3); \
+        if (ABL != 4) __syncthreads();                                                                      \
         cur ^= 1; ++s;                                                                                      \
     }
-    static_assert(AROWS == 4 && BROWS <= 4 && BK == 32, "store chunks are tied to the 4 MFMA groups of a K-step");
+    static_assert(AROWS <= 4 && BROWS <= 4 && BK == 32, "store chunks are tied to the 4 MFMA groups of a K-step");
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -208,6 +225,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     if (s < nsteps) FAV_STEP(0, 1, s + 2 < nsteps, s + 1 < nsteps);
 
 #undef FAV_LOAD_STEP
+#undef FAV_LOAD_CHUNK
+#undef FAV_TAP_SETUP
 #undef FAV_STORE_CHUNK
 #undef FAV_MFMA_GROUP
 #undef FAV_STEP
@@ -299,19 +318,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p)
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int ABL = 0>
 int launch_conv_t(const ConvArgs& a, hipStream_t st)
 {
     const int M = a.OH * a.OW;
-    const size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
+    size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
+    if (ABL == 5) lds = 100 * 1024;      // force one block per CU
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN>),
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     dim3 grid((M + BM - 1) / BM, a.COUTp / BN);
-    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, ABL>), grid, dim3(64 * WM * WN), lds, st, a);
     FAV_LAUNCH_CHECK("conv_mfma_kernel");
     return FAV_OK;
 }
@@ -523,6 +543,8 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     FAV_REQUIRE(c.COUTp % 32 == 0 && c.Kpad % BK == 0, "conv: COUTp=%d / Kpad=%d not tile aligned", c.COUTp, c.Kpad);
     FAV_REQUIRE(c.Kpad >= c.KH * c.KW * c.CIN, "conv: Kpad too small");
     FAV_REQUIRE(c.ups == 0 || c.ups == 1, "conv: upsample factor must be 1 or 2");
+    FAV_REQUIRE((c.CIN & (c.CIN - 1)) == 0, "conv: the channel pitch %d must be a power of two", c.CIN);
+    FAV_REQUIRE(c.KH * c.KW < 4096, "conv: kernel too large");
     FAV_REQUIRE((long long)((c.IH >> c.ups) + 1) * c.IWp * c.CIN < (1ll << 31) && (long long)c.COUTp * c.Kpad < (1ll << 31),
                 "conv: tensor too large for 32-bit element offsets");
     ConvArgs a;
@@ -534,7 +556,24 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN;
     a.COUT = c.COUT; a.COUTp = c.COUTp; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
     a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
-    if (c.COUTp % 128 == 0) return launch_conv_t<128, 2, 2>(a, st);
+    a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;
+    if (c.COUTp % 128 == 0) {
+        static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;     // tuning only: results are wrong for abl != 0,5
+        switch (abl) {
+        case 1: return launch_conv_t<128, 2, 2, 1>(a, st);
+        case 2: return launch_conv_t<128, 2, 2, 2>(a, st);
+        case 3: return launch_conv_t<128, 2, 2, 3>(a, st);
+        case 4: return launch_conv_t<128, 2, 2, 4>(a, st);
+        case 5: return launch_conv_t<128, 2, 2, 5>(a, st);
+        case 6: return launch_conv_t<128, 2, 2, 6>(a, st);
+        case 7: return launch_conv_t<128, 2, 2, 7>(a, st);
+        case 8: return launch_conv_t<128, 2, 2, 8>(a, st);
+        case 10: return launch_conv_t<128, 4, 2>(a, st);      // 8 waves: 32x64 per wave
+        case 11: return launch_conv_t<128, 2, 4>(a, st);      // 8 waves: 64x32 per wave
+        case 12: return launch_conv_t<128, 2, 2>(a, st);      // 4 waves: 64x64 per wave
+        default: return launch_conv_t<128, 4, 2>(a, st);     // product: 8 waves, 4 per SIMD with two blocks per CU
+        }
+    }
     if (c.COUTp % 64 == 0) return launch_conv_t<64, 2, 2>(a, st);
     return launch_conv_t<32, 4, 1>(a, st);
 }
