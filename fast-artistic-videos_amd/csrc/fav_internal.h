@@ -90,7 +90,12 @@ struct ConvLaunch {
     float tanh_mul = 1.f;
     float* out_planar = nullptr;    // [3][OH][OW] RGB  (deprocessed)   or null
     float* out_raw_nchw = nullptr;  // [3][OH][OW] BGR  (150*tanh)      or null
+    // stream-K hand-off state (conv_streamk_workspace_bytes() floats, conv_streamk_grid() flags, a launch-unique
+    // epoch > 0); null => plain data-parallel launch
+    float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;
 };
+size_t conv_streamk_workspace_bytes();
+int conv_streamk_grid();
 constexpr int CONV_BM = 128;
 inline int conv_mblocks(int OH, int OW) { return (OH * OW + CONV_BM - 1) / CONV_BM; }
 int launch_conv(const ConvLaunch& p, hipStream_t st);

@@ -37,8 +37,9 @@ struct ConvArgs {
     int IH, IW, IWp, ups, CIN;
     int COUT, COUTp, KH, KW, stride, pad, Kpad, OH, OW;
     int stages, relu1, relu2, final_mode;
-    int cin_shift, kw_magic;
+    int cin_shift, kw_magic, ntaps_magic;
     float tanh_mul;
+    float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;     // stream-K hand-off (null = data-parallel)
 };
 
 // branch-free form used inside the MFMA loop: lo = 0 for ReLU, -inf for none; identity = scale 1, shift 0
@@ -60,14 +61,24 @@ __device__ __forceinline__ float4 affine4(float4 v, const float* sc, const float
     return v;
 }
 
-template <int BN, int WM, int WN, int ABL = 0>   // ABL: ablation variants for tuning (FAV_ABL env), 0 = product kernel
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs p)
+// One kernel, two work distributions:
+//   SK = false  data-parallel: one block per output tile (grid = m-tiles x n-tiles);
+//   SK = true   stream-K: a fixed grid (2 blocks per CU) splits the flattened (tile, K-step) space evenly.
+//               A block's range is [tail of a tile shared with the previous block][whole tiles][head of a
+//               tile shared with the next block].  The block holding the HEAD (k = 0) of a split tile owns its
+//               epilogue and runs it LAST in its own timeline; the blocks holding the remaining K ranges
+//               write their partial accumulators FIRST in their timelines, publish a flag (agent-scope
+//               release), and the owner picks them up after an agent-scope acquire.  This removes the
+//               "515 tiles on 512 slots" quantisation that cost the residual layers ~20 %.
+template <int BN, int WM, int WN, int ABL = 0, bool SK = false>   // ABL: tuning ablations (FAV_ABL env), 0 = product
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfma_kernel(const ConvArgs p)   // 2 blocks per CU
 {
     constexpr int NT = 64 * WM * WN;           // threads per block (4 or 8 waves)
     constexpr int RP = NT / 8;                 // tile rows staged per pass (8 threads x 16 B per 32-wide K slice)
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AROWS = BM / RP, BROWS = (BN + RP - 1) / RP;
     static_assert(BM % RP == 0 && (BN % RP == 0 || BN < RP), "staging layout");
+    static_assert(AROWS <= 4 && BROWS <= 4 && BK == 32, "load/store chunks are tied to the 4 MFMA groups of a K-step");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [2][BM*LDSS]
     float* Bs = smem + 2 * BM * LDSS;         // [2][BN*LDSS]
@@ -75,16 +86,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (observed; used for L2 locality only).
-    // Give every XCD a contiguous range of M tiles so the 3x3/9x9 halo rows of neighbouring tiles hit its L2.
-    int mblock;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        mblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int nblock = blockIdx.y;
     const int M = p.OH * p.OW;
     const int CIN = p.CIN;
+    const int ntaps = p.KH * p.KW;
+    const int nsteps = p.Kpad / BK;
+    const int mtiles = (M + BM - 1) / BM, ntiles = p.COUTp / BN;
+
+    // XCD-aware block order: the dispatcher places block b on XCD b % 8 (observed; used for L2 locality only).
+    // Give every XCD a contiguous range of logical blocks so the halo rows of neighbouring tiles hit its L2
+    // (and stream-K hand-offs mostly stay inside one XCD).
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
 
     // transform tables: always two stages in the loop (identity = scale 1, shift 0, no ReLU floor), so the
     // K loop carries no data-dependent or uniform branches and the scheduler can interleave it with the MFMAs
@@ -94,135 +109,155 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
+    __syncthreads();
 
-    // per-thread staging assignment: row r0 + 32*i of the tile, 16-byte chunk c4 of the 32-wide K slice
+    // per-thread staging assignment: row r0 + RP*i of the tile, 16-byte chunk c4 of the 32-wide K slice
     const int c4 = t & 7, r0 = t >> 3;
-    int iy0[AROWS], ix0[AROWS];
-    bool rv[AROWS];
-#pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-        const int m = mblock * BM + r0 + RP * i;
-        rv[i] = m < M;
-        const int mm = rv[i] ? m : 0;
-        const int oy = mm / p.OW, ox = mm - oy * p.OW;
-        iy0[i] = oy * p.stride - p.pad;
-        ix0[i] = ox * p.stride - p.pad;
-    }
-    const int ntaps = p.KH * p.KW;
-    const int nsteps = p.Kpad / BK;
-    const float* wrow = p.wgt + (size_t)(nblock * BN + r0) * p.Kpad + c4 * 4;
+    // fragment read bases: lane l supplies row (l&31) and the k pair {r, 4+r} selected by (l>>5)
+    const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
+    // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
 
-    // Two register sets: while the MFMAs of step s run, the global loads of step s+2 are in flight (set L)
-    // and the data of step s+1 (set S, loaded one step earlier) is transformed and written to the other
-    // LDS buffer in four chunks interleaved with the four MFMA groups, so that VALU / LDS-store work
-    // executes in the shadow of the 64-cycle matrix instructions instead of in a phase of its own.
-    float4 ra0[AROWS], ra1[AROWS];
-    v4f rb0[BROWS], rb1[BROWS];
-    bool va0[AROWS], va1[AROWS];
-    int ci0 = 0, ci1 = 0;
+    long long u = 0, u_end = nsteps;
+    if (SK) {
+        const long long U = (long long)mtiles * ntiles * nsteps;
+        u = U * lb / gridDim.x; u_end = U * (lb + 1) / gridDim.x;
+    }
+
+    while (u < u_end) {
+        int mblock, nblock, k0 = 0, k1 = nsteps;
+        if (SK) {
+            const int tl = (int)(u / nsteps);
+            k0 = (int)(u - (long long)tl * nsteps);
+            k1 = (int)(u_end - u) < nsteps - k0 ? k0 + (int)(u_end - u) : nsteps;
+            mblock = tl / ntiles; nblock = tl - mblock * ntiles;
+        } else {
+            mblock = lb; nblock = blockIdx.y;
+        }
+        u += k1 - k0;
+
+        int iy0[AROWS], ix0[AROWS];
+        bool rv[AROWS];
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int m = mblock * BM + r0 + RP * i;
+            rv[i] = m < M;
+            const int mm = rv[i] ? m : 0;
+            const int oy = mm / p.OW, ox = mm - oy * p.OW;
+            iy0[i] = oy * p.stride - p.pad;
+            ix0[i] = ox * p.stride - p.pad;
+        }
+        const float* wrow = p.wgt + (size_t)(nblock * BN + r0) * p.Kpad + c4 * 4;
+
+        // Two register sets: while the MFMAs of step s run, the global loads of step s+2 are in flight (set L)
+        // and the data of step s+1 (set S, loaded one step earlier) is transformed and written to the other
+        // LDS buffer in chunks interleaved with the four MFMA groups, so that VALU / LDS-store work executes
+        // in the shadow of the 64-cycle matrix instructions instead of in a phase of its own.
+        float4 ra0[AROWS], ra1[AROWS];
+        v4f rb0[BROWS], rb1[BROWS];
+        bool va0[AROWS], va1[AROWS];
+        int ci0 = 0, ci1 = 0;
 
 // tap decomposition for K-step s_ and this thread's 16-byte chunk.  CIN is a power of two (checked on the
-// host), so k -> (tap, ci) is a shift; when CIN >= 32 the tap is the same for the whole K slice and the
-// compiler keeps it in scalar registers.  tap -> (ky, kx) uses a 16.16 reciprocal of KW (exact for tap < 4096).
+// host), so k -> (tap, ci) is a shift; tap -> (ky, kx) uses a 16.16 reciprocal of KW (exact for tap < 4096).
 #define FAV_TAP_SETUP(X, s_)                                                                                \
-    int ky##X, kx##X; bool tv##X;                                                                           \
-    {                                                                                                       \
-        const int kb_ = (s_) * BK + (p.cin_shift >= 5 ? 0 : c4 * 4);                                        \
-        const int tap_ = kb_ >> p.cin_shift;                                                                \
-        ci##X = ((s_) * BK + c4 * 4) & (CIN - 1);                                                           \
-        ky##X = (tap_ * p.kw_magic) >> 16; kx##X = tap_ - ky##X * p.KW;                                     \
-        tv##X = tap_ < ntaps;                                                                               \
-    }
+        int ky##X, kx##X; bool tv##X;                                                                       \
+        {                                                                                                   \
+            int tap_;                                                                                       \
+            if (p.cin_shift >= 5) {       /* K order (channel slice, tap, 32 ch): consecutive steps re-read  */ \
+                const int cs_ = ((s_) * p.ntaps_magic) >> 16;   /* the same lines shifted by one tap (L1 reuse) */ \
+                tap_ = (s_) - cs_ * ntaps;                                                                  \
+                ci##X = cs_ * BK + c4 * 4;                                                                  \
+            } else {                      /* K order (tap, ci): several taps per 32-wide slice               */ \
+                const int kb_ = (s_) * BK + c4 * 4;                                                         \
+                tap_ = kb_ >> p.cin_shift;                                                                  \
+                ci##X = kb_ & (CIN - 1);                                                                    \
+            }                                                                                               \
+            ky##X = (tap_ * p.kw_magic) >> 16; kx##X = tap_ - ky##X * p.KW;                                 \
+            tv##X = tap_ < ntaps;                                                                           \
+        }
 // global -> registers (set X), chunk q_ of 4: A row q_ and B row q_ of K-step s_ (raw values; the transform
 // is applied when they are written to LDS)
 #define FAV_LOAD_CHUNK(X, s_, q_)                                                                           \
-    if (ABL != 1 && ABL != 2 && ABL != 3) {                                                                 \
-        if ((q_) < AROWS) {                                                                                 \
-            constexpr int i_ = (q_) < AROWS ? (q_) : 0;                                                     \
-            const int iy_ = iy0[i_] + ky##X, ix_ = ix0[i_] + kx##X;                                         \
-            va##X[i_] = rv[i_] & tv##X & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
-            const int off_ = (ABL == 6 || ABL == 7) ? (lane & 7) * 4 : (va##X[i_] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci##X : 0); \
-            ra##X[i_] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */         \
-        }                                                                                                   \
-        if ((q_) < BROWS) {                                                                                 \
-            constexpr int j_ = (q_) < BROWS ? (q_) : 0;                                                     \
-            if (BN >= RP || r0 < BN) rb##X[j_] = *reinterpret_cast<const v4f*>((ABL == 6 || ABL == 8) ? p.wgt + (lane & 7) * 4 : wrow + (RP * j_) * p.Kpad + (s_) * BK); \
-        }                                                                                                   \
-    }
+        if (ABL != 1 && ABL != 2 && ABL != 3) {                                                             \
+            if ((q_) < AROWS) {                                                                             \
+                constexpr int i_ = (q_) < AROWS ? (q_) : 0;                                                 \
+                const int iy_ = iy0[i_] + ky##X, ix_ = ix0[i_] + kx##X;                                     \
+                va##X[i_] = rv[i_] & tv##X & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+                const int off_ = va##X[i_] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci##X : 0;   \
+                ra##X[i_] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */     \
+            }                                                                                               \
+            if ((q_) < BROWS) {                                                                             \
+                constexpr int j_ = (q_) < BROWS ? (q_) : 0;                                                 \
+                if (BN >= RP || r0 < BN) rb##X[j_] = *reinterpret_cast<const v4f*>(wrow + (RP * j_) * p.Kpad + (s_) * BK); \
+            }                                                                                               \
+        }
 #define FAV_LOAD_STEP(X, s_)                                                                                \
-    { FAV_TAP_SETUP(X, s_); FAV_LOAD_CHUNK(X, s_, 0); FAV_LOAD_CHUNK(X, s_, 1); FAV_LOAD_CHUNK(X, s_, 2); FAV_LOAD_CHUNK(X, s_, 3); }
-
+        { FAV_TAP_SETUP(X, s_); FAV_LOAD_CHUNK(X, s_, 0); FAV_LOAD_CHUNK(X, s_, 1); FAV_LOAD_CHUNK(X, s_, 2); FAV_LOAD_CHUNK(X, s_, 3); }
 // registers (set X) -> LDS buffer buf_, chunk q_ of 4: A row q_ (pending transform of the producer: IN
-// scale/shift [+ReLU], up to two stages; then zero for padding / out-of-range rows) and B row q_
+// scale/shift [+ReLU], two stages; then zero for padding / out-of-range rows) and B row q_
 #define FAV_STORE_CHUNK(X, buf_, q_)                                                                        \
-    if (ABL != 2 && ABL != 3) {                                                                             \
-        if ((q_) < AROWS) {                                                                                 \
-            float4 v_ = ra##X[(q_) < AROWS ? (q_) : 0];                                                     \
-            v_ = affine4_lo(v_, aff + ci##X, aff + CIN + ci##X, lo1);                                       \
-            v_ = affine4_lo(v_, aff + 2 * CIN + ci##X, aff + 3 * CIN + ci##X, lo2);                         \
-            const float m_ = va##X[(q_) < AROWS ? (q_) : 0] ? 1.f : 0.f;                                    \
-            v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_;                                                 \
-            *reinterpret_cast<float4*>(As + (buf_) * BM * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = v_;    \
-        }                                                                                                   \
-        if ((q_) < BROWS && (BN >= RP || r0 < BN))                                                          \
-            *reinterpret_cast<v4f*>(Bs + (buf_) * BN * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = rb##X[(q_) < BROWS ? (q_) : 0]; \
-    }
-
+        if (ABL != 2 && ABL != 3) {                                                                         \
+            if ((q_) < AROWS) {                                                                             \
+                float4 v_ = ra##X[(q_) < AROWS ? (q_) : 0];                                                 \
+                v_ = affine4_lo(v_, aff + ci##X, aff + CIN + ci##X, lo1);                                   \
+                v_ = affine4_lo(v_, aff + 2 * CIN + ci##X, aff + 3 * CIN + ci##X, lo2);                     \
+                const float m_ = va##X[(q_) < AROWS ? (q_) : 0] ? 1.f : 0.f;                                \
+                v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_;                                             \
+                *reinterpret_cast<float4*>(As + (buf_) * BM * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = v_; \
+            }                                                                                               \
+            if ((q_) < BROWS && (BN >= RP || r0 < BN))                                                      \
+                *reinterpret_cast<v4f*>(Bs + (buf_) * BN * LDSS + (r0 + RP * (q_)) * LDSS + c4 * 4) = rb##X[(q_) < BROWS ? (q_) : 0]; \
+        }
 // one group of MFMAs: fragment step kk_ of the current LDS buffer
 #define FAV_MFMA_GROUP(kk_)                                                                                 \
-    {                                                                                                       \
-        float4 af[TM], bf[TN];                                                                              \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = ABL == 3 ? make_float4(1.f + i, 2.f, 3.f, 4.f + (kk_)) : *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = ABL == 3 ? make_float4(1.f, 2.f + j, 3.f, 4.f) : *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);     \
-            }                                                                                               \
-    }
-
+        {                                                                                                   \
+            float4 af[TM], bf[TN];                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = ABL == 3 ? make_float4(1.f + i, 2.f, 3.f, 4.f + (kk_)) : *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = ABL == 3 ? make_float4(1.f, 2.f + j, 3.f, 4.f) : *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                           \
+        }
 // one K-step: LDS[cur] holds step s, set S holds step s+1 (raw), set L is free.
 #define FAV_STEP(L, S, do_load_, do_store_)                                                                 \
-    {                                                                                                       \
-        const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;                      \
-        const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;                      \
-        FAV_TAP_SETUP(L, s + 2);                                                                            \
-        FAV_MFMA_GROUP(0); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 0); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 0); \
-        FAV_MFMA_GROUP(1); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1); \
-        FAV_MFMA_GROUP(2); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2); \
-        FAV_MFMA_GROUP(3); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3); \
-        if (ABL != 4) __syncthreads();                                                                      \
-        cur ^= 1; ++s;                                                                                      \
-    }
-    static_assert(AROWS <= 4 && BROWS <= 4 && BK == 32, "store chunks are tied to the 4 MFMA groups of a K-step");
+        {                                                                                                   \
+            const float* a_base = As + cur * BM * LDSS + (wm * TM * 32) * LDSS + frag_off;                  \
+            const float* b_base = Bs + cur * BN * LDSS + (wn * TN * 32) * LDSS + frag_off;                  \
+            FAV_TAP_SETUP(L, s + 2);                                                                        \
+            FAV_MFMA_GROUP(0); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 0); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 0); \
+            FAV_MFMA_GROUP(1); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1); \
+            FAV_MFMA_GROUP(2); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2); \
+            FAV_MFMA_GROUP(3); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3); \
+            if (ABL != 4) __syncthreads();                                                                  \
+            cur ^= 1; ++s;                                                                                  \
+        }
 
-    f32x16 acc[TM][TN];
+        f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read bases: lane l supplies row (l&31) and the k pair {r, 4+r} selected by (l>>5)
-    const int frag_off = (lane & 31) * LDSS + (lane >> 5) * 4;
-    int cur = 0, s = 0;
+        int cur = 0, s = k0;
+        FAV_LOAD_STEP(0, k0);
+        FAV_STORE_CHUNK(0, 0, 0); FAV_STORE_CHUNK(0, 0, 1); FAV_STORE_CHUNK(0, 0, 2); FAV_STORE_CHUNK(0, 0, 3);
+        if (k0 + 1 < k1) FAV_LOAD_STEP(1, k0 + 1);
+        __syncthreads();
 
-    FAV_LOAD_STEP(0, 0);
-    __syncthreads();          // affine tables visible
-    FAV_STORE_CHUNK(0, 0, 0); FAV_STORE_CHUNK(0, 0, 1); FAV_STORE_CHUNK(0, 0, 2); FAV_STORE_CHUNK(0, 0, 3);
-    if (nsteps > 1) FAV_LOAD_STEP(1, 1);
-    __syncthreads();
-
-    while (s + 3 < nsteps) {          // steady state: no guards, two steps per trip (register sets swap roles)
-        FAV_STEP(0, 1, true, true);
-        FAV_STEP(1, 0, true, true);
-    }
-    if (s < nsteps) FAV_STEP(0, 1, s + 2 < nsteps, s + 1 < nsteps);
-    if (s < nsteps) FAV_STEP(1, 0, s + 2 < nsteps, s + 1 < nsteps);
-    if (s < nsteps) FAV_STEP(0, 1, s + 2 < nsteps, s + 1 < nsteps);
+        while (s + 3 < k1) {          // steady state: no guards, two steps per trip (register sets swap roles)
+            FAV_STEP(0, 1, true, true);
+            FAV_STEP(1, 0, true, true);
+        }
+        if (s < k1) FAV_STEP(0, 1, s + 2 < k1, s + 1 < k1);
+        if (s < k1) FAV_STEP(1, 0, s + 2 < k1, s + 1 < k1);
+        if (s < k1) FAV_STEP(0, 1, s + 2 < k1, s + 1 < k1);
 
 #undef FAV_LOAD_STEP
 #undef FAV_LOAD_CHUNK
@@ -230,95 +265,153 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 #undef FAV_STORE_CHUNK
 #undef FAV_MFMA_GROUP
 #undef FAV_STEP
-    // ---------------------------------------------------------------- epilogue
-    // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
-    const int m_wave = mblock * BM + wm * TM * 32;
-    const int n_wave = nblock * BN + wn * TN * 32;
 
-    if (p.final_mode) {
-        const float mean3[3] = {103.939f, 116.779f, 123.68f};   // preprocess.lua:48 (BGR)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n_wave + j * 32 + col;
-            if (n >= p.COUT || n >= 3) continue;
-            const float bv = p.bias[n];
+        // ------------------------------------------------------------ stream-K hand-off
+        constexpr int NV4 = TM * TN * 4;                     // float4 per thread in a partial tile
+        if (SK && k0 > 0) {
+            // contributor: dump the partial accumulators, publish (agent-scope release), next segment
+            float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                    if (m >= M) continue;
-                    const float v = tanhf(acc[i][j][r] + bv) * p.tanh_mul;           // models_video.lua:135-136
-                    if (p.out_raw) p.out_raw[(size_t)n * M + m] = v;
-                    if (p.out_planar) p.out_planar[(size_t)(2 - n) * M + m] = (v + mean3[n]) / 255.f;  // preprocess.lua:66-71
-                }
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        slot[(size_t)((i * TN + j) * 4 + q) * NT] =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
         }
-        return;
-    }
+        if (SK && k1 < nsteps) {
+            // owner of a split tile: the remaining K ranges were computed by the following logical blocks at
+            // the very start of their timelines; wait for each (one lane polls, relaxed), acquire, accumulate
+            const long long U = (long long)mtiles * ntiles * nsteps;
+            int covered = k1;
+            for (int nb = lb + 1; covered < nsteps && nb < (int)gridDim.x; ++nb) {
+                const long long nu0 = U * nb / gridDim.x, nu1 = U * (nb + 1) / gridDim.x;
+                const int span = (int)((nu1 - nu0) < (long long)(nsteps - covered) ? (nu1 - nu0) : (nsteps - covered));
+                if (t == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 26)) break;          // bounded: a wrong tile beats a hung GPU
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const float4* slot = reinterpret_cast<const float4*>(p.sk_ws) + (size_t)nb * NV4 * NT + t;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = slot[(size_t)((i * TN + j) * 4 + q) * NT];
+                            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                        }
+                covered += span;
+            }
+        }
 
-    float* red = smem;               // [WM][BN] (LDS is free again: the K loop ended on a barrier)
-    float* mean_s = smem + WM * BN;  // [BN]
-    const int cnt = min(BM, M - mblock * BM);
-    float lsum[TN];
+        // ------------------------------------------------------------ epilogue
+        const int m_wave = mblock * BM + wm * TM * 32;
+        const int n_wave = nblock * BN + wn * TN * 32;
+        if (p.final_mode) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n_wave + j * 32 + col;
-        const float bv = p.bias[n];
-        float s = 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_wave + j * 32 + col;
+                if (n < p.COUT && n < 3) {
+                    const float bv = p.bias[n];
+                    const float mean = n == 0 ? 103.939f : (n == 1 ? 116.779f : 123.68f);      // preprocess.lua:48 (BGR)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                const float v = acc[i][j][r] + bv;
-                acc[i][j][r] = v;
-                if (m < M) {
-                    if (n < p.COUT) p.out[(size_t)m * p.COUT + n] = v;
-                    s += v;
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                            if (m < M) {
+                                const float v = tanhf(acc[i][j][r] + bv) * p.tanh_mul;          // models_video.lua:135-136
+                                if (p.out_raw) p.out_raw[(size_t)n * M + m] = v;
+                                if (p.out_planar) p.out_planar[(size_t)(2 - n) * M + m] = (v + mean) / 255.f;  // preprocess.lua:66-71
+                            }
+                        }
                 }
             }
-        lsum[j] = s;
-    }
-    if (p.partials == nullptr) return;
+        } else {
+            float* red = smem;               // [WM][BN] (LDS is free again: the K loop ended on a barrier)
+            float* mean_s = smem + WM * BN;  // [BN]
+            const int cnt = min(BM, M - mblock * BM);
+            float lsum[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float s = lsum[j] + __shfl_xor(lsum[j], 32);
-        if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = s;
-    }
-    __syncthreads();
-    if (t < BN) {
-        float s = 0.f;
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_wave + j * 32 + col;
+                const float bv = p.bias[n];
+                float sm = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) s += red[w * BN + t];
-        mean_s[t] = s / (float)cnt;
-    }
-    __syncthreads();
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float mu = mean_s[(wn * TN + j) * 32 + col];
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                const float d = acc[i][j][r] - mu;
-                if (m < M) q = fmaf(d, d, q);
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                        const float v = acc[i][j][r] + bv;
+                        acc[i][j][r] = v;
+                        if (m < M) {
+                            if (n < p.COUT) p.out[(size_t)m * p.COUT + n] = v;
+                            sm += v;
+                        }
+                    }
+                lsum[j] = sm;
             }
-        q += __shfl_xor(q, 32);
-        if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = q;
-    }
-    __syncthreads();
-    if (t < BN) {
-        float q = 0.f;
+            if (p.partials != nullptr) {
 #pragma unroll
-        for (int w = 0; w < WM; ++w) q += red[w * BN + t];
-        p.partials[(size_t)mblock * p.COUTp + nblock * BN + t] = make_float2(mean_s[t], q);
+                for (int j = 0; j < TN; ++j) {
+                    const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
+                    if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = sm;
+                }
+                __syncthreads();
+                if (t < BN) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) sm += red[w * BN + t];
+                    mean_s[t] = sm / (float)cnt;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float mu = mean_s[(wn * TN + j) * 32 + col];
+                    float q = 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = m_wave + i * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                            const float d = acc[i][j][r] - mu;
+                            if (m < M) q = fmaf(d, d, q);
+                        }
+                    q += __shfl_xor(q, 32);
+                    if (lane < 32) red[wm * BN + (wn * TN + j) * 32 + lane] = q;
+                }
+                __syncthreads();
+                if (t < BN) {
+                    float q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) q += red[w * BN + t];
+                    p.partials[(size_t)mblock * p.COUTp + nblock * BN + t] = make_float2(mean_s[t], q);
+                }
+            }
+        }
+        if (SK) __syncthreads();         // LDS scratch of the epilogue vs the next segment's staging
     }
 }
 
-template <int BN, int WM, int WN, int ABL = 0>
+constexpr int SK_GRID = 512;            // stream-K grid: 2 blocks on each of the 256 CUs, all co-resident
+
+template <int BN, int WM, int WN, int ABL = 0, bool SK = false>
 int launch_conv_t(const ConvArgs& a, hipStream_t st)
 {
     const int M = a.OH * a.OW;
@@ -326,17 +419,35 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
     if (ABL == 5) lds = 100 * 1024;      // force one block per CU
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, ABL>),
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, ABL, SK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     dim3 grid((M + BM - 1) / BM, a.COUTp / BN);
-    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, ABL>), grid, dim3(64 * WM * WN), lds, st, a);
+    if (SK) {
+        // every stream-K block must be resident (owners wait for later blocks): size the grid from the occupancy
+        // the runtime reports for this instantiation, capped at the 2 blocks per CU the hand-off buffers are sized for
+        static int sk_blocks = 0;
+        if (!sk_blocks) {
+            int occ = 0, dev = 0; hipDeviceProp_t prop;
+            FAV_HIP(hipGetDevice(&dev));
+            FAV_HIP(hipGetDeviceProperties(&prop, dev));
+            FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, ABL, SK>, 64 * WM * WN, lds));
+            if (occ < 1) { set_error("stream-K conv: kernel does not fit on a CU"); return FAV_EHIP; }
+            sk_blocks = (occ >= 2 ? 2 : 1) * prop.multiProcessorCount;
+            if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
+        }
+        grid = dim3(sk_blocks, 1);
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, ABL, SK>), grid, dim3(64 * WM * WN), lds, st, a);
     FAV_LAUNCH_CHECK("conv_mfma_kernel");
     return FAV_OK;
 }
 
 }  // namespace
+
+size_t conv_streamk_workspace_bytes() { return (size_t)SK_GRID * BM * 128 * sizeof(float); }
+int conv_streamk_grid() { return SK_GRID; }
 
 // ------------------------------------------------------------------------------------------------
 // Last layer (c9s1-3: 64 -> 3 channels, 9x9): "row-folded" implicit GEMM.
@@ -557,9 +668,18 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.COUT = c.COUT; a.COUTp = c.COUTp; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
     a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
     a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;
+    a.ntaps_magic = (65536 + c.KH * c.KW - 1) / (c.KH * c.KW);
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch;
+    static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;   // tuning only: results are wrong for 1-4,6-8
+    // stream-K when the tile count is within a few waves of the 512 resident blocks (imbalance matters there)
+    const long long tiles = (long long)((c.OH * c.OW + BM - 1) / BM) * (c.COUTp / (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));
+    const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && abl != 13 && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID &&
+                    c.Kpad / BK >= 4;
     if (c.COUTp % 128 == 0) {
-        static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;     // tuning only: results are wrong for abl != 0,5
         switch (abl) {
+        case 21: if (sk) return launch_conv_t<128, 2, 2, 1, true>(a, st); break;
+        case 22: if (sk) return launch_conv_t<128, 2, 2, 2, true>(a, st); break;
+        case 23: if (sk) return launch_conv_t<128, 2, 2, 3, true>(a, st); break;
         case 1: return launch_conv_t<128, 2, 2, 1>(a, st);
         case 2: return launch_conv_t<128, 2, 2, 2>(a, st);
         case 3: return launch_conv_t<128, 2, 2, 3>(a, st);
@@ -568,13 +688,21 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
         case 6: return launch_conv_t<128, 2, 2, 6>(a, st);
         case 7: return launch_conv_t<128, 2, 2, 7>(a, st);
         case 8: return launch_conv_t<128, 2, 2, 8>(a, st);
-        case 10: return launch_conv_t<128, 4, 2>(a, st);      // 8 waves: 32x64 per wave
-        case 11: return launch_conv_t<128, 2, 4>(a, st);      // 8 waves: 64x32 per wave
         case 12: return launch_conv_t<128, 2, 2>(a, st);      // 4 waves: 64x64 per wave
-        default: return launch_conv_t<128, 4, 2>(a, st);     // product: 8 waves, 4 per SIMD with two blocks per CU
+        default: break;
         }
+        // product: 8 waves (32x64 per wave), 4 waves per SIMD with two blocks per CU
+        // product: stream-K with 4-wave blocks (64x64 per wave, no spills at 2 blocks/CU); FAV_SK=1 selects the
+        // 8-wave stream-K instance, FAV_SK=0 the data-parallel 8-wave instance (measured: 177.8 / 179.8 / 182.2 us)
+        static const int skmode = getenv("FAV_SK") ? atoi(getenv("FAV_SK")) : 2;
+        if (sk && skmode == 1) return launch_conv_t<128, 4, 2, 0, true>(a, st);
+        if (sk && skmode == 2) return launch_conv_t<128, 2, 2, 0, true>(a, st);
+        return launch_conv_t<128, 4, 2>(a, st);
     }
-    if (c.COUTp % 64 == 0) return launch_conv_t<64, 2, 2>(a, st);
+    if (c.COUTp % 64 == 0) {
+        static const int skmode = getenv("FAV_SK") ? atoi(getenv("FAV_SK")) : 2;
+        return (sk && skmode) ? launch_conv_t<64, 2, 2, 0, true>(a, st) : launch_conv_t<64, 2, 2>(a, st);
+    }
     return launch_conv_t<32, 4, 1>(a, st);
 }
 

@@ -50,16 +50,21 @@ int dev_upload(const std::vector<float>& h, size_t pad_to, float** out)
     return FAV_OK;
 }
 
-// repack [cout][cin][k][k] -> [coutp][kpad] with k-index = (ky*k + kx)*cinp + ci (channels-last taps)
+// repack [cout][cin][k][k] -> [coutp][kpad].  K order of the implicit GEMM (must match FAV_TAP_SETUP):
+//   cinp >= 32: k = ((ci/32)*taps + tap)*32 + ci%32   (channel slice outermost: consecutive K-steps shift by one tap)
+//   cinp <  32: k = tap*cinp + ci                     (several taps per 32-wide K slice)
 void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<float>& out)
 {
     out.assign((size_t)coutp * kpad, 0.f);
+    const int taps = L.k * L.k;
     for (int co = 0; co < L.cout; ++co)
         for (int ci = 0; ci < L.cin; ++ci)
             for (int ky = 0; ky < L.k; ++ky)
-                for (int kx = 0; kx < L.k; ++kx)
-                    out[(size_t)co * kpad + (size_t)(ky * L.k + kx) * cinp + ci] =
-                        L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+                for (int kx = 0; kx < L.k; ++kx) {
+                    const int tap = ky * L.k + kx;
+                    const size_t k = cinp >= 32 ? ((size_t)(ci / 32) * taps + tap) * 32 + ci % 32 : (size_t)tap * cinp + ci;
+                    out[(size_t)co * kpad + k] = L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+                }
 }
 
 bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul)
@@ -84,6 +89,7 @@ struct fav_net {
     std::vector<DevConvW> convs;  // traversal order
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
+    float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -103,7 +109,7 @@ struct fav_net {
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
-        (void)hipFree(ones); (void)hipFree(zeros);
+        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags);
     }
     int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
     int upload();
@@ -180,7 +186,11 @@ int fav_net::upload()
     int rc = upload_layers(layers, chan, maxc); if (rc) return rc;
     std::vector<float> o((size_t)maxc, 1.f), z((size_t)maxc, 0.f);
     rc = dev_upload(o, 0, &ones); if (rc) return rc;
-    return dev_upload(z, 0, &zeros);
+    rc = dev_upload(z, 0, &zeros); if (rc) return rc;
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_ws), conv_streamk_workspace_bytes()));
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_flags), conv_streamk_grid() * sizeof(unsigned)));
+    FAV_HIP(hipMemset(sk_flags, 0, conv_streamk_grid() * sizeof(unsigned)));
+    return FAV_OK;
 }
 
 int fav_net::alloc(size_t bytes, float** out)
@@ -201,7 +211,10 @@ int fav_net::alloc(size_t bytes, float** out)
 int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
     const float* wfold = (c.final_mode && !getenv("FAV_NO_FOLD")) ? convs[conv_index].wfold : nullptr;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : launch_conv(c, st); };
+    ConvLaunch cs = c;
+    cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
+    if (sk_epoch == 0xffffffffu) sk_epoch = 0;
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : launch_conv(cs, st); };
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
