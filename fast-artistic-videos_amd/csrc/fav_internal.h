@@ -104,7 +104,13 @@ bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride);
 int launch_conv_fold(const ConvLaunch& p, const float* wfold, hipStream_t st);
 
 // per-channel finalize of (mean, M2) partials -> scale/shift:  scale = gamma/sqrt(var+eps)
-int launch_in_finalize(const float* partials, int mblocks, int M, int block_pixels, int C, int Cpitch,
+// first layer (8-channel input pitch, 9x9): LDS-resident halo + weights, persistent blocks; partial statistics are
+// per 16x16 tile with explicit counts
+bool conv_c8_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups);
+int conv_c8_tiles(int OH, int OW);
+int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
+// counts: per-partial pixel counts or null (then block b holds min(block_pixels, M - b*block_pixels) pixels)
+int launch_in_finalize(const float* partials, const int* counts, int mblocks, int M, int block_pixels, int C, int Cpitch,
                        const float* gamma, const float* beta, float eps,
                        float* scale, float* shift, hipStream_t st);
 // statistics of t(x) over an NHWC tensor [M][C] -> partials [ceil(M/128)][C] float2

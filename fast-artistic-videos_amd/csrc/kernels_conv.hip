@@ -450,6 +450,188 @@ size_t conv_streamk_workspace_bytes() { return (size_t)SK_GRID * BM * 128 * size
 int conv_streamk_grid() { return SK_GRID; }
 
 // ------------------------------------------------------------------------------------------------
+// First layer (c9s1-32: 7(+1) -> 32 channels, 9x9, stride 1): LDS-resident halo + LDS-resident weights.
+// With 8 input channels a filter tap is exactly one k=8 MFMA quad, and the generic kernel would re-gather
+// the operand 81 times from global memory.  Here a persistent block (8 waves, one per CU) keeps all
+// 32 x 648 weights in LDS, stages the (16+8) x (16+8) pixel halo of a 16x16 output tile once (as two planes
+// of 4 channels so that the 16-byte fragment reads are conflict-free), and runs the 81 taps straight out of
+// LDS with immediate-offset ds_read_b128: no global loads, LDS stores or barriers inside the tap loop.  The
+// next tile's halo is prefetched into registers during the tap loop.  Epilogue: bias, NHWC store, per-tile
+// InstanceNorm partials (mean, M2, count).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int C8_T = 16;                  // output tile edge (16 x 16 pixels = 8 waves x 32)
+
+struct C8Args {
+    const float* in; const float* wgt; const float* bias;
+    float* out; float2* partials; int* counts;
+    int IH, IW, IWp, COUT, pad, OH, OW, Kpad, tiles_x, tiles_y;
+};
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
+{
+    constexpr int HW = C8_T + KS - 1;             // halo edge (24)
+    constexpr int HP = HW * HW;                   // halo pixels (576)
+    constexpr int NTAP = KS * KS;
+    constexpr int WS = NTAP * 8 + 4;              // weight row stride (floats): odd multiple of 16 B
+    constexpr int NH = (HP * 2 + 511) / 512;      // float4 per thread per halo
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;                             // [32][WS]
+    float* Hs = Ws + 32 * WS;                     // [2 buffers][2 planes][HP][4]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // weights -> LDS once per block ([n][tap*8 + ci], rows >= COUT are zero in the repacked tensor)
+    for (int e = t; e < 32 * NTAP * 2; e += 512) {
+        const int n = e / (NTAP * 2), c = e - n * (NTAP * 2);
+        *reinterpret_cast<v4f*>(Ws + n * WS + c * 4) = *reinterpret_cast<const v4f*>(p.wgt + (size_t)n * p.Kpad + c * 4);
+    }
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    float4 hreg[NH];
+#define C8_LOAD_HALO(tile_)                                                                         \
+    {                                                                                               \
+        const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
+        _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                            \
+            const int e_ = t + 512 * i;                                                             \
+            const int pix_ = e_ >> 1, hy_ = pix_ / HW, hx_ = pix_ - hy_ * HW;                       \
+            const int iy_ = ty_ * C8_T - p.pad + hy_, ix_ = tx_ * C8_T - p.pad + hx_;               \
+            const bool v_ = (e_ < HP * 2) & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+            const int off_ = v_ ? (iy_ * p.IWp + ix_) * 8 + (e_ & 1) * 4 : 0;                       \
+            const float4 x_ = *reinterpret_cast<const float4*>(p.in + off_);                        \
+            hreg[i] = v_ ? x_ : make_float4(0.f, 0.f, 0.f, 0.f);                                    \
+        }                                                                                           \
+    }
+#define C8_STORE_HALO(buf_)                                                                         \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                            \
+            const int e_ = t + 512 * i;                                                             \
+            if (e_ < HP * 2) *reinterpret_cast<float4*>(Hs + (((buf_) * 2 + (e_ & 1)) * HP + (e_ >> 1)) * 4) = hreg[i]; \
+        }                                                                                           \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) C8_LOAD_HALO(tile);
+    C8_STORE_HALO(0);
+    __syncthreads();
+
+    const int m = lane & 31, half = lane >> 5;
+    const int py = 2 * wave + (m >> 4), px = m & 15;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float* red = Hs + 4 * HP * 4;                 // [8 waves][32] + [32] scratch after the halo buffers
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) C8_LOAD_HALO(nxt);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* a_base = Hs + ((cur * 2 + half) * HP + py * HW + px) * 4;
+        const float* b_base = Ws + m * WS + half * 4;
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const float4 af = *reinterpret_cast<const float4*>(a_base + (ky * HW + kx) * 4);
+            const float4 bf = *reinterpret_cast<const float4*>(b_base + tap * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+        if (nxt < ntiles) C8_STORE_HALO(cur ^ 1);
+
+        // epilogue: rows of the MFMA tile are pixels (2 tile rows x 16 columns of this wave), columns are channels
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const float bv = p.bias[col];
+        float sm = 0.f;
+        int nvalid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mi = (r & 3) + 8 * (r >> 2) + rbase;
+            const int oy = ty * C8_T + 2 * wave + (mi >> 4), ox = tx * C8_T + (mi & 15);
+            const float v = acc[r] + bv;
+            acc[r] = v;
+            if (oy < p.OH && ox < p.OW) {
+                if (col < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + col] = v;
+                sm += v; ++nvalid;
+            }
+        }
+        if (p.partials != nullptr) {
+            const int vh = min(C8_T, p.OH - ty * C8_T), vw = min(C8_T, p.OW - tx * C8_T);
+            const int cnt = vh * vw;
+            sm += __shfl_xor(sm, 32);
+            if (lane < 32) red[wave * 32 + lane] = sm;
+            __syncthreads();
+            if (t < 32) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
+                red[256 + t] = a / (float)cnt;
+            }
+            __syncthreads();
+            const float mu = red[256 + col];
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mi = (r & 3) + 8 * (r >> 2) + rbase;
+                const int oy = ty * C8_T + 2 * wave + (mi >> 4), ox = tx * C8_T + (mi & 15);
+                const float d = acc[r] - mu;
+                if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+            }
+            q += __shfl_xor(q, 32);
+            __syncthreads();
+            if (lane < 32) red[wave * 32 + lane] = q;
+            __syncthreads();
+            if (t < 32) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
+                p.partials[(size_t)tile * 32 + t] = make_float2(red[256 + t], a);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+        }
+        (void)nvalid;
+        __syncthreads();            // next halo buffer written by every thread; red scratch free again
+        cur ^= 1;
+    }
+#undef C8_LOAD_HALO
+#undef C8_STORE_HALO
+}
+
+}  // namespace
+
+bool conv_c8_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups)
+{
+    return cin_pitch == 8 && coutp == 32 && k == 9 && stride == 1 && stages == 0 && ups == 0;
+}
+int conv_c8_tiles(int OH, int OW) { return ((OH + C8_T - 1) / C8_T) * ((OW + C8_T - 1) / C8_T); }
+
+int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv_c8_eligible(c.CIN, c.COUTp, c.KH, c.stride, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode,
+                "first-layer conv: not eligible");
+    FAV_REQUIRE(c.Kpad >= 81 * 8 && (long long)c.IH * c.IWp * 8 < (1ll << 31), "first-layer conv: bad shape");
+    C8Args a;
+    a.in = c.in; a.wgt = c.wgt; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
+    a.tiles_x = (c.OW + C8_T - 1) / C8_T; a.tiles_y = (c.OH + C8_T - 1) / C8_T;
+    constexpr int HWc = C8_T + 8, WSc = 81 * 8 + 4;
+    const size_t lds = (size_t)(32 * WSc + 4 * HWc * HWc * 4 + 8 * 32 + 32) * sizeof(float);
+    static int nblocks = 0;
+    if (!nblocks) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int dev = 0; hipDeviceProp_t prop;
+        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
+        nblocks = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_c8_kernel<9>), dim3(tiles < nblocks ? tiles : nblocks), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_c8_kernel");
+    return FAV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last layer (c9s1-3: 64 -> 3 channels, 9x9): "row-folded" implicit GEMM.
 // With only 3 output channels a pixels x channels GEMM would waste 29/32 of every MFMA.  Instead the
 // kx taps are folded into the N dimension: for one output row y
@@ -724,7 +906,7 @@ __device__ double block_sum_d(double v, double* sh)
     return r;
 }
 
-__global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials, int mblocks, int M, int bp,
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials, const int* counts, int mblocks, int M, int bp,
                                                           int Cpitch, const float* gamma, const float* beta,
                                                           float eps, float* scale, float* shift)
 {
@@ -732,13 +914,13 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0;
     for (int b = t; b < mblocks; b += 256) {
-        const int nb = min(bp, M - b * bp);
+        const int nb = counts ? counts[b] : min(bp, M - b * bp);
         s += (double)nb * (double)partials[(size_t)b * Cpitch + c].x;
     }
     const double mean = block_sum_d(s, sh) / (double)M;
     double q = 0;
     for (int b = t; b < mblocks; b += 256) {
-        const int nb = min(bp, M - b * bp);
+        const int nb = counts ? counts[b] : min(bp, M - b * bp);
         const float2 pr = partials[(size_t)b * Cpitch + c];
         const double d = (double)pr.x - mean;
         q += (double)pr.y + (double)nb * d * d;
@@ -869,10 +1051,10 @@ inline int grid_for(size_t total) { size_t b = (total + 255) / 256; return (int)
 
 }  // namespace
 
-int launch_in_finalize(const float* partials, int mblocks, int M, int block_pixels, int C, int Cpitch,
+int launch_in_finalize(const float* partials, const int* counts, int mblocks, int M, int block_pixels, int C, int Cpitch,
                        const float* gamma, const float* beta, float eps, float* scale, float* shift, hipStream_t st)
 {
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(C), dim3(256), 0, st, reinterpret_cast<const float2*>(partials),
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(C), dim3(256), 0, st, reinterpret_cast<const float2*>(partials), counts,
                        mblocks, M, block_pixels, Cpitch, gamma, beta, eps, scale, shift);
     FAV_LAUNCH_CHECK("in_finalize_kernel");
     return FAV_OK;

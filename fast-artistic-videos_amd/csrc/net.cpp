@@ -36,6 +36,7 @@ struct Act {
     Affine pre;                  // pending per-channel transform
     float* partials = nullptr;   // (mean, M2) tiles of the raw tensor from the producing conv, or null
     int mblocks = 0, ppitch = 0;
+    int* counts = nullptr;       // per-partial pixel counts (first-layer kernel) or null
     int H() const { return Hp << ups; }
     int W() const { return Wp << ups; }
 };
@@ -90,6 +91,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    bool use_c8 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -214,7 +216,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     ConvLaunch cs = c;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : launch_conv(cs, st); };
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(c, c8_counts, st) : launch_conv(cs, st)); };
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
@@ -224,7 +226,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    prof_tile[conv_index] = wfold ? 1 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32));
+    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));
     return rc;
 }
 
@@ -258,10 +260,14 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
             int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
-            nxt.mblocks = conv_mblocks(c.OH, c.OW); nxt.ppitch = d.coutp;
+            const bool c8 = conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !getenv("FAV_NO_C8");
+            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
+            if (want_stats && c8) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
+            c8_counts = c8 ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
+            use_c8 = false;
             cur = nxt;
             break;
         }
@@ -271,7 +277,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const int M = cur.Hp * cur.Wp;
             if (cur.data == nullptr || C != cur.C) { set_error("network: misplaced InstanceNormalization"); return FAV_EUNSUPPORTED; }
             if (cur.partials != nullptr && cur.pre.stages == 0) {
-                int rc = launch_in_finalize(cur.partials, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
+                int rc = launch_in_finalize(cur.partials, cur.counts, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
                                             d.scale, d.shift, st);
                 if (rc) return rc;
                 cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1;
@@ -283,11 +289,11 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 const int mb = (M + 127) / 128;
                 int rc = alloc((size_t)mb * C * 2 * sizeof(float), &part); if (rc) return rc;
                 rc = launch_stats(cur.data, M, C, cur.pre, part, st); if (rc) return rc;
-                rc = launch_in_finalize(part, mb, M, 128, C, C, d.gamma, d.beta, L.eps, d.scale, d.shift, st); if (rc) return rc;
+                rc = launch_in_finalize(part, nullptr, mb, M, 128, C, C, d.gamma, d.beta, L.eps, d.scale, d.shift, st); if (rc) return rc;
                 if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
                 else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             }
-            cur.partials = nullptr;
+            cur.partials = nullptr; cur.counts = nullptr;
             break;
         }
         case L_RELU:
@@ -521,7 +527,7 @@ extern "C" int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W, const
     if (!rc) rc = launch_conv(c, st);
     Affine t;
     if (!rc && gamma) {
-        rc = launch_in_finalize(dpart, mb, M, CONV_BM, Cout, coutp, gamma, beta, eps, dsc, dsh, st);
+        rc = launch_in_finalize(dpart, nullptr, mb, M, CONV_BM, Cout, coutp, gamma, beta, eps, dsc, dsh, st);
         t.scale1 = dsc; t.shift1 = dsh; t.relu1 = relu; t.stages = 1;
     }
     if (!rc) rc = launch_nhwc_to_nchw(dout, M, Cout, t, out, st);
