@@ -639,8 +639,8 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
 //                                                                               N = 3*9 = 27 -> 32,
 //                                                                               K = 9*64 = 576)
 //     out[y][x][c]  = sum_kx D[x+kx-p][(c,kx)]                                  (diagonal sum, done in LDS)
-// MFMA utilisation = 27/32 * 120/128 = 79 % instead of 9 %.  A block owns R = 8 output rows x 120 output
-// columns: every staged (transformed, nearest-upsampled) input row feeds up to 8 output rows with 8
+// MFMA utilisation = 27/32 * 120/128 = 79 % instead of 9 %.  A block (8 waves: 4 column groups x 2 row halves)
+// owns R = 8 output rows x 120 output columns: every staged (transformed, nearest-upsampled) input row feeds up to 8 output rows with 8
 // different ky weight slices, all 9 slices stay resident in LDS, and with x2 upsampling each physical
 // input row is staged once for its two logical rows.  Epilogue: bias, Tanh, MulConstant, VGG de-process.
 // ------------------------------------------------------------------------------------------------
@@ -659,10 +659,12 @@ struct FoldArgs {
 };
 
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
+__global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
 {
+    constexpr int NT = 512;                    // 8 waves: waves 0-3 own output rows 0-3, waves 4-7 rows 4-7 (same columns)
+    constexpr int RW = FOLD_R / 2;             // output rows per wave
     constexpr int S = CIN + 4;                 // LDS row stride (floats): odd multiple of 16 B -> conflict-free b128
-    constexpr int NV = CIN / 8;                // float4 per thread per staged row (2 threads per column)
+    constexpr int NV = CIN / 16;               // float4 per thread per staged row (4 threads per column)
     constexpr int KK = CIN / 8;                // fragment steps per row (8 k values each)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                          // [KH][32][S]
@@ -670,16 +672,19 @@ __global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
     float* aff = As + 2 * FOLD_M * S;          // [4][CIN]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wcol = wave & 3, wrow = wave >> 2;
     const int XO = FOLD_M - (p.KW - 1);        // output columns per block
     const int ox0 = blockIdx.x * XO, oy0 = blockIdx.y * FOLD_R;
     const int xs = ox0 - p.pad;                // first input column of the tile (may be negative)
 
-    if (p.stages >= 1)
-        for (int i = t; i < CIN; i += 256) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
-    if (p.stages >= 2)
-        for (int i = t; i < CIN; i += 256) { aff[2 * CIN + i] = p.scale2[i]; aff[3 * CIN + i] = p.shift2[i]; }
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
     // all ky weight slices -> LDS (wfold is [KH][32][CIN], zero rows for n >= COUT*KW)
-    for (int e = t; e < p.KH * 32 * (CIN / 4); e += 256) {
+    for (int e = t; e < p.KH * 32 * (CIN / 4); e += NT) {
         const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
         *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(p.wfold + (size_t)row * CIN + c4 * 4);
     }
@@ -687,11 +692,12 @@ __global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
     const int iy_lo = max(0, oy0 - p.pad), iy_hi = min(p.IH - 1, oy0 + FOLD_R - 1 + p.KH - 1 - p.pad);
     const int pr_lo = iy_lo >> p.ups, pr_hi = iy_hi >> p.ups;
 
-    // staging assignment: column xl = t>>1 of the tile, channel half (t&1)
-    const int xl = t >> 1, ch0 = (t & 1) * (CIN / 2);
+    // staging assignment: column xl = t>>2 of the tile, channel quarter (t&3)
+    const int xl = t >> 2, ch0 = (t & 3) * (CIN / 4);
     const int ix = xs + xl;
     const bool colv = ix >= 0 && ix < p.IW;
-    const size_t coloff = colv ? (size_t)(ix >> p.ups) * CIN + ch0 : 0;
+    const float colm = colv ? 1.f : 0.f;
+    const int coloff = colv ? (ix >> p.ups) * CIN + ch0 : 0;
     float4 ra[NV];
 
 #define FOLD_LOAD(pr_)                                                                              \
@@ -703,19 +709,16 @@ __global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
     {                                                                                               \
         float* dst_ = As + (buf_) * FOLD_M * S + xl * S + ch0;                                      \
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                            \
-            float4 v_ = ra[i];                                                                      \
-            if (p.stages >= 1) {                                                                    \
-                v_ = affine4(v_, aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, p.relu1);              \
-                if (p.stages >= 2) v_ = affine4(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, p.relu2); \
-            }                                                                                       \
-            if (!colv) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+            float4 v_ = affine4_lo(ra[i], aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, lo1);         \
+            v_ = affine4_lo(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, lo2);     \
+            v_.x *= colm; v_.y *= colm; v_.z *= colm; v_.w *= colm;                                 \
             *reinterpret_cast<float4*>(dst_ + 4 * i) = v_;                                          \
         }                                                                                           \
     }
 
-    f32x16 acc[FOLD_R];
+    f32x16 acc[RW];
 #pragma unroll
-    for (int y = 0; y < FOLD_R; ++y)
+    for (int y = 0; y < RW; ++y)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
 
@@ -729,17 +732,17 @@ __global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
     for (int pr = pr_lo; pr <= pr_hi; ++pr) {
         const bool more = pr < pr_hi;
         if (more) FOLD_LOAD(pr + 1);
-        const float* a_base = As + cur * FOLD_M * S + wave * 32 * S + frag;
+        const float* a_base = As + cur * FOLD_M * S + wcol * 32 * S + frag;
         const int iy_first = max(iy_lo, pr << p.ups), iy_last = min(iy_hi, ((pr + 1) << p.ups) - 1);
         for (int iy = iy_first; iy <= iy_last; ++iy) {
-            const int kyb = iy - oy0 + p.pad;          // ky for output row yy is kyb - yy
+            const int kyb = iy - oy0 + p.pad - wrow * RW;      // ky for this wave's output row yy is kyb - yy
 #pragma unroll 2
             for (int kk = 0; kk < KK; ++kk) {
                 const float4 af = *reinterpret_cast<const float4*>(a_base + kk * 8);
 #pragma unroll
-                for (int yy = 0; yy < FOLD_R; ++yy) {
+                for (int yy = 0; yy < RW; ++yy) {
                     const int ky = kyb - yy;
-                    if (ky >= 0 && ky < p.KH) {        // block-uniform
+                    if (ky >= 0 && ky < p.KH) {        // wave-uniform
                         const float4 bf = *reinterpret_cast<const float4*>(Bs + ky * 32 * S + frag + kk * 8);
                         acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[yy], 0, 0, 0);
                         acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[yy], 0, 0, 0);
@@ -760,16 +763,16 @@ __global__ __launch_bounds__(256) void conv_rowfold_kernel(const FoldArgs p)
     float* D = smem;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
 #pragma unroll
-    for (int yy = 0; yy < FOLD_R; ++yy)
+    for (int yy = 0; yy < RW; ++yy)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int xr = wave * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            D[(yy * FOLD_M + xr) * 33 + col] = acc[yy][r];
+            const int xr = wcol * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+            D[((wrow * RW + yy) * FOLD_M + xr) * 33 + col] = acc[yy][r];
         }
     __syncthreads();
     const size_t MO = (size_t)p.OH * p.OW;
     const int per_row = XO * p.COUT;
-    for (int e = t; e < FOLD_R * per_row; e += 256) {
+    for (int e = t; e < FOLD_R * per_row; e += NT) {
         const int yy = e / per_row, rem = e - yy * per_row;
         const int c = rem / XO, xo = rem - c * XO;
         const int oy = oy0 + yy, ox = ox0 + xo;
@@ -803,7 +806,7 @@ int launch_fold_t(const FoldArgs& a, hipStream_t st)
     }
     const int XO = FOLD_M - (a.KW - 1);
     dim3 grid((a.OW + XO - 1) / XO, (a.OH + FOLD_R - 1) / FOLD_R);
-    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), grid, dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_rowfold_kernel");
     return FAV_OK;
 }
