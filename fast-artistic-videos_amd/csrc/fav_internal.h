@@ -109,6 +109,10 @@ int launch_conv_fold(const ConvLaunch& p, const float* wfold, hipStream_t st);
 bool conv_c8_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups);
 int conv_c8_tiles(int OH, int OW);
 int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
+// 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
+bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
+int conv3_halo_tiles(int OH, int OW);
+int launch_conv3_halo(const ConvLaunch& p, int* counts, hipStream_t st);
 // counts: per-partial pixel counts or null (then block b holds min(block_pixels, M - b*block_pixels) pixels)
 int launch_in_finalize(const float* partials, const int* counts, int mblocks, int M, int block_pixels, int C, int Cpitch,
                        const float* gamma, const float* beta, float eps,

@@ -632,6 +632,311 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 layers (the ten 128->128 residual convolutions and c3s1-64: 71 % of the network's FLOPs):
+// halo-resident implicit GEMM.  The generic kernel re-gathers (and re-transforms) its activation operand
+// for every tap; measured, that global gather costs ~20 % of the kernel.  Here a block (8 waves, one per
+// CU, stream-K over all (tile, K-step) units) owns an 8 x 32 pixel output tile; for each 32-channel slice
+// the (8+2) x (32+2) pixel halo is gathered ONCE, transformed (producer's IN/ReLU stages, x2 nearest
+// upsample, zero padding) and kept in LDS, and the 9 taps read their A fragments straight from it with
+// conflict-free ds_read_b128 (a wave = one output row of 32 pixels, so the fragment rows are 32 consecutive
+// halo pixels).  Only the weight slice (BN x 32 per step) streams through LDS.  Global->LDS traffic per
+// MFMA drops 3x.  K order = (channel slice, tap, 32 channels): the same repacked weights as the generic
+// kernel.  Epilogue as the generic kernel (bias, NHWC store, per-tile IN partials with explicit counts).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int H3_TH = 8, H3_TW = 32;
+
+struct H3Args {
+    const float* in; const float* wgt; const float* bias;
+    const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+    float* out; float2* partials; int* counts;
+    float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;
+    int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
+    int stages, relu1, relu2;
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
+{
+    constexpr int NT = 512;
+    constexpr int HWD = H3_TW + 2, HP = (H3_TH + 2) * HWD;        // 34, 340 halo pixels
+    constexpr int TN = BN / 32;
+    constexpr int NHV = (HP * 8 + NT - 1) / NT;                   // float4 per thread per halo slice (6)
+    constexpr int BROWS = BN / 64;                                 // weight rows per thread per step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                           // [2][HP][LDSS]
+    float* Bs = Hs + 2 * HP * LDSS;             // [2][BN][LDSS]
+    float* aff = Bs + 2 * BN * LDSS;            // [4][CIN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int CIN = p.CIN;
+    const int nchunks = CIN >> 5, nsteps = nchunks * 9;
+    const int ntiles = p.tiles_x * p.tiles_y;
+
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int c4 = t & 7, r0 = t >> 3;                      // weight staging: row r0 (+64), 16-byte chunk c4
+    const int frag_k = (lane >> 5) * 4;                     // k pair {r, 4+r} by half-wave
+    const int m = lane & 31;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+
+    const int U = ntiles * nsteps;
+    int u = (int)((long long)U * lb / gridDim.x);
+    const int u_end = (int)((long long)U * (lb + 1) / gridDim.x);
+
+    while (u < u_end) {
+        const int tile = u / nsteps;
+        const int k0 = u - tile * nsteps;
+        const int k1 = (u_end - u) < nsteps - k0 ? k0 + (u_end - u) : nsteps;
+        u += k1 - k0;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int oy0 = ty * H3_TH, ox0 = tx * H3_TW;
+
+        // halo element assignment (fixed per tile): unit e = t + 512*i -> pixel e>>3, channel chunk e&7
+        int hoff[NHV]; float hmask[NHV];
+#pragma unroll
+        for (int i = 0; i < NHV; ++i) {
+            const int e = t + NT * i, pix = e >> 3;
+            const int hy = pix / HWD, hx = pix - hy * HWD;
+            const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+            const bool v = (e < HP * 8) & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+            hoff[i] = v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN + (e & 7) * 4 : 0;
+            hmask[i] = v ? 1.f : 0.f;
+        }
+        const float* wrow = p.wgt + (size_t)r0 * p.Kpad + c4 * 4;
+        float4 hr[NHV];
+        v4f rb[BROWS];
+
+#define H3_LOAD_HALO(chunk_)                                                                        \
+        { _Pragma("unroll") for (int i = 0; i < NHV; ++i) hr[i] = *reinterpret_cast<const float4*>(p.in + hoff[i] + (chunk_) * 32); }
+#define H3_STORE_HALO(buf_, chunk_)                                                                 \
+        { _Pragma("unroll") for (int i = 0; i < NHV; ++i) {                                         \
+            const int e_ = t + NT * i;                                                              \
+            const int ci_ = (chunk_) * 32 + (e_ & 7) * 4;                                           \
+            float4 v_ = affine4_lo(hr[i], aff + ci_, aff + CIN + ci_, lo1);                         \
+            v_ = affine4_lo(v_, aff + 2 * CIN + ci_, aff + 3 * CIN + ci_, lo2);                     \
+            v_.x *= hmask[i]; v_.y *= hmask[i]; v_.z *= hmask[i]; v_.w *= hmask[i];                 \
+            if (e_ < HP * 8) *reinterpret_cast<float4*>(Hs + ((buf_) * HP + (e_ >> 3)) * LDSS + (e_ & 7) * 4) = v_; \
+        } }
+#define H3_LOAD_B(s_)                                                                               \
+        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) rb[j] = *reinterpret_cast<const v4f*>(wrow + (64 * j) * p.Kpad + (s_) * BK); }
+#define H3_STORE_B(buf_)                                                                            \
+        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(Bs + ((buf_) * BN + r0 + 64 * j) * LDSS + c4 * 4) = rb[j]; }
+
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+        int cur = 0, hcur = 0;
+        {
+            const int c0 = (k0 * 7282) >> 16;               // k0 / 9 (exact for k0 < 4096)
+            H3_LOAD_HALO(c0); H3_LOAD_B(k0);
+            H3_STORE_HALO(0, c0); H3_STORE_B(0);
+        }
+        __syncthreads();
+
+        for (int s = k0; s < k1; ++s) {
+            const int c = (s * 7282) >> 16, tap = s - c * 9;
+            const int ky = (tap * 21846) >> 16, kx = tap - ky * 3;        // tap / 3
+            const bool first = (s == k0) | (tap == 0), last = (tap == 8) | (s == k1 - 1);
+            const bool next_chunk = (c + 1) * 9 < k1;
+            if (first && next_chunk) H3_LOAD_HALO(c + 1);
+            if (s + 1 < k1) H3_LOAD_B(s + 1);
+            const float* a_base = Hs + (hcur * HP + (wave + ky) * HWD + m + kx) * LDSS + frag_k;
+            const float* b_base = Bs + (cur * BN + m) * LDSS + frag_k;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float4 af = *reinterpret_cast<const float4*>(a_base + kk * 8);
+                float4 bf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + kk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[j].w, acc[j], 0, 0, 0);
+                }
+            }
+            if (s + 1 < k1) H3_STORE_B(cur ^ 1);
+            if (last && next_chunk) H3_STORE_HALO(hcur ^ 1, c + 1);
+            __syncthreads();
+            cur ^= 1;
+            if (tap == 8) hcur ^= 1;
+        }
+#undef H3_LOAD_HALO
+#undef H3_STORE_HALO
+#undef H3_LOAD_B
+#undef H3_STORE_B
+
+        // ------------------------------------------------------------ stream-K hand-off (see conv_mfma_kernel)
+        constexpr int NV4 = TN * 4;
+        if (k0 > 0) {
+            float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slot[(size_t)(j * 4 + q) * NT] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            continue;
+        }
+        if (k1 < nsteps) {
+            int covered = k1;
+            for (int nb = lb + 1; covered < nsteps && nb < (int)gridDim.x; ++nb) {
+                const int nu0 = (int)((long long)U * nb / gridDim.x), nu1 = (int)((long long)U * (nb + 1) / gridDim.x);
+                const int span = (nu1 - nu0) < (nsteps - covered) ? (nu1 - nu0) : (nsteps - covered);
+                if (t == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 26)) break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const float4* slot = reinterpret_cast<const float4*>(p.sk_ws) + (size_t)nb * NV4 * NT + t;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = slot[(size_t)(j * 4 + q) * NT];
+                        acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w;
+                    }
+                covered += span;
+            }
+        }
+
+        // ------------------------------------------------------------ epilogue: wave = output row, MFMA rows = columns
+        float* red = smem;                 // [8][BN] + [BN]   (the K loop ended on a barrier)
+        const int oy = oy0 + wave;
+        const int vh = min(H3_TH, p.OH - oy0), vw = min(H3_TW, p.OW - ox0);
+        const int cnt = vh * vw;
+        float lsum[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 32 + col;
+            const float bv = p.bias[n];
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                const float v = acc[j][r] + bv;
+                acc[j][r] = v;
+                if (oy < p.OH && ox < p.OW) {
+                    if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
+                    sm += v;
+                }
+            }
+            lsum[j] = sm;
+        }
+        if (p.partials != nullptr) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
+                if (lane < 32) red[wave * BN + j * 32 + lane] = sm;
+            }
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
+                red[8 * BN + t] = a / (float)cnt;
+            }
+            __syncthreads();
+            float lq[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float mu = red[8 * BN + j * 32 + col];
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                    const float d = acc[j][r] - mu;
+                    if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+                }
+                lq[j] = q + __shfl_xor(q, 32);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (lane < 32) red[wave * BN + j * 32 + lane] = lq[j];
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
+                p.partials[(size_t)tile * p.COUTp + t] = make_float2(red[8 * BN + t], a);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride)
+{
+    return k == 3 && stride == 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 && (coutp == 128 || coutp == 64);
+}
+int conv3_halo_tiles(int OH, int OW) { return ((OH + H3_TH - 1) / H3_TH) * ((OW + H3_TW - 1) / H3_TW); }
+
+int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv3_halo_eligible(c.CIN, c.COUTp, c.KH, c.stride) && c.KH == c.KW && !c.final_mode && c.sk_ws && c.sk_flags,
+                "halo conv: not eligible");
+    FAV_REQUIRE((long long)((c.IH >> c.ups) + 1) * c.IWp * c.CIN < (1ll << 31), "halo conv: tensor too large for 32-bit offsets");
+    H3Args a;
+    a.in = c.in; a.wgt = c.wgt; a.bias = c.bias;
+    a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
+    a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
+    a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
+    a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
+    a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
+    const int BNv = c.COUTp;
+    const size_t lds = (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 2 * BNv * LDSS + 4 * c.CIN) * sizeof(float);
+    static int nblocks = 0;
+    if (!nblocks) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int dev = 0; hipDeviceProp_t prop;
+        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
+        nblocks = prop.multiProcessorCount;          // one resident block per CU (LDS-limited): every stream-K block is resident
+        if (nblocks > SK_GRID) nblocks = SK_GRID;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = tiles * (c.CIN / 32) * 9 < nblocks ? 1 : nblocks;
+    if (BNv == 128) hipLaunchKernelGGL((conv3_halo_kernel<128>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3_halo_kernel<64>), dim3(grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv3_halo_kernel");
+    return FAV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last layer (c9s1-3: 64 -> 3 channels, 9x9): "row-folded" implicit GEMM.
 // With only 3 output channels a pixels x channels GEMM would waste 29/32 of every MFMA.  Instead the
 // kx taps are folded into the N dimension: for one output row y

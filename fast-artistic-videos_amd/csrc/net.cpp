@@ -91,7 +91,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
-    bool use_c8 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
+    bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -216,7 +216,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     ConvLaunch cs = c;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(c, c8_counts, st) : launch_conv(cs, st)); };
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(c, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : launch_conv(cs, st))); };
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
@@ -226,7 +226,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));
+    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 3 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32))));
     return rc;
 }
 
@@ -261,13 +261,14 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
             const bool c8 = conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !getenv("FAV_NO_C8");
-            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW); nxt.ppitch = d.coutp;
+            const bool h3 = conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !getenv("FAV_NO_H3");
+            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW)); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
-            if (want_stats && c8) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
+            if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
-            c8_counts = c8 ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8;
+            c8_counts = (c8 || h3) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
-            use_c8 = false;
+            use_c8 = false; use_h3 = false;
             cur = nxt;
             break;
         }
