@@ -453,7 +453,7 @@ int conv_streamk_grid() { return SK_GRID; }
 // First layer (c9s1-32: 7(+1) -> 32 channels, 9x9, stride 1): LDS-resident halo + LDS-resident weights.
 // With 8 input channels a filter tap is exactly one k=8 MFMA quad, and the generic kernel would re-gather
 // the operand 81 times from global memory.  Here a persistent block (8 waves, one per CU) keeps all
-// 32 x 648 weights in LDS, stages the (16+8) x (16+8) pixel halo of a 16x16 output tile once (as two planes
+// 32 x 648 weights in LDS, stages the (8+8) x (32+8) pixel halo of an 8x32 output tile once (as two planes
 // of 4 channels so that the 16-byte fragment reads are conflict-free), and runs the 81 taps straight out of
 // LDS with immediate-offset ds_read_b128: no global loads, LDS stores or barriers inside the tap loop.  The
 // next tile's halo is prefetched into registers during the tap loop.  Epilogue: bias, NHWC store, per-tile
@@ -461,7 +461,7 @@ int conv_streamk_grid() { return SK_GRID; }
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int C8_T = 16;                  // output tile edge (16 x 16 pixels = 8 waves x 32)
+constexpr int C8_TH = 8, C8_TW = 32;      // output tile: 8 rows x 32 columns, one row of 32 pixels per wave
 
 struct C8Args {
     const float* in; const float* wgt; const float* bias;
@@ -472,8 +472,8 @@ struct C8Args {
 template <int KS>
 __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
 {
-    constexpr int HW = C8_T + KS - 1;             // halo edge (24)
-    constexpr int HP = HW * HW;                   // halo pixels (576)
+    constexpr int HW = C8_TW + KS - 1;            // halo width (40)
+    constexpr int HP = (C8_TH + KS - 1) * HW;     // halo pixels (16 x 40 = 640)
     constexpr int NTAP = KS * KS;
     constexpr int WS = NTAP * 8 + 4;              // weight row stride (floats): odd multiple of 16 B
     constexpr int NH = (HP * 2 + 511) / 512;      // float4 per thread per halo
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
         _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                            \
             const int e_ = t + 512 * i;                                                             \
             const int pix_ = e_ >> 1, hy_ = pix_ / HW, hx_ = pix_ - hy_ * HW;                       \
-            const int iy_ = ty_ * C8_T - p.pad + hy_, ix_ = tx_ * C8_T - p.pad + hx_;               \
+            const int iy_ = ty_ * C8_TH - p.pad + hy_, ix_ = tx_ * C8_TW - p.pad + hx_;             \
             const bool v_ = (e_ < HP * 2) & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
             const int off_ = v_ ? (iy_ * p.IWp + ix_) * 8 + (e_ & 1) * 4 : 0;                       \
             const float4 x_ = *reinterpret_cast<const float4*>(p.in + off_);                        \
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
     __syncthreads();
 
     const int m = lane & 31, half = lane >> 5;
-    const int py = 2 * wave + (m >> 4), px = m & 15;
+    const int py = wave, px = m;                  // fragment rows = 32 consecutive halo pixels: conflict-free b128 reads
     const int col = lane & 31, rbase = 4 * (lane >> 5);
     float* red = Hs + 4 * HP * 4;                 // [8 waves][32] + [32] scratch after the halo buffers
     int cur = 0;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int mi = (r & 3) + 8 * (r >> 2) + rbase;
-            const int oy = ty * C8_T + 2 * wave + (mi >> 4), ox = tx * C8_T + (mi & 15);
+            const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
             const float v = acc[r] + bv;
             acc[r] = v;
             if (oy < p.OH && ox < p.OW) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
             }
         }
         if (p.partials != nullptr) {
-            const int vh = min(C8_T, p.OH - ty * C8_T), vw = min(C8_T, p.OW - tx * C8_T);
+            const int vh = min(C8_TH, p.OH - ty * C8_TH), vw = min(C8_TW, p.OW - tx * C8_TW);
             const int cnt = vh * vw;
             sm += __shfl_xor(sm, 32);
             if (lane < 32) red[wave * 32 + lane] = sm;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mi = (r & 3) + 8 * (r >> 2) + rbase;
-                const int oy = ty * C8_T + 2 * wave + (mi >> 4), ox = tx * C8_T + (mi & 15);
+                const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
                 const float d = acc[r] - mu;
                 if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
             }
@@ -605,7 +605,7 @@ bool conv_c8_eligible(int cin_pitch, int coutp, int k, int stride, int stages, i
 {
     return cin_pitch == 8 && coutp == 32 && k == 9 && stride == 1 && stages == 0 && ups == 0;
 }
-int conv_c8_tiles(int OH, int OW) { return ((OH + C8_T - 1) / C8_T) * ((OW + C8_T - 1) / C8_T); }
+int conv_c8_tiles(int OH, int OW) { return ((OH + C8_TH - 1) / C8_TH) * ((OW + C8_TW - 1) / C8_TW); }
 
 int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
 {
@@ -615,9 +615,9 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
     C8Args a;
     a.in = c.in; a.wgt = c.wgt; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
-    a.tiles_x = (c.OW + C8_T - 1) / C8_T; a.tiles_y = (c.OH + C8_T - 1) / C8_T;
-    constexpr int HWc = C8_T + 8, WSc = 81 * 8 + 4;
-    const size_t lds = (size_t)(32 * WSc + 4 * HWc * HWc * 4 + 8 * 32 + 32) * sizeof(float);
+    a.tiles_x = (c.OW + C8_TW - 1) / C8_TW; a.tiles_y = (c.OH + C8_TH - 1) / C8_TH;
+    constexpr int HPc = (C8_TH + 8) * (C8_TW + 8), WSc = 81 * 8 + 4;
+    const size_t lds = (size_t)(32 * WSc + 4 * HPc * 4 + 8 * 32 + 32) * sizeof(float);
     static int nblocks = 0;
     if (!nblocks) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
