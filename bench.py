@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--structure", type=int, default=0, help="1 = 4-argument (image-structure) checker mode")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
+                    "(fav_stream_prefetch_mask); default: on for --structure 1, off for the (7 us) 3-argument mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,6 +79,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.lookahead < 0:
+        args.lookahead = 1 if args.structure else 0
 
     # ---- weights: rank 0 parses the (synthetic, canonical-architecture) .t7 and broadcasts the packed blob
     ckpt = os.path.join(tempfile.gettempdir(), f"fav_bench_canonical_{os.getpid()}.t7")
@@ -102,9 +106,15 @@ def main():
 
     def step(i):
         k = i % ring
+        if args.lookahead:      # the masks of frames i+1, i+2 depend only on inputs that are already resident: queue them
+            k2 = (i + 2) % ring  # on the side queues BEFORE frame i's network so they overlap it (two in flight)
+            stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=bool(args.structure))
         stream.next_frame_flow(frames[k], bws[k], fws[k], use_structure=bool(args.structure), want_f32=False, out_u8=out8)
 
     stream.first_frame(frames[0], want_f32=False, out_u8=out8)
+    if args.lookahead:
+        stream.prefetch_mask(frames[0], bws[0], fws[0], use_structure=bool(args.structure))
+        stream.prefetch_mask(frames[1 % ring], bws[1 % ring], fws[1 % ring], use_structure=bool(args.structure))
     for i in range(args.warmup):
         step(i)
     net.profile_enable(True)
@@ -122,14 +132,48 @@ def main():
     prof = net.profile_read()
     dt = shard.max_over_ranks(dt, dev)
 
+    # not part of `value`: the same loop with the checker's 4-argument (image-structure) mode, which is what
+    # makeOptFlow_deepflow.sh:59 runs in production; its masks are computed two frames ahead on the side queues
+    extra = {}
+    if world == 1 and not args.structure:
+        def step4(i):
+            k2 = (i + 2) % ring
+            stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=True, want_f32=False, out_u8=out8)
+        stream.prefetch_mask(frames[0], bws[0], fws[0], use_structure=True)
+        stream.prefetch_mask(frames[1], bws[1], fws[1], use_structure=True)
+        for i in range(4):
+            step4(i)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        n4 = max(8, args.steps // 2)
+        for i in range(4, 4 + n4):
+            step4(i)
+        torch.cuda.synchronize()
+        extra["frames_per_s_4arg_structure_mode_lookahead"] = round(n4 / (time.perf_counter() - t1), 3)
+
     if rank == 0:
         fps = world * args.steps / dt
-        # roofline of the dominant kernel: the 128-wide implicit-GEMM instance (residual convs + d128), fp32 MFMA
-        dom = [(ms, n, macs) for (ms, n, macs, tile) in prof if tile == 128 and n > 0]
+        # roofline of the dominant kernel: the halo-resident 3x3 128->128 instance (the ten residual convolutions,
+        # 91.7 of the 152.8 GMAC per frame), fp32 MFMA.  achieved = useful FLOPs / HIP-event time of those launches.
+        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 428 and n > 0]
+        dom_name = "conv3_halo_kernel<128> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
+        if not dom:     # FAV_NO_H3: fall back to the generic 128-wide instance
+            dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 128 and n > 0]
+            dom_name = "conv_mfma_kernel<128,2,2,0,true> (3x3 128->128 residual convolutions + 64->128 stride-2)"
         flops = sum(2.0 * macs * n for ms, n, macs in dom); secs = sum(ms for ms, n, macs in dom) / 1e3
         nl = sum(n for ms, n, macs in dom)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
-        conv_ms = sum(ms for ms, n, macs, tile in prof) / max(1, args.steps)
+        conv_ms = sum(ms for ms, n, macs, kid in prof) / max(1, args.steps)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by scripts/gpu_pmc.sh from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "").startswith(dom_name.split(" ")[0]):
+                traffic = tj["hbm_bytes_per_launch"]
+        per_kernel = {}
+        for ms, n, macs, kid in prof:
+            if n:
+                k = per_kernel.setdefault(str(kid), [0.0, 0.0]); k[0] += ms / args.steps; k[1] += 2.0 * macs * n / args.steps
         line = {
             "metric": "stylized frames/sec end-to-end @1280x720", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -139,12 +183,15 @@ def main():
                                    "1 independent stream per GPU" % ("4-arg" if args.structure else "3-arg"),
                        "frame": [W, H], "streams": world, "parallelism": f"{world} independent streams, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_mfma_kernel<128,2,2> (3x3 128->128 residual convs + 64->128 stride-2)",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel": dom_name,
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
-                         "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None},
+                         "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None,
+                         "conv_stack_frac": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms > 0 else None,
+                         "per_kernel_ms_tflops": {k: [round(v[0], 4), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in per_kernel.items()}},
         }
+        line["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             layers = t7.extract_layers(t7.load(ckpt)["model"])
             line["cpu_baseline"] = cpu_baseline(layers, frames_h, bw_h[1], fw_h[1])

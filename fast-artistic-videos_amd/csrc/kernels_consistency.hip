@@ -99,7 +99,18 @@ __global__ __launch_bounds__(64) void iir_kernel(float* plane0, size_t plane_str
     float a1 = c.k * (m1 + c.pm * m0) + (c.a2 - c.e2) * a0;
     V1_(0) = a0; V1_(1) = a1;
     float mp = m1;
-    for (int x = 2; x < n; ++x) {
+    int x = 2;
+    for (; x + 8 <= n; x += 8) {          // loads are independent of the recurrence: fetch 8 samples, then run the chain
+        float mv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mv[q] = M_(x + q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float a = c.k * (mv[q] + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+            V1_(x + q) = a; a0 = a1; a1 = a; mp = mv[q];
+        }
+    }
+    for (; x < n; ++x) {
         const float mx = M_(x);
         const float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
         V1_(x) = a; a0 = a1; a1 = a; mp = mx;
@@ -113,10 +124,22 @@ __global__ __launch_bounds__(64) void iir_kernel(float* plane0, size_t plane_str
     M_(n - 1) = V1_(n - 1) + b1;
     M_(n - 2) = V1_(n - 2) + b0;
     // now b0 = v2(x+1), b1 = v2(x+2) for x = n-3; mo1 = m(x+1), mo2 = m(x+2)
-    for (int x = n - 3; x >= 0; --x) {
-        const float mx = M_(x);
+    int xb = n - 3;
+    for (; xb - 7 >= 0; xb -= 8) {
+        float mv[8], vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mv[q] = M_(xb - q); vv[q] = V1_(xb - q); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
+            M_(xb - q) = vv[q] + bv;
+            b1 = b0; b0 = bv; mo2 = mo1; mo1 = mv[q];
+        }
+    }
+    for (; xb >= 0; --xb) {
+        const float mx = M_(xb);
         const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-        M_(x) = V1_(x) + bv;
+        M_(xb) = V1_(xb) + bv;
         b1 = b0; b0 = bv; mo2 = mo1; mo1 = mx;
     }
 #undef M_
@@ -228,23 +251,135 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* v, size_t n, cons
     v[i] = x;
 }
 
-// CMatrix::avg: fp32 running sum in index order, then / size.  One wave: coalesced 64-wide loads,
-// the additions are serialised through lane order with readlane.
+// CMatrix::avg: fp32 running sum in index order, then / size (CMatrix.h:1245-1251).  The additions are inherently
+// sequential (each one rounds).  One wave runs the chain: 2048-element chunks are staged into LDS with coalesced loads
+// (prefetched a chunk ahead in registers), and the chain reads them back as broadcast float4s, so the only dependent
+// instruction per element is the v_add itself.  ~1.7 ms for 1280x720; it runs on the stream's side queue, overlapped with
+// the network of the previous frame.
 __global__ __launch_bounds__(64) void avg_kernel(const float* v, int n, float* avg_out)
 {
-    float acc = 0.f;
+    constexpr int CH = 2048;                        // elements per chunk (8 float4 per lane)
+    __shared__ __attribute__((aligned(16))) float buf[2][CH];
     const int lane = threadIdx.x;
-    int base = 0;
-    for (; base + 64 <= n; base += 64) {
-        const float x = v[base + lane];
+    float acc = 0.f;
+    const int nfull = n / CH;
+    const float4* v4 = reinterpret_cast<const float4*>(v);      // v is 256-byte aligned (workspace carve)
+    float4 r[8];
+    if (nfull > 0) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j));
+        for (int i = 0; i < 8; ++i) r[i] = v4[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&buf[0][(i * 64 + lane) * 4]) = r[i];
     }
-    if (base < n) {
+    int cur = 0;
+    for (int c = 0; c < nfull; ++c) {
+        const bool more = c + 1 < nfull;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = v4[(size_t)(c + 1) * (CH / 4) + i * 64 + lane];
+        }
+        const float4* b4 = reinterpret_cast<const float4*>(buf[cur]);
+#pragma unroll 16
+        for (int i = 0; i < CH / 4; ++i) {
+            const float4 q = b4[i];                 // same address in every lane: LDS broadcast
+            acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&buf[cur ^ 1][(i * 64 + lane) * 4]) = r[i];
+        }
+        cur ^= 1;
+    }
+    for (int base = nfull * CH; base < n; base += 64) {
         const float x = base + lane < n ? v[base + lane] : 0.f;
-        for (int j = 0; j < n - base; ++j) acc += __shfl(x, j);
+        const int m = n - base < 64 ? n - base : 64;
+        for (int j = 0; j < m; ++j) acc += __shfl(x, j);
     }
     if (lane == 0) *avg_out = acc / (float)n;
+}
+
+// recursiveSmoothX through LDS: a block owns 64 rows; 64x64 tiles are moved with coalesced row-major accesses and each
+// lane walks ITS row inside the tile (LDS pitch 65: conflict-free column walk), so the sequential recurrences of
+// CFilter.h:1426-1437 keep their exact order while global memory sees full lines.
+// [R][C] -> [C][R] per plane (32x32 LDS tiles, both sides coalesced); lets the X smoothing pass run as the coalesced
+// one-lane-per-line kernel on the transposed planes without changing a single floating-point operation
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, size_t plane_stride, int R, int C)
+{
+    __shared__ float tl[32][33];
+    const float* ip = in + (size_t)blockIdx.z * plane_stride;
+    float* op = out + (size_t)blockIdx.z * plane_stride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tl[j][tx] = ip[(size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * R + r0 + tx] = tl[tx][j];
+}
+
+__global__ __launch_bounds__(256) void iir_x_kernel(float* plane0, size_t plane_stride, float* scratch0, int H, int W, IIR c)
+{
+    __shared__ float tile[64 * 65];
+    __shared__ float tv1[64 * 65];
+    const int t = threadIdx.x, lane = t & 63, tr = t >> 6;        // 4 waves move the tiles, wave 0 runs the recurrences
+    const int row0 = blockIdx.x * 64;
+    const int nrows = min(64, H - row0);
+    float* mp = plane0 + (size_t)blockIdx.y * plane_stride;
+    float* v1p = scratch0 + (size_t)blockIdx.y * plane_stride;
+    const bool act = t < nrows;                                   // t < 64: this lane owns row t
+    if (W < 2) return;
+    float a0 = 0.f, a1 = 0.f, mprev = 0.f;
+    // forward sweep: v1
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int nc = min(64, W - x0);
+        for (int r = tr; r < nrows; r += 4)
+            if (lane < nc) tile[r * 65 + lane] = mp[(size_t)(row0 + r) * W + x0 + lane];
+        __syncthreads();
+        if (act)
+#pragma unroll 8
+            for (int j = 0; j < nc; ++j) {
+                const int x = x0 + j;
+                const float mx = tile[t * 65 + j];
+                float a;
+                if (x == 0) a = (0.5f - c.k * c.pm) * mx;
+                else if (x == 1) a = c.k * (mx + c.pm * mprev) + (c.a2 - c.e2) * a1;
+                else a = c.k * (mx + c.pm * mprev) + c.a2 * a1 - c.e2 * a0;
+                a0 = a1; a1 = a; mprev = mx;
+                tile[t * 65 + j] = a;
+            }
+        __syncthreads();
+        for (int r = tr; r < nrows; r += 4)
+            if (lane < nc) v1p[(size_t)(row0 + r) * W + x0 + lane] = tile[r * 65 + lane];
+        __syncthreads();
+    }
+    // backward sweep: v2, m = v1 + v2 (the original m(x+1), m(x+2) are carried in registers)
+    float b0 = 0.f, b1 = 0.f, mo1 = 0.f, mo2 = 0.f;
+    const int last_x0 = ((W - 1) / 64) * 64;
+    for (int x0 = last_x0; x0 >= 0; x0 -= 64) {
+        const int nc = min(64, W - x0);
+        for (int r = tr; r < nrows; r += 4)
+            if (lane < nc) {
+                tile[r * 65 + lane] = mp[(size_t)(row0 + r) * W + x0 + lane];
+                tv1[r * 65 + lane] = v1p[(size_t)(row0 + r) * W + x0 + lane];
+            }
+        __syncthreads();
+        if (act)
+#pragma unroll 8
+            for (int j = nc - 1; j >= 0; --j) {
+                const int x = x0 + j;
+                const float mx = tile[t * 65 + j];
+                float bv;
+                if (x == W - 1) bv = (0.5f + c.k * c.pm) * mx;
+                else if (x == W - 2) bv = c.k * ((c.pp - c.e2) * mo1) + (c.a2 - c.e2) * b0;
+                else bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
+                tile[t * 65 + j] = tv1[t * 65 + j] + bv;
+                b1 = b0; b0 = bv; mo2 = mo1; mo1 = mx;
+            }
+        __syncthreads();
+        for (int r = tr; r < nrows; r += 4)
+            if (lane < nc) mp[(size_t)(row0 + r) * W + x0 + lane] = tile[r * 65 + lane];
+        __syncthreads();
+    }
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -255,8 +390,8 @@ size_t structure_workspace_bytes(int W, int H)
 {
     const size_t n = (size_t)W * H;
     const size_t nb = (n + NB - 1) / NB;
-    // 3 planes + 3 scratch planes + corners + bmax + bpre + bmin + mm(2) + avg(1)
-    return align_up(n * 4, 256) * 7 + align_up(nb * 4, 256) * 3 + 256;
+    // 3 planes + 3 scratch planes + corners + 3 transposed planes + bmax + bpre + bmin + mm(2) + avg(1)
+    return align_up(n * 4, 256) * 10 + align_up(nb * 4, 256) * 3 + 256;
 }
 
 static void iir_constants(float sigma, IIR& c)
@@ -283,7 +418,8 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     float* planes = static_cast<float*>(ws);          // dxx, dyy, dxy
     float* scratch = planes + 3 * ps;
     float* corners = scratch + 3 * ps;
-    float* bmax = corners + ps;
+    float* tmp3 = corners + ps;
+    float* bmax = tmp3 + 3 * ps;
     float* bpre = bmax + align_up((size_t)nb * 4, 256) / 4;
     float* bmin = bpre + align_up((size_t)nb * 4, 256) / 4;
     float* mm = bmin + align_up((size_t)nb * 4, 256) / 4;   // [0]=cmax [1]=cmin [2]=avg
@@ -291,7 +427,10 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     const dim3 g2((W + 255) / 256, H);
     hipLaunchKernelGGL(moments_kernel, g2, dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H);
     // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane
-    hipLaunchKernelGGL(iir_kernel, dim3((H + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, H, W, 1, W, c);
+    // recursiveSmoothX: transpose -> one lane per (former) row walking coalesced memory -> transpose back
+    hipLaunchKernelGGL(transpose_kernel, dim3((W + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, st, planes, tmp3, ps, H, W);
+    hipLaunchKernelGGL(iir_kernel, dim3((H + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, H, W, H, 1, c);
+    hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (W + 31) / 32, 3), dim3(256), 0, st, tmp3, planes, ps, W, H);
     hipLaunchKernelGGL(iir_kernel, dim3((W + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, W, H, W, 1, c);
     hipLaunchKernelGGL(eigen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planes, planes + ps, planes + 2 * ps,
                        corners, n);

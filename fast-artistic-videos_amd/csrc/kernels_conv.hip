@@ -15,6 +15,7 @@
 // Tiling: 4 or 8 waves of 64 lanes.  Block tile 128 (M) x BN (N) x 32 (K), LDS double-buffered
 // [rows][36] (row stride 36 floats makes the 16-byte fragment reads conflict-free), register-staged
 // global->LDS copies issued two K-steps ahead and written to LDS in chunks interleaved with the MFMAs.
+#include <algorithm>
 #include <cstdlib>
 
 #include "fav_internal.h"
@@ -40,6 +41,7 @@ struct ConvArgs {
     int cin_shift, kw_magic, ntaps_magic;
     float tanh_mul;
     float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;     // stream-K hand-off (null = data-parallel)
+    int reserve_cus;
 };
 
 // branch-free form used inside the MFMA loop: lo = 0 for ReLU, -inf for none; identity = scale 1, shift 0
@@ -427,16 +429,17 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
     if (SK) {
         // every stream-K block must be resident (owners wait for later blocks): size the grid from the occupancy
         // the runtime reports for this instantiation, capped at the 2 blocks per CU the hand-off buffers are sized for
-        static int sk_blocks = 0;
-        if (!sk_blocks) {
+        static int sk_per_cu = 0, sk_cus = 0;
+        if (!sk_per_cu) {
             int occ = 0, dev = 0; hipDeviceProp_t prop;
             FAV_HIP(hipGetDevice(&dev));
             FAV_HIP(hipGetDeviceProperties(&prop, dev));
             FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, ABL, SK>, 64 * WM * WN, lds));
             if (occ < 1) { set_error("stream-K conv: kernel does not fit on a CU"); return FAV_EHIP; }
-            sk_blocks = (occ >= 2 ? 2 : 1) * prop.multiProcessorCount;
-            if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
+            sk_per_cu = occ >= 2 ? 2 : 1; sk_cus = prop.multiProcessorCount;
         }
+        int sk_blocks = sk_per_cu * std::max(1, sk_cus - a.reserve_cus);       // leave the reserved CUs to the side queues
+        if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
         grid = dim3(sk_blocks, 1);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, ABL, SK>), grid, dim3(64 * WM * WN), lds, st, a);
@@ -626,7 +629,8 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
         nblocks = prop.multiProcessorCount;
     }
     const int tiles = a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL((conv_c8_kernel<9>), dim3(tiles < nblocks ? tiles : nblocks), dim3(512), lds, st, a);
+    const int gridc8 = std::max(1, nblocks - c.reserve_cus);
+    hipLaunchKernelGGL((conv_c8_kernel<9>), dim3(tiles < gridc8 ? tiles : gridc8), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_c8_kernel");
     return FAV_OK;
 }
@@ -929,7 +933,8 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
         if (nblocks > SK_GRID) nblocks = SK_GRID;
     }
     const int tiles = a.tiles_x * a.tiles_y;
-    const int grid = tiles * (c.CIN / 32) * 9 < nblocks ? 1 : nblocks;
+    const int nres = std::max(1, nblocks - c.reserve_cus);
+    const int grid = tiles * (c.CIN / 32) * 9 < nres ? 1 : nres;
     if (BNv == 128) hipLaunchKernelGGL((conv3_halo_kernel<128>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((conv3_halo_kernel<64>), dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_halo_kernel");
@@ -1159,7 +1164,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
     a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;
     a.ntaps_magic = (65536 + c.KH * c.KW - 1) / (c.KH * c.KW);
-    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch;
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.reserve_cus = c.reserve_cus;
     static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;   // tuning only: results are wrong for 1-4,6-8
     // stream-K when the tile count is within a few waves of the 512 resident blocks (imbalance matters there)
     const long long tiles = (long long)((c.OH * c.OW + BM - 1) / BM) * (c.COUTp / (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));

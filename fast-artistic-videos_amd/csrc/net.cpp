@@ -91,6 +91,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
@@ -214,9 +215,10 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
     const float* wfold = (c.final_mode && !getenv("FAV_NO_FOLD")) ? convs[conv_index].wfold : nullptr;
     ConvLaunch cs = c;
+    cs.reserve_cus = reserve_cus;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(c, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : launch_conv(cs, st))); };
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : launch_conv(cs, st))); };
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
@@ -226,7 +228,8 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 3 : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32))));
+    // kernel id: 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), else the generic kernel's N tile
+    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 300 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32))));
     return rc;
 }
 
@@ -550,12 +553,39 @@ struct fav_stream {
     float* cert_tmp = nullptr; float* cert = nullptr;
     uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
     void* ws = nullptr; size_t ws_bytes = 0;
+    // look-ahead mask (fav_stream_prefetch_mask)
+    // two side queues with their own structure workspaces: the masks of frames i+1 and i+2 are computed concurrently
+    // (each 4-argument mask contains a ~3 ms sequential fp32 chain, CMatrix::avg), three look-ahead slots
+    static constexpr int NSIDE = 2, NPREF = 3;
+    hipStream_t side[NSIDE] = {nullptr, nullptr}; void* side_ws[NSIDE] = {nullptr, nullptr}; hipEvent_t ev_in = nullptr;
+    struct Pref { uint8_t* mask = nullptr; hipEvent_t done = nullptr; bool valid = false;
+                  const void *frame = nullptr, *bw = nullptr, *fw = nullptr; int structure = 0; };
+    Pref pref[NPREF]; int pref_next = 0, side_next = 0;
     ~fav_stream()
     {
         if (net) (void)hipSetDevice(net->device);
+        for (int i = 0; i < NSIDE; ++i) { if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); } (void)hipFree(side_ws[i]); }
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); }
         (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws);
     }
 };
+
+// While look-ahead masks are in flight the persistent / stream-K convolution grids leave SIDE_CUS CUs unclaimed
+// (fav_net::reserve_cus): the side queues' kernels (among them a ~3 ms single-wave sequential chain) find free CUs, and a
+// statically scheduled network block is never kept off the chip by them.
+static constexpr int SIDE_CUS = 8;
+static hipError_t create_side_stream(hipStream_t* st)
+{
+    if (getenv("FAV_SIDE_CUMASK")) {          // experiment: confine the side queues with a CU mask (measured: slower)
+        uint32_t mask[16] = {0};
+        mask[0] = (1u << SIDE_CUS) - 1;
+        hipError_t e = hipExtStreamCreateWithCUMask(st, 16, mask);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
 
 extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* o, fav_stream** out)
 {
@@ -575,7 +605,14 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
         hipMalloc(reinterpret_cast<void**>(&s->cert_tmp), n * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->cert), n * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->mask), n) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) { delete s; return hip_fail(hipErrorOutOfMemory, "hipMalloc(stream buffers)"); }
+    for (auto& pf : s->pref)
+        if (hipMalloc(reinterpret_cast<void**>(&pf.mask), n) != hipSuccess || hipEventCreateWithFlags(&pf.done, hipEventDisableTiming) != hipSuccess) {
+            delete s; return hip_fail(hipErrorOutOfMemory, "look-ahead slots"); }
+    for (int i = 0; i < fav_stream::NSIDE; ++i)
+        if (create_side_stream(&s->side[i]) != hipSuccess || hipMalloc(&s->side_ws[i], s->ws_bytes) != hipSuccess) {
+            delete s; return hip_fail(hipErrorOutOfMemory, "side queues"); }
     *out = s;
     return FAV_OK;
 }
@@ -635,12 +672,44 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
     FAV_HIP(hipSetDevice(s->net->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     // makeOptFlow_deepflow.sh:59: consistencyChecker backward_i_j.flo forward_j_i.flo reliable_i_j.pgm [frame_i.ppm]
+    for (auto& pf : s->pref)
+        if (pf.valid && pf.frame == frame_rgb_hwc && pf.bw == backward_flo && pf.fw == forward_flo && pf.structure == (use_structure != 0)) {
+            // the mask was computed ahead of time on the side stream
+            pf.valid = false;
+            FAV_HIP(hipStreamWaitEvent(st, pf.done, 0));
+            std::swap(s->mask, pf.mask);
+            return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+        }
+    // not prefetched: compute inline on the caller's stream (own workspace)
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->ws, s->ws_bytes, &structure, &avg, st); if (rc) return rc;
     }
     int rc = launch_consistency(backward_flo, forward_flo, structure, avg, s->mask, s->W, s->H, st); if (rc) return rc;
     return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+}
+
+extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                                        const float* forward_flo, int use_structure, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && forward_flo, "fav_stream_prefetch_mask: null argument");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->net->reserve_cus = SIDE_CUS;      // from now on the network's persistent grids leave the side queues' CUs alone
+    fav_stream::Pref& pf = s->pref[s->pref_next];
+    s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
+    const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;
+    hipStream_t sd = s->side[q];
+    FAV_HIP(hipEventRecord(s->ev_in, st));                 // inputs are complete at this point of the caller's stream
+    FAV_HIP(hipStreamWaitEvent(sd, s->ev_in, 0));          // (work enqueued on `stream` AFTER this call is not waited for)
+    const float* structure = nullptr; const float* avg = nullptr;
+    if (use_structure) {
+        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
+    }
+    int rc = launch_consistency(backward_flo, forward_flo, structure, avg, pf.mask, s->W, s->H, sd); if (rc) return rc;
+    FAV_HIP(hipEventRecord(pf.done, sd));
+    pf.valid = true; pf.frame = frame_rgb_hwc; pf.bw = backward_flo; pf.fw = forward_flo; pf.structure = use_structure != 0;
+    return FAV_OK;
 }
 
 extern "C" int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream)

@@ -58,7 +58,8 @@ EXPORTS = [
     "fav_net_create_from_blob", "fav_net_destroy", "fav_net_describe_host", "fav_t7_describe_host", "fav_net_param_count",
     "fav_net_output_size", "fav_net_forward", "fav_net_profile_enable", "fav_net_profile_read_host",
     "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
-    "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_get_state",
+    "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
+    "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
 ]
@@ -282,6 +283,10 @@ class Stream:
         _check(lib().fav_stream_next_frame_flow(self.h, _p(frame_u8_hwc), _p(backward_flo), _p(forward_flo),
                                                 1 if use_structure else 0, _p(f), _p(u), _stream()))
         return f, u
+
+    def prefetch_mask(self, frame_u8_hwc, backward_flo, forward_flo, use_structure=False):
+        _check(lib().fav_stream_prefetch_mask(self.h, _p(frame_u8_hwc), _p(backward_flo), _p(forward_flo),
+                                              1 if use_structure else 0, _stream()))
 
     def state(self):
         torch = _torch()

@@ -116,8 +116,9 @@ int fav_net_forward(fav_net* net, const float* in7, float* out3, int H, int W, f
 /* per-convolution timing with HIP events recorded on the forward's stream (bench / roofline use).
  * enable: every later forward records one event pair per convolution launch.  read: synchronises the
  * recorded events and returns, per convolution in network order, the summed milliseconds, the number of
- * launches, the useful MACs of one launch (no padding) and the N-tile width of the kernel instance that
- * ran it (128, 64 or 32); then clears the accumulators.  Arrays hold up to `capacity` entries. */
+ * launches, the useful MACs of one launch (no padding) and an id of the kernel instance that ran it (1 = row-folded
+ * last layer, 8 = first-layer kernel, 300+N = halo-resident 3x3 kernel with N output channels, otherwise the N tile
+ * 128/64/32 of the generic implicit-GEMM kernel); then clears the accumulators.  Arrays hold up to `capacity` entries. */
 int fav_net_profile_enable(fav_net* net, int on);
 int fav_net_profile_read_host(fav_net* net, int capacity, int* count, double* ms_sum, int* launches,
                               double* macs_per_launch, int* ntile);
@@ -160,6 +161,12 @@ int fav_stream_next_frame_cert(fav_stream* s, const uint8_t* frame_rgb_hwc, cons
 int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
                                const float* forward_flo, int use_structure,
                                float* out_rgb_f32, uint8_t* out_rgb8_hwc, fav_hipstream_t stream);
+/* optional look-ahead: start computing the consistency mask of a FUTURE frame on an internal side stream (the mask
+ * depends only on that frame and its two flows, not on the recurrent state), so the order-preserving 4-argument
+ * structure pass overlaps the network of the current frame.  The inputs must already be complete on `stream`.  The next
+ * fav_stream_next_frame_flow call with the same three pointers and mode consumes the prefetched mask. */
+int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
+                             const float* forward_flo, int use_structure, fav_hipstream_t stream);
 /* read / overwrite the recurrent state ([3][H][W] float RGB) -- for -continue_with */
 int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
 int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream);

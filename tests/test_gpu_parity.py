@@ -248,6 +248,27 @@ def test_stream_vs_oracle_recurrent(favlib, oracle, cuda, golden_dir, mode):
     assert np.array_equal(st.state().cpu().numpy(), outs[-1])
 
 
+def test_stream_mask_lookahead(favlib, oracle, cuda, golden_dir):
+    """fav_stream_prefetch_mask: the next frame's mask computed on the side stream gives identical frames"""
+    import torch
+    path = os.path.join(golden_dir, "tiny_model.t7")
+    h, w, n = 48, 72, 4
+    frames, bws, fws = _clip(h, w, n, 60)
+    net = favlib.Net(path, 0)
+    fr = [T(f, cuda) for f in frames]; bw = [None] + [T(b, cuda) for b in bws[1:]]; fw = [None] + [T(f, cuda) for f in fws[1:]]
+    for structure in (False, True):
+        a = favlib.Stream(net, h, w); b = favlib.Stream(net, h, w)
+        oa, _ = a.first_frame(fr[0]); ob, _ = b.first_frame(fr[0])
+        b.prefetch_mask(fr[1], bw[1], fw[1], structure)
+        for i in range(1, n):
+            oa, _ = a.next_frame_flow(fr[i], bw[i], fw[i], use_structure=structure)
+            if i + 1 < n:           # two masks in flight: i (not yet consumed) and i+1
+                b.prefetch_mask(fr[i + 1], bw[i + 1], fw[i + 1], structure)
+            ob, _ = b.next_frame_flow(fr[i], bw[i], fw[i], use_structure=structure)
+            assert torch.equal(oa, ob)
+            assert np.array_equal(b.last_mask().cpu().numpy(), oracle.consistency(bws[i], fws[i], frames[i] if structure else None))
+
+
 def test_stream_options(favlib, oracle, cuda, golden_dir):
     path = os.path.join(golden_dir, "tiny_model.t7")
     h, w = 48, 64
