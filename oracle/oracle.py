@@ -256,8 +256,9 @@ class Stylizer:
     """Recurrent per-frame loop: fast_artistic_video_core.lua:189-229 with the video CLI's
     callbacks (fast_artistic_video.lua:93-172); fill_occlusions = vgg-mean."""
 
-    def __init__(self, layers, border="stn", min_filter_r=7):
+    def __init__(self, layers, border="stn", min_filter_r=7, invert_occlusion=False, fix_occlusions=False):
         self.layers, self.border, self.r = layers, border, min_filter_r
+        self.invert, self.fix = invert_occlusion, fix_occlusions
         self.last = None        # last_frame_stylized: float RGB [3][H][W], unclamped (fav.lua:169)
 
     def first(self, frame_rgb01):
@@ -266,6 +267,14 @@ class Stylizer:
         return out
 
     def next(self, frame_rgb01, backward_flow_uv, cert01):
+        cert01 = np.ascontiguousarray(cert01, np.float32)
+        if self.invert:                                                       # fav.lua:104-106: cert:add(-1):mul(-1)
+            cert01 = (cert01 + np.float32(-1)) * np.float32(-1)
+        if self.fix:                                                          # fav.lua:79-86,107-110
+            ones = np.ones((1,) + cert01.shape, np.float32)
+            tmp = warp(ones, flo_to_lua(backward_flow_uv), self.border)[0]
+            tmp = np.maximum(np.sign(tmp + np.float32(-0.5)), 0).astype(np.float32)
+            cert01 = cert01 * tmp
         cert = min_filter(cert01, self.r)                                     # core:207
         warped = warp(self.last, flo_to_lua(backward_flow_uv), self.border)  # fav.lua:153-158
         out = deprocess(net_forward(self.layers, assemble(frame_rgb01, warped, cert)))

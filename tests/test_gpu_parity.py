@@ -276,14 +276,16 @@ def test_stream_options(favlib, oracle, cuda, golden_dir):
     layers = _layers(path)
     net = favlib.Net(path, 0)
     mask = oracle.consistency(bws[1], fws[1])
+    big = bws[1] + np.float32(9.0)        # push part of the frame out of bounds so -fix_occlusions has something to fix
     for border, bname in ((favlib.BORDER_STN, "stn"), (favlib.BORDER_CPU, "cpu")):
-        st = favlib.Stream(net, h, w, border=border, min_filter_r=3, invert_occlusion=True)
-        o0, _ = st.first_frame(T(frames[0], cuda))
-        o1, _ = st.next_frame_cert(T(frames[1], cuda), T(bws[1], cuda), T(255 - mask, cuda))
-        ref = oracle.Stylizer(layers, border=bname, min_filter_r=3)
-        ref.first(_f01(frames[0]))
-        r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
-        assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+        for fix in (False, True):
+            st = favlib.Stream(net, h, w, border=border, min_filter_r=3, invert_occlusion=True, fix_occlusions=fix)
+            o0, _ = st.first_frame(T(frames[0], cuda))
+            o1, _ = st.next_frame_cert(T(frames[1], cuda), T(big, cuda), T(255 - mask, cuda))
+            ref = oracle.Stylizer(layers, border=bname, min_filter_r=3, invert_occlusion=True, fix_occlusions=fix)
+            ref.first(_f01(frames[0]))
+            r1 = ref.next(_f01(frames[1]), big, (255 - mask).astype(np.float32) / np.float32(255))
+            assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4, (bname, fix)
     with pytest.raises(favlib.FavError, match="multiples of 4"):
         favlib.Stream(net, 50, 64)
     st = favlib.Stream(net, h, w)
