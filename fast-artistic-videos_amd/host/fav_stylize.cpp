@@ -23,6 +23,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -270,8 +271,10 @@ int main(int argc, char** argv)
     if (hipStreamCreate(&st) != hipSuccess) die("hipStreamCreate failed");
     fav_stream* fs = nullptr;
     int W = 0, H = 0;
-    uint8_t *d_frame = nullptr, *d_cert = nullptr, *d_out8 = nullptr; float *d_bw = nullptr, *d_fw = nullptr;
-    const int nslots = 4;
+    struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
+    Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
+    uint8_t* d_out8 = nullptr;
+    const int nslots = std::max(1, o.i("writers")) + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
     int slot = 0;
 
@@ -292,27 +295,80 @@ int main(int argc, char** argv)
         }
     }
 
-    std::thread loader;
-    FrameIn next = load(start, !have_resume && start != 1);
+    // Host pipeline: DEPTH loader threads read + decode frames i+1.. while the GPU works on frame i; decoded
+    // inputs are copied into pinned staging sets so the H2D copies are true async DMA.
+    constexpr int DEPTH = 3;
+    struct Pinned { uint8_t* frame = nullptr; float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr; };
+    Pinned pin[DEPTH + 1];
+    bool pinned_ready = false;
+    auto load_pinned = [&](int i, bool first_of_run, int set) {
+        FrameIn in = load(i, first_of_run);
+        if (in.ok && pinned_ready && in.W == W && in.H == H) {
+            const size_t n = (size_t)W * H;
+            memcpy(pin[set].frame, in.frame, n * 3);
+            if (in.bw) memcpy(pin[set].bw, in.bw, n * 8);
+            if (in.fw) memcpy(pin[set].fw, in.fw, n * 8);
+            if (in.cert) memcpy(pin[set].cert, in.cert, n);
+            const bool hb = in.bw, hf = in.fw, hc = in.cert;
+            in.release();
+            in.frame = pin[set].frame; in.bw = hb ? pin[set].bw : nullptr; in.fw = hf ? pin[set].fw : nullptr; in.cert = hc ? pin[set].cert : nullptr;
+            in.index = -i - 1;               // marks "pinned, do not free"
+        }
+        return in;
+    };
+    auto idx_ok = [&](int i) { return backward ? i >= end : i <= end; };
+    std::deque<std::pair<int, std::thread>> inflight;      // (slot set, thread)
+    std::vector<FrameIn> ready(DEPTH + 1);
+    int next_to_issue = start, sets_used = 0;
+    auto issue = [&]() {
+        while ((int)inflight.size() < DEPTH && idx_ok(next_to_issue)) {
+            const int i = next_to_issue, set = sets_used % (DEPTH + 1);
+            const bool fo = (i == start) && !have_resume && start != 1;
+            inflight.emplace_back(set, std::thread([&, i, fo, set] { ready[set] = load_pinned(i, fo, set); }));
+            next_to_issue += inc; ++sets_used;
+        }
+    };
+
     bool first = true;
     const auto t_begin = std::chrono::steady_clock::now();
-    int done = 0;
-    for (int i = start; backward ? i >= end : i <= end; i += inc) {
-        FrameIn cur = next;
-        if (!cur.ok) break;                                                                                   // core:196-197
-        const int ni = i + inc;
-        const bool has_next = backward ? ni >= end : ni <= end;
-        next = FrameIn();
-        if (has_next) loader = std::thread([&, ni] { next = load(ni, false); });
+    double t_wait_load = 0, t_gpu = 0, t_wait_writer = 0;
+    int done = 0, dset = 0;
+    auto upload = [&](const FrameIn& f, const Dev& dv) {          // async H2D of one frame's inputs (pinned -> device)
+        const size_t n = (size_t)W * H;
+        hipMemcpyAsync(dv.frame, f.frame, n * 3, hipMemcpyHostToDevice, st);
+        if (f.bw) hipMemcpyAsync(dv.bw, f.bw, n * 8, hipMemcpyHostToDevice, st);
+        if (f.fw) hipMemcpyAsync(dv.fw, f.fw, n * 8, hipMemcpyHostToDevice, st);
+        if (f.cert) hipMemcpyAsync(dv.cert, f.cert, n, hipMemcpyHostToDevice, st);
+    };
+    auto pop_next = [&](FrameIn& out) {
+        if (inflight.empty()) return false;
+        const auto tl = std::chrono::steady_clock::now();
+        const int set = inflight.front().first;
+        inflight.front().second.join(); inflight.pop_front();
+        out = ready[set];
+        t_wait_load += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl).count();
+        return out.ok;
+    };
+    // the first frame is loaded synchronously (its size sizes every buffer)
+    FrameIn cur = load(start, !have_resume && start != 1), nxt;
+    bool have_next = false;
+    next_to_issue = start + inc;
+    for (int i = start; idx_ok(i) && cur.ok; i += inc) {                                                      // core:196-197
         if (first) {
             if (have_resume && (-W != cur.W || -H != cur.H)) die("-continue_with: previous PNG size differs from the frames");
             W = cur.W; H = cur.H;
             fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0};
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
             const size_t n = (size_t)W * H;
-            if (hipMalloc((void**)&d_frame, n * 3) || hipMalloc((void**)&d_cert, n) || hipMalloc((void**)&d_out8, n * 3) ||
-                hipMalloc((void**)&d_bw, n * 8) || hipMalloc((void**)&d_fw, n * 8)) die("hipMalloc failed");
+            if (hipMalloc((void**)&d_out8, n * 3)) die("hipMalloc failed");
+            for (auto& dv : dev)
+                if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
+                    hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
             for (auto& p : h_out) if (hipHostMalloc((void**)&p, n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+            for (auto& p : pin)
+                if (hipHostMalloc((void**)&p.frame, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, n * 8, hipHostMallocDefault) ||
+                    hipHostMalloc((void**)&p.fw, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&p.cert, n, hipHostMallocDefault)) die("hipHostMalloc failed");
+            pinned_ready = true;
             if (have_resume) {
                 float* d_state = nullptr;
                 if (hipMalloc((void**)&d_state, n * 12) != hipSuccess) die("hipMalloc failed");
@@ -320,49 +376,62 @@ int main(int argc, char** argv)
                 check(fav_stream_set_state(fs, d_state, st), "fav_stream_set_state");
                 hipStreamSynchronize(st); hipFree(d_state);
             }
+            upload(cur, dev[dset]);
+            hipStreamSynchronize(st);                    // the first frame's host buffers are malloc'ed: release them now
             first = false;
         } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
-        const size_t n = (size_t)W * H;
+        issue();                                         // keep DEPTH loads in flight
         const auto t0 = std::chrono::steady_clock::now();
-        hipMemcpyAsync(d_frame, cur.frame, n * 3, hipMemcpyHostToDevice, st);
-        if (cur.single) {
-            check(fav_stream_first_frame(fs, d_frame, nullptr, d_out8, st), "fav_stream_first_frame");        // core:203-204
-        } else {
-            hipMemcpyAsync(d_bw, cur.bw, n * 8, hipMemcpyHostToDevice, st);
-            if (fused_check) {
-                hipMemcpyAsync(d_fw, cur.fw, n * 8, hipMemcpyHostToDevice, st);
-                check(fav_stream_next_frame_flow(fs, d_frame, d_bw, d_fw, o.i("structure"), nullptr, d_out8, st), "fav_stream_next_frame_flow");
-            } else {
-                hipMemcpyAsync(d_cert, cur.cert, n, hipMemcpyHostToDevice, st);
-                check(fav_stream_next_frame_cert(fs, d_frame, d_bw, d_cert, nullptr, d_out8, st), "fav_stream_next_frame_cert");   // core:206-208
-            }
+        // frame i+1: wait for its loader, upload it, and start its consistency mask on the side queues so the
+        // (sequential, ~3 ms) 4-argument structure pass overlaps frame i's network
+        have_next = idx_ok(i + inc) && pop_next(nxt);
+        const Dev& dc = dev[dset];
+        const Dev& dn = dev[(dset + 1) % 3];
+        if (have_next) {
+            if (nxt.W != W || nxt.H != H) die("frame size changed inside the sequence");
+            upload(nxt, dn);
+            if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
-        writers.wait_below((size_t)nslots - 1);          // a free pinned slot
+        if (cur.single) {
+            check(fav_stream_first_frame(fs, dc.frame, nullptr, d_out8, st), "fav_stream_first_frame");       // core:203-204
+        } else if (fused_check) {
+            check(fav_stream_next_frame_flow(fs, dc.frame, dc.bw, dc.fw, o.i("structure"), nullptr, d_out8, st), "fav_stream_next_frame_flow");
+        } else {
+            check(fav_stream_next_frame_cert(fs, dc.frame, dc.bw, dc.cert, nullptr, d_out8, st), "fav_stream_next_frame_cert");   // core:206-208
+        }
+        const auto tw = std::chrono::steady_clock::now();
+        writers.wait_below((size_t)nslots - 1);          // a free pinned output slot
+        t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         uint8_t* hb = h_out[slot]; slot = (slot + 1) % nslots;
-        hipMemcpyAsync(hb, d_out8, n * 3, hipMemcpyDeviceToHost, st);
+        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess) die("GPU error while stylising a frame");
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t_gpu += ms / 1e3;
         if (cur.single) printf("Elapsed time for stylizing frame independently:%g\n", ms / 1000.0);           // core:155
         else printf("Elapsed time for stylizing frame:%g\n", ms / 1000.0);                                   // core:177
         char nm[4096]; snprintf(nm, sizeof nm, "%s-%05d.png", o.s("output_prefix").c_str(), i);              // fav.lua:161
-        printf("Writing output image to %s\n", nm); fflush(stdout);
+        printf("Writing output image to %s\n", nm);
         mkdirs_for(nm);
         const int lvl = o.i("png_level");
         const std::string path = nm;
         writers.submit([hb, path, W, H, lvl] { if (fav_write_png_rgb8_host(path.c_str(), hb, W, H, lvl)) fprintf(stderr, "%s\n", fav_last_error()); });
-        cur.release();
+        if (cur.index >= 0) cur.release();               // malloc'ed (first frame); pinned sets are reused
         ++done;
-        if (loader.joinable()) loader.join();
+        if (!have_next) break;
+        cur = nxt; dset = (dset + 1) % 3;
     }
-    if (loader.joinable()) loader.join();
-    next.release();
+    for (auto& pr : inflight) pr.second.join();
+    for (auto& r : ready) if (r.index >= 0) r.release();
+    fflush(stdout);
     writers.wait_below(0);
     if (o.i("timing")) {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-        printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f}\n", done, s, done / s);
+        printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f}\n",
+               done, s, done / s, t_wait_load, t_gpu, t_wait_writer);
     }
     fav_stream_destroy(fs); fav_net_destroy(net);
-    hipFree(d_frame); hipFree(d_cert); hipFree(d_out8); hipFree(d_bw); hipFree(d_fw);
+    hipFree(d_out8); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
     for (auto p : h_out) hipHostFree(p);
+    for (auto& p : pin) { hipHostFree(p.frame); hipHostFree(p.bw); hipHostFree(p.fw); hipHostFree(p.cert); }
     return 0;
 }
