@@ -94,3 +94,39 @@ def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
     r = subprocess.run([shim, "fast_artistic_video.lua", "-input_pattern", str(tmp_path / "no_%05d.ppm"), "-create_inconsistent",
                         "-model_vid", model, "-gpu", "0"], capture_output=True, text=True)
     assert r.returncode == 0 and "Model loaded." in r.stdout
+
+
+def test_fav_stylize_loop_flags(oracle, favlib, tmp_path, golden_dir):
+    """-num_frames, -create_inconsistent and -continue_with (fast_artistic_video_core.lua:189-204; the resume path reloads
+    the previous PNG as the 8-bit recurrent state -- documented deviation, the reference's video CLI cannot resume)"""
+    from PIL import Image
+    h, w, n = 48, 64, 4
+    frames, bws, fws = _write_clip(oracle, tmp_path, h, w, n, 70)
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    layers = t7.extract_layers(t7.load(model)["model"])
+    exe = os.path.join(BIN, "fav_stylize")
+    common = ["-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
+              "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "0", "-model_vid", model, "-gpu", "0"]
+    f01 = lambda u8: np.transpose(u8, (2, 0, 1)).astype(np.float32) / np.float32(255)
+    # -num_frames 2: only two outputs
+    r = subprocess.run([exe] + common + ["-output_prefix", str(tmp_path / "a" / "out"), "-num_frames", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(tmp_path / "a" / "out-00002.png") and not os.path.exists(tmp_path / "a" / "out-00003.png")
+    # -create_inconsistent: every frame is stylised without a prior (func_is_single_image, fast_artistic_video.lua:172)
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-create_inconsistent", "-model_vid", model, "-gpu", "0",
+                        "-output_prefix", str(tmp_path / "b" / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for i in range(1, n + 1):
+        want = oracle.to_u8_hwc(oracle.Stylizer(layers).first(f01(frames[i - 1])))
+        got = np.asarray(Image.open(str(tmp_path / "b" / f"out-{i:05d}.png")))
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    # -continue_with 3 after the 2-frame run: frame 3 warps the reloaded out-00002.png
+    r = subprocess.run([exe] + common + ["-output_prefix", str(tmp_path / "a" / "out"), "-continue_with", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    prev = np.asarray(Image.open(str(tmp_path / "a" / "out-00002.png")))
+    ref = oracle.Stylizer(layers); ref.last = f01(prev)
+    m = oracle.consistency(bws[2], fws[2])
+    want = oracle.to_u8_hwc(ref.next(f01(frames[2]), bws[2], m.astype(np.float32) / np.float32(255)))
+    got = np.asarray(Image.open(str(tmp_path / "a" / "out-00003.png")))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert os.path.exists(tmp_path / "a" / "out-00004.png")
