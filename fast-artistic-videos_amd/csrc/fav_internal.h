@@ -37,7 +37,7 @@ int ensure_device();   // FAV_OK or FAV_ENODEVICE
 // ------------------------------------------------------------------------------------------------
 // host-side description of a parsed checkpoint (t7_reader.cpp)
 // ------------------------------------------------------------------------------------------------
-enum LayerType { L_PAD, L_CONV, L_IN, L_RELU, L_RES, L_UP, L_TANH, L_MUL, L_IDENTITY };
+enum LayerType { L_PAD, L_CONV, L_IN, L_RELU, L_RES, L_UP, L_TANH, L_MUL, L_IDENTITY, L_BN };
 
 struct Layer {
     LayerType type = L_IDENTITY;
@@ -45,9 +45,10 @@ struct Layer {
     int pl = 0, pr = 0, pt = 0, pb = 0;
     // conv
     int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
+    int transposed = 0, adj = 0;    // nn.SpatialFullConvolution: w is [cin][cout][k][k]
     std::vector<float> w, b;        // [cout][cin][k][k], [cout] (may be empty)
-    // instance norm
-    std::vector<float> gamma, beta;
+    // instance norm / batch norm (evaluate mode: running mean / var)
+    std::vector<float> gamma, beta, mean, var;
     float eps = 1e-5f;
     // upsample / mul / shave
     int scale = 1;
@@ -75,6 +76,7 @@ struct ConvLaunch {
     int IH = 0, IW = 0;             // logical input size (after `ups` nearest upsampling)
     int IWp = 0;                    // physical row pitch in pixels
     int ups = 0;                    // log2 of the nearest-upsample factor applied on load (0|1)
+    int stuff = 0;                  // with ups=1: zero-stuffed instead of replicated (transposed convolution as a convolution)
     int CIN = 0;                    // physical channels (multiple of 4)
     Affine pre;                     // applied on load (zero padding is applied AFTER it)
     const float* wgt = nullptr;     // [COUTp][Kpad], k = tap*CIN + ci

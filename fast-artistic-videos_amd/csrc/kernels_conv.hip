@@ -35,7 +35,7 @@ struct ConvArgs {
     const float* in; const float* wgt; const float* bias;
     const float* scale1; const float* shift1; const float* scale2; const float* shift2;
     float* out; float2* partials; float* out_planar; float* out_raw;
-    int IH, IW, IWp, ups, CIN;
+    int IH, IW, IWp, ups, stuff, CIN;
     int COUT, COUTp, KH, KW, stride, pad, Kpad, OH, OW;
     int stages, relu1, relu2, final_mode;
     int cin_shift, kw_magic, ntaps_magic;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
             if ((q_) < AROWS) {                                                                             \
                 constexpr int i_ = (q_) < AROWS ? (q_) : 0;                                                 \
                 const int iy_ = iy0[i_] + ky##X, ix_ = ix0[i_] + kx##X;                                     \
-                va##X[i_] = rv[i_] & tv##X & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+                va##X[i_] = rv[i_] & tv##X & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW) & (((iy_ | ix_) & p.stuff) == 0); \
                 const int off_ = va##X[i_] ? ((iy_ >> p.ups) * p.IWp + (ix_ >> p.ups)) * CIN + ci##X : 0;   \
                 ra##X[i_] = *reinterpret_cast<const float4*>(p.in + off_);   /* 32-bit element offset */     \
             }                                                                                               \
@@ -1149,6 +1149,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     FAV_REQUIRE(c.COUTp % 32 == 0 && c.Kpad % BK == 0, "conv: COUTp=%d / Kpad=%d not tile aligned", c.COUTp, c.Kpad);
     FAV_REQUIRE(c.Kpad >= c.KH * c.KW * c.CIN, "conv: Kpad too small");
     FAV_REQUIRE(c.ups == 0 || c.ups == 1, "conv: upsample factor must be 1 or 2");
+    FAV_REQUIRE(!c.stuff || c.ups == 1, "conv: zero-stuffing needs the x2 index map");
     FAV_REQUIRE((c.CIN & (c.CIN - 1)) == 0, "conv: the channel pitch %d must be a power of two", c.CIN);
     FAV_REQUIRE(c.KH * c.KW < 4096, "conv: kernel too large");
     FAV_REQUIRE((long long)((c.IH >> c.ups) + 1) * c.IWp * c.CIN < (1ll << 31) && (long long)c.COUTp * c.Kpad < (1ll << 31),
@@ -1159,7 +1160,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials);
     a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
-    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.stuff = c.stuff ? 1 : 0; a.CIN = c.CIN;
     a.COUT = c.COUT; a.COUTp = c.COUTp; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad;
     a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
     a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;

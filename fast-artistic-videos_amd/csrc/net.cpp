@@ -54,6 +54,8 @@ int dev_upload(const std::vector<float>& h, size_t pad_to, float** out)
 // repack [cout][cin][k][k] -> [coutp][kpad].  K order of the implicit GEMM (must match FAV_TAP_SETUP):
 //   cinp >= 32: k = ((ci/32)*taps + tap)*32 + ci%32   (channel slice outermost: consecutive K-steps shift by one tap)
 //   cinp <  32: k = tap*cinp + ci                     (several taps per 32-wide K slice)
+// nn.SpatialFullConvolution (weight [cin][cout][k][k]) runs as a stride-1 convolution over the zero-stuffed input with the
+// taps flipped: out[oy] = sum_ky' stuffed[oy + ky' - (k-1-p)] * w[k-1-ky'].
 void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<float>& out)
 {
     out.assign((size_t)coutp * kpad, 0.f);
@@ -64,7 +66,9 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
                 for (int kx = 0; kx < L.k; ++kx) {
                     const int tap = ky * L.k + kx;
                     const size_t k = cinp >= 32 ? ((size_t)(ci / 32) * taps + tap) * 32 + ci % 32 : (size_t)tap * cinp + ci;
-                    out[(size_t)co * kpad + k] = L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+                    out[(size_t)co * kpad + k] = L.transposed
+                        ? L.w[(((size_t)ci * L.cout + co) * L.k + (L.k - 1 - ky)) * L.k + (L.k - 1 - kx)]
+                        : L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
                 }
 }
 
@@ -138,7 +142,10 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             repack_weights(L, d.cinp, d.coutp, d.kpad, w);
             int rc = dev_upload(w, 0, &d.wgt); if (rc) return rc;
             rc = dev_upload(L.b, (size_t)d.coutp, &d.bias); if (rc) return rc;
-            if (conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
+            if (L.transposed && (L.stride != 2 || L.adj != 1 || L.pad > L.k - 1)) {
+                set_error("network: SpatialFullConvolution is supported for stride 2, adj 1 (models_video.lua:99-102), got s=%d adj=%d", L.stride, L.adj);
+                return FAV_EUNSUPPORTED; }
+            if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
                 // [ky][n = c*k + kx][ci] for the row-folded last-layer kernel
                 std::vector<float> wf((size_t)L.k * 32 * d.cinp, 0.f);
                 for (int co = 0; co < L.cout; ++co)
@@ -161,6 +168,19 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
             ins.push_back(d);
             params += 2 * (long long)L.gamma.size();
+        } else if (L.type == L_BN) {
+            if ((int)L.mean.size() != chan_pitch) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan_pitch); return FAV_EFORMAT; }
+            // evaluate mode: a fixed per-channel affine, folded into the consumer's load like InstanceNorm's
+            std::vector<float> sc(L.mean.size()), sh(L.mean.size());
+            for (size_t i = 0; i < sc.size(); ++i) {
+                const double s = (double)L.gamma[i] / std::sqrt((double)L.var[i] + (double)L.eps);
+                sc[i] = (float)s; sh[i] = (float)((double)L.beta[i] - (double)L.mean[i] * s);
+            }
+            DevIN d;
+            int rc = dev_upload(sc, 0, &d.scale); if (rc) return rc;
+            rc = dev_upload(sh, 0, &d.shift); if (rc) return rc;
+            ins.push_back(d);
+            params += 4 * (long long)L.mean.size();
         } else if (L.type == L_RES) {
             int cp = chan_pitch;
             int rc = upload_layers(L.block, cp, maxc); if (rc) return rc;
@@ -184,7 +204,9 @@ int fav_net::upload()
         if (layers[i].type == L_PAD) { set_error("network: reflection padding is only supported as the first layer (padding_type reflect-start)"); return FAV_EUNSUPPORTED; }
     in_channels = 0;
     for (const Layer& L : layers) if (L.type == L_CONV) { in_channels = L.cin; break; }
-    if (in_channels != 7) { set_error("network: first convolution has %d input channels; the video hot path needs 7 (models_video.lua:57)", in_channels); return FAV_EUNSUPPORTED; }
+    if (in_channels != 7 && in_channels != 3) {
+        set_error("network: first convolution has %d input channels; video models take 7 (models_video.lua:57), image models 3", in_channels);
+        return FAV_EUNSUPPORTED; }
     int chan = 8, maxc = 8;
     int rc = upload_layers(layers, chan, maxc); if (rc) return rc;
     std::vector<float> o((size_t)maxc, 1.f), z((size_t)maxc, 0.f);
@@ -247,9 +269,16 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             c.pre = cur.pre;
             c.wgt = d.wgt; c.bias = d.bias; c.COUT = L.cout; c.COUTp = d.coutp; c.KH = c.KW = L.k; c.stride = L.stride;
             c.pad = L.pad; c.Kpad = d.kpad;
-            c.OH = (c.IH + 2 * L.pad - L.k) / L.stride + 1;
-            c.OW = (c.IW + 2 * L.pad - L.k) / L.stride + 1;
-            if (c.IH + 2 * L.pad < L.k || c.IW + 2 * L.pad < L.k) { set_error("network: input too small for the architecture"); return FAV_EINVAL; }
+            if (L.transposed) {
+                // stride-2 transposed convolution = stride-1 convolution over the zero-stuffed input (size 2*in with adj 1)
+                if (cur.ups != 0) { set_error("network: SpatialFullConvolution directly after an upsampling is unsupported"); return FAV_EUNSUPPORTED; }
+                c.ups = 1; c.stuff = 1; c.IH = 2 * cur.Hp; c.IW = 2 * cur.Wp; c.stride = 1; c.pad = L.k - 1 - L.pad;
+                c.OH = c.IH + 2 * c.pad - L.k + 1; c.OW = c.IW + 2 * c.pad - L.k + 1;
+            } else {
+                c.OH = (c.IH + 2 * L.pad - L.k) / L.stride + 1;
+                c.OW = (c.IW + 2 * L.pad - L.k) / L.stride + 1;
+            }
+            if (c.IH + 2 * c.pad < L.k || c.IW + 2 * c.pad < L.k) { set_error("network: input too small for the architecture"); return FAV_EINVAL; }
             bool has_tanh = false; float mul = 1.f;
             const bool is_final = top && only_tail(ls, li + 1, has_tanh, mul) && has_tanh && L.cout == 3;
             Act nxt;
@@ -263,8 +292,9 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
             int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
-            const bool c8 = conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !getenv("FAV_NO_C8");
-            const bool h3 = conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !getenv("FAV_NO_H3");
+            if (is_final && L.transposed) { set_error("network: a transposed convolution as the last layer is unsupported"); return FAV_EUNSUPPORTED; }
+            const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !getenv("FAV_NO_C8");
+            const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !getenv("FAV_NO_H3");
             nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW)); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
@@ -297,6 +327,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
                 else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             }
+            cur.partials = nullptr; cur.counts = nullptr;
+            break;
+        }
+        case L_BN: {
+            const DevIN& d = ins[in_cursor++];
+            if (cur.data == nullptr || (int)L.mean.size() != cur.C) { set_error("network: misplaced SpatialBatchNormalization"); return FAV_EUNSUPPORTED; }
+            if (cur.pre.stages >= 2) { set_error("network: more than two stacked normalisations on one tensor are unsupported"); return FAV_EUNSUPPORTED; }
+            if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
+            else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             cur.partials = nullptr; cur.counts = nullptr;
             break;
         }
@@ -344,7 +383,8 @@ void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
     int h = H + 2 * pad, w = W + 2 * pad;
     std::function<void(const std::vector<Layer>&)> walk = [&](const std::vector<Layer>& ls) {
         for (const Layer& L : ls) {
-            if (L.type == L_CONV) { h = (h + 2 * L.pad - L.k) / L.stride + 1; w = (w + 2 * L.pad - L.k) / L.stride + 1; }
+            if (L.type == L_CONV && L.transposed) { h = (h - 1) * L.stride - 2 * L.pad + L.k + L.adj; w = (w - 1) * L.stride - 2 * L.pad + L.k + L.adj; }
+            else if (L.type == L_CONV) { h = (h + 2 * L.pad - L.k) / L.stride + 1; w = (w + 2 * L.pad - L.k) / L.stride + 1; }
             else if (L.type == L_UP) { h *= L.scale; w *= L.scale; }
             else if (L.type == L_RES) walk(L.block);
         }
@@ -492,7 +532,7 @@ extern "C" int fav_net_forward(fav_net* net, const float* in7, float* out3, int 
         net->stage_bytes = bytes;
     }
     float* in8 = net->stage;
-    int rc = launch_nchw_to_nhwc_pad(in7, 7, H, W, net->pad, 8, in8, st); if (rc) return rc;
+    int rc = launch_nchw_to_nhwc_pad(in7, net->in_channels, H, W, net->pad, 8, in8, st); if (rc) return rc;
     return net->forward_padded(in8, H, W, nullptr, out3, st);
 }
 
@@ -545,6 +585,7 @@ extern "C" int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W, const
 // ================================================================================================
 struct fav_stream {
     fav_net* net = nullptr;
+    fav_net* img_net = nullptr;  // optional -model_img: stylises frames that have no prior (core.lua:59-66,146)
     int H = 0, W = 0;
     fav_stream_opts opts{};
     float* state = nullptr;      // last_frame_stylized: [3][H][W] float RGB, unclamped (fav.lua:169)
@@ -636,8 +677,22 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = launch_prep_input(frame_rgb_hwc, nullptr, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st);
     if (rc) return rc;
-    rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
+    fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
+    rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
     return stream_finish(s, out_rgb_f32, out_rgb8_hwc, st);
+}
+
+extern "C" int fav_stream_set_image_net(fav_stream* s, fav_net* image_net)
+{
+    FAV_REQUIRE(s, "fav_stream_set_image_net: null stream");
+    if (image_net) {
+        FAV_REQUIRE(image_net->device == s->net->device, "fav_stream_set_image_net: the image model lives on another device");
+        FAV_REQUIRE(image_net->pad == s->net->pad, "fav_stream_set_image_net: image model pads %d px, video model %d px (both read the same padded input)", image_net->pad, s->net->pad);
+        int Ho, Wo; image_net->out_size(s->H, s->W, &Ho, &Wo);
+        FAV_REQUIRE(Ho == s->H && Wo == s->W, "fav_stream_set_image_net: the image model maps %dx%d to %dx%d", s->W, s->H, Wo, Ho);
+    }
+    s->img_net = image_net;
+    return FAV_OK;
 }
 
 static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, const uint8_t* mask, float* out_f32, uint8_t* out_u8,

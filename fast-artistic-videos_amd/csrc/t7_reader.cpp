@@ -228,6 +228,34 @@ int module_to_layers(const Val* m, std::vector<Layer>& out)
         if (bias && bias->kind == Val::TENSOR) {
             if (!tensor_to_floats(bias, L.b) || (!L.b.empty() && L.b.size() != (size_t)L.cout)) { set_error(".t7: bad convolution bias"); return FAV_EFORMAT; }
         }
+    } else if (c == "nn.SpatialFullConvolution" || c == "cudnn.SpatialFullConvolution") {
+        double cin, cout, kw, kh, dw = 1, dh = 1, pw = 0, ph = 0, aw = 0, ah = 0;
+        if (!num_field(m, "nInputPlane", cin) || !num_field(m, "nOutputPlane", cout) || !num_field(m, "kW", kw) || !num_field(m, "kH", kh)) {
+            set_error(".t7: SpatialFullConvolution without size fields"); return FAV_EFORMAT; }
+        num_field(m, "dW", dw); num_field(m, "dH", dh); num_field(m, "padW", pw); num_field(m, "padH", ph); num_field(m, "adjW", aw); num_field(m, "adjH", ah);
+        if (kw != kh || dw != dh || pw != ph || aw != ah) { set_error(".t7: non-square full-convolution geometry is unsupported"); return FAV_EUNSUPPORTED; }
+        L.type = L_CONV; L.transposed = 1; L.cin = (int)cin; L.cout = (int)cout; L.k = (int)kw; L.stride = (int)dw; L.pad = (int)pw; L.adj = (int)aw;
+        if (!tensor_to_floats(field(m, "weight"), L.w) || L.w.size() != (size_t)L.cin * L.cout * L.k * L.k) {
+            set_error(".t7: full-convolution weight has %zu elements, expected %d", L.w.size(), L.cin * L.cout * L.k * L.k); return FAV_EFORMAT; }
+        const Val* bias = field(m, "bias");
+        if (bias && bias->kind == Val::TENSOR) {
+            if (!tensor_to_floats(bias, L.b) || (!L.b.empty() && L.b.size() != (size_t)L.cout)) { set_error(".t7: bad full-convolution bias"); return FAV_EFORMAT; }
+        }
+    } else if (c == "nn.SpatialBatchNormalization" || c == "cudnn.SpatialBatchNormalization") {
+        // evaluate mode (core.lua:47): y = (x - running_mean) / sqrt(running_var + eps) * weight + bias
+        L.type = L_BN;
+        if (num_field(m, "eps", a)) L.eps = (float)a;
+        if (!tensor_to_floats(field(m, "running_mean"), L.mean) || L.mean.empty()) { set_error(".t7: SpatialBatchNormalization without running_mean"); return FAV_EFORMAT; }
+        if (!tensor_to_floats(field(m, "running_var"), L.var) || L.var.empty()) {
+            std::vector<float> rstd;                     // old checkpoints: running_std = 1/sqrt(var + eps)
+            if (!tensor_to_floats(field(m, "running_std"), rstd) || rstd.size() != L.mean.size()) { set_error(".t7: SpatialBatchNormalization without running_var"); return FAV_EFORMAT; }
+            L.var.resize(rstd.size());
+            for (size_t i = 0; i < rstd.size(); ++i) L.var[i] = (float)(1.0 / ((double)rstd[i] * rstd[i]) - (double)L.eps);
+        }
+        tensor_to_floats(field(m, "weight"), L.gamma); tensor_to_floats(field(m, "bias"), L.beta);
+        if (L.gamma.empty()) L.gamma.assign(L.mean.size(), 1.f);
+        if (L.beta.empty()) L.beta.assign(L.mean.size(), 0.f);
+        if (L.var.size() != L.mean.size() || L.gamma.size() != L.mean.size() || L.beta.size() != L.mean.size()) { set_error(".t7: bad SpatialBatchNormalization parameters"); return FAV_EFORMAT; }
     } else if (c == "nn.InstanceNormalization") {
         L.type = L_IN;
         if (!tensor_to_floats(field(m, "weight"), L.gamma) || !tensor_to_floats(field(m, "bias"), L.beta) ||
@@ -280,8 +308,8 @@ void pack_layers(const std::vector<Layer>& ls, W& w)
         w.i32((int)L.type);
         w.i32(L.pl); w.i32(L.pr); w.i32(L.pt); w.i32(L.pb);
         w.i32(L.cin); w.i32(L.cout); w.i32(L.k); w.i32(L.stride); w.i32(L.pad);
-        w.i32(L.scale); w.i32(L.shave); w.f32(L.mul); w.f32(L.eps);
-        w.vec(L.w); w.vec(L.b); w.vec(L.gamma); w.vec(L.beta);
+        w.i32(L.scale); w.i32(L.shave); w.f32(L.mul); w.f32(L.eps); w.i32(L.transposed); w.i32(L.adj);
+        w.vec(L.w); w.vec(L.b); w.vec(L.gamma); w.vec(L.beta); w.vec(L.mean); w.vec(L.var);
         pack_layers(L.block, w);
     }
 }
@@ -306,8 +334,8 @@ void unpack_layers(R& r, std::vector<Layer>& ls, int depth)
         L.type = (LayerType)r.i32();
         L.pl = r.i32(); L.pr = r.i32(); L.pt = r.i32(); L.pb = r.i32();
         L.cin = r.i32(); L.cout = r.i32(); L.k = r.i32(); L.stride = r.i32(); L.pad = r.i32();
-        L.scale = r.i32(); L.shave = r.i32(); L.mul = r.f32(); L.eps = r.f32();
-        r.vec(L.w); r.vec(L.b); r.vec(L.gamma); r.vec(L.beta);
+        L.scale = r.i32(); L.shave = r.i32(); L.mul = r.f32(); L.eps = r.f32(); L.transposed = r.i32(); L.adj = r.i32();
+        r.vec(L.w); r.vec(L.b); r.vec(L.gamma); r.vec(L.beta); r.vec(L.mean); r.vec(L.var);
         unpack_layers(r, L.block, depth + 1);
         if (!r.ok) return;
     }
@@ -341,7 +369,7 @@ int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob)
     blob.clear();
     W w{blob};
     w.i32(0x42564146);   // "FAVB"
-    w.i32(1);
+    w.i32(2);
     pack_layers(layers, w);
     return FAV_OK;
 }
@@ -349,7 +377,7 @@ int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob)
 int blob_unpack(const void* blob, size_t bytes, std::vector<Layer>& out)
 {
     R r{static_cast<const uint8_t*>(blob), bytes};
-    if (r.i32() != 0x42564146 || r.i32() != 1) { set_error("weight blob: bad magic/version"); return FAV_EFORMAT; }
+    if (r.i32() != 0x42564146 || r.i32() != 2) { set_error("weight blob: bad magic/version"); return FAV_EFORMAT; }
     unpack_layers(r, out, 0);
     if (!r.ok) { set_error("weight blob: truncated or corrupt"); return FAV_EFORMAT; }
     return FAV_OK;
@@ -363,7 +391,11 @@ std::string describe_layers(const std::vector<Layer>& layers, int indent)
     for (const Layer& L : layers) {
         switch (L.type) {
         case L_PAD: snprintf(buf, sizeof buf, "pad %d %d %d %d", L.pl, L.pr, L.pt, L.pb); break;
-        case L_CONV: snprintf(buf, sizeof buf, "conv %d %d %d %d %d bias=%d", L.cin, L.cout, L.k, L.stride, L.pad, L.b.empty() ? 0 : 1); break;
+        case L_CONV:
+            if (L.transposed) snprintf(buf, sizeof buf, "fullconv %d %d %d %d %d adj=%d bias=%d", L.cin, L.cout, L.k, L.stride, L.pad, L.adj, L.b.empty() ? 0 : 1);
+            else snprintf(buf, sizeof buf, "conv %d %d %d %d %d bias=%d", L.cin, L.cout, L.k, L.stride, L.pad, L.b.empty() ? 0 : 1);
+            break;
+        case L_BN: snprintf(buf, sizeof buf, "bn %zu", L.mean.size()); break;
         case L_IN: snprintf(buf, sizeof buf, "in %zu", L.gamma.size()); break;
         case L_RELU: snprintf(buf, sizeof buf, "relu"); break;
         case L_RES: snprintf(buf, sizeof buf, "res shave=%d", L.shave); break;

@@ -219,7 +219,6 @@ int main(int argc, char** argv)
         die("Must give -flow_pattern and -occlusions_pattern");                                              // fav.lua:180-182
     if (o.i("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement lives in oracle/ and is test infrastructure only)");
     if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
-    if (o.s("model_img") != "self") die("-model_img <file>: image models (SpatialFullConvolution) are not supported yet; use -model_img self");
     if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
     if (o.s("fill_occlusions") != "vgg-mean") die("-fill_occlusions uniform-random is not supported (unseeded in the reference: core.lua:109)");
     const int border = o.s("warp_border") == "cpu" ? FAV_BORDER_CPU : FAV_BORDER_STN;
@@ -229,6 +228,11 @@ int main(int argc, char** argv)
     fav_net* net = nullptr;
     if (fav_net_create(o.s("model_vid").c_str(), o.i("gpu"), &net)) die(fav_last_error());                   // core.lua:39-43
     printf("Model loaded.\n");
+    fav_net* net_img = nullptr;                                                                              // core.lua:59-66
+    if (o.s("model_img") != "self") {
+        if (fav_net_create(o.s("model_img").c_str(), o.i("gpu"), &net_img)) die(fav_last_error());
+        printf("Model loaded.\n");
+    }
 
     const int num_frames = o.i("num_frames");
     const bool backward = o.f("backward");
@@ -359,6 +363,7 @@ int main(int argc, char** argv)
             W = cur.W; H = cur.H;
             fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0};
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
+            if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
             const size_t n = (size_t)W * H;
             if (hipMalloc((void**)&d_out8, n * 3)) die("hipMalloc failed");
             for (auto& dv : dev)
@@ -429,7 +434,7 @@ int main(int argc, char** argv)
         printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f}\n",
                done, s, done / s, t_wait_load, t_gpu, t_wait_writer);
     }
-    fav_stream_destroy(fs); fav_net_destroy(net);
+    fav_stream_destroy(fs); fav_net_destroy(net); fav_net_destroy(net_img);
     hipFree(d_out8); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
     for (auto p : h_out) hipHostFree(p);
     for (auto& p : pin) { hipHostFree(p.frame); hipHostFree(p.bw); hipHostFree(p.fw); hipHostFree(p.cert); }

@@ -58,7 +58,7 @@ EXPORTS = [
     "fav_net_create_from_blob", "fav_net_destroy", "fav_net_describe_host", "fav_t7_describe_host", "fav_net_param_count",
     "fav_net_output_size", "fav_net_forward", "fav_net_profile_enable", "fav_net_profile_read_host",
     "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
-    "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
+    "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
@@ -214,6 +214,10 @@ def describe_layers(layers, indent: int = 0) -> str:
     for L in layers:
         t = L["type"]
         if t == "pad": out.append(f"{pad}pad {L['l']} {L['r']} {L['t']} {L['b']}")
+        elif t == "fullconv":
+            ci, co, k, _ = L["w"].shape
+            out.append(f"{pad}fullconv {ci} {co} {k} {L['stride']} {L['pad']} adj={L['adj']} bias={0 if L['b'] is None else 1}")
+        elif t == "bn": out.append(f"{pad}bn {len(L['mean'])}")
         elif t == "conv":
             co, ci, k, _ = L["w"].shape
             out.append(f"{pad}conv {ci} {co} {k} {L['stride']} {L['pad']} bias={0 if L['b'] is None else 1}")
@@ -257,6 +261,10 @@ class Stream:
             lib().fav_stream_destroy(self.h); self.h = None
 
     __del__ = close
+
+    def set_image_net(self, img_net: Optional[Net]):
+        self._img = img_net      # keep alive
+        _check(lib().fav_stream_set_image_net(self.h, img_net.h if img_net is not None else None))
 
     def _outs(self, dev, want_f32, want_u8):
         torch = _torch()

@@ -207,6 +207,17 @@ def extract_layers(module) -> List[dict]:
             b = m.get("bias"); b = None if b is None or np.size(b) == 0 else np.asarray(b, np.float32)
             out.append({"type": "conv", "w": w, "b": b, "stride": int(m["dW"]), "pad": int(m.get("padW", 0))})
             assert int(m["dW"]) == int(m["dH"]) and int(m.get("padW", 0)) == int(m.get("padH", 0))
+        elif c == "nn.SpatialFullConvolution":
+            cin, cout, kw, kh = int(m["nInputPlane"]), int(m["nOutputPlane"]), int(m["kW"]), int(m["kH"])
+            w = np.asarray(m["weight"], np.float32).reshape(cin, cout, kh, kw)
+            b = m.get("bias"); b = None if b is None or np.size(b) == 0 else np.asarray(b, np.float32)
+            out.append({"type": "fullconv", "w": w, "b": b, "stride": int(m["dW"]), "pad": int(m.get("padW", 0)), "adj": int(m.get("adjW", 0))})
+        elif c == "nn.SpatialBatchNormalization":
+            var = m.get("running_var")
+            if var is None:    # very old checkpoints store running_std = 1/sqrt(var + eps)
+                std = np.asarray(m["running_std"], np.float64); var = 1.0 / (std * std) - float(m.get("eps", 1e-5))
+            out.append({"type": "bn", "mean": np.asarray(m["running_mean"], np.float32), "var": np.asarray(var, np.float32),
+                        "gamma": np.asarray(m["weight"], np.float32), "beta": np.asarray(m["bias"], np.float32), "eps": float(m.get("eps", 1e-5))})
         elif c == "nn.InstanceNormalization":
             out.append({"type": "in", "gamma": np.asarray(m["weight"], np.float32),
                         "beta": np.asarray(m["bias"], np.float32), "eps": float(m.get("eps", 1e-5))})
@@ -242,6 +253,22 @@ def _conv(rng, cin, cout, k, s, p):
         "gradInput": np.zeros((0,), np.float32)})
 
 
+def _fullconv(rng, cin, cout, k, s, p, adj):
+    std = np.sqrt(2.0 / (cin * k * k))
+    w = (rng.standard_normal((cin, cout, k, k)) * std).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+    return TorchObject("nn.SpatialFullConvolution", {
+        "nInputPlane": cin, "nOutputPlane": cout, "kW": k, "kH": k, "dW": s, "dH": s, "padW": p, "padH": p, "adjW": adj, "adjH": adj,
+        "weight": w, "bias": b, "_type": "torch.FloatTensor", "train": False})
+
+
+def _bnorm(rng, c):
+    return TorchObject("nn.SpatialBatchNormalization", {
+        "eps": 1e-5, "momentum": 0.1, "affine": True, "train": False,
+        "running_mean": rng.standard_normal(c).astype(np.float32), "running_var": rng.uniform(0.5, 2.0, c).astype(np.float32),
+        "weight": rng.uniform(0.0, 1.0, c).astype(np.float32), "bias": rng.uniform(-0.2, 0.2, c).astype(np.float32)})
+
+
 def _inorm(rng, c):
     # InstanceNormalization.lua:18-30: weight ~ U(0,1), bias = 0; nested bn is baggage the reader skips
     bn = TorchObject("nn.SpatialBatchNormalization", {"eps": 1e-5, "momentum": 0.1, "affine": True, "train": True,
@@ -264,14 +291,17 @@ def _sequential(mods):
                                          "gradInput": np.zeros((0,), np.float32)})
 
 
+IMAGE_ARCH = "c9s1-32,d64,d128,R128,R128,R128,R128,R128,u64,u32,c9s1-3"        # train_video.lua:21 (fast-neural-style image models)
+
+
 def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
-                tanh_constant: float = 150.0, insert_pad: bool = True) -> TorchObject:
+                tanh_constant: float = 150.0, insert_pad: bool = True, use_instance_norm: bool = True) -> TorchObject:
     """Mirror of models_video.lua:55-140 for padding_type='reflect-start', use_instance_norm=1."""
     rng = np.random.default_rng(seed)
     mods = []
     prev = in_channels
     items = arch.split(",")
-    n_res, down = 0, 1
+    n_res, down, res_down = 0, 1, 1
     for i, v in enumerate(items):
         needs_bn = needs_relu = True
         c0 = v[0]
@@ -282,10 +312,13 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
             nxt = int(v[1:]); mods.append(_conv(rng, prev, nxt, 3, 2, 1)); down *= 2   # :90-93
         elif c0 == "U":
             nxt = prev; mods.append(_simple("nn.SpatialUpSamplingNearest", scale_factor=int(v[1:])))  # :94-98
+        elif c0 == "u":
+            nxt = int(v[1:]); mods.append(_fullconv(rng, prev, nxt, 3, 2, 1, 1)); down //= 2          # :99-102
         elif c0 == "R":
-            nxt = int(v[1:]); n_res += 1
-            block = _sequential([_conv(rng, nxt, nxt, 3, 1, 0), _inorm(rng, nxt), _simple("nn.ReLU", inplace=True),
-                                 _conv(rng, nxt, nxt, 3, 1, 0), _inorm(rng, nxt)])              # :10-39
+            nxt = int(v[1:]); n_res += 1; res_down = down
+            norm = _inorm if use_instance_norm else _bnorm
+            block = _sequential([_conv(rng, nxt, nxt, 3, 1, 0), norm(rng, nxt), _simple("nn.ReLU", inplace=True),
+                                 _conv(rng, nxt, nxt, 3, 1, 0), norm(rng, nxt)])                # :10-39
             concat = TorchObject("nn.ConcatTable", {"modules": [block, _simple("nn.ShaveImage", size=2)]})
             mods.append(_sequential([concat, _simple("nn.CAddTable", inplace=False)]))            # :41-53
             needs_bn = needs_relu = False
@@ -293,14 +326,14 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
             raise ValueError(f"arch item {v!r} is outside the hot-path scope")
         if i == len(items) - 1:
             needs_bn = needs_relu = False                                                        # :117-120
-        if needs_bn: mods.append(_inorm(rng, nxt))
+        if needs_bn: mods.append(_inorm(rng, nxt) if use_instance_norm else _bnorm(rng, nxt))
         if needs_relu: mods.append(_simple("nn.ReLU", inplace=True))
         prev = nxt
     mods.append(_simple("nn.Tanh"))
     mods.append(_simple("nn.MulConstant", constant_scalar=float(tanh_constant), inplace=False))
     mods.append(_simple("nn.TotalVariation", strength=1e-6))
     if insert_pad and n_res:
-        p = 2 * n_res * down     # train_video.lua:319-325: 2 px/side/block at 1/down res (40 for 5 blocks at 1/4)
+        p = 2 * n_res * res_down  # train_video.lua:319-325: 2 px/side/block at 1/res_down res (40 for 5 blocks at 1/4)
         mods.insert(0, TorchObject("nn.SpatialReflectionPadding",
                                    {"pad_l": p, "pad_r": p, "pad_t": p, "pad_b": p,
                                     "_type": "torch.FloatTensor", "train": False}))

@@ -146,6 +146,10 @@ typedef struct fav_stream_opts {
 
 int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* opts_host, fav_stream** out);
 void fav_stream_destroy(fav_stream* s);
+/* -model_img <file>: a separate 3-channel image model (fast_artistic_video_core.lua:59-66,146) that stylises frames
+ * without a prior (fav_stream_first_frame).  NULL restores 'self' (the video model with an all-occluded prior).  The
+ * image model must use the same leading reflection padding as the video model.  Not owned by the stream. */
+int fav_stream_set_image_net(fav_stream* s, fav_net* image_net);
 /* first frame / -create_inconsistent: core.lua:121-158 with model_img == 'self'.
  * frame_rgb_hwc: P6 payload [H][W][3] u8.  out_rgb_f32 [3][H][W] float RGB (deprocessed, unclamped)
  * and/or out_rgb8_hwc [H][W][3] u8 (image.save quantisation); either may be NULL. */

@@ -350,6 +350,51 @@ void orc_conv2d(const float* in, int Cin, int H, int W, const float* weight, con
     }
 }
 
+/* nn.SpatialFullConvolution(nIn, nOut, kW, kH, dW, dH, padW, padH, adjW, adjH) (models_video.lua:88,102) [recalled: Torch7 nn]:
+ * transposed convolution, weight [Cin][Cout][kH][kW]; out size = (in-1)*s - 2p + k + adj;
+ * out[co][iy*s - p + ky][ix*s - p + kx] += in[ci][iy][ix] * w[ci][co][ky][kx].  fp64 accumulation. */
+void orc_full_conv2d(const float* in, int Cin, int H, int W, const float* weight, const float* bias,
+                     int Cout, int k, int s, int p, int adj, float* out)
+{
+    int OH = (H - 1) * s - 2 * p + k + adj, OW = (W - 1) * s - 2 * p + k + adj;
+#pragma omp parallel for
+    for (int co = 0; co < Cout; ++co) {
+        double* acc = (double*)malloc(sizeof(double) * OH * OW);
+        for (int i = 0; i < OH * OW; ++i) acc[i] = bias ? (double)bias[co] : 0.0;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int iy = 0; iy < H; ++iy)
+                for (int ix = 0; ix < W; ++ix) {
+                    double x = in[((size_t)ci * H + iy) * W + ix];
+                    for (int ky = 0; ky < k; ++ky) {
+                        int oy = iy * s - p + ky; if (oy < 0 || oy >= OH) continue;
+                        for (int kx = 0; kx < k; ++kx) {
+                            int ox = ix * s - p + kx; if (ox < 0 || ox >= OW) continue;
+                            acc[(size_t)oy * OW + ox] += x * (double)weight[(((size_t)ci * Cout + co) * k + ky) * k + kx];
+                        }
+                    }
+                }
+        for (int i = 0; i < OH * OW; ++i) out[(size_t)co * OH * OW + i] = (float)acc[i];
+        free(acc);
+    }
+}
+
+/* nn.SpatialBatchNormalization in evaluate mode (models_video.lua:24,35,126; model:evaluate() core.lua:47) [recalled]:
+ * y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta.  In place; relu fuses a following nn.ReLU. */
+void orc_batchnorm_eval(float* x, int C, int H, int W, const float* mean, const float* var, const float* gamma,
+                        const float* beta, float eps, int relu)
+{
+    size_t n = (size_t)H * W;
+    for (int c = 0; c < C; ++c) {
+        float* p = x + (size_t)c * n;
+        double invstd = 1.0 / sqrt((double)var[c] + (double)eps);
+        float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            float v = (float)(((double)p[i] - (double)mean[c]) * invstd) * g + b;
+            p[i] = (relu && v < 0.0f) ? 0.0f : v;
+        }
+    }
+}
+
 /* nn.InstanceNormalization (InstanceNormalization.lua:33-53): SpatialBatchNormalization in
  * training mode over a 1 x (N*C) x H x W view => per-channel mean and BIASED variance over H*W,
  * y = (x - mean) / sqrt(var + eps) * gamma + beta; two-pass, fp64 accumulators [recalled].

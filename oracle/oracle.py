@@ -188,6 +188,26 @@ def conv2d(x, w, b, stride, pad):
     return out
 
 
+def full_conv2d(x, w, b, stride, pad, adj):
+    x, px = _f(x); w, pw = _f(w)
+    cin, h, ww = x.shape; _, cout, k, _ = w.shape
+    oh, ow = (h - 1) * stride - 2 * pad + k + adj, (ww - 1) * stride - 2 * pad + k + adj
+    out = np.empty((cout, oh, ow), np.float32)
+    pb = _f(b)[1] if b is not None else None
+    bb = _f(b)[0] if b is not None else None
+    lib().orc_full_conv2d(px, cin, h, ww, pw, bb.ctypes.data_as(C.POINTER(C.c_float)) if bb is not None else None, cout, k, stride, pad, adj,
+                          out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def batchnorm_eval_(x, mean, var, gamma, beta, eps=1e-5, relu=False):
+    assert x.dtype == np.float32 and x.flags.c_contiguous
+    m, pm = _f(mean); v, pv = _f(var); g, pg = _f(gamma); b, pb = _f(beta)
+    lib().orc_batchnorm_eval(x.ctypes.data_as(C.POINTER(C.c_float)), x.shape[0], x.shape[1], x.shape[2], pm, pv, pg, pb,
+                             C.c_float(eps), 1 if relu else 0)
+    return x
+
+
 def instnorm_(x, gamma, beta, eps=1e-5, relu=False):
     assert x.dtype == np.float32 and x.flags.c_contiguous
     g, pg = _f(gamma); b, pb = _f(beta)
@@ -228,6 +248,12 @@ def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None)
             x = reflect_pad(x, L["l"], L["r"], L["t"], L["b"])
         elif t == "conv":
             x = conv2d(x, L["w"], L["b"], L["stride"], L["pad"])
+        elif t == "fullconv":
+            x = full_conv2d(x, L["w"], L["b"], L["stride"], L["pad"], L["adj"])
+        elif t == "bn":
+            relu = i + 1 < len(layers) and layers[i + 1]["type"] == "relu"
+            x = batchnorm_eval_(x, L["mean"], L["var"], L["gamma"], L["beta"], L["eps"], relu)
+            if relu: i += 1
         elif t == "in":
             relu = i + 1 < len(layers) and layers[i + 1]["type"] == "relu"
             x = instnorm_(x, L["gamma"], L["beta"], L["eps"], relu)
@@ -261,7 +287,11 @@ class Stylizer:
         self.invert, self.fix = invert_occlusion, fix_occlusions
         self.last = None        # last_frame_stylized: float RGB [3][H][W], unclamped (fav.lua:169)
 
-    def first(self, frame_rgb01):
+    def first(self, frame_rgb01, image_layers=None):
+        if image_layers is not None:       # model_img:forward(pre) -- core.lua:146
+            out = deprocess(net_forward(image_layers, preprocess(frame_rgb01)))
+            self.last = out
+            return out
         out = deprocess(net_forward(self.layers, assemble(frame_rgb01, None, None)))
         self.last = out
         return out

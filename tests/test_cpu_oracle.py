@@ -134,6 +134,24 @@ def test_oracle_layers_vs_torch(oracle):
     assert np.array_equal(oracle.shave_add(blk, x, 2), blk + x[:, 2:-2, 2:-2])
 
 
+def test_oracle_image_model_layers_vs_torch(oracle):
+    """nn.SpatialFullConvolution / nn.SpatialBatchNormalization(evaluate) of the first-frame image models"""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((6, 7, 9)).astype(np.float32)
+    w = rng.standard_normal((6, 4, 3, 3)).astype(np.float32); b = rng.standard_normal(4).astype(np.float32)
+    ref = F.conv_transpose2d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                             stride=2, padding=1, output_padding=1)[0].numpy()
+    got = oracle.full_conv2d(x, w, b, 2, 1, 1)
+    assert got.shape == (4, 14, 18) and np.abs(got - ref).max() < 1e-5
+    mean = rng.standard_normal(6).astype(np.float32); var = rng.uniform(0.5, 2, 6).astype(np.float32)
+    g = rng.random(6).astype(np.float32); bt = rng.standard_normal(6).astype(np.float32)
+    ref = F.batch_norm(torch.from_numpy(x)[None].double(), torch.from_numpy(mean).double(), torch.from_numpy(var).double(),
+                       torch.from_numpy(g).double(), torch.from_numpy(bt).double(), False, 0.1, 1e-5)[0].numpy()
+    assert np.abs(oracle.batchnorm_eval_(x.copy(), mean, var, g, bt, 1e-5) - ref).max() < 1e-5
+
+
 def _convs(ls):
     for L in ls:
         if L["type"] == "conv": yield L
@@ -190,6 +208,12 @@ def test_cpp_t7_reader_matches_python_reader(favlib, golden_dir, tmp_path):
     assert favlib.describe_t7(p) == favlib.describe_layers(t7.extract_layers(t7.load(p)["model"]))
     blob = favlib.pack_checkpoint(p)
     assert blob[:4] == b"FAVB" and len(blob) > 1679235 * 4
+    for inorm in (True, False):      # first-frame image models: SpatialFullConvolution, optional BatchNorm
+        pi = str(tmp_path / f"img{int(inorm)}.t7")
+        t7.make_synthetic_checkpoint(pi, arch=t7.IMAGE_ARCH, seed=4, in_channels=3, use_instance_norm=inorm)
+        d = favlib.describe_t7(pi)
+        assert d == favlib.describe_layers(t7.extract_layers(t7.load(pi)["model"]))
+        assert "fullconv 128 64 3 2 1 adj=1" in d and ("in 64" in d if inorm else "bn 64" in d)
     # malformed inputs fail with a status, never crash
     bad = str(tmp_path / "bad.t7")
     with open(bad, "wb") as f:

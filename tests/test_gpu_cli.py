@@ -89,6 +89,19 @@ def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
     r = subprocess.run([exe, "-input_pattern", "x", "-flow_pattern", "a", "-occlusions_pattern", "b", "-model_vid", str(tmp_path / "none.t7")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "Could not load model" in r.stderr                             # core.lua:41
+    # -model_img <file>: the first frame goes through a separate image model (core.lua:59-66,146)
+    from PIL import Image
+    import oracle as O
+    pi = str(tmp_path / "img.t7")
+    t7.make_synthetic_checkpoint(pi, arch="c9s1-8,d16,d32,R32,R32,u16,u8,c9s1-3", seed=5, in_channels=3)
+    fr = synth.smooth_frame(48, 64, 9); O.write_pnm(str(tmp_path / "one_00001.ppm"), fr)
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "one_%05d.ppm"), "-create_inconsistent", "-model_vid", model, "-model_img", pi,
+                        "-gpu", "0", "-output_prefix", str(tmp_path / "img" / "out")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("Model loaded.") == 2, r.stderr
+    want = O.to_u8_hwc(O.deprocess(O.net_forward(t7.extract_layers(t7.load(pi)["model"]),
+                                                 O.preprocess(np.transpose(fr, (2, 0, 1)).astype(np.float32) / np.float32(255)))))
+    got = np.asarray(Image.open(str(tmp_path / "img" / "out-00001.png")))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
     # th shim used by the unmodified shell drivers
     shim = os.path.join(ROOT, "fast-artistic-videos_amd", "host", "th")
     r = subprocess.run([shim, "fast_artistic_video.lua", "-input_pattern", str(tmp_path / "no_%05d.ppm"), "-create_inconsistent",

@@ -192,10 +192,42 @@ def test_canonical_network_vs_oracle(favlib, oracle, cuda, canonical):
     assert np.abs(ref).max() > 100 and np.abs(ref).std() > 20     # not saturated / not trivial
 
 
+@pytest.mark.parametrize("inorm", [True, False])
+def test_image_model_vs_oracle(favlib, oracle, cuda, tmp_path, golden_dir, inorm):
+    """-model_img <file> -- 3-channel image model with nn.SpatialFullConvolution ('u' layers,
+    models_video.lua:99-102) and InstanceNorm or evaluate-mode BatchNorm, used for frames without a prior (core.lua:59-66,146)"""
+    pi = str(tmp_path / "img.t7")
+    t7.make_synthetic_checkpoint(pi, arch="c9s1-8,d16,d32,R32,R32,u16,u8,c9s1-3", seed=5, in_channels=3, use_instance_norm=inorm)
+    img_layers = _layers(pi)
+    net_img = favlib.Net(pi, 0)
+    assert net_img.describe() == favlib.describe_layers(img_layers)
+    x = (np.random.default_rng(2).standard_normal((3, 40, 56)) * 50).astype(np.float32)
+    got = net_img.forward(T(x, cuda)).cpu().numpy()
+    ref = oracle.net_forward(img_layers, x)
+    assert got.shape == ref.shape == (3, 40, 56)
+    assert np.abs(got - ref).max() <= 5e-2
+    # in the pipeline: first frame through the image model, the following ones through the video model
+    vid = os.path.join(golden_dir, "tiny_model.t7")
+    h, w = 48, 64
+    frames, bws, fws = _clip(h, w, 2, 80)
+    net = favlib.Net(vid, 0)
+    st = favlib.Stream(net, h, w)
+    st.set_image_net(net_img)
+    o0, _ = st.first_frame(T(frames[0], cuda))
+    o1, _ = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda))
+    ref_s = oracle.Stylizer(_layers(vid))
+    r0 = ref_s.first(_f01(frames[0]), image_layers=img_layers)
+    assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+    ref_s.last = o0.cpu().numpy()
+    m = oracle.consistency(bws[1], fws[1])
+    r1 = ref_s.next(_f01(frames[1]), bws[1], m.astype(np.float32) / np.float32(255))
+    assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+
+
 def test_unsupported_models_fail_with_status(favlib, cuda, tmp_path):
-    p = str(tmp_path / "img.t7")
-    t7.make_synthetic_checkpoint(p, arch="c9s1-8,d16,R16,U2,c9s1-3", seed=2, in_channels=3)
-    with pytest.raises(favlib.FavError, match="7"):
+    p = str(tmp_path / "odd.t7")
+    t7.make_synthetic_checkpoint(p, arch="c9s1-8,d16,R16,U2,c9s1-3", seed=2, in_channels=5)
+    with pytest.raises(favlib.FavError, match="5 input channels"):
         favlib.Net(p, 0)
     with pytest.raises(favlib.FavError):
         favlib.Net(str(tmp_path / "missing.t7"), 0)
