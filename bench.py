@@ -73,11 +73,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfav has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("FAV_BENCH_BACKEND", "nccl")       # "gloo": launch-path smoke test with several ranks on one GPU
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPUs visible (one process per GPU)")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    cdev = dev if backend == "nccl" else torch.device("cpu")    # device of the collective buffers
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.lookahead < 0:
         args.lookahead = 1 if args.structure else 0
@@ -89,7 +98,7 @@ def main():
     if rank == 0:
         t7.make_synthetic_checkpoint(ckpt, seed=1234)
         blob = fav_amd.pack_checkpoint(ckpt)
-    blob = shard.broadcast_blob(blob, dev)             # RCCL over xGMI: 6.7 MB, once, before the timed region
+    blob = shard.broadcast_blob(blob, cdev)            # RCCL over xGMI: 6.7 MB, once, before the timed region
     net = fav_amd.Net(blob=blob, device=local)
     stream = fav_amd.Stream(net, H, W)
 
@@ -130,7 +139,7 @@ def main():
     dt = time.perf_counter() - t0
     net.profile_enable(False)
     prof = net.profile_read()
-    dt = shard.max_over_ranks(dt, dev)
+    dt = shard.max_over_ranks(dt, cdev)
 
     # not part of `value`: the same loop with the checker's 4-argument (image-structure) mode, which is what
     # makeOptFlow_deepflow.sh:59 runs in production; its masks are computed two frames ahead on the side queues
