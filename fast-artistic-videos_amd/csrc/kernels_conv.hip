@@ -649,7 +649,7 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int H3_TH = 8, H3_TW = 32;
+constexpr int H3_TH = 8, H3_TW = 32;   // output tile: 8 rows (one per wave) x 32 pixels
 
 struct H3Args {
     const float* in; const float* wgt; const float* bias;
@@ -658,26 +658,47 @@ struct H3Args {
     float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;
     int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
     int stages, relu1, relu2;
+    long long* dbg;          // optional in-kernel timeline (FAV_H3_DBG), 24 slots per block
 };
 
-template <int BN>
+// fp32 MFMA and the vector ALU do not overlap on a SIMD (measured: scripts/mfma_mix.hip -- every VALU instruction in the
+// loop costs its issue cycles in matrix throughput), so the K loop is built to need almost none:
+//   * the nine taps of a channel slice are unrolled: tap offsets, the weight ring slot (tap % 3) and the halo piece index
+//     are compile-time constants, i.e. immediate offsets on per-thread base registers that are set once per tile/slice
+//   * global addresses are scalar base (advanced by the scalar ALU) + a per-thread 32-bit offset fixed for the tile
+//   * what is left per step: the IN/ReLU transform of one 16-byte halo piece (6 of 9 steps)
+// Software pipeline of one K step (32 channels of one tap; 4 fragment groups of 8 channels):
+//   start  : weights of step s+1 (in registers since step s-1) -> LDS ring slot (s+1)%3; issue the global load of step
+//            s+2's weights and of one sixth of the NEXT channel slice's halo
+//   groups : the A/B fragments of group g+1 are read from LDS into the other register set while group g's 16 MFMAs issue;
+//            the last group prefetches group 0 of step s+1, so no LDS latency is exposed in the steady state
+//   barrier: one per step, between groups 1 and 2 -- it publishes ring slot (s+1)%3 half a step before its first read
+//            and is never followed by a dependent LDS read (three slots make the write-after-read side safe)
+//   end    : the halo piece, transformed, -> the other halo buffer
+template <int BN, bool S2>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
 {
     constexpr int NT = 512;
     constexpr int HWD = H3_TW + 2, HP = (H3_TH + 2) * HWD;        // 34, 340 halo pixels
     constexpr int TN = BN / 32;
-    constexpr int NHV = (HP * 8 + NT - 1) / NT;                   // float4 per thread per halo slice (6)
+    constexpr int NHV = (HP * 8 + NT - 1) / NT;                   // 16-byte halo pieces per thread per slice (6)
+    constexpr int ALIAS = NT * NHV - HP * 8;                       // units past the end alias earlier ones (same data, same slot)
     constexpr int BROWS = BN / 64;                                 // weight rows per thread per step
+    static_assert(NHV <= 8, "a slice's halo pieces must all be staged before its last tap");
+    static_assert(ALIAS % 8 == 0 && ALIAS <= NT, "halo aliasing");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                           // [2][HP][LDSS]
-    float* Bs = Hs + 2 * HP * LDSS;             // [2][BN][LDSS]
-    float* aff = Bs + 2 * BN * LDSS;            // [4][CIN]
+    float* Bs = Hs + 2 * HP * LDSS;             // [3][BN][LDSS]
+    float* aff = Bs + 3 * BN * LDSS;            // [4][CIN]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int CIN = p.CIN;
     const int nchunks = CIN >> 5, nsteps = nchunks * 9;
     const int ntiles = p.tiles_x * p.tiles_y;
 
+    int dbi = 0;
+#define DBG_T() { if (p.dbg && t == 0 && dbi < 22) p.dbg[blockIdx.x * 24 + dbi++] = wall_clock64(); }
+    DBG_T();
     int lb;
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -691,10 +712,19 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int c4 = t & 7, r0 = t >> 3;                      // weight staging: row r0 (+64), 16-byte chunk c4
+    const int c4 = t & 7, r0 = t >> 3;                      // staging: weight row r0 (+64) / halo pixel r0 (+64 i), 16-byte chunk c4
     const int frag_k = (lane >> 5) * 4;                     // k pair {r, 4+r} by half-wave
     const int m = lane & 31;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
+    // per-thread bases; everything else in the K loop is an immediate or a scalar
+    const unsigned wofs = (unsigned)(r0 * p.Kpad + c4 * 4) * 4u;            // byte offset of this thread's weight chunk in a step
+    const unsigned wrow64 = (unsigned)(64 * p.Kpad) * 4u;
+    float* const bst = Bs + r0 * LDSS + c4 * 4;                             // weight staging slot
+    float* const hst = Hs + r0 * LDSS + c4 * 4;                             // halo staging slot of piece 0, buffer 0
+    const int hst_last = (t + NT * (NHV - 1) >= HP * 8) ? (NT * (NHV - 1) - ALIAS) / 8 * LDSS : 64 * (NHV - 1) * LDSS;
+    const float* const afr = Hs + (wave * HWD + m) * LDSS + frag_k;         // A fragments: tap (0,0), buffer 0
+    const float* const bfr = Bs + m * LDSS + frag_k;                        // B fragments: ring slot 0
+    const float* const affr = aff + c4 * 4;
 
     const int U = ntiles * nsteps;
     int u = (int)((long long)U * lb / gridDim.x);
@@ -707,85 +737,133 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         u += k1 - k0;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         const int oy0 = ty * H3_TH, ox0 = tx * H3_TW;
+        DBG_T();   /* work item start */
 
-        // halo element assignment (fixed per tile): unit e = t + 512*i -> pixel e>>3, channel chunk e&7
+        // halo piece i: unit e = t + 512*i -> halo pixel e>>3, channel chunk e&7; per tile: element offset (0 if outside) and mask
         int hoff[NHV]; float hmask[NHV];
 #pragma unroll
         for (int i = 0; i < NHV; ++i) {
-            const int e = t + NT * i, pix = e >> 3;
-            const int hy = pix / HWD, hx = pix - hy * HWD;
+            int e = t + NT * i; e -= e >= HP * 8 ? ALIAS : 0;
+            const int pix = e >> 3, hy = (pix * 1928) >> 16, hx = pix - hy * HWD;
             const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
-            const bool v = (e < HP * 8) & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
-            hoff[i] = v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN + (e & 7) * 4 : 0;
+            const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+            hoff[i] = ((v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN : 0) + c4 * 4) * 4;       // bytes
             hmask[i] = v ? 1.f : 0.f;
         }
-        const float* wrow = p.wgt + (size_t)r0 * p.Kpad + c4 * 4;
-        float4 hr[NHV];
-        v4f rb[BROWS];
+        const int c_first = (k0 * 7282) >> 16, tap0 = k0 - c_first * 9;      // k / 9 (exact for k < 4096)
+        const int c_last = ((k1 - 1) * 7282) >> 16, tapE = k1 - c_last * 9;
 
-#define H3_LOAD_HALO(chunk_)                                                                        \
-        { _Pragma("unroll") for (int i = 0; i < NHV; ++i) hr[i] = *reinterpret_cast<const float4*>(p.in + hoff[i] + (chunk_) * 32); }
-#define H3_STORE_HALO(buf_, chunk_)                                                                 \
-        { _Pragma("unroll") for (int i = 0; i < NHV; ++i) {                                         \
-            const int e_ = t + NT * i;                                                              \
-            const int ci_ = (chunk_) * 32 + (e_ & 7) * 4;                                           \
-            float4 v_ = affine4_lo(hr[i], aff + ci_, aff + CIN + ci_, lo1);                         \
-            v_ = affine4_lo(v_, aff + 2 * CIN + ci_, aff + 3 * CIN + ci_, lo2);                     \
-            v_.x *= hmask[i]; v_.y *= hmask[i]; v_.z *= hmask[i]; v_.w *= hmask[i];                 \
-            if (e_ < HP * 8) *reinterpret_cast<float4*>(Hs + ((buf_) * HP + (e_ >> 3)) * LDSS + (e_ & 7) * 4) = v_; \
-        } }
-#define H3_LOAD_B(s_)                                                                               \
-        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) rb[j] = *reinterpret_cast<const v4f*>(wrow + (64 * j) * p.Kpad + (s_) * BK); }
-#define H3_STORE_B(buf_)                                                                            \
-        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(Bs + ((buf_) * BN + r0 + 64 * j) * LDSS + c4 * 4) = rb[j]; }
+        float4 hr; v4f rb[BROWS];
+        v4f sc1, sh1, sc2, sh2;             // IN/ReLU stages of the slice being staged, this thread's 4 channels
+#define H3_AFF(chunk_)                                                                              \
+        { sc1 = *reinterpret_cast<const v4f*>(affr + (chunk_) * 32); sh1 = *reinterpret_cast<const v4f*>(affr + CIN + (chunk_) * 32); \
+          if (S2) { sc2 = *reinterpret_cast<const v4f*>(affr + 2 * CIN + (chunk_) * 32); sh2 = *reinterpret_cast<const v4f*>(affr + 3 * CIN + (chunk_) * 32); } }
+#define H3_XFORM(v_, m_)                                                                            \
+        { v_.x = fmaxf(fmaf(v_.x, sc1.x, sh1.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc1.y, sh1.y), lo1);  \
+          v_.z = fmaxf(fmaf(v_.z, sc1.z, sh1.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc1.w, sh1.w), lo1);  \
+          if (S2) { v_.x = fmaxf(fmaf(v_.x, sc2.x, sh2.x), lo2); v_.y = fmaxf(fmaf(v_.y, sc2.y, sh2.y), lo2); \
+                    v_.z = fmaxf(fmaf(v_.z, sc2.z, sh2.z), lo2); v_.w = fmaxf(fmaf(v_.w, sc2.w, sh2.w), lo2); } \
+          v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_; }
+#define H3_HLDS(i_) ((i_) == NHV - 1 ? hst_last : 64 * (i_) * LDSS)
+#define H3_LOAD_B(src_)                                                                             \
+        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) rb[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(src_) + (wofs + j * wrow64)); }
+#define H3_STORE_B(slot_)                                                                           \
+        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(bst + ((slot_) * BN + 64 * j) * LDSS) = rb[j]; }
 
+        {
+            // prologue: this slice's whole halo -> buffer 0; the pieces of the next slice that the skipped taps would have
+            // staged -> buffer 1; all loads in flight before the first store
+            const char* in0 = reinterpret_cast<const char*>(p.in + c_first * 32);
+            const char* in1 = reinterpret_cast<const char*>(p.in + min(c_first + 1, c_last) * 32);
+            float4 q0[NHV], q1[NHV];
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]);
+            H3_LOAD_B(p.wgt + k0 * BK);
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) if (i < tap0) q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
+            H3_AFF(c_first);
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) { H3_XFORM(q0[i], hmask[i]); *reinterpret_cast<float4*>(hst + H3_HLDS(i)) = q0[i]; }
+            const int slot0 = tap0 - 3 * ((tap0 * 21846) >> 16);      // tap0 % 3
+            *reinterpret_cast<v4f*>(bst + (slot0 * BN) * LDSS) = rb[0];
+            if (BROWS == 2) *reinterpret_cast<v4f*>(bst + (slot0 * BN + 64) * LDSS) = rb[BROWS - 1];
+            H3_LOAD_B(p.wgt + min(k0 + 1, nsteps - 1) * BK);
+            H3_AFF(min(c_first + 1, c_last));
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) if (i < tap0) { H3_XFORM(q1[i], hmask[i]); *reinterpret_cast<float4*>(hst + HP * LDSS + H3_HLDS(i)) = q1[i]; }
+        }
         f32x16 acc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-        int cur = 0, hcur = 0;
-        {
-            const int c0 = (k0 * 7282) >> 16;               // k0 / 9 (exact for k0 < 4096)
-            H3_LOAD_HALO(c0); H3_LOAD_B(k0);
-            H3_STORE_HALO(0, c0); H3_STORE_B(0);
-        }
         __syncthreads();
 
-        for (int s = k0; s < k1; ++s) {
-            const int c = (s * 7282) >> 16, tap = s - c * 9;
-            const int ky = (tap * 21846) >> 16, kx = tap - ky * 3;        // tap / 3
-            const bool first = (s == k0) | (tap == 0), last = (tap == 8) | (s == k1 - 1);
-            const bool next_chunk = (c + 1) * 9 < k1;
-            if (first && next_chunk) H3_LOAD_HALO(c + 1);
-            if (s + 1 < k1) H3_LOAD_B(s + 1);
-            const float* a_base = Hs + (hcur * HP + (wave + ky) * HWD + m + kx) * LDSS + frag_k;
-            const float* b_base = Bs + (cur * BN + m) * LDSS + frag_k;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float4 af = *reinterpret_cast<const float4*>(a_base + kk * 8);
-                float4 bf[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + kk * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[j].x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[j].y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[j].z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[j].w, acc[j], 0, 0, 0);
-                }
-            }
-            if (s + 1 < k1) H3_STORE_B(cur ^ 1);
-            if (last && next_chunk) H3_STORE_HALO(hcur ^ 1, c + 1);
-            __syncthreads();
-            cur ^= 1;
-            if (tap == 8) hcur ^= 1;
+        v4f fa[2], fb[2][TN];
+#define H3_FRAG(set_, ap_, bp_)                                                                     \
+        { fa[set_] = *reinterpret_cast<const v4f*>(ap_);                                            \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[set_][j] = *reinterpret_cast<const v4f*>((bp_) + j * 32 * LDSS); }
+#define H3_MFMA(set_)                                                                               \
+        { _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                          \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].x, fb[set_][j].x, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].y, fb[set_][j].y, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].z, fb[set_][j].z, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].w, fb[set_][j].w, acc[j], 0, 0, 0); } }
+#define H3_GROUP(nds_)                                                                              \
+        { __builtin_amdgcn_sched_group_barrier(0x100, nds_, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4 * TN, 0); }
+        // one K step with compile-time tap; ac = this slice's halo buffer, an = the other one (read by tap 8's prefetch,
+        // written by the piece stores)
+#define H3_STEP(TAP)                                                                                \
+        if ((TAP) >= t_lo && (TAP) < t_hi) {                                                        \
+            constexpr int KY = (TAP) / 3, KX = (TAP) % 3, CB = (TAP) % 3, NB = ((TAP) + 1) % 3;     \
+            constexpr int AO = (KY * HWD + KX) * LDSS, BO = CB * BN * LDSS;                         \
+            constexpr int AN = (TAP) == 8 ? 0 : (((TAP) + 1) / 3 * HWD + ((TAP) + 1) % 3) * LDSS;   \
+            const float* an_ = (TAP) == 8 ? a_nx : a_cu;                                            \
+            H3_FRAG(1, a_cu + AO + 8, bfr + BO + 8);                                                \
+            H3_STORE_B(NB);                                                                         \
+            H3_LOAD_B(p.wgt + min(sg + (TAP) + 2, nsteps - 1) * BK);                                \
+            if ((TAP) < NHV) hr = *reinterpret_cast<const float4*>(in_n + hoff[(TAP) < NHV ? (TAP) : 0]); \
+            H3_MFMA(0); H3_GROUP(1 + TN);                                                           \
+            H3_FRAG(0, a_cu + AO + 16, bfr + BO + 16); H3_MFMA(1); H3_GROUP(1 + TN);                \
+            __syncthreads();                                                                        \
+            H3_FRAG(1, a_cu + AO + 24, bfr + BO + 24); H3_MFMA(0); H3_GROUP(1 + TN);                \
+            H3_FRAG(0, an_ + AN, bfr + NB * BN * LDSS);                                             \
+            if ((TAP) < NHV) { H3_XFORM(hr, hmask[(TAP) < NHV ? (TAP) : 0]); *reinterpret_cast<float4*>(h_nx + H3_HLDS((TAP) < NHV ? (TAP) : 0)) = hr; } \
+            H3_MFMA(1); H3_GROUP(1 + TN);                                                           \
         }
-#undef H3_LOAD_HALO
-#undef H3_STORE_HALO
+
+        {
+            // fragments of the first step's group 0
+            const int ky = (tap0 * 21846) >> 16, kx = tap0 - ky * 3;
+            const int slot0 = kx;                                           // tap0 % 3
+            H3_FRAG(0, afr + (ky * HWD + kx) * LDSS, bfr + slot0 * BN * LDSS);
+        }
+        DBG_T();   /* loop start */
+        const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
+        for (int c = c_first; c <= c_last; ++c) {
+            const int t_lo = c == c_first ? tap0 : 0, t_hi = c == c_last ? tapE : 9;
+            const int par = (c - c_first) & 1;                              // halo buffer of this slice
+            const float* a_cu = afr + par * (HP * LDSS);
+            const float* a_nx = afr + (par ^ 1) * (HP * LDSS);
+            float* h_nx = hst + (par ^ 1) * (HP * LDSS);
+            const int cn = min(c + 1, c_last);                              // no next slice: the pieces land in the unused buffer
+            const char* in_n = reinterpret_cast<const char*>(p.in + cn * 32);
+            const int sg = c * 9;
+            if (c != c_first) H3_AFF(cn);                                   // (the prologue loaded the first pair)
+            H3_STEP(0) H3_STEP(1) H3_STEP(2) H3_STEP(3) H3_STEP(4) H3_STEP(5) H3_STEP(6) H3_STEP(7) H3_STEP(8)
+        }
+        __syncthreads();                    // the epilogue reuses the staging memory
+        DBG_T();   /* loop end */
+        if (p.dbg && t == 0 && k1 - k0 > 20) { p.dbg[blockIdx.x * 24 + 21] = clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] = wall_clock64() - wk0; p.dbg[blockIdx.x * 24 + 20] = k1 - k0; }
+#undef H3_AFF
+#undef H3_XFORM
+#undef H3_HLDS
 #undef H3_LOAD_B
 #undef H3_STORE_B
+#undef H3_FRAG
+#undef H3_MFMA
+#undef H3_GROUP
+#undef H3_STEP
 
         // ------------------------------------------------------------ stream-K hand-off (see conv_mfma_kernel)
         constexpr int NV4 = TN * 4;
@@ -804,6 +882,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                 __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
+            DBG_T(); DBG_T();
             continue;
         }
         if (k1 < nsteps) {
@@ -832,8 +911,9 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             }
         }
 
+        DBG_T();   /* fixup end */
         // ------------------------------------------------------------ epilogue: wave = output row, MFMA rows = columns
-        float* red = smem;                 // [8][BN] + [BN]   (the K loop ended on a barrier)
+        float* red = smem;                 // [8][BN] + [BN]
         const int oy = oy0 + wave;
         const int vh = min(H3_TH, p.OH - oy0), vw = min(H3_TW, p.OW - ox0);
         const int cnt = vh * vw;
@@ -896,7 +976,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             }
         }
         __syncthreads();
+        DBG_T();   /* epilogue end */
     }
+    if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
+#undef DBG_T
 }
 
 }  // namespace
@@ -907,9 +990,60 @@ bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride)
 }
 int conv3_halo_tiles(int OH, int OW) { return ((OH + H3_TH - 1) / H3_TH) * ((OW + H3_TW - 1) / H3_TW); }
 
+// FAV_H3_DBG=n: print the in-kernel timeline (prologue / K loop / stream-K fix-up / epilogue, shader clock) of the n-th launch
+static void h3_debug_report(const long long* h, int grid)
+{
+    long long t0 = h[0];
+    for (int b = 0; b < grid; ++b) t0 = std::min(t0, h[b * 24]);
+    double sum[4] = {0, 0, 0, 0}, tend = 0, ck = 0, wk = 0, steps = 0; int items = 0;
+    for (int b = 0; b < grid; ++b) {
+        const long long* r = &h[b * 24]; const int n = (int)r[23];
+        for (int i = 1; i + 4 < n + 1 && i + 4 <= 21; i += 5) {
+            for (int q = 0; q < 4; ++q) sum[q] += (r[i + q + 1] - r[i + q]) * 0.01;
+            ++items; tend = std::max(tend, (r[i + 4] - t0) * 0.01);
+        }
+        ck += r[21]; wk += r[22]; steps += r[20];
+    }
+    fprintf(stderr, "H3DBG grid=%d items=%d  K loop: %.0f clk/step, %.3f GHz, %.3f us/step;  per block: prologue %.2f  loop %.2f  fix-up %.2f  epilogue %.2f us;  last block ends at %.2f us\n",
+            grid, items, steps ? ck / steps : 0.0, wk ? ck / (wk * 10.0) : 0.0, steps ? wk * 0.01 / steps : 0.0,
+            sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, tend);
+}
+
+template <int BN, bool S2>
+static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t st)
+{
+    const size_t lds = (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 4 * cin) * sizeof(float);
+    static int cus = 0;
+    if (!cus) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<BN, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int dev = 0, occ = 0; hipDeviceProp_t prop;
+        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv3_halo_kernel<BN, S2>, 512, lds));
+        if (occ < 1) { set_error("halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
+        cus = prop.multiProcessorCount;          // one block per CU: every stream-K block must be resident
+    }
+    int nres = std::max(1, cus - reserve_cus);
+    if (nres > SK_GRID) nres = SK_GRID;
+    const int tiles = a0.tiles_x * a0.tiles_y;
+    const int grid = tiles * (cin / 32) * 9 < nres ? 1 : nres;
+    H3Args a = a0; a.dbg = nullptr;
+    static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
+    static long long* dbuf = nullptr;
+    const bool dbg = dbg_n > 0 && BN == 128 && --dbg_n == 0;
+    if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), SK_GRID * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, SK_GRID * 24 * 8, st)); a.dbg = dbuf; }
+    hipLaunchKernelGGL((conv3_halo_kernel<BN, S2>), dim3(grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv3_halo_kernel");
+    if (dbg) {
+        std::vector<long long> h((size_t)SK_GRID * 24);
+        FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost));
+        h3_debug_report(h.data(), grid);
+    }
+    return FAV_OK;
+}
+
 int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
 {
-    FAV_REQUIRE(conv3_halo_eligible(c.CIN, c.COUTp, c.KH, c.stride) && c.KH == c.KW && !c.final_mode && c.sk_ws && c.sk_flags,
+    FAV_REQUIRE(conv3_halo_eligible(c.CIN, c.COUTp, c.KH, c.stride) && c.KH == c.KW && !c.final_mode && !c.stuff && c.sk_ws && c.sk_flags,
                 "halo conv: not eligible");
     FAV_REQUIRE((long long)((c.IH >> c.ups) + 1) * c.IWp * c.CIN < (1ll << 31), "halo conv: tensor too large for 32-bit offsets");
     H3Args a;
@@ -921,24 +1055,9 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
     a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
-    const int BNv = c.COUTp;
-    const size_t lds = (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 2 * BNv * LDSS + 4 * c.CIN) * sizeof(float);
-    static int nblocks = 0;
-    if (!nblocks) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int dev = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
-        nblocks = prop.multiProcessorCount;          // one resident block per CU (LDS-limited): every stream-K block is resident
-        if (nblocks > SK_GRID) nblocks = SK_GRID;
-    }
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int nres = std::max(1, nblocks - c.reserve_cus);
-    const int grid = tiles * (c.CIN / 32) * 9 < nres ? 1 : nres;
-    if (BNv == 128) hipLaunchKernelGGL((conv3_halo_kernel<128>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3_halo_kernel<64>), dim3(grid), dim3(512), lds, st, a);
-    FAV_LAUNCH_CHECK("conv3_halo_kernel");
-    return FAV_OK;
+    const bool s2 = c.pre.stages >= 2;
+    if (c.COUTp == 128) return s2 ? launch_h3_t<128, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false>(a, c.CIN, c.reserve_cus, st);
+    return s2 ? launch_h3_t<64, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false>(a, c.CIN, c.reserve_cus, st);
 }
 
 // ------------------------------------------------------------------------------------------------
