@@ -165,7 +165,7 @@ def main():
         # roofline of the dominant kernel: the halo-resident 3x3 128->128 instance (the ten residual convolutions,
         # 91.7 of the 152.8 GMAC per frame), fp32 MFMA.  achieved = useful FLOPs / HIP-event time of those launches.
         dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 428 and n > 0]
-        dom_name = "conv3_halo_kernel<128> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
+        dom_name = "conv3_halo_kernel<128, false> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
         if not dom:     # FAV_NO_H3: fall back to the generic 128-wide instance
             dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 128 and n > 0]
             dom_name = "conv_mfma_kernel<128,2,2,0,true> (3x3 128->128 residual convolutions + 64->128 stride-2)"

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
     constexpr int NHV = (HP * 8 + NT - 1) / NT;                   // 16-byte halo pieces per thread per slice (6)
     constexpr int ALIAS = NT * NHV - HP * 8;                       // units past the end alias earlier ones (same data, same slot)
     constexpr int BROWS = BN / 64;                                 // weight rows per thread per step
-    static_assert(NHV <= 8, "a slice's halo pieces must all be staged before its last tap");
+    static_assert(NHV == 6, "two halo pieces per tap row");
     static_assert(ALIAS % 8 == 0 && ALIAS <= NT, "halo aliasing");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                           // [2][HP][LDSS]
@@ -726,20 +726,23 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
     const float* const bfr = Bs + m * LDSS + frag_k;                        // B fragments: ring slot 0
     const float* const affr = aff + c4 * 4;
 
-    const int U = ntiles * nsteps;
+    // stream-K work unit: one tap row (3 K steps) of one channel slice of one tile.  Inside a unit kx, the weight ring
+    // slot (= kx) and the position of the halo pieces are compile-time constants; ky and the slice are scalars.
+    const int nunits = nchunks * 3;
+    const int U = ntiles * nunits;
     int u = (int)((long long)U * lb / gridDim.x);
     const int u_end = (int)((long long)U * (lb + 1) / gridDim.x);
 
     while (u < u_end) {
-        const int tile = u / nsteps;
-        const int k0 = u - tile * nsteps;
-        const int k1 = (u_end - u) < nsteps - k0 ? k0 + (u_end - u) : nsteps;
+        const int tile = u / nunits;
+        const int k0 = u - tile * nunits;
+        const int k1 = (u_end - u) < nunits - k0 ? k0 + (u_end - u) : nunits;
         u += k1 - k0;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         const int oy0 = ty * H3_TH, ox0 = tx * H3_TW;
         DBG_T();   /* work item start */
 
-        // halo piece i: unit e = t + 512*i -> halo pixel e>>3, channel chunk e&7; per tile: element offset (0 if outside) and mask
+        // halo piece i: unit e = t + 512*i -> halo pixel e>>3, channel chunk e&7; per tile: byte offset (chunk 0 if outside) and mask
         int hoff[NHV]; float hmask[NHV];
 #pragma unroll
         for (int i = 0; i < NHV; ++i) {
@@ -747,13 +750,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             const int pix = e >> 3, hy = (pix * 1928) >> 16, hx = pix - hy * HWD;
             const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
             const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
-            hoff[i] = ((v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN : 0) + c4 * 4) * 4;       // bytes
+            hoff[i] = ((v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN : 0) + c4 * 4) * 4;
             hmask[i] = v ? 1.f : 0.f;
         }
-        const int c_first = (k0 * 7282) >> 16, tap0 = k0 - c_first * 9;      // k / 9 (exact for k < 4096)
-        const int c_last = ((k1 - 1) * 7282) >> 16, tapE = k1 - c_last * 9;
+        const int c_first = (k0 * 21846) >> 16, ky0 = k0 - c_first * 3;      // k / 3
+        const int c_last = ((k1 - 1) * 21846) >> 16;
 
-        float4 hr; v4f rb[BROWS];
+        float4 hr; float hm; v4f rb[BROWS];
         v4f sc1, sh1, sc2, sh2;             // IN/ReLU stages of the slice being staged, this thread's 4 channels
 #define H3_AFF(chunk_)                                                                              \
         { sc1 = *reinterpret_cast<const v4f*>(affr + (chunk_) * 32); sh1 = *reinterpret_cast<const v4f*>(affr + CIN + (chunk_) * 32); \
@@ -771,26 +774,24 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(bst + ((slot_) * BN + 64 * j) * LDSS) = rb[j]; }
 
         {
-            // prologue: this slice's whole halo -> buffer 0; the pieces of the next slice that the skipped taps would have
-            // staged -> buffer 1; all loads in flight before the first store
+            // prologue: this slice's whole halo -> buffer 0; the pieces of the next slice that the skipped tap rows would
+            // have staged -> buffer 1; all loads in flight before the first store
             const char* in0 = reinterpret_cast<const char*>(p.in + c_first * 32);
             const char* in1 = reinterpret_cast<const char*>(p.in + min(c_first + 1, c_last) * 32);
             float4 q0[NHV], q1[NHV];
 #pragma unroll
             for (int i = 0; i < NHV; ++i) q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]);
-            H3_LOAD_B(p.wgt + k0 * BK);
+            H3_LOAD_B(p.wgt + k0 * 3 * BK);
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) if (i < tap0) q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
             H3_AFF(c_first);
 #pragma unroll
             for (int i = 0; i < NHV; ++i) { H3_XFORM(q0[i], hmask[i]); *reinterpret_cast<float4*>(hst + H3_HLDS(i)) = q0[i]; }
-            const int slot0 = tap0 - 3 * ((tap0 * 21846) >> 16);      // tap0 % 3
-            *reinterpret_cast<v4f*>(bst + (slot0 * BN) * LDSS) = rb[0];
-            if (BROWS == 2) *reinterpret_cast<v4f*>(bst + (slot0 * BN + 64) * LDSS) = rb[BROWS - 1];
-            H3_LOAD_B(p.wgt + min(k0 + 1, nsteps - 1) * BK);
+            H3_STORE_B(0);
+            H3_LOAD_B(p.wgt + min(k0 * 3 + 1, nsteps - 1) * BK);
             H3_AFF(min(c_first + 1, c_last));
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) if (i < tap0) { H3_XFORM(q1[i], hmask[i]); *reinterpret_cast<float4*>(hst + HP * LDSS + H3_HLDS(i)) = q1[i]; }
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) { H3_XFORM(q1[i], hmask[i]); *reinterpret_cast<float4*>(hst + HP * LDSS + H3_HLDS(i)) = q1[i]; }
         }
         f32x16 acc[TN];
 #pragma unroll
@@ -811,50 +812,46 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].w, fb[set_][j].w, acc[j], 0, 0, 0); } }
 #define H3_GROUP(nds_)                                                                              \
         { __builtin_amdgcn_sched_group_barrier(0x100, nds_, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4 * TN, 0); }
-        // one K step with compile-time tap; ac = this slice's halo buffer, an = the other one (read by tap 8's prefetch,
-        // written by the piece stores)
-#define H3_STEP(TAP)                                                                                \
-        if ((TAP) >= t_lo && (TAP) < t_hi) {                                                        \
-            constexpr int KY = (TAP) / 3, KX = (TAP) % 3, CB = (TAP) % 3, NB = ((TAP) + 1) % 3;     \
-            constexpr int AO = (KY * HWD + KX) * LDSS, BO = CB * BN * LDSS;                         \
-            constexpr int AN = (TAP) == 8 ? 0 : (((TAP) + 1) / 3 * HWD + ((TAP) + 1) % 3) * LDSS;   \
-            const float* an_ = (TAP) == 8 ? a_nx : a_cu;                                            \
-            H3_FRAG(1, a_cu + AO + 8, bfr + BO + 8);                                                \
+        // one K step, kx = KX (compile time).  a_cu = A fragments of this tap row, a_nu = of the next unit's; the halo
+        // piece staged in this step (KX < 2) is piece 2*ky + KX of the next slice
+#define H3_STEP(KX)                                                                                 \
+        {   constexpr int NB = ((KX) + 1) % 3;                                                      \
+            const float* an_ = (KX) == 2 ? a_nu : a_cu + ((KX) + 1) * LDSS;                         \
+            H3_FRAG(1, a_cu + (KX) * LDSS + 8, bfr + (KX) * BN * LDSS + 8);                         \
             H3_STORE_B(NB);                                                                         \
-            H3_LOAD_B(p.wgt + min(sg + (TAP) + 2, nsteps - 1) * BK);                                \
-            if ((TAP) < NHV) hr = *reinterpret_cast<const float4*>(in_n + hoff[(TAP) < NHV ? (TAP) : 0]); \
+            H3_LOAD_B(p.wgt + min(sg + (KX) + 2, nsteps - 1) * BK);                                 \
+            if ((KX) < 2) { hr = *reinterpret_cast<const float4*>(in_n + ((KX) == 0 ? ho0 : ho1)); hm = (KX) == 0 ? hm0 : hm1; } \
             H3_MFMA(0); H3_GROUP(1 + TN);                                                           \
-            H3_FRAG(0, a_cu + AO + 16, bfr + BO + 16); H3_MFMA(1); H3_GROUP(1 + TN);                \
+            H3_FRAG(0, a_cu + (KX) * LDSS + 16, bfr + (KX) * BN * LDSS + 16); H3_MFMA(1); H3_GROUP(1 + TN); \
             __syncthreads();                                                                        \
-            H3_FRAG(1, a_cu + AO + 24, bfr + BO + 24); H3_MFMA(0); H3_GROUP(1 + TN);                \
-            H3_FRAG(0, an_ + AN, bfr + NB * BN * LDSS);                                             \
-            if ((TAP) < NHV) { H3_XFORM(hr, hmask[(TAP) < NHV ? (TAP) : 0]); *reinterpret_cast<float4*>(h_nx + H3_HLDS((TAP) < NHV ? (TAP) : 0)) = hr; } \
+            H3_FRAG(1, a_cu + (KX) * LDSS + 24, bfr + (KX) * BN * LDSS + 24); H3_MFMA(0); H3_GROUP(1 + TN); \
+            H3_FRAG(0, an_, bfr + NB * BN * LDSS);                                                  \
+            if ((KX) < 2) { H3_XFORM(hr, hm); *reinterpret_cast<float4*>(h_nx + ((KX) == 0 ? hl0 : hl1)) = hr; } \
             H3_MFMA(1); H3_GROUP(1 + TN);                                                           \
         }
 
-        {
-            // fragments of the first step's group 0
-            const int ky = (tap0 * 21846) >> 16, kx = tap0 - ky * 3;
-            const int slot0 = kx;                                           // tap0 % 3
-            H3_FRAG(0, afr + (ky * HWD + kx) * LDSS, bfr + slot0 * BN * LDSS);
-        }
+        H3_FRAG(0, afr + ky0 * HWD * LDSS, bfr);           // fragments of the first step's group 0
         DBG_T();   /* loop start */
         const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
-        for (int c = c_first; c <= c_last; ++c) {
-            const int t_lo = c == c_first ? tap0 : 0, t_hi = c == c_last ? tapE : 9;
-            const int par = (c - c_first) & 1;                              // halo buffer of this slice
-            const float* a_cu = afr + par * (HP * LDSS);
-            const float* a_nx = afr + (par ^ 1) * (HP * LDSS);
+        int c = c_first, ky = ky0, par = 0;
+        for (int uu = k0; uu < k1; ++uu) {
+            const float* a_cu = afr + (par * HP + ky * HWD) * LDSS;
+            const float* a_nu = ky == 2 ? afr + (par ^ 1) * (HP * LDSS) : a_cu + HWD * LDSS;
             float* h_nx = hst + (par ^ 1) * (HP * LDSS);
             const int cn = min(c + 1, c_last);                              // no next slice: the pieces land in the unused buffer
             const char* in_n = reinterpret_cast<const char*>(p.in + cn * 32);
-            const int sg = c * 9;
-            if (c != c_first) H3_AFF(cn);                                   // (the prologue loaded the first pair)
-            H3_STEP(0) H3_STEP(1) H3_STEP(2) H3_STEP(3) H3_STEP(4) H3_STEP(5) H3_STEP(6) H3_STEP(7) H3_STEP(8)
+            const int sg = uu * 3;
+            // the two halo pieces of this unit: 2*ky and 2*ky + 1 (uniform selects)
+            const int ho0 = ky == 0 ? hoff[0] : (ky == 1 ? hoff[2] : hoff[4]), ho1 = ky == 0 ? hoff[1] : (ky == 1 ? hoff[3] : hoff[5]);
+            const float hm0 = ky == 0 ? hmask[0] : (ky == 1 ? hmask[2] : hmask[4]), hm1 = ky == 0 ? hmask[1] : (ky == 1 ? hmask[3] : hmask[5]);
+            const int hl0 = 128 * ky * LDSS, hl1 = ky == 2 ? hst_last : (128 * ky + 64) * LDSS;
+            H3_AFF(cn);
+            H3_STEP(0) H3_STEP(1) H3_STEP(2)
+            if (++ky == 3) { ky = 0; ++c; par ^= 1; }
         }
         __syncthreads();                    // the epilogue reuses the staging memory
         DBG_T();   /* loop end */
-        if (p.dbg && t == 0 && k1 - k0 > 20) { p.dbg[blockIdx.x * 24 + 21] = clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] = wall_clock64() - wk0; p.dbg[blockIdx.x * 24 + 20] = k1 - k0; }
+        if (p.dbg && t == 0 && k1 - k0 > 6) { p.dbg[blockIdx.x * 24 + 21] = clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] = wall_clock64() - wk0; p.dbg[blockIdx.x * 24 + 20] = (k1 - k0) * 3; }
 #undef H3_AFF
 #undef H3_XFORM
 #undef H3_HLDS
@@ -885,11 +882,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             DBG_T(); DBG_T();
             continue;
         }
-        if (k1 < nsteps) {
+        if (k1 < nunits) {
             int covered = k1;
-            for (int nb = lb + 1; covered < nsteps && nb < (int)gridDim.x; ++nb) {
+            for (int nb = lb + 1; covered < nunits && nb < (int)gridDim.x; ++nb) {
                 const int nu0 = (int)((long long)U * nb / gridDim.x), nu1 = (int)((long long)U * (nb + 1) / gridDim.x);
-                const int span = (nu1 - nu0) < (nsteps - covered) ? (nu1 - nu0) : (nsteps - covered);
+                const int span = (nu1 - nu0) < (nunits - covered) ? (nu1 - nu0) : (nunits - covered);
                 if (t == 0) {
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
@@ -1025,7 +1022,7 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t s
     int nres = std::max(1, cus - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
     const int tiles = a0.tiles_x * a0.tiles_y;
-    const int grid = tiles * (cin / 32) * 9 < nres ? 1 : nres;
+    const int grid = tiles * (cin / 32) * 3 < nres ? 1 : nres;      // (stream-K units: tap rows)
     H3Args a = a0; a.dbg = nullptr;
     static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;

@@ -21,12 +21,12 @@ for f in sorted(glob.glob("$O/pmc_${TAG}_*/*counter_collection.csv")):
         for c, v in d.items():
             out.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
 json.dump(out, open("$O/pmc_$TAG.json", "w"), indent=1, sort_keys=True)
-dom = [k for k in out if k.startswith("fav::conv3_halo_kernel<128>")]
+dom = [k for k in out if k.startswith("fav::conv3_halo_kernel<128, false>")]
 if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
     f, w = out[dom[0]]["FETCH_SIZE"]["mean"], out[dom[0]]["WRITE_SIZE"]["mean"]
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of
     # 16-B/lane coalesced streams (this kernel's loads are all 16 B/lane) -> doubled; WRITE_SIZE taken as is (uncalibrated)
-    json.dump({"kernel": "conv3_halo_kernel<128>", "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
+    json.dump({"kernel": "conv3_halo_kernel<128, false>", "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
                "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of the kernel in "
                        "bench.py; read side doubled per the gfx950 FETCH_SIZE calibration; algorithmic bytes per launch: ~64 MB "
