@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
                     "(fav_stream_prefetch_mask); default: on for --structure 1, off for the (7 us) 3-argument mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational 4-argument-mode pass after the timed region "
+                    "(used for the rocprofv3 runs, so that the per-kernel averages cover the timed configuration only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -144,7 +146,7 @@ def main():
     # not part of `value`: the same loop with the checker's 4-argument (image-structure) mode, which is what
     # makeOptFlow_deepflow.sh:59 runs in production; its masks are computed two frames ahead on the side queues
     extra = {}
-    if world == 1 and not args.structure:
+    if world == 1 and not args.structure and not args.no_extra:
         def step4(i):
             k2 = (i + 2) % ring
             stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_list.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${TAG}_$N -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/pmc_${TAG}_$N.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${TAG}_$N -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/pmc_${TAG}_$N.log 2>&1
 done
 cd $R
 python - <<PY
