@@ -152,4 +152,29 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
 int launch_consistency(const float* f1_flo, const float* f2_flo, const float* structure, const float* avg,
                        uint8_t* out, int W, int H, hipStream_t st);
 
+// cube-map orchestration kernels (kernels_vr.hip)
+int launch_vr_rotate(const float* src, float* dst, int H, int W, int mode, hipStream_t st);           // 1: +90, 2: -90, 3: 180
+int launch_vr_accum(float* acc, const float* w, const float* div, size_t n, int first, hipStream_t st);
+int launch_vr_cert(const uint8_t* cert_u8, const float* m0, const float* m1, const float* m2, const float* m3, float* out, size_t n,
+                   hipStream_t st);
+int launch_vr_prior(const float* lfw, const float* border, const float* grad, const float* cert, const float* m, const float* m2,
+                    float* out, size_t n, hipStream_t st);
+int launch_vr_blend(const float* seg, const float* borders, const float* g, const float* anti, float* out, size_t n, hipStream_t st);
+int launch_vr_median(const float* src, float* dst, int H, int W, int r, hipStream_t st);
+int launch_vr_strip(const float* face, int FH, int FW, int cy, int cx, int CH, int CW, int mode, float* strip, int SH, int SW,
+                    int x0, hipStream_t st);
+int launch_vr_prep(const uint8_t* frame_hwc, const float* prior, const float* cert, int fill_random, unsigned seed, unsigned index,
+                   int H, int W, int pad, float* in8, hipStream_t st);
+int launch_vr_flo_to_lua(const float* flo_uv, float* lua_dydx, size_t n, hipStream_t st);
+
 }  // namespace fav
+
+struct fav_net;
+namespace fav {
+int net_device(const fav_net* n);
+int net_pad(const fav_net* n);
+int net_in_channels(const fav_net* n);
+void net_out_size(const fav_net* n, int H, int W, int* Ho, int* Wo);
+int net_forward_padded(fav_net* n, const float* in8, int H, int W, float* out_planar, hipStream_t st);
+}  // namespace fav
+

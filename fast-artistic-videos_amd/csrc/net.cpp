@@ -612,6 +612,15 @@ struct fav_stream {
     }
 };
 
+// internal accessors for the other host units (vr.cpp)
+namespace fav {
+int net_device(const fav_net* n) { return n->device; }
+int net_pad(const fav_net* n) { return n->pad; }
+int net_in_channels(const fav_net* n) { return n->in_channels; }
+void net_out_size(const fav_net* n, int H, int W, int* Ho, int* Wo) { n->out_size(H, W, Ho, Wo); }
+int net_forward_padded(fav_net* n, const float* in8, int H, int W, float* out_planar, hipStream_t st) { return n->forward_padded(in8, H, W, out_planar, nullptr, st); }
+}  // namespace fav
+
 // While look-ahead masks are in flight the persistent / stream-K convolution grids leave SIDE_CUS CUs unclaimed
 // (fav_net::reserve_cus): the side queues' kernels (among them a ~3 ms single-wave sequential chain) find free CUs, and a
 // statically scheduled network block is never kept off the chip by them.

@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
     L.fav_net_destroy.argtypes = [C.c_void_p]; L.fav_net_destroy.restype = None
     L.fav_stream_destroy.argtypes = [C.c_void_p]; L.fav_stream_destroy.restype = None
     L.fav_free_host.argtypes = [C.c_void_p]; L.fav_free_host.restype = None
+    L.fav_vr_destroy.argtypes = [C.c_void_p]; L.fav_vr_destroy.restype = None
     _lib = L
     return L
 
@@ -62,6 +63,8 @@ EXPORTS = [
     "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
+    "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
+    "fav_vr_map_host",
 ]
 
 
@@ -314,6 +317,66 @@ class Stream:
         # device-to-device copy through torch's runtime (same HIP context)
         src = _from_ptr_u8(ptr, self.H * self.W, self.net.device)
         out.view(-1).copy_(src)
+        return out
+
+
+class _VROpts(C.Structure):
+    _fields_ = [("overlap_w", C.c_int), ("overlap_h", C.c_int), ("occlusions_min_filter", C.c_int), ("median_filter", C.c_int),
+                ("fill_random", C.c_int), ("seed", C.c_uint), ("create_inconsistent", C.c_int),
+                ("create_inconsistent_border", C.c_int), ("out_equi_w", C.c_int), ("out_equi_h", C.c_int), ("border_mode", C.c_int)]
+
+
+def vr_map_host(kind: int, hplus: int, wplus: int, overlap: int, median: int = 3, out_w: int = 0, out_h: int = 0) -> np.ndarray:
+    """Static maps of the cube-map orchestration (vr_helper.lua), computed on the host: no device needed."""
+    shape = (2, out_h, out_w) if kind == 4 else (2, hplus, wplus)
+    out = np.empty(shape, np.float32)
+    _check(lib().fav_vr_map_host(kind, hplus, wplus, overlap, median, out_w, out_h, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+class VR:
+    """360-degree cube-map orchestration (fast_artistic_video_vr.lua): six faces per frame, see include/fav.h."""
+
+    def __init__(self, net: Net, hplus: int, wplus: int, overlap_w: int = 20, overlap_h: int = 20, min_filter_r: int = 7,
+                 median: int = 3, out_equi_w: int = 0, out_equi_h: int = 0, fill_random: bool = False, seed: int = 1,
+                 image_net: Optional[Net] = None, create_inconsistent: bool = False, create_inconsistent_border: bool = False,
+                 border: int = BORDER_STN):
+        self.net, self.img, self.H, self.W = net, image_net, hplus, wplus
+        o = _VROpts(overlap_w, overlap_h, min_filter_r, median, int(fill_random), seed, int(create_inconsistent),
+                    int(create_inconsistent_border), out_equi_w, out_equi_h, border)
+        hd = C.c_void_p()
+        _check(lib().fav_vr_create(net.h, image_net.h if image_net is not None else None, hplus, wplus, C.byref(o), C.byref(hd)))
+        self.h = hd
+        sz = [C.c_int() for _ in range(6)]
+        _check(lib().fav_vr_output_sizes(self.h, *[C.byref(x) for x in sz]))
+        self.equi_w, self.equi_h, self.cube_w, self.cube_h, self.filt_w, self.filt_h = [x.value for x in sz]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fav_vr_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def face(self, i: int, frame_u8_hwc, backward_flo=None, cert_u8=None):
+        torch = _torch()
+        out = torch.empty((3, self.H, self.W), dtype=torch.float32, device=frame_u8_hwc.device)
+        _check(lib().fav_vr_face(self.h, i, _p(frame_u8_hwc), _p(backward_flo), _p(cert_u8), _p(out), _stream()))
+        return out
+
+    def finish_frame(self, want_equi: bool = True, want_cube: bool = True):
+        torch = _torch()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        e = torch.empty((self.equi_h, self.equi_w, 3), dtype=torch.uint8, device=dev) if (want_equi and self.equi_w) else None
+        c = torch.empty((self.cube_h, self.cube_w, 3), dtype=torch.uint8, device=dev) if (want_cube and self.cube_w) else None
+        _check(lib().fav_vr_finish_frame(self.h, _p(e), _p(c), _stream()))
+        return e, c
+
+    def get(self, which: int, k: int = 0):
+        torch = _torch()
+        shape = {0: (3, self.H, self.W), 1: (3, self.H, self.W), 2: (3, self.filt_h, self.filt_w),
+                 3: (3, self.equi_h, self.equi_w), 4: (3, self.cube_h, self.cube_w)}[which]
+        out = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        _check(lib().fav_vr_get_f32(self.h, which, k, _p(out), _stream()))
         return out
 
 

@@ -177,6 +177,42 @@ int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstrea
 /* device pointer of the last certainty mask used (u8 [H][W], before the min filter) -- tests */
 const uint8_t* fav_stream_last_mask(const fav_stream* s);
 
+/* ---- 360-degree cube-map orchestration --------------------------------------------
+ * Replaces the callbacks fast_artistic_video_vr.lua passes to run_fast_neural_video (fast_artistic_video_core.lua:189-229):
+ * func_load_cert (:204-237), func_make_last_frame_warped (:239-302), func_is_single_image (:304-310), func_save_image /
+ * blend_other_sides (:454-559), with the static maps of fast_artistic_video/vr_helper.lua:3-184.  Faces are hplus x wplus
+ * (face + overlap); face index i is 1-based and frame-major, mode = (i-1) % 6 walks the processing order of file ids
+ * {6,1,2,5,3,4} (:103); the caller maps ids to files.  `-fill_occlusions uniform-random` is an unseeded torch.rand in the
+ * reference (core.lua:108-117); here it is a documented counter RNG keyed by (seed, i, channel, y, x). */
+typedef struct fav_vr fav_vr;
+typedef struct fav_vr_opts {
+    int overlap_w, overlap_h;        /* -overlap_pixel_w / _h (fast_artistic_video_vr.lua:42-43); even, > 10 */
+    int occlusions_min_filter;       /* :36 */
+    int median_filter;               /* :50; 0, 3 or 5 */
+    int fill_random;                 /* -fill_occlusions uniform-random (1) | vgg-mean (0) */
+    unsigned seed;                   /* of the documented RNG */
+    int create_inconsistent;         /* :39 */
+    int create_inconsistent_border;  /* :40 */
+    int out_equi_w, out_equi_h;      /* :46-47; 0 = no equirectangular output */
+    int border_mode;                 /* fav_border of every warp (the reference's GPU path: FAV_BORDER_STN) */
+} fav_vr_opts;
+int fav_vr_create(fav_net* video_net, fav_net* image_net_or_null, int hplus, int wplus, const fav_vr_opts* opts, fav_vr** out);
+void fav_vr_destroy(fav_vr* v);
+/* one cube face.  frame: u8 [hplus][wplus][3]; backward_flo ([H][W][2] .flo payload) and cert_pgm (u8 [H][W]) are required
+ * from the second frame on (i >= 7) and ignored before; out_rgb_f32 ([3][H][W], may be NULL) receives the stylised face */
+int fav_vr_face(fav_vr* v, int i, const uint8_t* frame_rgb_hwc, const float* backward_flo, const uint8_t* cert_pgm,
+                float* out_rgb_f32, fav_hipstream_t stream);
+/* after the sixth face of a frame: post-blend (the blended faces become the next frame's warp sources), median filter,
+ * equirectangular image (u8 [out_equi_h][out_equi_w][3]) and / or cube-map strip (u8 [cube_h][cube_w][3]); either may be NULL */
+int fav_vr_finish_frame(fav_vr* v, uint8_t* equi_rgb8_hwc, uint8_t* cubemap_rgb8_hwc, fav_hipstream_t stream);
+int fav_vr_output_sizes(const fav_vr* v, int* equi_w, int* equi_h, int* cube_w, int* cube_h, int* filtered_w, int* filtered_h);
+/* float views for tests: which = 0 this frame's raw face k, 1 blended face k, 2 median-filtered face k, 3 equirectangular
+ * image, 4 cube-map strip (device to device copy) */
+int fav_vr_get_f32(const fav_vr* v, int which, int k, float* out_dev, fav_hipstream_t stream);
+/* the static maps, computed on the host (no device needed): kind 0..3 = perspective map left/right/top/bottom
+ * ([2][hplus][wplus], `overlap` = the crop along that axis), 4 = cube->equirectangular map ([2][out_h][out_w]) */
+int fav_vr_map_host(int kind, int hplus, int wplus, int overlap, int median_filter, int out_w, int out_h, float* out_host);
+
 /* ---- host-side formats (A1, A9) ----------------------------------------------------------------
  * .flo: flowFileLoader.lua:14-34 / consistencyChecker.cpp:16-36 (tag read, not validated);
  * P6/P5 8-bit binary PNM; PNG writer (RGB8, zlib).  Buffers are malloc'ed; free with fav_free_host. */

@@ -241,3 +241,49 @@ def test_host_formats_roundtrip(favlib, oracle, tmp_path):
     assert np.array_equal(np.asarray(Image.open(png)), img)
     with pytest.raises(favlib.FavError):
         favlib.read_flo(str(tmp_path / "nope.flo"))
+
+
+# ------------------------------------------------------------------------------------------ cube-map orchestration (8f rank 1)
+def test_vr_static_maps_host_vs_oracle(favlib):
+    """The perspective / equirectangular maps are host code (double, Lua operation order): libfav's C++ and the numpy
+    restatement of vr_helper.lua must agree bit for bit, and every crop column / row must be defined exactly once."""
+    import vr_oracle as V
+    for (hp, wp, ow, oh) in [(96, 96, 32, 32), (64, 80, 20, 24), (224, 224, 64, 64)]:
+        want = [V.warp_map_left(hp, ow, wp), V.warp_map_right(hp, ow, wp), V.warp_map_top(wp, oh, hp), V.warp_map_bottom(wp, oh, hp)]
+        for k, m in enumerate(want):
+            got = favlib.vr_map_host(k, hp, wp, ow if k < 2 else oh)
+            assert np.array_equal(got, m), (hp, wp, k)
+            defined = (m[0] != 99999)
+            assert int(defined.any(axis=0).sum()) == (ow if k < 2 else wp) and int(defined.any(axis=1).sum()) == (hp if k < 2 else oh)
+    e = V.equirect_map(96 - 2, 96 - 2, 32 - 1, 32 - 1, 128, 64)
+    assert np.array_equal(favlib.vr_map_host(4, 96, 96, 32, 3, 128, 64), e)
+    # every equirectangular sample lands inside the 6-face strip
+    ys = e[0] + np.arange(64, dtype=np.float32)[:, None]; xs = e[1] + np.arange(128, dtype=np.float32)[None, :]
+    assert ys.min() >= 0 and ys.max() <= 94 and xs.min() >= 0 and xs.max() <= 6 * 94
+
+
+def test_vr_oracle_properties(oracle, golden_dir):
+    """Size-independent properties of the orchestration restatement: rotations compose, the left/right (top/bottom) masks
+    mirror each other, a constant-colour cube stays constant through prior blending, post-blend and both output maps."""
+    import vr_oracle as V
+    from fav_amd import t7
+    a = np.random.default_rng(0).random((3, 5, 7)).astype(np.float32)
+    assert np.array_equal(V.rotate_minus90(V.rotate90(a)), a) and np.array_equal(V.rotate180(V.rotate180(a)), a)
+    assert np.array_equal(V.rotate90(V.rotate90(a)), V.rotate180(a))
+    m = V.median_filter(a, 3)
+    assert m.shape == (3, 3, 5) and np.array_equal(m[0, 0, 0], np.sort(a[0, :3, :3].ravel())[4])
+    layers = t7.extract_layers(t7.load(os.path.join(golden_dir, "tiny_model.t7"))["model"])
+    vr = V.VRStylizer(layers, 64, 64, overlap_w=24, overlap_h=24, median=3, out_equi_w=64, out_equi_h=32)
+    # (the left/right and top/bottom maps are near mirrors, not exact ones: the Lua loops run over fractional coordinates)
+    for a_, b_ in ((vr.mask_left[0], vr.mask_right[0][:, ::-1]), (vr.mask_top[0], vr.mask_bottom[0][::-1])):
+        assert a_.min() >= 0 and a_.max() <= 1 and abs(int((a_ > 0).sum()) - int((b_ > 0).sum())) <= 0.1 * (a_ > 0).sum() and np.abs(a_ - b_).mean() < 0.05
+    assert vr.mask_all.max() == 1.0 and vr.mask_all_div.min() == 1.0 and vr.mask_all_div.max() <= 2.0
+    const = np.full((3, 64, 64), 0.25, np.float32)
+    vr.last = [const.copy() for _ in range(6)]
+    vr._finish()
+    inner = (slice(None), slice(12, 52), slice(12, 52))
+    for k in range(6):
+        assert np.abs(vr.blended[k][inner] - 0.25).max() <= 1e-6        # away from the outer rim the blend is an average of equals
+    assert np.abs(vr.equi - 0.25).max() <= 1e-5 and np.abs(vr.cubemap - 0.25).max() <= 1e-5
+    u = V.fill_uniform(3, 11, 16, 16)
+    assert u.min() >= 0 and u.max() < 1 and 0.4 < u.mean() < 0.6 and not np.array_equal(u, V.fill_uniform(3, 12, 16, 16))

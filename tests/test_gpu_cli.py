@@ -143,3 +143,52 @@ def test_fav_stylize_loop_flags(oracle, favlib, tmp_path, golden_dir):
     got = np.asarray(Image.open(str(tmp_path / "a" / "out-00003.png")))
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
     assert os.path.exists(tmp_path / "a" / "out-00004.png")
+
+
+def test_fav_stylize_vr_matches_oracle(oracle, favlib, tmp_path, golden_dir):
+    """`th fast_artistic_video_vr.lua` contract (stylizeVRVideo_deepflow.sh:68-83 patterns): two frames of six faces, files named
+    by face id in processing order {6,1,2,5,3,4}; the equirectangular and cube-map PNGs are compared with oracle/vr_oracle.py."""
+    from PIL import Image
+    import vr_oracle as V
+    hp = wp = 64
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    rng = np.random.default_rng(5)
+    kw = dict(overlap_w=24, overlap_h=24, median=3, out_equi_w=96, out_equi_h=48, fill_random=True, seed=9)
+    ref = V.VRStylizer(t7.extract_layers(t7.load(model)["model"]), hp, wp, **kw)
+    want = []
+    for fr in (1, 2):
+        for mode, face in enumerate(V.PROC_ORDER):
+            i = (fr - 1) * 6 + mode + 1
+            f = synth.smooth_frame(hp, wp, 700 + i)
+            oracle.write_pnm(str(tmp_path / f"frame_{fr:05d}-{face}.ppm"), f)
+            bw = ce = None
+            if fr > 1:
+                os.makedirs(tmp_path / f"flow_768-{face}", exist_ok=True)
+                bw = synth.backward_flow(hp, wp, 800 + i)
+                ce = ((rng.random((hp, wp)) > 0.2) * 255).astype(np.uint8)
+                oracle.write_flo(str(tmp_path / f"flow_768-{face}" / f"backward_{fr}_{fr-1}.flo"), bw)
+                oracle.write_pnm(str(tmp_path / f"flow_768-{face}" / f"reliable_{fr}_{fr-1}.pgm"), ce)
+            ref.face(i, np.transpose(f, (2, 0, 1)).astype(np.float32) / np.float32(255), bw,
+                     ce.astype(np.float32) / np.float32(255) if ce is not None else None)
+        want.append((oracle.to_u8_hwc(ref.equi), oracle.to_u8_hwc(ref.cubemap)))
+    cmd = [os.path.join(ROOT, "fast-artistic-videos_amd", "host", "th"), "fast_artistic_video_vr.lua",
+           "-input_pattern", str(tmp_path / "frame_%05d-%d.ppm"),
+           "-flow_pattern", str(tmp_path / "flow_768-%d" / "backward_[%d]_{%d}.flo"),
+           "-occlusions_pattern", str(tmp_path / "flow_768-%d" / "reliable_[%d]_{%d}.pgm"),
+           "-output_prefix", str(tmp_path / "res" / "out"), "-backend", "cuda", "-use_cudnn", "1", "-gpu", "0",
+           "-model_vid", model, "-model_img", "self", "-overlap_pixel_h", "24", "-overlap_pixel_w", "24",
+           "-out_equi", "-out_equi_w", "96", "-out_equi_h", "48", "-out_cubemap", "-fill_occlusions", "uniform-random", "-seed", "9"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for fr in (1, 2):
+        e = np.asarray(Image.open(str(tmp_path / "res" / f"out-{fr:05d}_equi.png")))
+        c = np.asarray(Image.open(str(tmp_path / "res" / f"out-{fr:05d}_cubemap.png")))
+        assert e.shape == want[fr - 1][0].shape and c.shape == want[fr - 1][1].shape
+        # free-running comparison through 12 network evaluations: a few LSB of drift, high PSNR
+        for got, ref8 in ((e, want[fr - 1][0]), (c, want[fr - 1][1])):
+            mse = np.mean((got.astype(np.float64) - ref8.astype(np.float64)) ** 2)
+            assert np.abs(got.astype(int) - ref8.astype(int)).max() <= 3 and (mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 50.0), f"frame {fr}"
+    assert not os.path.exists(str(tmp_path / "res" / "out-00003_equi.png"))
+    for bad in (["-gpu", "-1"], ["-evaluate"], ["-continue_with", "2"], ["-backward"]):
+        rb = subprocess.run(cmd + bad, capture_output=True, text=True)
+        assert rb.returncode != 0 and rb.stderr.strip(), bad

@@ -1,0 +1,105 @@
+"""GPU parity of the 360-degree cube-map orchestration against oracle/vr_oracle.py, through the C ABI
+(fav_vr_*).  Tolerances: elementwise stages 1e-5 (they inherit the warp's 1e-5), network faces as in test_gpu_parity.py
+(2e-4 teacher-forced / 1e-3 free-running, de-processed units), u8 outputs within 1 LSB of the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+from fav_amd import synth, t7
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _f01(u8):
+    return np.transpose(u8, (2, 0, 1)).astype(np.float32) / np.float32(255)
+
+
+def _inputs(hp, wp, frames, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for fr in range(frames):
+        for mode in range(6):
+            i = fr * 6 + mode + 1
+            f = synth.smooth_frame(hp, wp, seed + i)
+            bw = synth.backward_flow(hp, wp, seed + 50 + i) if i >= 7 else None
+            ce = ((rng.random((hp, wp)) > 0.15) * 255).astype(np.uint8) if i >= 7 else None
+            out.append((i, f, bw, ce))
+    return out
+
+
+@pytest.mark.parametrize("cfg", [dict(fill_random=False, median=3), dict(fill_random=True, median=3), dict(fill_random=False, median=0)],
+                         ids=["vgg-mean", "uniform-random", "no-median"])
+def test_vr_two_frames_vs_oracle(favlib, oracle, cuda, golden_dir, cfg):
+    import vr_oracle as V
+    path = os.path.join(golden_dir, "tiny_model.t7")
+    layers = t7.extract_layers(t7.load(path)["model"])
+    hp = wp = 64
+    kw = dict(overlap_w=24, overlap_h=24, out_equi_w=96, out_equi_h=48, seed=7, **cfg)
+    net = favlib.Net(path, 0)
+    vr = favlib.VR(net, hp, wp, **kw)
+    ref = V.VRStylizer(layers, hp, wp, **kw)          # free-running oracle
+    assert (vr.filt_h, vr.filt_w) == ref_shape(hp, wp, cfg["median"])
+    for (i, f, bw, ce) in _inputs(hp, wp, 2, 300):
+        mode = (i - 1) % 6
+        # teacher-forced oracle: continues from the GPU's faces of this frame / blended faces of the previous frame
+        tf = V.VRStylizer(layers, hp, wp, **kw)
+        for k in range(mode):
+            tf.last[k] = vr.get(0, k).cpu().numpy()
+        if i >= 7:
+            tf.prev = [vr.get(1, k).cpu().numpy() for k in range(6)]
+        got = vr.face(i, T(f, cuda), T(bw, cuda) if bw is not None else None, T(ce, cuda) if ce is not None else None).cpu().numpy()
+        cert01 = ce.astype(np.float32) / np.float32(255) if ce is not None else None
+        if mode < 5:
+            want_tf = tf.face(i, _f01(f), bw, cert01)
+        else:
+            tf._finish = lambda: None                  # the sixth face: compare the face only, outputs below
+            want_tf = tf.face(i, _f01(f), bw, cert01)
+        assert np.abs(got - want_tf).max() <= 2e-4, f"face {i} (mode {mode}) teacher-forced"
+        want = ref.face(i, _f01(f), bw, cert01)
+        assert np.abs(got - want).max() <= 2e-3, f"face {i} (mode {mode}) free-running drift"
+        if mode == 5:
+            raw = [vr.get(0, k).cpu().numpy() for k in range(6)]
+            e8, c8 = vr.finish_frame()
+            chk = V.VRStylizer(layers, hp, wp, **kw); chk.last = raw; chk._finish()       # oracle post-processing of the GPU's faces
+            for k in range(6):
+                assert np.abs(vr.get(1, k).cpu().numpy() - chk.blended[k]).max() <= 1e-5, f"blended face {k}"
+                assert np.abs(vr.get(2, k).cpu().numpy() - chk.filtered[k]).max() <= 1e-5, f"median-filtered face {k}"
+            assert np.abs(vr.get(3).cpu().numpy() - chk.equi).max() <= 1e-5
+            assert np.abs(vr.get(4).cpu().numpy() - chk.cubemap).max() <= 1e-5
+            assert np.abs(e8.cpu().numpy().astype(int) - oracle.to_u8_hwc(chk.equi).astype(int)).max() <= 1
+            assert np.abs(c8.cpu().numpy().astype(int) - oracle.to_u8_hwc(chk.cubemap).astype(int)).max() <= 1
+            assert e8.shape == (48, 96, 3) and c8.shape == (chk.cubemap.shape[1], chk.cubemap.shape[2], 3)
+
+
+def ref_shape(hp, wp, median):
+    r = median // 2
+    return (hp - 2 * r, wp - 2 * r)
+
+
+def test_vr_static_masks_and_errors(favlib, oracle, cuda, golden_dir):
+    import vr_oracle as V
+    path = os.path.join(golden_dir, "tiny_model.t7")
+    layers = t7.extract_layers(t7.load(path)["model"])
+    net = favlib.Net(path, 0)
+    hp, wp = 64, 80                                   # non-square faces: the first frame's modes 0..3 need no rotation
+    vr = favlib.VR(net, hp, wp, overlap_w=20, overlap_h=24, median=3)
+    ref = V.VRStylizer(layers, hp, wp, overlap_w=20, overlap_h=24, median=3)
+    for (i, f, bw, ce) in _inputs(hp, wp, 1, 500)[:4]:
+        got = vr.face(i, T(f, cuda)).cpu().numpy()
+        want = ref.face(i, _f01(f))
+        assert np.abs(got - want).max() <= 2e-3
+    with pytest.raises(favlib.FavError, match="square"):
+        vr.face(5, T(synth.smooth_frame(hp, wp, 1), cuda))
+    with pytest.raises(favlib.FavError, match="missing"):
+        vr.finish_frame()
+    with pytest.raises(favlib.FavError, match="overlap"):
+        favlib.VR(net, 64, 64, overlap_w=8, overlap_h=24)
+    vr2 = favlib.VR(net, 64, 64, overlap_w=24, overlap_h=24)
+    with pytest.raises(favlib.FavError, match="in order"):
+        vr2.face(3, T(synth.smooth_frame(64, 64, 1), cuda))
