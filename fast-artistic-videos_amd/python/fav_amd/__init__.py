@@ -352,8 +352,12 @@ class VR:
         self.equi_w, self.equi_h, self.cube_w, self.cube_h, self.filt_w, self.filt_h = [x.value for x in sz]
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().fav_vr_destroy(self.h); self.h = None
+        if getattr(self, "h", None) and lib is not None:
+            try:
+                lib().fav_vr_destroy(self.h)
+            except Exception:      # interpreter shutdown
+                pass
+            self.h = None
 
     __del__ = close
 
