@@ -100,6 +100,27 @@ extern "C" int fav_assemble_input_f32(const float* frame_rgb, const float* warpe
     return launch_assemble(frame_rgb, warped_rgb, cert, in7, H, W, static_cast<hipStream_t>(stream));
 }
 
+// temporal-consistency metric of the reference's -evaluate mode (fast_artistic_video.lua:128-151) without the VGG terms
+extern "C" int fav_temporal_loss_host(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_pgm,
+                                      int H, int W, int border_mode, double* loss_host, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(prev_rgb && cur_rgb && backward_flo && cert_pgm && loss_host && H > 0 && W > 0, "fav_temporal_loss_host: bad argument");
+    int rc = ensure_device(); if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* part = nullptr;
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&part), 256 * sizeof(double)));
+    rc = launch_temporal_loss(prev_rgb, cur_rgb, backward_flo, cert_pgm, border_mode, H, W, part, st);
+    double h[256];
+    if (!rc && hipMemcpyAsync(h, part, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
+    (void)hipFree(part);
+    if (rc) return rc;
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += h[i];
+    *loss_host = s / (3.0 * (double)H * (double)W);
+    return FAV_OK;
+}
+
 // ================================================================================================
 // host-side formats
 // ================================================================================================

@@ -145,6 +145,8 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo,
                       const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
+int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,
+                         int H, int W, double* partial256, hipStream_t st);
 
 size_t structure_workspace_bytes(int W, int H);
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes,

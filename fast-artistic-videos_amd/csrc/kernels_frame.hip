@@ -200,6 +200,33 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* rgb, uint8_t
     }
 }
 
+// temporal-consistency term of func_eval (fast_artistic_video.lua:128-151): sum over c,y,x of
+// (warp(prev)[c] * cert - cur[c] * cert)^2, fp64 partial sums per block (the caller adds them in block order and divides
+// by 3*H*W = nn.MSECriterion's mean)
+__global__ __launch_bounds__(256) void temporal_loss_kernel(const float* prev_rgb, const float* cur_rgb, const float2* bw_flo,
+                                                            const uint8_t* cert_u8, int border, int H, int W, double* partial)
+{
+    __shared__ double red[256];
+    const size_t n = (size_t)H * W;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        const float2 f = bw_flo[i];
+        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
+        const float cv = (float)cert_u8[i] / 255.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = sample(prev_rgb + c * n, t) * cv, b = cur_rgb[c * n + i] * cv;
+            const float d = a - b;
+            acc += (double)d * (double)d;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 }  // namespace
 
 int launch_warp(const float* img, const float* flow, float* out, int B, int C, int H, int W, int Ho, int Wo, int border,
@@ -241,6 +268,15 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const flo
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
                        prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8);
     FAV_LAUNCH_CHECK("prep_input_kernel");
+    return FAV_OK;
+}
+
+int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,
+                         int H, int W, double* partial256, hipStream_t st)
+{
+    hipLaunchKernelGGL(temporal_loss_kernel, dim3(256), dim3(256), 0, st, prev_rgb, cur_rgb, reinterpret_cast<const float2*>(backward_flo),
+                       cert_u8, border, H, W, partial256);
+    FAV_LAUNCH_CHECK("temporal_loss_kernel");
     return FAV_OK;
 }
 

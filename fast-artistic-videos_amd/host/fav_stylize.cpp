@@ -10,7 +10,8 @@
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
 // makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>,
-// -writers <n>, -timing <0|1>.
+// -writers <n>, -timing <0|1>, -temporal_eval_file <path> (the temporal-consistency number of -evaluate, fav.lua:128-151,
+// with the frame's own flow and certainty: one line of ';'-separated per-frame values, one line with their mean).
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -202,7 +203,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}};
+           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}, {"temporal_eval_file", ""}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
            {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
     for (int a = 1; a < argc; ++a) {
@@ -278,6 +279,7 @@ int main(int argc, char** argv)
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
     Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
     uint8_t* d_out8 = nullptr;
+    float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = std::max(1, o.i("writers")) + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
     int slot = 0;
@@ -397,12 +399,23 @@ int main(int argc, char** argv)
             upload(nxt, dn);
             if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
+        const bool teval = !o.s("temporal_eval_file").empty();
+        if (teval && !d_prev) { if (hipMalloc((void**)&d_prev, (size_t)W * H * 12) || hipMalloc((void**)&d_cur, (size_t)W * H * 12)) die("hipMalloc failed"); }
+        if (teval && !cur.single) check(fav_stream_get_state(fs, d_prev, st), "fav_stream_get_state");
         if (cur.single) {
             check(fav_stream_first_frame(fs, dc.frame, nullptr, d_out8, st), "fav_stream_first_frame");       // core:203-204
         } else if (fused_check) {
             check(fav_stream_next_frame_flow(fs, dc.frame, dc.bw, dc.fw, o.i("structure"), nullptr, d_out8, st), "fav_stream_next_frame_flow");
         } else {
             check(fav_stream_next_frame_cert(fs, dc.frame, dc.bw, dc.cert, nullptr, d_out8, st), "fav_stream_next_frame_cert");   // core:206-208
+        }
+        if (teval) {                                     // fav.lua:128-151 (third number)
+            double tl = 0.0;
+            if (!cur.single) {
+                check(fav_stream_get_state(fs, d_cur, st), "fav_stream_get_state");
+                check(fav_temporal_loss_host(d_prev, d_cur, dc.bw, fused_check ? fav_stream_last_mask(fs) : dc.cert, H, W, border, &tl, st), "fav_temporal_loss_host");
+            }
+            temporal.push_back(tl);
         }
         const auto tw = std::chrono::steady_clock::now();
         writers.wait_below((size_t)nslots - 1);          // a free pinned output slot
@@ -429,12 +442,21 @@ int main(int argc, char** argv)
     for (auto& r : ready) if (r.index >= 0) r.release();
     fflush(stdout);
     writers.wait_below(0);
+    if (!temporal.empty()) {                             // core.lua:231-238 layout: values joined by ';', then the mean
+        FILE* f = fopen(o.s("temporal_eval_file").c_str(), "a");
+        if (!f) die("cannot open " + o.s("temporal_eval_file"));
+        double sum = 0.0;
+        for (size_t k = 0; k < temporal.size(); ++k) { fprintf(f, "%s%.9g", k ? ";" : "", temporal[k]); sum += temporal[k]; }
+        fprintf(f, "\n%.9g\n", sum / (double)temporal.size());
+        fclose(f);
+    }
     if (o.i("timing")) {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f}\n",
                done, s, done / s, t_wait_load, t_gpu, t_wait_writer);
     }
     fav_stream_destroy(fs); fav_net_destroy(net); fav_net_destroy(net_img);
+    hipFree(d_prev); hipFree(d_cur);
     hipFree(d_out8); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
     for (auto p : h_out) hipHostFree(p);
     for (auto& p : pin) { hipHostFree(p.frame); hipHostFree(p.bw); hipHostFree(p.fw); hipHostFree(p.cert); }

@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host",
+    "fav_vr_map_host", "fav_temporal_loss_host",
 ]
 
 
@@ -318,6 +318,15 @@ class Stream:
         src = _from_ptr_u8(ptr, self.H * self.W, self.net.device)
         out.view(-1).copy_(src)
         return out
+
+
+def temporal_loss(prev_rgb, cur_rgb, backward_flo, cert_u8, border: int = BORDER_STN) -> float:
+    """fast_artistic_video.lua:128-151: MSE between the flow-warped previous and the current stylised frame on reliable pixels."""
+    _chk_f32(prev_rgb, "prev_rgb"); _chk_f32(cur_rgb, "cur_rgb")
+    _, h, w = prev_rgb.shape
+    out = C.c_double()
+    _check(lib().fav_temporal_loss_host(_p(prev_rgb), _p(cur_rgb), _p(backward_flo), _p(cert_u8), h, w, border, C.byref(out), _stream()))
+    return out.value
 
 
 class _VROpts(C.Structure):

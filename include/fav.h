@@ -177,6 +177,14 @@ int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstrea
 /* device pointer of the last certainty mask used (u8 [H][W], before the min filter) -- tests */
 const uint8_t* fav_stream_last_mask(const fav_stream* s);
 
+/* ---- temporal-consistency metric -------------------------------------------------
+ * The third number of func_eval (fast_artistic_video.lua:128-151, -evaluate without the VGG terms):
+ * MSE(warp(prev_stylised, flow) * cert, cur_stylised * cert) over 3*H*W elements (nn.MSECriterion).  prev / cur: [3][H][W]
+ * float RGB (what fav_stream_get_state returns), backward_flo: .flo payload, cert_pgm: u8 [H][W].  Synchronises `stream`;
+ * the value is written to host memory. */
+int fav_temporal_loss_host(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_pgm,
+                           int H, int W, int border_mode, double* loss_host, fav_hipstream_t stream);
+
 /* ---- 360-degree cube-map orchestration --------------------------------------------
  * Replaces the callbacks fast_artistic_video_vr.lua passes to run_fast_neural_video (fast_artistic_video_core.lua:189-229):
  * func_load_cert (:204-237), func_make_last_frame_warped (:239-302), func_is_single_image (:304-310), func_save_image /

@@ -278,6 +278,15 @@ def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None)
     return x
 
 
+def temporal_loss(prev_rgb, cur_rgb, backward_flow_uv, cert01, border: str = "stn") -> float:
+    """fast_artistic_video.lua:128-151 (third number of func_eval): nn.MSECriterion between the flow-warped previous and the
+    current stylised frame, both multiplied by the certainty; accumulated in fp64 here."""
+    wpd = warp(prev_rgb, flo_to_lua(backward_flow_uv), border)
+    c = np.asarray(cert01, np.float32)[None]
+    d = (wpd * c).astype(np.float32) - (np.asarray(cur_rgb, np.float32) * c).astype(np.float32)
+    return float(np.mean(d.astype(np.float64) ** 2))
+
+
 class Stylizer:
     """Recurrent per-frame loop: fast_artistic_video_core.lua:189-229 with the video CLI's
     callbacks (fast_artistic_video.lua:93-172); fill_occlusions = vgg-mean."""

@@ -75,6 +75,21 @@ def test_fav_stylize_matches_oracle_loop(oracle, favlib, tmp_path, golden_dir, f
         assert png.shape == want.shape
         assert np.abs(png.astype(int) - want.astype(int)).max() <= 1, f"frame {i}"
     assert not os.path.exists(str(tmp_path / "out" / f"out-{n+1:05d}.png"))     # loop stops at the first missing frame
+    if not fused:      # additive -temporal_eval_file: the temporal-consistency number of -evaluate (fav.lua:128-151)
+        ev = str(tmp_path / "temporal.txt")
+        r = subprocess.run(cmd + ["-temporal_eval_file", ev], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        vals = [float(x) for x in open(ev).read().split("\n")[0].split(";")]
+        ref2 = oracle.Stylizer(t7.extract_layers(t7.load(model)["model"])); prev = None; want_t = []
+        for i in range(1, n + 1):
+            f01 = np.transpose(frames[i - 1], (2, 0, 1)).astype(np.float32) / np.float32(255)
+            m01 = masks[i].astype(np.float32) / np.float32(255) if i > 1 else None
+            out = ref2.first(f01) if i == 1 else ref2.next(f01, bws[i - 1], m01)
+            want_t.append(0.0 if i == 1 else oracle.temporal_loss(prev, out, bws[i - 1], m01))
+            prev = out
+        assert len(vals) == n and vals[0] == 0.0
+        assert all(abs(a - b) <= 0.05 * b + 1e-7 for a, b in zip(vals[1:], want_t[1:])), (vals, want_t)
+        assert abs(float(open(ev).read().split("\n")[1]) - sum(vals) / n) <= 1e-6 * max(sum(vals) / n, 1e-9)
 
 
 def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):

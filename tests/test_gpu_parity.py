@@ -381,3 +381,17 @@ def test_canonical_640x360_frame_vs_oracle(favlib, oracle, cuda, canonical):
     r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
     assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
     assert psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
+
+
+def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
+    """the temporal-consistency number of -evaluate (fast_artistic_video.lua:128-151)."""
+    h, w = 90, 130
+    rng = np.random.default_rng(3)
+    prev = rng.random((3, h, w)).astype(np.float32) * 1.2 - 0.1
+    bw = synth.backward_flow(h, w, 5)
+    cert = ((rng.random((h, w)) > 0.3) * 255).astype(np.uint8)
+    cur = oracle.warp(prev, oracle.flo_to_lua(bw)) + rng.normal(0, 0.02, (3, h, w)).astype(np.float32)
+    want = oracle.temporal_loss(prev, cur, bw, cert.astype(np.float32) / np.float32(255))
+    got = favlib.temporal_loss(T(prev, cuda), T(cur, cuda), T(bw, cuda), T(cert, cuda))
+    assert want > 1e-5 and abs(got - want) <= 1e-5 * want
+    assert favlib.temporal_loss(T(prev, cuda), T(oracle.warp(prev, oracle.flo_to_lua(bw)), cuda), T(bw, cuda), T(cert, cuda)) <= 1e-12
