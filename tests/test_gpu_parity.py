@@ -395,3 +395,24 @@ def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
     got = favlib.temporal_loss(T(prev, cuda), T(cur, cuda), T(bw, cuda), T(cert, cuda))
     assert want > 1e-5 and abs(got - want) <= 1e-5 * want
     assert favlib.temporal_loss(T(prev, cuda), T(oracle.warp(prev, oracle.flo_to_lua(bw)), cuda), T(bw, cuda), T(cert, cuda)) <= 1e-12
+
+
+@pytest.mark.parametrize("arch,size", [
+    ("c3s1-32,U2,c3s1-64,c3s1-128,c3s1-128,c9s1-3", (37, 45)),      # halo<64> with TWO pending stages + x2 upsample; halo<128> with 64 and 128 input channels
+    ("c3s1-64,c3s1-64,U2,c3s1-128,c9s1-3", (50, 26)),               # ragged tiles (rows % 8, columns % 32 != 0), fewer work units than CUs
+    ("c9s1-32,d64,R64,R64,U2,c3s1-32,c9s1-3", (64, 72)),            # residual blocks at 64 channels (halo<64>, shave), reflection pad 8
+], ids=["two-stage-ups", "ragged", "res64"])
+def test_halo_kernel_variants_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
+    """Networks built to reach every instantiation / edge of the halo-resident 3x3 kernel (conv3_halo_kernel<BN,S2>)."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=77)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    h, w = size
+    x = (np.random.default_rng(11).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-2, err
+    assert np.abs(ref).std() > 5
