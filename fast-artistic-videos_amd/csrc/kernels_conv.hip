@@ -1288,6 +1288,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && abl != 13 && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID &&
                     c.Kpad / BK >= 4;
     if (c.COUTp % 128 == 0) {
+#ifdef FAV_ABLATIONS          // tuning builds only (make CXXEXTRA=-DFAV_ABLATIONS; scripts/abl.sh): the instances below give wrong results
         switch (abl) {
         case 21: if (sk) return launch_conv_t<128, 2, 2, 1, true>(a, st); break;
         case 22: if (sk) return launch_conv_t<128, 2, 2, 2, true>(a, st); break;
@@ -1303,6 +1304,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
         case 12: return launch_conv_t<128, 2, 2>(a, st);      // 4 waves: 64x64 per wave
         default: break;
         }
+#endif
         // product: 8 waves (32x64 per wave), 4 waves per SIMD with two blocks per CU
         // product: stream-K with 4-wave blocks (64x64 per wave, no spills at 2 blocks/CU); FAV_SK=1 selects the
         // 8-wave stream-K instance, FAV_SK=0 the data-parallel 8-wave instance (measured: 177.8 / 179.8 / 182.2 us)
