@@ -84,7 +84,25 @@ __global__ __launch_bounds__(256) void vr_blend_kernel(const float* seg, const f
     for (int c = 0; c < 3; ++c) out[c * n + i] = seg[c * n + i] * anti[i] + borders[c * n + i] * g[i];
 }
 
-// utils.median_filter (utils.lua:151-159): r x r windows, no padding -> [3][H-r+1][W-r+1], lower median; r <= 5
+// utils.median_filter (utils.lua:151-159): r x r windows, no padding -> [3][H-r+1][W-r+1], lower median.
+// r = 3 (the reference's default): 19-exchange min/max network on registers (exact value of the 5th smallest);
+// r = 5: partial selection sort (rare).
+#define FAV_CSWAP(a, b) { const float lo_ = fminf(a, b); b = fmaxf(a, b); a = lo_; }
+__global__ __launch_bounds__(256) void median3_kernel(const float* src, float* dst, int H, int W)
+{
+    const int OW = W - 2, OH = H - 2;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+    if (x >= OW) return;
+    const float* p = src + ((size_t)c * H + y) * W + x;
+    float p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[W], p4 = p[W + 1], p5 = p[W + 2], p6 = p[2 * W], p7 = p[2 * W + 1], p8 = p[2 * W + 2];
+    FAV_CSWAP(p1, p2) FAV_CSWAP(p4, p5) FAV_CSWAP(p7, p8) FAV_CSWAP(p0, p1) FAV_CSWAP(p3, p4) FAV_CSWAP(p6, p7)
+    FAV_CSWAP(p1, p2) FAV_CSWAP(p4, p5) FAV_CSWAP(p7, p8) FAV_CSWAP(p0, p3) FAV_CSWAP(p5, p8) FAV_CSWAP(p4, p7)
+    FAV_CSWAP(p3, p6) FAV_CSWAP(p1, p4) FAV_CSWAP(p2, p5) FAV_CSWAP(p4, p7) FAV_CSWAP(p4, p2) FAV_CSWAP(p6, p4)
+    FAV_CSWAP(p4, p2)
+    dst[((size_t)c * OH + y) * OW + x] = p4;
+}
+#undef FAV_CSWAP
+
 __global__ __launch_bounds__(256) void median_kernel(const float* src, float* dst, int H, int W, int r)
 {
     const int OW = W - r + 1, OH = H - r + 1;
@@ -220,7 +238,8 @@ int launch_vr_blend(const float* seg, const float* borders, const float* g, cons
 int launch_vr_median(const float* src, float* dst, int H, int W, int r, hipStream_t st)
 {
     FAV_REQUIRE(r >= 1 && r <= 5 && (r & 1) && H >= r && W >= r, "median filter: window %d unsupported (odd, <= 5)", r);
-    hipLaunchKernelGGL(median_kernel, dim3((W - r + 1 + 255) / 256, H - r + 1, 3), dim3(256), 0, st, src, dst, H, W, r);
+    if (r == 3) hipLaunchKernelGGL(median3_kernel, dim3((W - 2 + 255) / 256, H - 2, 3), dim3(256), 0, st, src, dst, H, W);
+    else hipLaunchKernelGGL(median_kernel, dim3((W - r + 1 + 255) / 256, H - r + 1, 3), dim3(256), 0, st, src, dst, H, W, r);
     FAV_LAUNCH_CHECK("median_kernel");
     return FAV_OK;
 }

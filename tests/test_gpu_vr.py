@@ -33,8 +33,9 @@ def _inputs(hp, wp, frames, seed):
     return out
 
 
-@pytest.mark.parametrize("cfg", [dict(fill_random=False, median=3), dict(fill_random=True, median=3), dict(fill_random=False, median=0)],
-                         ids=["vgg-mean", "uniform-random", "no-median"])
+@pytest.mark.parametrize("cfg", [dict(fill_random=False, median=3), dict(fill_random=True, median=3), dict(fill_random=False, median=0),
+                                 dict(fill_random=False, median=5)],
+                         ids=["vgg-mean", "uniform-random", "no-median", "median5"])
 def test_vr_two_frames_vs_oracle(favlib, oracle, cuda, golden_dir, cfg):
     import vr_oracle as V
     path = os.path.join(golden_dir, "tiny_model.t7")
