@@ -100,6 +100,15 @@ extern "C" int fav_assemble_input_f32(const float* frame_rgb, const float* warpe
     return launch_assemble(frame_rgb, warped_rgb, cert, in7, H, W, static_cast<hipStream_t>(stream));
 }
 
+// left-to-right fp32 sum, bit-identical to `float s = 0; for (i) s += x[i];` (CMatrix::avg, CMatrix.h:1245-1251), evaluated
+// with the parallel parity-transducer scan of kernels_consistency.hip
+extern "C" int fav_sequential_sum_f32(const float* x, size_t n, float* sum_out, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(x && sum_out && n > 0, "fav_sequential_sum_f32: bad argument");
+    int rc = ensure_device(); if (rc) return rc;
+    return launch_sequential_sum(x, n, sum_out, static_cast<hipStream_t>(stream));
+}
+
 // temporal-consistency metric of the reference's -evaluate mode (fast_artistic_video.lua:128-151) without the VGG terms
 extern "C" int fav_temporal_loss_host(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_pgm,
                                       int H, int W, int border_mode, double* loss_host, fav_hipstream_t stream)

@@ -151,6 +151,7 @@ int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const floa
 size_t structure_workspace_bytes(int W, int H);
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes,
                      const float** structure_out, const float** avg_out, hipStream_t st);
+int launch_sequential_sum(const float* x, size_t n, float* sum_out, hipStream_t st);
 int launch_consistency(const float* f1_flo, const float* f2_flo, const float* structure, const float* avg,
                        uint8_t* out, int W, int H, hipStream_t st);
 

@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host", "fav_temporal_loss_host",
+    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32",
 ]
 
 
@@ -318,6 +318,15 @@ class Stream:
         src = _from_ptr_u8(ptr, self.H * self.W, self.net.device)
         out.view(-1).copy_(src)
         return out
+
+
+def sequential_sum(x) -> float:
+    """fp32 left-to-right sum with per-step rounding (CMatrix::avg's arithmetic), evaluated by the exact parallel scan."""
+    torch = _torch()
+    _chk_f32(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _check(lib().fav_sequential_sum_f32(_p(x), C.c_size_t(x.numel()), _p(out), _stream()))
+    return out
 
 
 def temporal_loss(prev_rgb, cur_rgb, backward_flo, cert_u8, border: int = BORDER_STN) -> float:

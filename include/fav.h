@@ -177,6 +177,11 @@ int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstrea
 /* device pointer of the last certainty mask used (u8 [H][W], before the min filter) -- tests */
 const uint8_t* fav_stream_last_mask(const fav_stream* s);
 
+/* fp32 sum in index order with the rounding of every partial sum: bit-identical to `float s = 0; for (i) s += x[i];`, the
+ * arithmetic of CMatrix::avg (consistencyChecker/CMatrix.h:1245-1251) that the 4-argument checker depends on.  Evaluated in
+ * parallel (exact parity-transducer scan; kernels_consistency.hip).  x, sum_out: device pointers. */
+int fav_sequential_sum_f32(const float* x, size_t n, float* sum_out, fav_hipstream_t stream);
+
 /* ---- temporal-consistency metric -------------------------------------------------
  * The third number of func_eval (fast_artistic_video.lua:128-151, -evaluate without the VGG terms):
  * MSE(warp(prev_stylised, flow) * cert, cur_stylised * cert) over 3*H*W elements (nn.MSECriterion).  prev / cur: [3][H][W]

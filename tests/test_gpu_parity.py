@@ -416,3 +416,36 @@ def test_halo_kernel_variants_in_networks(favlib, oracle, cuda, tmp_path, arch, 
     err = np.abs(got - ref).max()
     assert err <= 5e-2, err
     assert np.abs(ref).std() > 5
+
+
+def _seq_sum(x):
+    return np.add.accumulate(x.astype(np.float32), dtype=np.float32)[-1]     # sequential, one rounding per element
+
+
+@pytest.mark.parametrize("case", ["uniform", "ties", "mixed", "negatives", "zeros", "all-zero", "tiny", "structure-like"])
+def test_sequential_sum_bit_exact(favlib, cuda, case):
+    """CMatrix::avg's arithmetic (CMatrix.h:1245-1251) evaluated by the parallel parity-transducer scan: bit-identical to the
+    scalar loop, including exact round-to-even ties, binade crossings, and the inputs that force the native fallback."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n = 921600
+    if case == "uniform":
+        x = rng.random(n, dtype=np.float32)
+    elif case == "ties":                      # multiples of 2^-12: once the sum passes 2^12 every few additions is an exact tie
+        x = (rng.integers(0, 4096, n) * 2.0 ** -12).astype(np.float32)
+    elif case == "mixed":
+        x = (10.0 ** rng.uniform(-9, 3, n)).astype(np.float32)
+    elif case == "negatives":
+        x = rng.random(n, dtype=np.float32); x[rng.random(n) < 0.01] *= -1
+    elif case == "zeros":
+        x = rng.random(n, dtype=np.float32); x[rng.random(n) < 0.7] = 0; x[:20000] = 0
+    elif case == "all-zero":
+        x = np.zeros(70000, np.float32)
+    elif case == "tiny":
+        x = rng.random(37, dtype=np.float32)
+    else:                                     # what the checker feeds it: mostly small values, a few near 1
+        x = (rng.random(n) ** 6).astype(np.float32)
+    got = favlib.sequential_sum(T(x, cuda)).cpu().numpy()[0]
+    want = _seq_sum(x)
+    assert got.tobytes() == want.tobytes(), (case, got, want)
+    if case == "uniform":                     # and it is NOT what a pairwise / fp64 sum gives: the test is sensitive
+        assert np.float32(x.astype(np.float64).sum()) != want
