@@ -759,7 +759,8 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && forward_flo, "fav_stream_prefetch_mask: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->net->reserve_cus = SIDE_CUS;      // from now on the network's persistent grids leave the side queues' CUs alone
+    static const int side_cus = getenv("FAV_SIDE_CUS") ? atoi(getenv("FAV_SIDE_CUS")) : SIDE_CUS;   // (tuning knob)
+    s->net->reserve_cus = side_cus;      // from now on the network's persistent grids leave the side queues' CUs alone
     fav_stream::Pref& pf = s->pref[s->pref_next];
     s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
     const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;

@@ -21,6 +21,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* thread cap for the small test problems: with hundreds of host threads the fork/join of every tiny loop dominates */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------
  * A2  warp, GPU semantics ("stn"): stnbdhw/BilinearSamplerBDHW.cu:48-109

@@ -39,6 +39,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n: int) -> None:
+    """Cap the OpenMP team (tests on many-core hosts: the problems are tiny, fork/join would dominate)."""
+    lib().orc_set_threads(int(n))
+
+
 def _f(a):
     a = np.ascontiguousarray(a, np.float32)
     return a, a.ctypes.data_as(C.POINTER(C.c_float))

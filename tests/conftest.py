@@ -23,6 +23,7 @@ def golden_dir():
 def oracle():
     import oracle as O
     O.build()
+    O.set_threads(min(16, len(os.sched_getaffinity(0))))      # small problems: a 256-thread team costs more than it computes
     return O
 
 

@@ -371,6 +371,7 @@ def test_canonical_640x360_frame_vs_oracle(favlib, oracle, cuda, canonical):
     frames, bws, fws = _clip(h, w, 2, 50)
     net = favlib.Net(canonical, 0)
     st = favlib.Stream(net, h, w)
+    oracle.set_threads(len(os.sched_getaffinity(0)))        # a real-size problem: use the whole host (conftest caps the team at 16)
     o0, _ = st.first_frame(T(frames[0], cuda))
     o1, u1 = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda), want_u8=True)
     ref = oracle.Stylizer(layers)
@@ -381,6 +382,7 @@ def test_canonical_640x360_frame_vs_oracle(favlib, oracle, cuda, canonical):
     r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
     assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
     assert psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
+    oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
 
 
 def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
