@@ -479,71 +479,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
         if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * R + r0 + tx] = tl[tx][j];
 }
 
-__global__ __launch_bounds__(256) void iir_x_kernel(float* plane0, size_t plane_stride, float* scratch0, int H, int W, IIR c)
-{
-    __shared__ float tile[64 * 65];
-    __shared__ float tv1[64 * 65];
-    const int t = threadIdx.x, lane = t & 63, tr = t >> 6;        // 4 waves move the tiles, wave 0 runs the recurrences
-    const int row0 = blockIdx.x * 64;
-    const int nrows = min(64, H - row0);
-    float* mp = plane0 + (size_t)blockIdx.y * plane_stride;
-    float* v1p = scratch0 + (size_t)blockIdx.y * plane_stride;
-    const bool act = t < nrows;                                   // t < 64: this lane owns row t
-    if (W < 2) return;
-    float a0 = 0.f, a1 = 0.f, mprev = 0.f;
-    // forward sweep: v1
-    for (int x0 = 0; x0 < W; x0 += 64) {
-        const int nc = min(64, W - x0);
-        for (int r = tr; r < nrows; r += 4)
-            if (lane < nc) tile[r * 65 + lane] = mp[(size_t)(row0 + r) * W + x0 + lane];
-        __syncthreads();
-        if (act)
-#pragma unroll 8
-            for (int j = 0; j < nc; ++j) {
-                const int x = x0 + j;
-                const float mx = tile[t * 65 + j];
-                float a;
-                if (x == 0) a = (0.5f - c.k * c.pm) * mx;
-                else if (x == 1) a = c.k * (mx + c.pm * mprev) + (c.a2 - c.e2) * a1;
-                else a = c.k * (mx + c.pm * mprev) + c.a2 * a1 - c.e2 * a0;
-                a0 = a1; a1 = a; mprev = mx;
-                tile[t * 65 + j] = a;
-            }
-        __syncthreads();
-        for (int r = tr; r < nrows; r += 4)
-            if (lane < nc) v1p[(size_t)(row0 + r) * W + x0 + lane] = tile[r * 65 + lane];
-        __syncthreads();
-    }
-    // backward sweep: v2, m = v1 + v2 (the original m(x+1), m(x+2) are carried in registers)
-    float b0 = 0.f, b1 = 0.f, mo1 = 0.f, mo2 = 0.f;
-    const int last_x0 = ((W - 1) / 64) * 64;
-    for (int x0 = last_x0; x0 >= 0; x0 -= 64) {
-        const int nc = min(64, W - x0);
-        for (int r = tr; r < nrows; r += 4)
-            if (lane < nc) {
-                tile[r * 65 + lane] = mp[(size_t)(row0 + r) * W + x0 + lane];
-                tv1[r * 65 + lane] = v1p[(size_t)(row0 + r) * W + x0 + lane];
-            }
-        __syncthreads();
-        if (act)
-#pragma unroll 8
-            for (int j = nc - 1; j >= 0; --j) {
-                const int x = x0 + j;
-                const float mx = tile[t * 65 + j];
-                float bv;
-                if (x == W - 1) bv = (0.5f + c.k * c.pm) * mx;
-                else if (x == W - 2) bv = c.k * ((c.pp - c.e2) * mo1) + (c.a2 - c.e2) * b0;
-                else bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-                tile[t * 65 + j] = tv1[t * 65 + j] + bv;
-                b1 = b0; b0 = bv; mo2 = mo1; mo1 = mx;
-            }
-        __syncthreads();
-        for (int r = tr; r < nrows; r += 4)
-            if (lane < nc) mp[(size_t)(row0 + r) * W + x0 + lane] = tile[r * 65 + lane];
-        __syncthreads();
-    }
-}
-
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
