@@ -131,6 +131,18 @@ int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int C
 // NHWC [M][C] with transform -> NCHW [C][M]
 int launch_nhwc_to_nchw(const float* in, int M, int C, const Affine& t, float* out, hipStream_t st);
 
+#ifdef __HIPCC__
+// counter RNG standing in for the reference's unseeded torch.rand (core.lua:109); oracle: vr_oracle.fill_uniform
+__device__ __forceinline__ float fill_uniform(unsigned seed, unsigned index, unsigned c, unsigned y, unsigned x)
+{
+    unsigned k = seed * 0x9E3779B1u + index * 0x85EBCA77u + c * 0xC2B2AE3Du + y * 0x27D4EB2Fu + x * 0x165667B1u;
+    k ^= k >> 15; k *= 0x2C1B3C6Du;
+    k ^= k >> 12; k *= 0x297A2D39u;
+    k ^= k >> 15;
+    return (float)(k >> 8) * (1.0f / 16777216.0f);
+}
+#endif
+
 // frame-level kernels (kernels_frame.hip / kernels_consistency.hip)
 int launch_warp(const float* img, const float* flow, float* out, int B, int C, int H, int W, int Ho, int Wo,
                 int border, hipStream_t st);
@@ -143,7 +155,8 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
                         int r, float* cert_tmp, float* cert, int H, int W, hipStream_t st);
 // fused A2+A6+A7+reflection pad: writes the padded NHWC8 network input
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo,
-                      const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st);
+                      const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st,
+                      int fill_random = 0, unsigned seed = 0, unsigned index = 0);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
 int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,
                          int H, int W, double* partial256, hipStream_t st);

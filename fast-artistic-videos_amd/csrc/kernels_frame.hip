@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void cert_raw_kernel(const uint8_t* mask, cons
 //   ch 0..2 content (BGR, mean-subtracted), ch 3..5 masked warped prior, ch 6 certainty, ch 7 zero
 __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb,
                                                          const float2* bw_flo, const float* cert, int border, int H,
-                                                         int W, int pad, float* in8)
+                                                         int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
 {
     const int Wp = W + 2 * pad;
     const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
@@ -169,17 +169,25 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
     lo.x = rgb[2] * 255.f - 103.939f;
     lo.y = rgb[1] * 255.f - 116.779f;
     lo.z = rgb[0] * 255.f - 123.68f;
+    // generate_fill (core.lua:108-117): 0 (vgg-mean) or pre(u) * (1 - cert) with u the documented counter RNG
+    float fb = 0.f, fg = 0.f, fr = 0.f;
+    const float cv = prev_rgb != nullptr ? cert[i] : 0.f;
+    if (fill_random) {
+        const float cinv = (cv + -1.f) * -1.f;
+        fb = (fill_uniform(seed, index, 2, y, x) * 255.f - 103.939f) * cinv;
+        fg = (fill_uniform(seed, index, 1, y, x) * 255.f - 116.779f) * cinv;
+        fr = (fill_uniform(seed, index, 0, y, x) * 255.f - 123.68f) * cinv;
+    }
     if (prev_rgb != nullptr) {
         const float2 f = bw_flo[i];                                     // .flo payload: (u, v) = (dx, dy)
         const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
-        const float cv = cert[i];
         const float wr = sample(prev_rgb, t), wg = sample(prev_rgb + n, t), wb = sample(prev_rgb + 2 * n, t);
-        lo.w = (wb * 255.f - 103.939f) * cv + 0.f;
-        hi.x = (wg * 255.f - 116.779f) * cv + 0.f;
-        hi.y = (wr * 255.f - 123.68f) * cv + 0.f;
+        lo.w = fb + (wb * 255.f - 103.939f) * cv;                       // torch.add(fill, prev_warped_masked), core:169
+        hi.x = fg + (wg * 255.f - 116.779f) * cv;
+        hi.y = fr + (wr * 255.f - 123.68f) * cv;
         hi.z = cv;
     } else {
-        lo.w = 0.f; hi.x = 0.f; hi.y = 0.f; hi.z = 0.f;                 // core:133-138: zero prior, zero mask
+        lo.w = fb; hi.x = fg; hi.y = fr; hi.z = 0.f;                    // core:133-138: fill only, zero mask
     }
     hi.w = 0.f;
     float4* o = reinterpret_cast<float4*>(in8 + ((size_t)yp * Wp + xp) * 8);
@@ -263,10 +271,10 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
 }
 
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo, const float* cert,
-                      int border, int H, int W, int pad, float* in8, hipStream_t st)
+                      int border, int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index)
 {
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
-                       prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8);
+                       prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
     FAV_LAUNCH_CHECK("prep_input_kernel");
     return FAV_OK;
 }

@@ -136,16 +136,6 @@ __global__ __launch_bounds__(256) void strip_kernel(const float* face, int FH, i
         strip[((size_t)c * SH + i) * SW + x0 + j] = face[((size_t)c * FH + sy) * FW + sx];
 }
 
-// counter RNG standing in for the reference's unseeded torch.rand (core.lua:109); oracle/vr_oracle.py: fill_uniform
-__device__ __forceinline__ float fill_uniform(unsigned seed, unsigned index, unsigned c, unsigned y, unsigned x)
-{
-    unsigned k = seed * 0x9E3779B1u + index * 0x85EBCA77u + c * 0xC2B2AE3Du + y * 0x27D4EB2Fu + x * 0x165667B1u;
-    k ^= k >> 15; k *= 0x2C1B3C6Du;
-    k ^= k >> 12; k *= 0x297A2D39u;
-    k ^= k >> 15;
-    return (float)(k >> 8) * (1.0f / 16777216.0f);
-}
-
 __device__ __forceinline__ int reflect_i(int i, int n)
 {
     if (i < 0) i = -i;

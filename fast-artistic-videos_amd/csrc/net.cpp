@@ -590,6 +590,7 @@ struct fav_stream {
     fav_stream_opts opts{};
     float* state = nullptr;      // last_frame_stylized: [3][H][W] float RGB, unclamped (fav.lua:169)
     bool has_state = false;
+    unsigned frame_counter = 0;  // 1-based index of the frame being stylised (key of the uniform-random fill)
     float* in8 = nullptr;        // padded NHWC8 network input
     float* cert_tmp = nullptr; float* cert = nullptr;
     uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
@@ -646,7 +647,7 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
     FAV_HIP(hipSetDevice(net->device));
     fav_stream* s = new fav_stream();
     s->net = net; s->H = H; s->W = W;
-    if (o) s->opts = *o; else { s->opts.border_mode = FAV_BORDER_STN; s->opts.occlusions_min_filter = 7; s->opts.invert_occlusion = 0; s->opts.fix_occlusions = 0; }
+    if (o) s->opts = *o; else { s->opts.border_mode = FAV_BORDER_STN; s->opts.occlusions_min_filter = 7; s->opts.invert_occlusion = 0; s->opts.fix_occlusions = 0; s->opts.fill_random = 0; s->opts.seed = 0; }
     if (s->opts.occlusions_min_filter < 1) s->opts.occlusions_min_filter = 1;
     const size_t n = (size_t)H * W;
     s->ws_bytes = structure_workspace_bytes(W, H);
@@ -684,7 +685,10 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     FAV_REQUIRE(s && frame_rgb_hwc, "fav_stream_first_frame: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = launch_prep_input(frame_rgb_hwc, nullptr, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st);
+    ++s->frame_counter;
+    // the image model sees only the three content channels (core.lua:146): no fill there
+    int rc = launch_prep_input(frame_rgb_hwc, nullptr, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
+                               s->img_net ? 0 : s->opts.fill_random, s->opts.seed, s->frame_counter);
     if (rc) return rc;
     fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
     rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
@@ -711,7 +715,9 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
     int rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
                                  s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
     if (rc) return rc;
-    rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st);
+    ++s->frame_counter;
+    rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
+                           s->opts.fill_random, s->opts.seed, s->frame_counter);
     if (rc) return rc;
     rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
     return stream_finish(s, out_f32, out_u8, st);

@@ -10,6 +10,7 @@
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
 // makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>,
+// -seed <n> (key of the documented RNG behind -fill_occlusions uniform-random, unseeded in the reference),
 // -writers <n>, -timing <0|1>, -temporal_eval_file <path> (the temporal-consistency number of -evaluate, fav.lua:128-151,
 // with the frame's own flow and certainty: one line of ';'-separated per-frame values, one line with their mean).
 #include <hip/hip_runtime.h>
@@ -203,7 +204,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}, {"temporal_eval_file", ""}};
+           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
            {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
     for (int a = 1; a < argc; ++a) {
@@ -221,7 +222,7 @@ int main(int argc, char** argv)
     if (o.i("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement lives in oracle/ and is test infrastructure only)");
     if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
     if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
-    if (o.s("fill_occlusions") != "vgg-mean") die("-fill_occlusions uniform-random is not supported (unseeded in the reference: core.lua:109)");
+    if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     const int border = o.s("warp_border") == "cpu" ? FAV_BORDER_CPU : FAV_BORDER_STN;
 
     if (fav_device_count() <= 0) die(std::string("ERROR: ") + fav_last_error());
@@ -363,7 +364,8 @@ int main(int argc, char** argv)
         if (first) {
             if (have_resume && (-W != cur.W || -H != cur.H)) die("-continue_with: previous PNG size differs from the frames");
             W = cur.W; H = cur.H;
-            fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0};
+            fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0,
+                               o.s("fill_occlusions") == "uniform-random" ? 1 : 0, (unsigned)o.i("seed")};
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
             if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
             const size_t n = (size_t)W * H;

@@ -245,16 +245,16 @@ def pack_checkpoint(t7_path: str) -> bytes:
 
 class _Opts(C.Structure):
     _fields_ = [("border_mode", C.c_int), ("occlusions_min_filter", C.c_int), ("invert_occlusion", C.c_int),
-                ("fix_occlusions", C.c_int)]
+                ("fix_occlusions", C.c_int), ("fill_random", C.c_int), ("seed", C.c_uint)]
 
 
 class Stream:
     """One video stream: the recurrent per-frame pipeline (fast_artistic_video_core.lua:194-211)."""
 
     def __init__(self, net: Net, h: int, w: int, border: int = BORDER_STN, min_filter_r: int = 7,
-                 invert_occlusion: bool = False, fix_occlusions: bool = False):
+                 invert_occlusion: bool = False, fix_occlusions: bool = False, fill_random: bool = False, seed: int = 1):
         self.net, self.H, self.W = net, h, w
-        o = _Opts(border, min_filter_r, int(invert_occlusion), int(fix_occlusions))
+        o = _Opts(border, min_filter_r, int(invert_occlusion), int(fix_occlusions), int(fill_random), seed)
         hd = C.c_void_p()
         _check(lib().fav_stream_create(net.h, h, w, C.byref(o), C.byref(hd)))
         self.h = hd

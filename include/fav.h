@@ -142,6 +142,9 @@ typedef struct fav_stream_opts {
     int occlusions_min_filter; /* -occlusions_min_filter (default 7) */
     int invert_occlusion;      /* -invert_occlusion */
     int fix_occlusions;        /* -fix_occlusions */
+    int fill_random;           /* -fill_occlusions uniform-random (1) | vgg-mean (0): core.lua:108-117.  The reference's
+                                  torch.rand is unseeded; here u = counter RNG(seed, frame counter, channel, y, x), see fav_vr */
+    unsigned seed;
 } fav_stream_opts;
 
 int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* opts_host, fav_stream** out);

@@ -296,21 +296,34 @@ class Stylizer:
     """Recurrent per-frame loop: fast_artistic_video_core.lua:189-229 with the video CLI's
     callbacks (fast_artistic_video.lua:93-172); fill_occlusions = vgg-mean."""
 
-    def __init__(self, layers, border="stn", min_filter_r=7, invert_occlusion=False, fix_occlusions=False):
+    def __init__(self, layers, border="stn", min_filter_r=7, invert_occlusion=False, fix_occlusions=False,
+                 fill_random=False, seed=1):
         self.layers, self.border, self.r = layers, border, min_filter_r
         self.invert, self.fix = invert_occlusion, fix_occlusions
+        self.fill_random, self.seed, self.count = fill_random, seed, 0      # -fill_occlusions uniform-random (core.lua:108-117)
         self.last = None        # last_frame_stylized: float RGB [3][H][W], unclamped (fav.lua:169)
 
+    def _fill(self, cert):
+        """generate_fill with the documented counter RNG (vr_oracle.fill_uniform) instead of the unseeded torch.rand."""
+        from vr_oracle import fill_uniform
+        _, h, w = cert.shape
+        return preprocess(fill_uniform(self.seed, self.count, h, w)) * ((cert + np.float32(-1)) * np.float32(-1))
+
     def first(self, frame_rgb01, image_layers=None):
+        self.count += 1
         if image_layers is not None:       # model_img:forward(pre) -- core.lua:146
             out = deprocess(net_forward(image_layers, preprocess(frame_rgb01)))
             self.last = out
             return out
-        out = deprocess(net_forward(self.layers, assemble(frame_rgb01, None, None)))
+        x = assemble(frame_rgb01, None, None)
+        if self.fill_random:
+            x[3:6] = self._fill(np.zeros((1,) + x.shape[1:], np.float32))
+        out = deprocess(net_forward(self.layers, x))
         self.last = out
         return out
 
     def next(self, frame_rgb01, backward_flow_uv, cert01):
+        self.count += 1
         cert01 = np.ascontiguousarray(cert01, np.float32)
         if self.invert:                                                       # fav.lua:104-106: cert:add(-1):mul(-1)
             cert01 = (cert01 + np.float32(-1)) * np.float32(-1)
@@ -321,6 +334,9 @@ class Stylizer:
             cert01 = cert01 * tmp
         cert = min_filter(cert01, self.r)                                     # core:207
         warped = warp(self.last, flo_to_lua(backward_flow_uv), self.border)  # fav.lua:153-158
-        out = deprocess(net_forward(self.layers, assemble(frame_rgb01, warped, cert)))
+        x = assemble(frame_rgb01, warped, cert)
+        if self.fill_random:
+            x[3:6] = self._fill(cert[None]) + x[3:6]
+        out = deprocess(net_forward(self.layers, x))
         self.last = out
         return out

@@ -318,6 +318,18 @@ def test_stream_options(favlib, oracle, cuda, golden_dir):
             ref.first(_f01(frames[0]))
             r1 = ref.next(_f01(frames[1]), big, (255 - mask).astype(np.float32) / np.float32(255))
             assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4, (bname, fix)
+    # -fill_occlusions uniform-random (core.lua:108-117) with the documented counter RNG: first frame = noise prior, then
+    # noise only where the certainty is low; a different seed must give a different frame
+    st = favlib.Stream(net, h, w, fill_random=True, seed=5)
+    ref = oracle.Stylizer(layers, fill_random=True, seed=5)
+    o0, _ = st.first_frame(T(frames[0], cuda)); r0 = ref.first(_f01(frames[0]))
+    assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+    ref.last = o0.cpu().numpy()
+    o1, _ = st.next_frame_cert(T(frames[1], cuda), T(bws[1], cuda), T(mask, cuda))
+    r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
+    assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+    st2 = favlib.Stream(net, h, w, fill_random=True, seed=6)
+    assert np.abs(st2.first_frame(T(frames[0], cuda))[0].cpu().numpy() - o0.cpu().numpy()).max() > 1e-3
     with pytest.raises(favlib.FavError, match="multiples of 4"):
         favlib.Stream(net, 50, 64)
     st = favlib.Stream(net, h, w)
