@@ -137,9 +137,9 @@ extern "C" void fav_free_host(void* p) { free(p); }
 
 // flowFileLoader.lua:14-34 / consistencyChecker.cpp:16-36: float tag (not validated), int32 W, int32 H,
 // then H*W interleaved (u, v) little-endian float32
-extern "C" int fav_read_flo_host(const char* path, float** uv_out, int* W, int* H)
+// dst == null: malloc the payload (returned through *uv_out); else read into dst (capacity in floats)
+static int read_flo(const char* path, float** uv_out, float* dst, size_t capacity, int* W, int* H)
 {
-    FAV_REQUIRE(path && uv_out && W && H, "fav_read_flo_host: null argument");
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("Could not open %s", path); return FAV_EIO; }
     float tag; int w = 0, h = 0;
@@ -147,12 +147,26 @@ extern "C" int fav_read_flo_host(const char* path, float** uv_out, int* W, int* 
         (long long)w * h > (1ll << 28)) {
         fclose(f); set_error("%s: bad .flo header", path); return FAV_EFORMAT; }
     const size_t n = (size_t)w * h * 2;
-    float* d = static_cast<float*>(malloc(n * sizeof(float)));
+    if (dst && n > capacity) { fclose(f); set_error("%s: %dx%d flow does not fit the caller's buffer", path, w, h); return FAV_EINVAL; }
+    float* d = dst ? dst : static_cast<float*>(malloc(n * sizeof(float)));
     if (!d) { fclose(f); set_error("out of host memory"); return FAV_EIO; }
-    if (fread(d, sizeof(float), n, f) != n) { fclose(f); free(d); set_error("%s: truncated .flo payload", path); return FAV_EFORMAT; }
+    if (fread(d, sizeof(float), n, f) != n) { fclose(f); if (!dst) free(d); set_error("%s: truncated .flo payload", path); return FAV_EFORMAT; }
     fclose(f);
-    *uv_out = d; *W = w; *H = h;
+    if (uv_out) *uv_out = d;
+    *W = w; *H = h;
     return FAV_OK;
+}
+
+extern "C" int fav_read_flo_host(const char* path, float** uv_out, int* W, int* H)
+{
+    FAV_REQUIRE(path && uv_out && W && H, "fav_read_flo_host: null argument");
+    return read_flo(path, uv_out, nullptr, 0, W, H);
+}
+
+extern "C" int fav_read_flo_into_host(const char* path, float* uv_buf, size_t capacity_floats, int* W, int* H)
+{
+    FAV_REQUIRE(path && uv_buf && W && H, "fav_read_flo_into_host: null argument");
+    return read_flo(path, nullptr, uv_buf, capacity_floats, W, H);
 }
 
 static bool pnm_token(FILE* f, char* buf, size_t cap)
@@ -170,9 +184,8 @@ static bool pnm_token(FILE* f, char* buf, size_t cap)
 }
 
 // binary P6 / P5, maxval 255 (what ffmpeg and consistencyChecker write; image.load accepts the same)
-extern "C" int fav_read_pnm_host(const char* path, uint8_t** data_out, int* W, int* H, int* channels)
+static int read_pnm(const char* path, uint8_t** data_out, uint8_t* dst, size_t capacity, int* W, int* H, int* channels)
 {
-    FAV_REQUIRE(path && data_out && W && H && channels, "fav_read_pnm_host: null argument");
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("Could not open %s", path); return FAV_EIO; }
     char tok[64];
@@ -185,12 +198,26 @@ extern "C" int fav_read_pnm_host(const char* path, uint8_t** data_out, int* W, i
     if (!ch || w <= 0 || h <= 0 || maxv != 255 || (long long)w * h > (1ll << 28)) {
         fclose(f); set_error("%s: not a binary 8-bit P5/P6 file", path); return FAV_EFORMAT; }
     const size_t n = (size_t)w * h * ch;
-    uint8_t* d = static_cast<uint8_t*>(malloc(n));
+    if (dst && n > capacity) { fclose(f); set_error("%s: %dx%dx%d image does not fit the caller's buffer", path, w, h, ch); return FAV_EINVAL; }
+    uint8_t* d = dst ? dst : static_cast<uint8_t*>(malloc(n));
     if (!d) { fclose(f); set_error("out of host memory"); return FAV_EIO; }
-    if (fread(d, 1, n, f) != n) { fclose(f); free(d); set_error("%s: truncated image payload", path); return FAV_EFORMAT; }
+    if (fread(d, 1, n, f) != n) { fclose(f); if (!dst) free(d); set_error("%s: truncated image payload", path); return FAV_EFORMAT; }
     fclose(f);
-    *data_out = d; *W = w; *H = h; *channels = ch;
+    if (data_out) *data_out = d;
+    *W = w; *H = h; *channels = ch;
     return FAV_OK;
+}
+
+extern "C" int fav_read_pnm_host(const char* path, uint8_t** data_out, int* W, int* H, int* channels)
+{
+    FAV_REQUIRE(path && data_out && W && H && channels, "fav_read_pnm_host: null argument");
+    return read_pnm(path, data_out, nullptr, 0, W, H, channels);
+}
+
+extern "C" int fav_read_pnm_into_host(const char* path, uint8_t* buf, size_t capacity_bytes, int* W, int* H, int* channels)
+{
+    FAV_REQUIRE(path && buf && W && H && channels, "fav_read_pnm_into_host: null argument");
+    return read_pnm(path, nullptr, buf, capacity_bytes, W, H, channels);
 }
 
 // CMatrix::writeToPGM header (CMatrix.h:1064): "P5\n%d %d\n255\n"; written to a temp file and renamed so
@@ -227,16 +254,19 @@ extern "C" int fav_write_png_rgb8_host(const char* path, const uint8_t* rgb_hwc,
 {
     FAV_REQUIRE(path && rgb_hwc && W > 0 && H > 0, "fav_write_png_rgb8_host: bad argument");
     const size_t stride = (size_t)W * 3;
-    std::vector<uint8_t> raw((stride + 1) * H);
+    // per-thread scratch that persists across calls: a writer pool would otherwise fault in ~8 MB of fresh pages per frame
+    // on every thread, and the page-fault path serialises on the process's address-space lock
+    static thread_local std::vector<uint8_t> raw, comp, out;
+    raw.resize((stride + 1) * H);
     for (int y = 0; y < H; ++y) {
         raw[(stride + 1) * y] = 0;   // filter type 0 (None)
         memcpy(raw.data() + (stride + 1) * y + 1, rgb_hwc + stride * y, stride);
     }
     uLongf clen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> comp(clen);
+    if (comp.size() < clen) comp.resize(clen);
     if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), zlib_level < 0 ? 1 : zlib_level) != Z_OK) {
         set_error("zlib deflate failed"); return FAV_EIO; }
-    std::vector<uint8_t> out;
+    out.clear();
     const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     out.insert(out.end(), sig, sig + 8);
     std::vector<uint8_t> ihdr;

@@ -3,8 +3,9 @@
 // ({..} = index i-1, [..] = index i; fast_artistic_video.lua:70-77), same 1-based frame loop that stops
 // at the first missing frame (core.lua:196-197), same "<prefix>-%05d.png" outputs (fav.lua:161).
 //
-// Host structure: a loader thread reads/decodes frame i+1 (PPM, .flo, .pgm) while the GPU works on
-// frame i; PNG deflate + file writes run on a small pool so they never stall the GPU.  All compute
+// Host structure: loader threads read/decode frames i+1.. (PPM, .flo, .pgm) into pinned staging while the GPU works on
+// frame i; uploads run on their own queue; the host enqueues frame i before it waits for frame i-1 (so the GPU never idles
+// between frames); PNG deflate + file writes run on a small pool.  All compute
 // goes through libfav's C ABI (fav_stream_*); there is no CPU backend (-gpu -1 is rejected).
 //
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
@@ -204,7 +205,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "4"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}};
+           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
            {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
     for (int a = 1; a < argc; ++a) {
@@ -241,12 +242,16 @@ int main(int argc, char** argv)
     const int start = backward ? num_frames - 1 : o.i("continue_with"), end = backward ? 1 : num_frames, inc = backward ? -1 : 1;   // core:189-191
     const double poll = o.d("poll_timeout");
 
-    auto load = [&](int i, bool first_of_run) {
-        FrameIn in; in.index = i;
+    struct Pinned { uint8_t* frame = nullptr; float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr; };
+    size_t pin_px = 0;                       // capacity of a pinned staging set in pixels (0: none yet)
+    // pd != null: decode straight into that pinned staging set (no allocation, no second copy)
+    auto load = [&](int i, bool first_of_run, const Pinned* pd) {
+        FrameIn in; in.index = pd ? -i - 1 : i;              // negative index marks "pinned, do not free"
         const std::string fp = fmt_int(o.s("input_pattern"), i);
         if (!file_exists(fp)) return in;                                                                     // fav.lua:93-97 -> nil -> break
         int ch;
-        check(fav_read_pnm_host(fp.c_str(), &in.frame, &in.W, &in.H, &ch), fp.c_str());
+        if (pd) { check(fav_read_pnm_into_host(fp.c_str(), pd->frame, pin_px * 3, &in.W, &in.H, &ch), fp.c_str()); in.frame = pd->frame; }
+        else check(fav_read_pnm_host(fp.c_str(), &in.frame, &in.W, &in.H, &ch), fp.c_str());
         if (ch != 3) die(fp + ": expected a colour (P6) frame");
         in.single = (i == 1) || o.f("create_inconsistent") || first_of_run;                                 // fav.lua:172
         if (!in.single) {
@@ -255,33 +260,42 @@ int main(int argc, char** argv)
             if (fused_check) {
                 const std::string ff = flow_name(o.s("forward_flow_pattern"), i - 1, i);
                 wait_for_file(fl, poll); wait_for_file(ff, poll);
-                check(fav_read_flo_host(ff.c_str(), &in.fw, &w, &h), ff.c_str());
+                if (pd) { check(fav_read_flo_into_host(ff.c_str(), pd->fw, pin_px * 2, &w, &h), ff.c_str()); in.fw = pd->fw; }
+                else check(fav_read_flo_host(ff.c_str(), &in.fw, &w, &h), ff.c_str());
                 if (w != in.W || h != in.H) die(ff + ": size differs from the frame");
             } else {
                 const std::string cp = flow_name(o.s("occlusions_pattern"), i - 1, i);
                 wait_for_file(cp, poll);                                                                     // fav.lua:102
                 int cch;
-                check(fav_read_pnm_host(cp.c_str(), &in.cert, &w, &h, &cch), cp.c_str());
+                if (pd) { check(fav_read_pnm_into_host(cp.c_str(), pd->cert, pin_px, &w, &h, &cch), cp.c_str()); in.cert = pd->cert; }
+                else check(fav_read_pnm_host(cp.c_str(), &in.cert, &w, &h, &cch), cp.c_str());
                 if (cch != 1 || w != in.W || h != in.H) die(cp + ": expected a P5 mask of the frame's size");
                 wait_for_file(fl, poll);
             }
-            check(fav_read_flo_host(fl.c_str(), &in.bw, &w, &h), fl.c_str());
+            if (pd) { check(fav_read_flo_into_host(fl.c_str(), pd->bw, pin_px * 2, &w, &h), fl.c_str()); in.bw = pd->bw; }
+            else check(fav_read_flo_host(fl.c_str(), &in.bw, &w, &h), fl.c_str());
             if (w != in.W || h != in.H) die(fl + ": size differs from the frame");
         }
         in.ok = true;
         return in;
     };
 
-    Pool writers(std::max(1, o.i("writers")));
-    hipStream_t st;
-    if (hipStreamCreate(&st) != hipSuccess) die("hipStreamCreate failed");
+    // PNG deflate is the slowest host stage (level 1: ~25-100 MB/s per thread depending on the content): size the pool from the host
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nwriters = o.i("writers") > 0 ? o.i("writers") : std::max(4, std::min(32, hw / 8));
+    Pool writers(nwriters);
+    hipStream_t st, st_copy;                 // compute queue; upload queue (the next frame's inputs travel while this frame computes)
+    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess) die("hipStreamCreate failed");
+    hipEvent_t ev_up[3], ev_done[2];
+    for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
+    for (auto& e : ev_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
     fav_stream* fs = nullptr;
     int W = 0, H = 0;
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
     Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
     uint8_t* d_out8 = nullptr;
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
-    const int nslots = std::max(1, o.i("writers")) + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
+    const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
     int slot = 0;
 
@@ -304,25 +318,10 @@ int main(int argc, char** argv)
 
     // Host pipeline: DEPTH loader threads read + decode frames i+1.. while the GPU works on frame i; decoded
     // inputs are copied into pinned staging sets so the H2D copies are true async DMA.
-    constexpr int DEPTH = 3;
-    struct Pinned { uint8_t* frame = nullptr; float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr; };
+    constexpr int DEPTH = 6;
     Pinned pin[DEPTH + 1];
     bool pinned_ready = false;
-    auto load_pinned = [&](int i, bool first_of_run, int set) {
-        FrameIn in = load(i, first_of_run);
-        if (in.ok && pinned_ready && in.W == W && in.H == H) {
-            const size_t n = (size_t)W * H;
-            memcpy(pin[set].frame, in.frame, n * 3);
-            if (in.bw) memcpy(pin[set].bw, in.bw, n * 8);
-            if (in.fw) memcpy(pin[set].fw, in.fw, n * 8);
-            if (in.cert) memcpy(pin[set].cert, in.cert, n);
-            const bool hb = in.bw, hf = in.fw, hc = in.cert;
-            in.release();
-            in.frame = pin[set].frame; in.bw = hb ? pin[set].bw : nullptr; in.fw = hf ? pin[set].fw : nullptr; in.cert = hc ? pin[set].cert : nullptr;
-            in.index = -i - 1;               // marks "pinned, do not free"
-        }
-        return in;
-    };
+    auto load_pinned = [&](int i, bool first_of_run, int set) { return load(i, first_of_run, pinned_ready ? &pin[set] : nullptr); };
     auto idx_ok = [&](int i) { return backward ? i >= end : i <= end; };
     std::deque<std::pair<int, std::thread>> inflight;      // (slot set, thread)
     std::vector<FrameIn> ready(DEPTH + 1);
@@ -340,12 +339,32 @@ int main(int argc, char** argv)
     const auto t_begin = std::chrono::steady_clock::now();
     double t_wait_load = 0, t_gpu = 0, t_wait_writer = 0;
     int done = 0, dset = 0;
-    auto upload = [&](const FrameIn& f, const Dev& dv) {          // async H2D of one frame's inputs (pinned -> device)
-        const size_t n = (size_t)W * H;
-        hipMemcpyAsync(dv.frame, f.frame, n * 3, hipMemcpyHostToDevice, st);
-        if (f.bw) hipMemcpyAsync(dv.bw, f.bw, n * 8, hipMemcpyHostToDevice, st);
-        if (f.fw) hipMemcpyAsync(dv.fw, f.fw, n * 8, hipMemcpyHostToDevice, st);
-        if (f.cert) hipMemcpyAsync(dv.cert, f.cert, n, hipMemcpyHostToDevice, st);
+    auto upload = [&](const FrameIn& f, int set) {                // async H2D of one frame's inputs (pinned -> device) on the copy queue
+        const size_t n = (size_t)W * H; const Dev& dv = dev[set];
+        hipMemcpyAsync(dv.frame, f.frame, n * 3, hipMemcpyHostToDevice, st_copy);
+        if (f.bw) hipMemcpyAsync(dv.bw, f.bw, n * 8, hipMemcpyHostToDevice, st_copy);
+        if (f.fw) hipMemcpyAsync(dv.fw, f.fw, n * 8, hipMemcpyHostToDevice, st_copy);
+        if (f.cert) hipMemcpyAsync(dv.cert, f.cert, n, hipMemcpyHostToDevice, st_copy);
+        hipEventRecord(ev_up[set], st_copy);
+        hipStreamWaitEvent(st, ev_up[set], 0);                     // everything enqueued on the compute queue from here on sees them
+    };
+    // the host runs one frame ahead of the GPU: frame i is enqueued before frame i-1's completion is awaited
+    struct Pending { bool valid = false; int index = 0; bool single = false; uint8_t* hb = nullptr; int ev = 0;
+                     std::chrono::steady_clock::time_point t0; };
+    Pending pend;
+    auto finish = [&](Pending& pd) {
+        if (!pd.valid) return;
+        if (hipEventSynchronize(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd.t0).count();
+        if (pd.single) printf("Elapsed time for stylizing frame independently:%g\n", ms / 1000.0);           // core:155
+        else printf("Elapsed time for stylizing frame:%g\n", ms / 1000.0);                                   // core:177
+        char nm[4096]; snprintf(nm, sizeof nm, "%s-%05d.png", o.s("output_prefix").c_str(), pd.index);       // fav.lua:161
+        printf("Writing output image to %s\n", nm);
+        mkdirs_for(nm);
+        const int lvl = o.i("png_level");
+        const std::string path = nm; uint8_t* hb = pd.hb; const int w_ = W, h_ = H;
+        writers.submit([hb, path, w_, h_, lvl] { if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error()); });
+        pd.valid = false;
     };
     auto pop_next = [&](FrameIn& out) {
         if (inflight.empty()) return false;
@@ -357,7 +376,7 @@ int main(int argc, char** argv)
         return out.ok;
     };
     // the first frame is loaded synchronously (its size sizes every buffer)
-    FrameIn cur = load(start, !have_resume && start != 1), nxt;
+    FrameIn cur = load(start, !have_resume && start != 1, nullptr), nxt;
     bool have_next = false;
     next_to_issue = start + inc;
     for (int i = start; idx_ok(i) && cur.ok; i += inc) {                                                      // core:196-197
@@ -377,7 +396,7 @@ int main(int argc, char** argv)
             for (auto& p : pin)
                 if (hipHostMalloc((void**)&p.frame, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, n * 8, hipHostMallocDefault) ||
                     hipHostMalloc((void**)&p.fw, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&p.cert, n, hipHostMallocDefault)) die("hipHostMalloc failed");
-            pinned_ready = true;
+            pin_px = n; pinned_ready = true;
             if (have_resume) {
                 float* d_state = nullptr;
                 if (hipMalloc((void**)&d_state, n * 12) != hipSuccess) die("hipMalloc failed");
@@ -385,8 +404,8 @@ int main(int argc, char** argv)
                 check(fav_stream_set_state(fs, d_state, st), "fav_stream_set_state");
                 hipStreamSynchronize(st); hipFree(d_state);
             }
-            upload(cur, dev[dset]);
-            hipStreamSynchronize(st);                    // the first frame's host buffers are malloc'ed: release them now
+            upload(cur, dset);
+            hipStreamSynchronize(st_copy);               // the first frame's host buffers are malloc'ed: release them now
             first = false;
         } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
         issue();                                         // keep DEPTH loads in flight
@@ -398,7 +417,7 @@ int main(int argc, char** argv)
         const Dev& dn = dev[(dset + 1) % 3];
         if (have_next) {
             if (nxt.W != W || nxt.H != H) die("frame size changed inside the sequence");
-            upload(nxt, dn);
+            upload(nxt, (dset + 1) % 3);
             if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
         const bool teval = !o.s("temporal_eval_file").empty();
@@ -420,26 +439,22 @@ int main(int argc, char** argv)
             temporal.push_back(tl);
         }
         const auto tw = std::chrono::steady_clock::now();
-        writers.wait_below((size_t)nslots - 1);          // a free pinned output slot
+        writers.wait_below((size_t)nslots - 2);          // a free pinned output slot (one more is held by the frame in flight)
         t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         uint8_t* hb = h_out[slot]; slot = (slot + 1) % nslots;
-        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st);
-        if (hipStreamSynchronize(st) != hipSuccess) die("GPU error while stylising a frame");
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        t_gpu += ms / 1e3;
-        if (cur.single) printf("Elapsed time for stylizing frame independently:%g\n", ms / 1000.0);           // core:155
-        else printf("Elapsed time for stylizing frame:%g\n", ms / 1000.0);                                   // core:177
-        char nm[4096]; snprintf(nm, sizeof nm, "%s-%05d.png", o.s("output_prefix").c_str(), i);              // fav.lua:161
-        printf("Writing output image to %s\n", nm);
-        mkdirs_for(nm);
-        const int lvl = o.i("png_level");
-        const std::string path = nm;
-        writers.submit([hb, path, W, H, lvl] { if (fav_write_png_rgb8_host(path.c_str(), hb, W, H, lvl)) fprintf(stderr, "%s\n", fav_last_error()); });
+        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st);     // stream order protects d_out8 from frame i+1
+        Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
+        hipEventRecord(ev_done[now.ev], st);
+        const auto tg = std::chrono::steady_clock::now();
+        finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i is already queued
+        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        pend = now;
         if (cur.index >= 0) cur.release();               // malloc'ed (first frame); pinned sets are reused
         ++done;
         if (!have_next) break;
         cur = nxt; dset = (dset + 1) % 3;
     }
+    finish(pend);
     for (auto& pr : inflight) pr.second.join();
     for (auto& r : ready) if (r.index >= 0) r.release();
     fflush(stdout);

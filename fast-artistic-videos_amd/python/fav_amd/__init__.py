@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32",
+    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host",
 ]
 
 

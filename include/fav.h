@@ -234,6 +234,9 @@ int fav_vr_map_host(int kind, int hplus, int wplus, int overlap, int median_filt
  * P6/P5 8-bit binary PNM; PNG writer (RGB8, zlib).  Buffers are malloc'ed; free with fav_free_host. */
 int fav_read_flo_host(const char* path, float** uv_out, int* W, int* H);
 int fav_read_pnm_host(const char* path, uint8_t** data_out, int* W, int* H, int* channels);
+/* the same readers into a caller-provided (e.g. pinned) buffer: no allocation, FAV_EINVAL if the payload does not fit */
+int fav_read_flo_into_host(const char* path, float* uv_buf, size_t capacity_floats, int* W, int* H);
+int fav_read_pnm_into_host(const char* path, uint8_t* buf, size_t capacity_bytes, int* W, int* H, int* channels);
 int fav_write_pgm_host(const char* path, const uint8_t* data, int W, int H);
 int fav_write_png_rgb8_host(const char* path, const uint8_t* rgb_hwc, int W, int H, int zlib_level);
 void fav_free_host(void* p);

@@ -25,7 +25,7 @@ for i in range(1, N + 1):
         os.symlink(f"{d}/src/r{i % 4}.pgm", f"{d}/flow/reliable_{i}_{i-1}.pgm")
 exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
 base = [exe, "-input_pattern", d + "/frame_%05d.ppm", "-flow_pattern", d + "/flow/backward_[%d]_{%d}.flo", "-occlusions_pattern", d + "/flow/reliable_[%d]_{%d}.pgm",
-        "-model_vid", model, "-model_img", "self", "-gpu", "0", "-timing", "1", "-writers", "16"]
+        "-model_vid", model, "-model_img", "self", "-gpu", "0", "-timing", "1", "-writers", os.environ.get("FAV_E2E_WRITERS", "16")]
 res = {"frames": N, "consistencyChecker_process_s_per_pair_4arg": round(t_chk, 4)}
 for name, extra in [("cert_mode_png1", ["-output_prefix", d + "/o1/out"]), ("cert_mode_png0", ["-output_prefix", d + "/o2/out", "-png_level", "0"]),
                     ("fused_3arg_png1", ["-output_prefix", d + "/o3/out", "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo", "-structure", "0"]),
@@ -33,5 +33,6 @@ for name, extra in [("cert_mode_png1", ["-output_prefix", d + "/o1/out"]), ("cer
     r = subprocess.run(base + extra, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     res[name] = json.loads(line[-1])["fps_end_to_end"] if line else ("FAILED: " + r.stderr[-200:])
+    if line and os.environ.get("FAV_E2E_VERBOSE"): res[name + "_detail"] = json.loads(line[-1])
 print(json.dumps(res))
 shutil.rmtree(d, ignore_errors=True)

@@ -338,3 +338,26 @@ def test_cpp_t7_reader_survives_damaged_files(favlib, golden_dir, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     ok, bad = map(int, r.stdout.split())
     assert ok + bad == len(cases) and bad >= 30          # every truncation fails; a flipped payload byte may still parse
+
+
+def test_into_buffer_readers(favlib, oracle, tmp_path):
+    """fav_read_flo_into_host / fav_read_pnm_into_host: the loaders' no-allocation variants (pinned staging in fav_stylize)."""
+    L = favlib.lib()
+    h, w = 23, 31
+    uv = synth.random_flow(h, w, 1); img = synth.random_frame(h, w, 2); m = (synth.random_frame(h, w, 3)[..., 0])
+    pf, pi, pm = (str(tmp_path / n) for n in ("a.flo", "a.ppm", "a.pgm"))
+    oracle.write_flo(pf, uv); oracle.write_pnm(pi, img); oracle.write_pnm(pm, m)
+    W, H, ch = C.c_int(), C.c_int(), C.c_int()
+    fb = np.zeros(h * w * 2, np.float32)
+    assert L.fav_read_flo_into_host(pf.encode(), fb.ctypes.data_as(C.c_void_p), C.c_size_t(fb.size), C.byref(W), C.byref(H)) == 0
+    assert (W.value, H.value) == (w, h) and np.array_equal(fb.reshape(h, w, 2), uv)
+    ib = np.zeros(h * w * 3 + 5, np.uint8)
+    assert L.fav_read_pnm_into_host(pi.encode(), ib.ctypes.data_as(C.c_void_p), C.c_size_t(ib.size), C.byref(W), C.byref(H), C.byref(ch)) == 0
+    assert ch.value == 3 and np.array_equal(ib[:h * w * 3].reshape(h, w, 3), img)
+    mb = np.zeros(h * w, np.uint8)
+    assert L.fav_read_pnm_into_host(pm.encode(), mb.ctypes.data_as(C.c_void_p), C.c_size_t(mb.size), C.byref(W), C.byref(H), C.byref(ch)) == 0
+    assert ch.value == 1 and np.array_equal(mb.reshape(h, w), m)
+    # too small a buffer is an error, not an overrun
+    assert L.fav_read_flo_into_host(pf.encode(), fb.ctypes.data_as(C.c_void_p), C.c_size_t(fb.size - 1), C.byref(W), C.byref(H)) == -1
+    assert L.fav_read_pnm_into_host(pi.encode(), ib.ctypes.data_as(C.c_void_p), C.c_size_t(h * w * 3 - 1), C.byref(W), C.byref(H), C.byref(ch)) == -1
+    assert b"does not fit" in L.fav_last_error()
