@@ -161,6 +161,18 @@ def main():
             step4(i)
         torch.cuda.synchronize()
         extra["frames_per_s_4arg_structure_mode_lookahead"] = round(n4 / (time.perf_counter() - t1), 3)
+        # informational, NOT the parity mode and not `value`: the optional fast mode with bf16 operands in the halo-resident 3x3
+        # convolutions (fav_net_set_precision; tests gate it at >= 45 dB PSNR against the fp32 oracle)
+        net.profile_enable(False)
+        net.set_precision(True)
+        for i in range(4):
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=False, want_f32=False, out_u8=out8)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for i in range(4, 4 + n4):
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=False, want_f32=False, out_u8=out8)
+        torch.cuda.synchronize()
+        extra["frames_per_s_bf16_operand_fast_mode_3arg"] = round(n4 / (time.perf_counter() - t1), 3)
+        net.set_precision(False)
 
     if rank == 0:
         fps = world * args.steps / dt

@@ -80,6 +80,7 @@ struct ConvLaunch {
     int CIN = 0;                    // physical channels (multiple of 4)
     Affine pre;                     // applied on load (zero padding is applied AFTER it)
     const float* wgt = nullptr;     // [COUTp][Kpad], k = tap*CIN + ci
+    const unsigned short* wgt16 = nullptr;   // bf16 copy of wgt: selects the bf16-operand halo kernel (fast mode) when set
     const float* bias = nullptr;    // [COUTp]
     int COUT = 0, COUTp = 0;        // valid / padded (multiple of the N tile) output channels
     int KH = 0, KW = 0, stride = 1, pad = 0;

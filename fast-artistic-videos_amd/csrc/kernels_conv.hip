@@ -658,6 +658,7 @@ struct H3Args {
     float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;
     int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
     int stages, relu1, relu2;
+    const unsigned short* wgt16;   // bf16 copy of the weights (fast mode) or null
     long long* dbg;          // optional in-kernel timeline (FAV_H3_DBG), 24 slots per block
 };
 
@@ -979,6 +980,315 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
 #undef DBG_T
 }
 
+// ------------------------------------------------------------------------------------------------
+// Optional fast mode (NOT the parity mode): the same halo-resident kernel with the two operands rounded to
+// bf16 on their way into LDS (activations after the pending IN/ReLU transform, weights pre-rounded on the host) and
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 activations in HBM).  One K step = 2 matrix instructions per 32x32 tile
+// instead of 16, so the kernel turns from MFMA-bound into staging-bound.  Selected per network with fav_net_set_precision.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int BN, bool S2>
+__global__ __launch_bounds__(512, 2) void conv3_halo_bf16_kernel(const H3Args p)
+{
+    constexpr int NT = 512;
+    constexpr int HWD = H3_TW + 2, HP = (H3_TH + 2) * HWD;        // 34, 340 halo pixels
+    constexpr int TN = BN / 32;
+    constexpr int NHV = (HP * 8 + NT - 1) / NT;                   // 16-byte halo pieces per thread per slice (6)
+    constexpr int ALIAS = NT * NHV - HP * 8;                       // units past the end alias earlier ones (same data, same slot)
+    static_assert(NHV == 6, "two halo pieces per tap row");
+    static_assert(ALIAS % 8 == 0 && ALIAS <= NT, "halo aliasing");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LB = 40;                      // LDS row stride in bf16 units: 32 channels + 8 pad = 80 bytes (conflict-free ds_read_b128)
+    unsigned short* Hs = reinterpret_cast<unsigned short*>(smem);    // [2][HP][LB]   bf16
+    unsigned short* Bs = Hs + 2 * HP * LB;                           // [3][BN][LB]   bf16
+    float* aff = reinterpret_cast<float*>(Bs + 3 * BN * LB);         // [4][CIN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int CIN = p.CIN;
+    const int nchunks = CIN >> 5, nsteps = nchunks * 9;
+    const int ntiles = p.tiles_x * p.tiles_y;
+
+    int dbi = 0;
+#define DBG_T() { if (p.dbg && t == 0 && dbi < 22) p.dbg[blockIdx.x * 24 + dbi++] = wall_clock64(); }
+    DBG_T();
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int c4 = t & 7, r0 = t >> 3;                      // staging: weight row r0 (+64) / halo pixel r0 (+64 i), 16-byte chunk c4
+    const int frag_k = (lane >> 5) * 8;                     // 8 consecutive channels per half-wave (one 32x32x16 operand)
+    const int m = lane & 31;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    // per-thread bases; everything else in the K loop is an immediate or a scalar
+    const int wr = t >> 2, wc = t & 3;                                      // weight staging: row wr, 16-byte chunk wc (8 bf16)
+    const bool wact = wr < BN;
+    const unsigned wofs = (unsigned)(wr * p.Kpad + wc * 8) * 2u;            // byte offset of this thread's weight chunk in a step
+    unsigned short* const bst = Bs + wr * LB + wc * 8;                      // weight staging slot
+    unsigned short* const hst = Hs + r0 * LB + c4 * 4;                      // halo staging slot of piece 0, buffer 0 (4 bf16 = 8 bytes)
+    const int hst_last = (t + NT * (NHV - 1) >= HP * 8) ? (NT * (NHV - 1) - ALIAS) / 8 * LB : 64 * (NHV - 1) * LB;
+    const unsigned short* const afr = Hs + (wave * HWD + m) * LB + frag_k;  // A fragments: tap (0,0), buffer 0
+    const unsigned short* const bfr = Bs + m * LB + frag_k;                 // B fragments: ring slot 0
+    const float* const affr = aff + c4 * 4;
+
+    // stream-K work unit: one tap row (3 K steps) of one channel slice of one tile.  Inside a unit kx, the weight ring
+    // slot (= kx) and the position of the halo pieces are compile-time constants; ky and the slice are scalars.
+    const int nunits = nchunks * 3;
+    const int U = ntiles * nunits;
+    int u = (int)((long long)U * lb / gridDim.x);
+    const int u_end = (int)((long long)U * (lb + 1) / gridDim.x);
+
+    while (u < u_end) {
+        const int tile = u / nunits;
+        const int k0 = u - tile * nunits;
+        const int k1 = (u_end - u) < nunits - k0 ? k0 + (u_end - u) : nunits;
+        u += k1 - k0;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int oy0 = ty * H3_TH, ox0 = tx * H3_TW;
+        DBG_T();   /* work item start */
+
+        // halo piece i: unit e = t + 512*i -> halo pixel e>>3, channel chunk e&7; per tile: byte offset (chunk 0 if outside) and mask
+        int hoff[NHV]; float hmask[NHV];
+#pragma unroll
+        for (int i = 0; i < NHV; ++i) {
+            int e = t + NT * i; e -= e >= HP * 8 ? ALIAS : 0;
+            const int pix = e >> 3, hy = (pix * 1928) >> 16, hx = pix - hy * HWD;
+            const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx;
+            const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+            hoff[i] = ((v ? ((iy >> p.ups) * p.IWp + (ix >> p.ups)) * CIN : 0) + c4 * 4) * 4;
+            hmask[i] = v ? 1.f : 0.f;
+        }
+        const int c_first = (k0 * 21846) >> 16, ky0 = k0 - c_first * 3;      // k / 3
+        const int c_last = ((k1 - 1) * 21846) >> 16;
+
+        float4 hr; float hm; v4f rb;
+        v4f sc1, sh1, sc2, sh2;             // IN/ReLU stages of the slice being staged, this thread's 4 channels
+#define H3_AFF(chunk_)                                                                              \
+        { sc1 = *reinterpret_cast<const v4f*>(affr + (chunk_) * 32); sh1 = *reinterpret_cast<const v4f*>(affr + CIN + (chunk_) * 32); \
+          if (S2) { sc2 = *reinterpret_cast<const v4f*>(affr + 2 * CIN + (chunk_) * 32); sh2 = *reinterpret_cast<const v4f*>(affr + 3 * CIN + (chunk_) * 32); } }
+#define H3_XFORM(v_, m_)                                                                            \
+        { v_.x = fmaxf(fmaf(v_.x, sc1.x, sh1.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc1.y, sh1.y), lo1);  \
+          v_.z = fmaxf(fmaf(v_.z, sc1.z, sh1.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc1.w, sh1.w), lo1);  \
+          if (S2) { v_.x = fmaxf(fmaf(v_.x, sc2.x, sh2.x), lo2); v_.y = fmaxf(fmaf(v_.y, sc2.y, sh2.y), lo2); \
+                    v_.z = fmaxf(fmaf(v_.z, sc2.z, sh2.z), lo2); v_.w = fmaxf(fmaf(v_.w, sc2.w, sh2.w), lo2); } \
+          v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_; }
+#define H3_HLDS(i_) ((i_) == NHV - 1 ? hst_last : 64 * (i_) * LB)
+#define H3_PUT(dst_, v_) { const bf16x2 lo_ = __builtin_convertvector(f32x2{v_.x, v_.y}, bf16x2), hi_ = __builtin_convertvector(f32x2{v_.z, v_.w}, bf16x2); \
+                         uint2 w_; w_.x = __builtin_bit_cast(unsigned, lo_); w_.y = __builtin_bit_cast(unsigned, hi_); *reinterpret_cast<uint2*>(dst_) = w_; }
+#define H3_LOAD_B(src_)  { if (wact) rb = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(src_) + wofs); }
+#define H3_STORE_B(slot_) { if (wact) *reinterpret_cast<v4f*>(bst + (slot_) * BN * LB) = rb; }
+
+        {
+            // prologue: this slice's whole halo -> buffer 0; the pieces of the next slice that the skipped tap rows would
+            // have staged -> buffer 1; all loads in flight before the first store
+            const char* in0 = reinterpret_cast<const char*>(p.in + c_first * 32);
+            const char* in1 = reinterpret_cast<const char*>(p.in + min(c_first + 1, c_last) * 32);
+            float4 q0[NHV], q1[NHV];
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]);
+            H3_LOAD_B(p.wgt16 + k0 * 3 * BK);
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
+            H3_AFF(c_first);
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) { H3_XFORM(q0[i], hmask[i]); H3_PUT(hst + H3_HLDS(i), q0[i]); }
+            H3_STORE_B(0);
+            H3_LOAD_B(p.wgt16 + min(k0 * 3 + 1, nsteps - 1) * BK);
+            H3_AFF(min(c_first + 1, c_last));
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) { H3_XFORM(q1[i], hmask[i]); H3_PUT(hst + HP * LB + H3_HLDS(i), q1[i]); }
+        }
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        __syncthreads();
+
+        bf16x8 fa[2], fb[2][TN];
+#define H3_FRAG(set_, ap_, bp_)                                                                     \
+        { fa[set_] = *reinterpret_cast<const bf16x8*>(ap_);                                         \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[set_][j] = *reinterpret_cast<const bf16x8*>((bp_) + j * 32 * LB); }
+#define H3_MFMA(set_)                                                                               \
+        { _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set_], fb[set_][j], acc[j], 0, 0, 0); }
+#define H3_GROUP(nds_)                                                                              \
+        { __builtin_amdgcn_sched_group_barrier(0x100, nds_, 0); __builtin_amdgcn_sched_group_barrier(0x008, TN, 0); }
+        // one K step (32 channels of one tap = two 16-channel MFMA groups), kx = KX (compile time)
+#define H3_STEP(KX)                                                                                 \
+        {   constexpr int NB = ((KX) + 1) % 3;                                                      \
+            const unsigned short* an_ = (KX) == 2 ? a_nu : a_cu + ((KX) + 1) * LB;                  \
+            H3_FRAG(1, a_cu + (KX) * LB + 16, bfr + (KX) * BN * LB + 16);                           \
+            H3_STORE_B(NB);                                                                         \
+            H3_LOAD_B(p.wgt16 + min(sg + (KX) + 2, nsteps - 1) * BK);                               \
+            if ((KX) < 2) { hr = *reinterpret_cast<const float4*>(in_n + ((KX) == 0 ? ho0 : ho1)); hm = (KX) == 0 ? hm0 : hm1; } \
+            H3_MFMA(0); H3_GROUP(1 + TN);                                                           \
+            __syncthreads();                                                                        \
+            H3_FRAG(0, an_, bfr + NB * BN * LB);                                                    \
+            if ((KX) < 2) { H3_XFORM(hr, hm); H3_PUT(h_nx + ((KX) == 0 ? hl0 : hl1), hr); }         \
+            H3_MFMA(1); H3_GROUP(1 + TN);                                                           \
+        }
+
+        H3_FRAG(0, afr + ky0 * HWD * LB, bfr);             // fragments of the first step's first group
+        DBG_T();   /* loop start */
+        const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
+        int c = c_first, ky = ky0, par = 0;
+        for (int uu = k0; uu < k1; ++uu) {
+            const unsigned short* a_cu = afr + (par * HP + ky * HWD) * LB;
+            const unsigned short* a_nu = ky == 2 ? afr + (par ^ 1) * (HP * LB) : a_cu + HWD * LB;
+            unsigned short* h_nx = hst + (par ^ 1) * (HP * LB);
+            const int cn = min(c + 1, c_last);                              // no next slice: the pieces land in the unused buffer
+            const char* in_n = reinterpret_cast<const char*>(p.in + cn * 32);
+            const int sg = uu * 3;
+            const int ho0 = ky == 0 ? hoff[0] : (ky == 1 ? hoff[2] : hoff[4]), ho1 = ky == 0 ? hoff[1] : (ky == 1 ? hoff[3] : hoff[5]);
+            const float hm0 = ky == 0 ? hmask[0] : (ky == 1 ? hmask[2] : hmask[4]), hm1 = ky == 0 ? hmask[1] : (ky == 1 ? hmask[3] : hmask[5]);
+            const int hl0 = 128 * ky * LB, hl1 = ky == 2 ? hst_last : (128 * ky + 64) * LB;
+            H3_AFF(cn);
+            H3_STEP(0) H3_STEP(1) H3_STEP(2)
+            if (++ky == 3) { ky = 0; ++c; par ^= 1; }
+        }
+        __syncthreads();                    // the epilogue reuses the staging memory
+        DBG_T();   /* loop end */
+        if (p.dbg && t == 0 && k1 - k0 > 6) { p.dbg[blockIdx.x * 24 + 21] = clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] = wall_clock64() - wk0; p.dbg[blockIdx.x * 24 + 20] = (k1 - k0) * 3; }
+#undef H3_AFF
+#undef H3_XFORM
+#undef H3_HLDS
+#undef H3_PUT
+#undef H3_LOAD_B
+#undef H3_STORE_B
+#undef H3_FRAG
+#undef H3_MFMA
+#undef H3_GROUP
+#undef H3_STEP
+
+        // ------------------------------------------------------------ stream-K hand-off (see conv_mfma_kernel)
+        constexpr int NV4 = TN * 4;
+        if (k0 > 0) {
+            float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slot[(size_t)(j * 4 + q) * NT] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            DBG_T(); DBG_T();
+            continue;
+        }
+        if (k1 < nunits) {
+            int covered = k1;
+            for (int nb = lb + 1; covered < nunits && nb < (int)gridDim.x; ++nb) {
+                const int nu0 = (int)((long long)U * nb / gridDim.x), nu1 = (int)((long long)U * (nb + 1) / gridDim.x);
+                const int span = (nu1 - nu0) < (nunits - covered) ? (nu1 - nu0) : (nunits - covered);
+                if (t == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 26)) break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const float4* slot = reinterpret_cast<const float4*>(p.sk_ws) + (size_t)nb * NV4 * NT + t;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = slot[(size_t)(j * 4 + q) * NT];
+                        acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w;
+                    }
+                covered += span;
+            }
+        }
+
+        DBG_T();   /* fixup end */
+        // ------------------------------------------------------------ epilogue: wave = output row, MFMA rows = columns
+        float* red = smem;                 // [8][BN] + [BN]
+        const int oy = oy0 + wave;
+        const int vh = min(H3_TH, p.OH - oy0), vw = min(H3_TW, p.OW - ox0);
+        const int cnt = vh * vw;
+        float lsum[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 32 + col;
+            const float bv = p.bias[n];
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                const float v = acc[j][r] + bv;
+                acc[j][r] = v;
+                if (oy < p.OH && ox < p.OW) {
+                    if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
+                    sm += v;
+                }
+            }
+            lsum[j] = sm;
+        }
+        if (p.partials != nullptr) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
+                if (lane < 32) red[wave * BN + j * 32 + lane] = sm;
+            }
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
+                red[8 * BN + t] = a / (float)cnt;
+            }
+            __syncthreads();
+            float lq[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float mu = red[8 * BN + j * 32 + col];
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                    const float d = acc[j][r] - mu;
+                    if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+                }
+                lq[j] = q + __shfl_xor(q, 32);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (lane < 32) red[wave * BN + j * 32 + lane] = lq[j];
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
+                p.partials[(size_t)tile * p.COUTp + t] = make_float2(red[8 * BN + t], a);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+        }
+        __syncthreads();
+        DBG_T();   /* epilogue end */
+    }
+    if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
+#undef DBG_T
+}
+
+
 }  // namespace
 
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride)
@@ -1006,16 +1316,18 @@ static void h3_debug_report(const long long* h, int grid)
             sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, tend);
 }
 
-template <int BN, bool S2>
+template <int BN, bool S2, bool BF>
 static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t st)
 {
-    const size_t lds = (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 4 * cin) * sizeof(float);
+    const auto kern = BF ? conv3_halo_bf16_kernel<BN, S2> : conv3_halo_kernel<BN, S2>;
+    const size_t lds = BF ? (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * 40 + 3 * BN * 40) * 2 + (size_t)4 * cin * sizeof(float)
+                          : (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 4 * cin) * sizeof(float);
     static int cus = 0;
     if (!cus) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<BN, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int dev = 0, occ = 0; hipDeviceProp_t prop;
         FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
-        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv3_halo_kernel<BN, S2>, 512, lds));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
         if (occ < 1) { set_error("halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
         cus = prop.multiProcessorCount;          // one block per CU: every stream-K block must be resident
     }
@@ -1026,9 +1338,9 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t s
     H3Args a = a0; a.dbg = nullptr;
     static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;
-    const bool dbg = dbg_n > 0 && BN == 128 && --dbg_n == 0;
+    const bool dbg = dbg_n > 0 && BN == 128 && !BF && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), SK_GRID * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, SK_GRID * 24 * 8, st)); a.dbg = dbuf; }
-    hipLaunchKernelGGL((conv3_halo_kernel<BN, S2>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_halo_kernel");
     if (dbg) {
         std::vector<long long> h((size_t)SK_GRID * 24);
@@ -1053,8 +1365,13 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
     a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
     const bool s2 = c.pre.stages >= 2;
-    if (c.COUTp == 128) return s2 ? launch_h3_t<128, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false>(a, c.CIN, c.reserve_cus, st);
-    return s2 ? launch_h3_t<64, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false>(a, c.CIN, c.reserve_cus, st);
+    a.wgt16 = c.wgt16;
+    if (c.wgt16) {           // fast mode: bf16 operands
+        if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, st);
+        return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, st);
+    }
+    if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, false>(a, c.CIN, c.reserve_cus, st);
+    return s2 ? launch_h3_t<64, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, false>(a, c.CIN, c.reserve_cus, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ using namespace fav;
 namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
-struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
 struct Act {
@@ -95,6 +95,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
@@ -113,7 +114,7 @@ struct fav_net {
     {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
-        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); }
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags);
@@ -142,6 +143,12 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             repack_weights(L, d.cinp, d.coutp, d.kpad, w);
             int rc = dev_upload(w, 0, &d.wgt); if (rc) return rc;
             rc = dev_upload(L.b, (size_t)d.coutp, &d.bias); if (rc) return rc;
+            if (!L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride)) {      // bf16 copy for the fast mode (round to nearest even)
+                std::vector<unsigned short> w16(w.size());
+                for (size_t i = 0; i < w.size(); ++i) { unsigned b; memcpy(&b, &w[i], 4); w16[i] = (unsigned short)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16); }
+                FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.wgt16), w16.size() * 2));
+                FAV_HIP(hipMemcpy(d.wgt16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+            }
             if (L.transposed && (L.stride != 2 || L.adj != 1 || L.pad > L.k - 1)) {
                 set_error("network: SpatialFullConvolution is supported for stride 2, adj 1 (models_video.lua:99-102), got s=%d adj=%d", L.stride, L.adj);
                 return FAV_EUNSUPPORTED; }
@@ -299,6 +306,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
+            if (h3 && precision == 1) c.wgt16 = d.wgt16;
             c8_counts = (c8 || h3) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
             use_c8 = false; use_h3 = false;
@@ -612,6 +620,13 @@ struct fav_stream {
         (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws);
     }
 };
+
+extern "C" int fav_net_set_precision(fav_net* net, int mode)
+{
+    FAV_REQUIRE(net && (mode == 0 || mode == 1), "fav_net_set_precision: mode must be FAV_PRECISION_FP32 or FAV_PRECISION_BF16_OPERANDS");
+    net->precision = mode;
+    return FAV_OK;
+}
 
 // internal accessors for the other host units (vr.cpp)
 namespace fav {

@@ -11,6 +11,7 @@
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
 // makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>,
+// -precision <fp32|bf16> (fp32 = parity mode, default; bf16 = optional fast mode, see include/fav.h),
 // -seed <n> (key of the documented RNG behind -fill_occlusions uniform-random, unseeded in the reference),
 // -writers <n>, -timing <0|1>, -temporal_eval_file <path> (the temporal-consistency number of -evaluate, fav.lua:128-151,
 // with the frame's own flow and certainty: one line of ';'-separated per-frame values, one line with their mean).
@@ -205,7 +206,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}};
+           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
            {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
     for (int a = 1; a < argc; ++a) {
@@ -230,6 +231,8 @@ int main(int argc, char** argv)
     if (hipSetDevice(o.i("gpu")) != hipSuccess) die("cannot select -gpu " + o.s("gpu"));
     fav_net* net = nullptr;
     if (fav_net_create(o.s("model_vid").c_str(), o.i("gpu"), &net)) die(fav_last_error());                   // core.lua:39-43
+    if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
+    check(fav_net_set_precision(net, o.s("precision") == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
     printf("Model loaded.\n");
     fav_net* net_img = nullptr;                                                                              // core.lua:59-66
     if (o.s("model_img") != "self") {

@@ -5,7 +5,7 @@
 // "<prefix>-%05d_equi.png" / "<prefix>-%05d_cubemap.png" (:541,552).  All compute goes through libfav's C ABI (fav_vr_*);
 // there is no CPU backend.  Not provided (rejected with a message): -evaluate, -backward, -smooth_certainty and
 // -continue_with > 1 (in the reference that option reloads per-face PNGs which func_save_image no longer writes, :521-523).
-// Additive flags: -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>.
+// Additive flags: -precision <fp32|bf16>, -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>.
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -77,7 +77,7 @@ int main(int argc, char** argv)
         {"cudnn_benchmark", "0"}, {"evaluation_file", "evaluation.txt"}, {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""},
         {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
         {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
-        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}};
+        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"}};
     std::map<std::string, bool> b = {
         {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},
         {"create_inconsistent_border", false}, {"backward", false}, {"out_equi", false}, {"out_cubemap", false}, {"evaluate", false},
@@ -108,6 +108,8 @@ int main(int argc, char** argv)
     hipc(hipSetDevice(I("gpu")), "hipSetDevice");
     fav_net* vid = nullptr; fav_net* img = nullptr;
     if (fav_net_create(v["model_vid"].c_str(), I("gpu"), &vid)) die(std::string("ERROR: Could not load model from ") + v["model_vid"] + " (" + fav_last_error() + ")");
+    if (v["precision"] != "fp32" && v["precision"] != "bf16") die("-precision must be fp32 or bf16");
+    check(fav_net_set_precision(vid, v["precision"] == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
     if (!v["model_img"].empty() && v["model_img"] != "self")
         if (fav_net_create(v["model_img"].c_str(), I("gpu"), &img)) die(std::string("ERROR: Could not load model from ") + v["model_img"] + " (" + fav_last_error() + ")");
 

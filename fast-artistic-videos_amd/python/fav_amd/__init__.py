@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host",
+    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision",
 ]
 
 
@@ -165,10 +165,18 @@ class Net:
         self.h, self.device = h, device
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().fav_net_destroy(self.h); self.h = None
+        if getattr(self, "h", None) and lib is not None:
+            try:
+                lib().fav_net_destroy(self.h)
+            except Exception:      # interpreter shutdown
+                pass
+            self.h = None
 
     __del__ = close
+
+    def set_precision(self, bf16_operands: bool):
+        """False: fp32 parity mode (default); True: bf16 operands in the 3x3 halo convolutions (fast mode, not bit-compatible)."""
+        _check(lib().fav_net_set_precision(self.h, 1 if bf16_operands else 0))
 
     def describe(self) -> str:
         buf = C.create_string_buffer(1 << 16)
@@ -260,8 +268,12 @@ class Stream:
         self.h = hd
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().fav_stream_destroy(self.h); self.h = None
+        if getattr(self, "h", None) and lib is not None:
+            try:
+                lib().fav_stream_destroy(self.h)
+            except Exception:      # interpreter shutdown
+                pass
+            self.h = None
 
     __del__ = close
 

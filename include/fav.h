@@ -135,6 +135,13 @@ int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W,
  * Replaces one iteration of run_fast_neural_video's loop (fast_artistic_video_core.lua:194-211)
  * with the video CLI's callbacks (fast_artistic_video.lua:93-172).  Holds the recurrent state
  * last_frame_stylized (float, unclamped: fast_artistic_video.lua:169) on the device. */
+/* Arithmetic of the network.  FAV_PRECISION_FP32 (default) is the parity mode: fp32 operands, exact fp32 MFMA.  The optional
+ * fast mode FAV_PRECISION_BF16_OPERANDS rounds the operands of the halo-resident 3x3 convolutions (the
+ * residual blocks and c3s1-64: 71 % of the FLOPs) to bf16 on their way into LDS, accumulates in fp32 and keeps every
+ * activation in fp32; it is NOT bit-compatible with the reference and is gated by PSNR against the fp32 oracle in the tests. */
+enum fav_precision { FAV_PRECISION_FP32 = 0, FAV_PRECISION_BF16_OPERANDS = 1 };
+int fav_net_set_precision(fav_net* net, int mode);
+
 typedef struct fav_stream fav_stream;
 
 typedef struct fav_stream_opts {

@@ -242,7 +242,22 @@ def shave_add(block, skip, s):
     return out
 
 
-def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None) -> np.ndarray:
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 (round to nearest even) -> fp32: the operand rounding of the product's optional fast mode."""
+    b = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((b + np.uint32(0x7FFF) + ((b >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.view(np.float32)
+
+
+def _bf16_conv(L: dict) -> bool:
+    """the convolutions the fast mode touches: 3x3, stride 1, 32..256 input channels in multiples of 32, <= 128 outputs
+    padded to 64 or 128 (= conv3_halo_eligible in the product)"""
+    cout, cin, kh, kw = L["w"].shape
+    cp = (cout + 31) // 32 * 32
+    return kh == 3 and kw == 3 and L["stride"] == 1 and cin % 32 == 0 and 32 <= cin <= 256 and cp in (64, 128)
+
+
+def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None, bf16_ops: bool = False) -> np.ndarray:
     """model:forward(input) for the layer list of fav_amd.t7.extract_layers
     (fast_artistic_video_core.lua:172; models_video.lua:55-140).  x: [7][H][W] -> [3][H'][W']."""
     x = np.ascontiguousarray(x, np.float32)
@@ -252,7 +267,10 @@ def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None)
         if t == "pad":
             x = reflect_pad(x, L["l"], L["r"], L["t"], L["b"])
         elif t == "conv":
-            x = conv2d(x, L["w"], L["b"], L["stride"], L["pad"])
+            if bf16_ops and _bf16_conv(L):      # FAV_PRECISION_BF16_OPERANDS: both operands rounded, wide accumulation
+                x = conv2d(bf16_round(x), bf16_round(L["w"]), L["b"], L["stride"], L["pad"])
+            else:
+                x = conv2d(x, L["w"], L["b"], L["stride"], L["pad"])
         elif t == "fullconv":
             x = full_conv2d(x, L["w"], L["b"], L["stride"], L["pad"], L["adj"])
         elif t == "bn":
@@ -266,7 +284,7 @@ def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None)
         elif t == "relu":
             x = np.maximum(x, 0)
         elif t == "res":
-            y = net_forward(L["block"], x)
+            y = net_forward(L["block"], x, None, bf16_ops)
             x = shave_add(y, x, L["shave"]) if L["shave"] else y + x
         elif t == "up":
             x = upsample(x, L["s"])

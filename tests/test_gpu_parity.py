@@ -463,3 +463,30 @@ def test_sequential_sum_bit_exact(favlib, cuda, case):
     assert got.tobytes() == want.tobytes(), (case, got, want)
     if case == "uniform":                     # and it is NOT what a pairwise / fp64 sum gives: the test is sensitive
         assert np.float32(x.astype(np.float64).sum()) != want
+
+
+def test_bf16_operand_fast_mode(favlib, oracle, cuda, canonical):
+    """optional fast mode (bf16 operands in the halo-resident 3x3 convolutions, fp32 accumulation and
+    activations).  Checked against an oracle that rounds the same operands, and gated by PSNR against the fp32 oracle."""
+    layers = _layers(canonical)
+    net = favlib.Net(canonical, 0)
+    x = (np.random.default_rng(5).standard_normal((7, 64, 96)) * 60).astype(np.float32)
+    ref32 = oracle.net_forward(layers, x)
+    ref16 = oracle.net_forward(layers, x, bf16_ops=True)
+    got32 = net.forward(T(x, cuda)).cpu().numpy()
+    net.set_precision(True)
+    got16 = net.forward(T(x, cuda)).cpu().numpy()
+    net.set_precision(False)
+    again32 = net.forward(T(x, cuda)).cpu().numpy()
+    assert np.array_equal(got32, again32)                       # the switch is clean
+    assert np.abs(got32 - ref32).max() <= 5e-2
+    d = np.abs(got16 - got32).max()
+    assert d > 1e-2, "the fast mode must actually change the arithmetic"
+    # same rounding in the oracle: what remains is accumulation order and bf16 rounding flips of activations that sit near a
+    # tie (the InstanceNorm statistics differ in the last fp32 bits), i.e. a fraction of the mode's own error
+    rms = lambda a: float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+    assert rms(got16 - ref16) <= 0.75 * rms(ref16 - ref32) + 1e-3
+    assert 0.5 <= rms(got16 - ref32) / rms(ref16 - ref32) <= 1.5          # and its error against fp32 is the oracle-predicted one
+    # quality gate vs the fp32 reference, 8-bit output space (measured: 50 dB)
+    to8 = lambda o: oracle.to_u8_hwc(oracle.deprocess(o))
+    assert psnr8(to8(got16), to8(ref32)) >= 45.0
