@@ -93,23 +93,40 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* img, const float
     for (int c = 0; c < C; ++c) ob[(size_t)c * on] = sample(ib + (size_t)c * H * W, t);
 }
 
+// utils.min_filter (utils.lua:161-169): 1 - maxpool_{r x r, stride 1, pad r/2}(1 - cert); max-pooling pads with -inf, i.e. the
+// windows are truncated at the borders.  max is exact and order-free, so the r x r window is evaluated separably on an LDS
+// tile (rows, then columns): 2r instead of r*r taps, each input element read from memory once per tile.
+constexpr int MF_TX = 64, MF_TY = 16, MF_RMAX = 15;
 __global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, float* out, int H, int W, int r)
 {
-    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const int p = r / 2;
-    float m = -INFINITY;
-    for (int dy = -p; dy < r - p; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -p; dx < r - p; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            const float v = cert[(size_t)yy * W + xx] * -1.f + 1.f;     // MulConstant(-1), AddConstant(1)
-            m = fmaxf(m, v);
-        }
+    __shared__ float a[MF_TY + MF_RMAX - 1][MF_TX + MF_RMAX];        // 1 - cert, -inf outside the image
+    __shared__ float b[MF_TY + MF_RMAX - 1][MF_TX + 1];              // row maxima
+    const int t = threadIdx.x, p = r / 2;
+    const int x0 = blockIdx.x * MF_TX, y0 = blockIdx.y * MF_TY;
+    const int TW = MF_TX + r - 1, THh = MF_TY + r - 1;
+    for (int e = t; e < TW * THh; e += 256) {
+        const int ly = e / TW, lx = e - ly * TW;
+        const int yy = y0 + ly - p, xx = x0 + lx - p;
+        float v = -INFINITY;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = cert[(size_t)yy * W + xx] * -1.f + 1.f;     // MulConstant(-1), AddConstant(1)
+        a[ly][lx] = v;
     }
-    out[(size_t)y * W + x] = m * -1.f + 1.f;
+    __syncthreads();
+    for (int e = t; e < MF_TX * THh; e += 256) {
+        const int ly = e / MF_TX, lx = e - ly * MF_TX;
+        float m = -INFINITY;
+        for (int d = 0; d < r; ++d) m = fmaxf(m, a[ly][lx + d]);
+        b[ly][lx] = m;
+    }
+    __syncthreads();
+    for (int e = t; e < MF_TX * MF_TY; e += 256) {
+        const int ly = e / MF_TX, lx = e - ly * MF_TX;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        float m = -INFINITY;
+        for (int d = 0; d < r; ++d) m = fmaxf(m, b[ly + d][lx]);
+        out[(size_t)y * W + x] = m * -1.f + 1.f;
+    }
 }
 
 __device__ __forceinline__ float vgg_mean(int c) { return c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f); }
@@ -248,7 +265,8 @@ int launch_warp(const float* img, const float* flow, float* out, int B, int C, i
 
 int launch_min_filter_f32(const float* cert, float* out, int H, int W, int r, hipStream_t st)
 {
-    hipLaunchKernelGGL(min_filter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, cert, out, H, W, r);
+    FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
+    hipLaunchKernelGGL(min_filter_kernel, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, cert, out, H, W, r);
     FAV_LAUNCH_CHECK("min_filter_kernel");
     return FAV_OK;
 }
