@@ -100,14 +100,26 @@ __global__ __launch_bounds__(64) void iir_kernel(float* plane0, size_t plane_str
     V1_(0) = a0; V1_(1) = a1;
     float mp = m1;
     int x = 2;
-    for (; x + 8 <= n; x += 8) {          // loads are independent of the recurrence: fetch 8 samples, then run the chain
-        float mv[8];
+    // The loads are independent of the recurrence, the kernel is latency-bound (one wave per 64 lines, ~35 waves in all):
+    // samples travel in groups of G, and the next group is already in flight while the chain runs over the current one.
+    constexpr int G = 32;
+    if (x + G <= n) {
+        float cur[G], nxt[G];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) mv[q] = M_(x + q);
+        for (int q = 0; q < G; ++q) cur[q] = M_(x + q);
+        for (; x + G <= n; x += G) {
+            const bool more = x + 2 * G <= n;
+            if (more) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float a = c.k * (mv[q] + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
-            V1_(x + q) = a; a0 = a1; a1 = a; mp = mv[q];
+                for (int q = 0; q < G; ++q) nxt[q] = M_(x + G + q);
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const float a = c.k * (cur[q] + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+                V1_(x + q) = a; a0 = a1; a1 = a; mp = cur[q];
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) cur[q] = nxt[q];
         }
     }
     for (; x < n; ++x) {
@@ -125,15 +137,24 @@ __global__ __launch_bounds__(64) void iir_kernel(float* plane0, size_t plane_str
     M_(n - 2) = V1_(n - 2) + b0;
     // now b0 = v2(x+1), b1 = v2(x+2) for x = n-3; mo1 = m(x+1), mo2 = m(x+2)
     int xb = n - 3;
-    for (; xb - 7 >= 0; xb -= 8) {
-        float mv[8], vv[8];
+    if (xb - (G - 1) >= 0) {
+        float cm[G], cv[G], nm[G], nv[G];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { mv[q] = M_(xb - q); vv[q] = V1_(xb - q); }
+        for (int q = 0; q < G; ++q) { cm[q] = M_(xb - q); cv[q] = V1_(xb - q); }
+        for (; xb - (G - 1) >= 0; xb -= G) {
+            const bool more = xb - (2 * G - 1) >= 0;
+            if (more) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-            M_(xb - q) = vv[q] + bv;
-            b1 = b0; b0 = bv; mo2 = mo1; mo1 = mv[q];
+                for (int q = 0; q < G; ++q) { nm[q] = M_(xb - G - q); nv[q] = V1_(xb - G - q); }
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
+                M_(xb - q) = cv[q] + bv;
+                b1 = b0; b0 = bv; mo2 = mo1; mo1 = cm[q];
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) { cm[q] = nm[q]; cv[q] = nv[q]; }
         }
     }
     for (; xb >= 0; --xb) {
