@@ -14,6 +14,10 @@
  *     the caller owns every buffer it passes.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns
  *     without synchronising (NULL = the default stream).
+ *   - concurrency: a fav_net owns one activation arena and one stream-K workspace, so it executes ONE forward at a time --
+ *     everything that shares a net (its fav_streams, a fav_vr) must be enqueued on the same HIP stream or be ordered by the
+ *     caller; independent videos on one GPU use one fav_net each (6.7 MB of weights).  Handles are not locked: do not call
+ *     into the same handle from two host threads at once.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
  *     FAV_ENODEVICE.
  */
