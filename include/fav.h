@@ -16,8 +16,10 @@
  *     without synchronising (NULL = the default stream).
  *   - concurrency: a fav_net owns one activation arena and one stream-K workspace, so it executes ONE forward at a time --
  *     everything that shares a net (its fav_streams, a fav_vr) must be enqueued on the same HIP stream or be ordered by the
- *     caller; independent videos on one GPU use one fav_net each (6.7 MB of weights).  Handles are not locked: do not call
- *     into the same handle from two host threads at once.
+ *     caller.  The persistent / stream-K convolution kernels size their grids to the whole device (minus the CUs reserved for
+ *     the library's own look-ahead queues) and hand partial tiles between co-resident blocks: two networks must therefore not
+ *     run CONCURRENTLY on one device either -- enqueue several nets on one HIP stream (or one process per GPU, as bench.py
+ *     does).  Handles are not locked: do not call into the same handle from two host threads at once.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
  *     FAV_ENODEVICE.
  */
