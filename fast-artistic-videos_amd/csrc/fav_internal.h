@@ -96,6 +96,7 @@ struct ConvLaunch {
     // stream-K hand-off state (conv_streamk_workspace_bytes() floats, conv_streamk_grid() flags, a launch-unique
     // epoch > 0); null => plain data-parallel launch
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;
+    unsigned* sk_err = nullptr;     // host-mapped error word (device pointer): set by a hand-off wait that timed out
     int reserve_cus = 0;            // CUs left to concurrent side-queue work: persistent / stream-K grids shrink by this many
 };
 size_t conv_streamk_workspace_bytes();

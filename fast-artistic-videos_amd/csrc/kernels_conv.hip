@@ -41,6 +41,7 @@ struct ConvArgs {
     int cin_shift, kw_magic, ntaps_magic;
     float tanh_mul;
     float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;     // stream-K hand-off (null = data-parallel)
+    unsigned* sk_err;        // host-mapped word set when a hand-off wait times out (null = not reported)
     int reserve_cus;
 };
 
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) break;          // bounded: a wrong tile beats a hung GPU
+                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // bounded, and reported to the host
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -655,7 +656,7 @@ struct H3Args {
     const float* in; const float* wgt; const float* bias;
     const float* scale1; const float* shift1; const float* scale2; const float* shift2;
     float* out; float2* partials; int* counts;
-    float* sk_ws; unsigned* sk_flags; unsigned sk_epoch;
+    float* sk_ws; unsigned* sk_flags; unsigned sk_epoch; unsigned* sk_err;
     int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
     int stages, relu1, relu2;
     const unsigned short* wgt16;   // bf16 copy of the weights (fast mode) or null
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) break;
+                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_bf16_kernel(const H3Args p)
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) break;
+                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -1360,7 +1361,7 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
     a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
-    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch;
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.sk_err = c.sk_err;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
     a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
@@ -1598,7 +1599,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.Kpad = c.Kpad; a.OH = c.OH; a.OW = c.OW; a.final_mode = c.final_mode; a.tanh_mul = c.tanh_mul;
     a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;
     a.ntaps_magic = (65536 + c.KH * c.KW - 1) / (c.KH * c.KW);
-    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.reserve_cus = c.reserve_cus;
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.sk_err = c.sk_err; a.reserve_cus = c.reserve_cus;
     static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;   // tuning only: results are wrong for 1-4,6-8
     // stream-K when the tile count is within a few waves of the 512 resident blocks (imbalance matters there)
     const long long tiles = (long long)((c.OH * c.OW + BM - 1) / BM) * (c.COUTp / (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));

@@ -95,6 +95,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
@@ -117,7 +118,7 @@ struct fav_net {
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
-        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags);
+        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
     }
     int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
     int upload();
@@ -222,6 +223,9 @@ int fav_net::upload()
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_ws), conv_streamk_workspace_bytes()));
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_flags), conv_streamk_grid() * sizeof(unsigned)));
     FAV_HIP(hipMemset(sk_flags, 0, conv_streamk_grid() * sizeof(unsigned)));
+    FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&sk_err_host), sizeof(unsigned), hipHostMallocMapped));
+    *sk_err_host = 0;
+    FAV_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&sk_err_dev), sk_err_host, 0));
     return FAV_OK;
 }
 
@@ -246,6 +250,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
+    cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
     auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : launch_conv(cs, st))); };
     if (!profiling) return go();
@@ -404,6 +409,12 @@ void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
 int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)
 {
     FAV_HIP(hipSetDevice(device));
+    if (sk_err_host && *reinterpret_cast<volatile unsigned*>(sk_err_host)) {      // reported by an earlier launch of this net
+        *sk_err_host = 0;
+        set_error("a stream-K hand-off between convolution blocks timed out in an earlier launch of this network: its result was "
+                  "wrong (two networks running concurrently on one device? see the concurrency note in fav.h)");
+        return FAV_EHIP;
+    }
     if (H != curH || W != curW) {
         if (!bufs.empty()) {
             FAV_HIP(hipDeviceSynchronize());
