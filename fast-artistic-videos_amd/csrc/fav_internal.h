@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -31,6 +33,17 @@ int hip_fail(hipError_t e, const char* what);
             return FAV_EINVAL;                 \
         }                                      \
     } while (0)
+
+// No exception may cross the C ABI (include/fav.h): entry points that parse untrusted files run their body inside this pair.
+#define FAV_ABI_TRY try {
+#define FAV_ABI_CATCH(where_)                                                                                            \
+    } catch (const std::bad_alloc&) {                                                                                   \
+        ::fav::set_error(where_ ": out of memory while parsing (damaged size field?)"); return FAV_EFORMAT;                \
+    } catch (const std::exception& e__) {                                                                               \
+        ::fav::set_error(where_ ": %s", e__.what()); return FAV_EFORMAT;                                                  \
+    } catch (...) {                                                                                                     \
+        ::fav::set_error(where_ ": unexpected exception"); return FAV_EFORMAT;                                            \
+    }
 
 int ensure_device();   // FAV_OK or FAV_ENODEVICE
 

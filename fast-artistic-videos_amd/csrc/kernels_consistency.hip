@@ -28,9 +28,13 @@ __global__ __launch_bounds__(256) void consistency_kernel(const float2* f1, cons
     const float2 fa = f1[i];                           // (u, v) of flow1 at a
     const float bx = (float)ax + fa.x;                 // :102
     const float by = (float)ay + fa.y;                 // :103
+    // :104-109 `x1 < 0 || x2 >= W || y1 < 0 || y2 >= H` evaluated on the floats: the same predicate for every finite in-range
+    // value (floor(b) < 0 <=> b < 0; floor(b) + 1 >= W <=> b >= W - 1), and for |flow| >= 2^31, +-inf and NaN -- where the
+    // reference's cvttsd2si yields INT_MIN, i.e. "x1 < 0" -- it also gives 0 without the GPU's saturating conversion
+    // (INT_MAX + 1 wraps, passes the integer test and gathers out of bounds).
+    if (!(bx >= 0.f) || !(by >= 0.f) || bx >= (float)(W - 1) || by >= (float)(H - 1)) { out[i] = 0; return; }
     const int x1 = (int)floorf(bx), y1 = (int)floorf(by);
     const int x2 = x1 + 1, y2 = y1 + 1;
-    if (x1 < 0 || x2 >= W || y1 < 0 || y2 >= H) { out[i] = 0; return; }       // :108-109
     const float alphaX = bx - (float)x1, alphaY = by - (float)y1;             // :110
     const float2 p11 = f2[(size_t)y1 * W + x1], p21 = f2[(size_t)y1 * W + x2];
     const float2 p12 = f2[(size_t)y2 * W + x1], p22 = f2[(size_t)y2 * W + x2];

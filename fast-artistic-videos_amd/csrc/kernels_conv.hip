@@ -27,6 +27,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: struc
 
 namespace {
 
+// Launch-time facts that are cached per kernel instantiation are kept PER DEVICE (function attributes and CU counts belong to
+// the device that is current at the launch): a single process may drive several GPUs.
+constexpr int MAX_DEVICES = 64;
+inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+
 constexpr int BM = CONV_BM;   // 128 output pixels per block
 constexpr int BK = 32;        // K elements per step
 constexpr int LDSS = 36;      // LDS row stride in floats (144 B: 16-B aligned, conflict-free b128 reads)
@@ -420,26 +425,26 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
     const int M = a.OH * a.OW;
     size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
     if (ABL == 5) lds = 100 * 1024;      // force one block per CU
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
+    const int dv = cur_dev();
+    static bool attr_done[MAX_DEVICES] = {};   // per instantiation and device
+    if (!attr_done[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, ABL, SK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr_done[dv] = true;
     }
     dim3 grid((M + BM - 1) / BM, a.COUTp / BN);
     if (SK) {
         // every stream-K block must be resident (owners wait for later blocks): size the grid from the occupancy
         // the runtime reports for this instantiation, capped at the 2 blocks per CU the hand-off buffers are sized for
-        static int sk_per_cu = 0, sk_cus = 0;
-        if (!sk_per_cu) {
-            int occ = 0, dev = 0; hipDeviceProp_t prop;
-            FAV_HIP(hipGetDevice(&dev));
-            FAV_HIP(hipGetDeviceProperties(&prop, dev));
+        static int sk_per_cu[MAX_DEVICES] = {}, sk_cus[MAX_DEVICES] = {};
+        if (!sk_per_cu[dv]) {
+            int occ = 0; hipDeviceProp_t prop;
+            FAV_HIP(hipGetDeviceProperties(&prop, dv));
             FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, ABL, SK>, 64 * WM * WN, lds));
             if (occ < 1) { set_error("stream-K conv: kernel does not fit on a CU"); return FAV_EHIP; }
-            sk_per_cu = occ >= 2 ? 2 : 1; sk_cus = prop.multiProcessorCount;
+            sk_per_cu[dv] = occ >= 2 ? 2 : 1; sk_cus[dv] = prop.multiProcessorCount;
         }
-        int sk_blocks = sk_per_cu * std::max(1, sk_cus - a.reserve_cus);       // leave the reserved CUs to the side queues
+        int sk_blocks = sk_per_cu[dv] * std::max(1, sk_cus[dv] - a.reserve_cus);       // leave the reserved CUs to the side queues
         if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
         grid = dim3(sk_blocks, 1);
     }
@@ -622,15 +627,16 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
     a.tiles_x = (c.OW + C8_TW - 1) / C8_TW; a.tiles_y = (c.OH + C8_TH - 1) / C8_TH;
     constexpr int HPc = (C8_TH + 8) * (C8_TW + 8), WSc = 81 * 8 + 4;
     const size_t lds = (size_t)(32 * WSc + 4 * HPc * 4 + 8 * 32 + 32) * sizeof(float);
-    static int nblocks = 0;
-    if (!nblocks) {
+    const int dv = cur_dev();
+    static int nblocks[MAX_DEVICES] = {};
+    if (!nblocks[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int dev = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
-        nblocks = prop.multiProcessorCount;
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        nblocks[dv] = prop.multiProcessorCount;
     }
     const int tiles = a.tiles_x * a.tiles_y;
-    const int gridc8 = std::max(1, nblocks - c.reserve_cus);
+    const int gridc8 = std::max(1, nblocks[dv] - c.reserve_cus);
     hipLaunchKernelGGL((conv_c8_kernel<9>), dim3(tiles < gridc8 ? tiles : gridc8), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_c8_kernel");
     return FAV_OK;
@@ -1323,16 +1329,17 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t s
     const auto kern = BF ? conv3_halo_bf16_kernel<BN, S2> : conv3_halo_kernel<BN, S2>;
     const size_t lds = BF ? (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * 40 + 3 * BN * 40) * 2 + (size_t)4 * cin * sizeof(float)
                           : (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 4 * cin) * sizeof(float);
-    static int cus = 0;
-    if (!cus) {
+    const int dv = cur_dev();
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int dev = 0, occ = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDevice(&dev)); FAV_HIP(hipGetDeviceProperties(&prop, dev));
+        int occ = 0; hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
         FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
         if (occ < 1) { set_error("halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
-        cus = prop.multiProcessorCount;          // one block per CU: every stream-K block must be resident
+        cus[dv] = prop.multiProcessorCount;          // one block per CU
     }
-    int nres = std::max(1, cus - reserve_cus);
+    int nres = std::max(1, cus[dv] - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
     const int tiles = a0.tiles_x * a0.tiles_y;
     const int grid = tiles * (cin / 32) * 3 < nres ? 1 : nres;      // (stream-K units: tap rows)
@@ -1542,11 +1549,12 @@ int launch_fold_t(const FoldArgs& a, hipStream_t st)
     const size_t epi = (size_t)FOLD_R * FOLD_M * 33 * sizeof(float);
     if (epi > lds) lds = epi;
     if (lds > 160 * 1024) { set_error("row-folded conv: %zu bytes of LDS needed", lds); return FAV_EUNSUPPORTED; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    const int dv = cur_dev();
+    static bool attr_done[MAX_DEVICES] = {};
+    if (!attr_done[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_kernel<CIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr_done[dv] = true;
     }
     const int XO = FOLD_M - (a.KW - 1);
     dim3 grid((a.OW + XO - 1) / XO, (a.OH + FOLD_R - 1) / FOLD_R);

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 
 #include "fav_internal.h"
 
@@ -70,6 +71,14 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
                         ? L.w[(((size_t)ci * L.cout + co) * L.k + (L.k - 1 - ky)) * L.k + (L.k - 1 - kx)]
                         : L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
                 }
+}
+
+// Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
+struct Tuning { bool no_fold, no_c8, no_h3; };
+const Tuning& tuning()
+{
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr};
+    return t;
 }
 
 bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul)
@@ -133,7 +142,8 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
 {
     for (Layer& L : ls) {
         if (L.type == L_CONV) {
-            DevConvW d;
+            convs.emplace_back();                 // registered first: the destructor frees whatever a failed upload leaves behind
+            DevConvW& d = convs.back();
             d.cinp = chan_pitch;
             if (L.cin > chan_pitch || (chan_pitch != 8 && L.cin != chan_pitch)) {
                 set_error("network: conv expects %d input channels, producer has %d", L.cin, chan_pitch); return FAV_EFORMAT; }
@@ -163,18 +173,17 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                                 wf[((size_t)ky * 32 + co * L.k + kx) * d.cinp + ci] = L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
                 rc = dev_upload(wf, 0, &d.wfold); if (rc) return rc;
             }
-            convs.push_back(d);
             params += (long long)L.w.size() + (long long)L.b.size();
             chan_pitch = L.cout;
             maxc = std::max(maxc, std::max(d.coutp, d.cinp));
         } else if (L.type == L_IN) {
             if ((int)L.gamma.size() != chan_pitch) { set_error("network: InstanceNormalization(%zu) after %d channels", L.gamma.size(), chan_pitch); return FAV_EFORMAT; }
-            DevIN d;
+            ins.emplace_back();
+            DevIN& d = ins.back();
             int rc = dev_upload(L.gamma, 0, &d.gamma); if (rc) return rc;
             rc = dev_upload(L.beta, 0, &d.beta); if (rc) return rc;
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.scale), L.gamma.size() * sizeof(float)));
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
-            ins.push_back(d);
             params += 2 * (long long)L.gamma.size();
         } else if (L.type == L_BN) {
             if ((int)L.mean.size() != chan_pitch) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan_pitch); return FAV_EFORMAT; }
@@ -184,10 +193,10 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 const double s = (double)L.gamma[i] / std::sqrt((double)L.var[i] + (double)L.eps);
                 sc[i] = (float)s; sh[i] = (float)((double)L.beta[i] - (double)L.mean[i] * s);
             }
-            DevIN d;
+            ins.emplace_back();
+            DevIN& d = ins.back();
             int rc = dev_upload(sc, 0, &d.scale); if (rc) return rc;
             rc = dev_upload(sh, 0, &d.shift); if (rc) return rc;
-            ins.push_back(d);
             params += 4 * (long long)L.mean.size();
         } else if (L.type == L_RES) {
             int cp = chan_pitch;
@@ -246,7 +255,7 @@ int fav_net::alloc(size_t bytes, float** out)
 
 int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
-    const float* wfold = (c.final_mode && !getenv("FAV_NO_FOLD")) ? convs[conv_index].wfold : nullptr;
+    const float* wfold = (c.final_mode && !tuning().no_fold) ? convs[conv_index].wfold : nullptr;
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
@@ -295,6 +304,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const bool is_final = top && only_tail(ls, li + 1, has_tanh, mul) && has_tanh && L.cout == 3;
             Act nxt;
             nxt.Hp = c.OH; nxt.Wp = c.OW; nxt.C = L.cout;
+            if (is_final && L.transposed) { set_error("network: a transposed convolution as the last layer is unsupported"); return FAV_EUNSUPPORTED; }
             if (is_final) {
                 c.final_mode = 1; c.tanh_mul = mul; c.out_planar = out_planar; c.out_raw_nchw = out_raw;
                 int rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
@@ -304,9 +314,8 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
             int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
-            if (is_final && L.transposed) { set_error("network: a transposed convolution as the last layer is unsupported"); return FAV_EUNSUPPORTED; }
-            const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !getenv("FAV_NO_C8");
-            const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !getenv("FAV_NO_H3");
+            const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
+            const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
             nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW)); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
@@ -444,16 +453,19 @@ extern "C" int fav_net_create(const char* t7_path_host, int device, fav_net** ou
 {
     FAV_REQUIRE(t7_path_host && out, "fav_net_create: null argument");
     int rc = ensure_device(); if (rc) return rc;
-    fav_net* net = new fav_net();
+    FAV_ABI_TRY
+    std::unique_ptr<fav_net> net(new fav_net());
     net->device = device;
     rc = t7_parse_model(t7_path_host, net->layers);
-    if (rc) { delete net; return rc; }
-    return finish_create(net, out);
+    if (rc) return rc;
+    return finish_create(net.release(), out);
+    FAV_ABI_CATCH("fav_net_create")
 }
 
 extern "C" int fav_net_pack_host(const char* t7_path_host, void* blob_host, size_t capacity, size_t* bytes)
 {
     FAV_REQUIRE(t7_path_host && bytes, "fav_net_pack_host: null argument");
+    FAV_ABI_TRY
     std::vector<Layer> layers;
     int rc = t7_parse_model(t7_path_host, layers); if (rc) return rc;
     std::vector<uint8_t> blob;
@@ -464,20 +476,35 @@ extern "C" int fav_net_pack_host(const char* t7_path_host, void* blob_host, size
         memcpy(blob_host, blob.data(), blob.size());
     }
     return FAV_OK;
+    FAV_ABI_CATCH("fav_net_pack_host")
 }
 
 extern "C" int fav_net_create_from_blob(const void* blob_host, size_t bytes, int device, fav_net** out)
 {
     FAV_REQUIRE(blob_host && out, "fav_net_create_from_blob: null argument");
     int rc = ensure_device(); if (rc) return rc;
-    fav_net* net = new fav_net();
+    FAV_ABI_TRY
+    std::unique_ptr<fav_net> net(new fav_net());
     net->device = device;
     rc = blob_unpack(blob_host, bytes, net->layers);
-    if (rc) { delete net; return rc; }
-    return finish_create(net, out);
+    if (rc) return rc;
+    return finish_create(net.release(), out);
+    FAV_ABI_CATCH("fav_net_create_from_blob")
 }
 
 extern "C" void fav_net_destroy(fav_net* net) { delete net; }
+
+extern "C" int fav_net_check(fav_net* net)
+{
+    FAV_REQUIRE(net, "fav_net_check: null net");
+    if (net->sk_err_host && *reinterpret_cast<volatile unsigned*>(net->sk_err_host)) {
+        *net->sk_err_host = 0;
+        set_error("a stream-K hand-off between convolution blocks timed out: the frame(s) computed since the last check are wrong "
+                  "(another context holding compute units of this device? see the concurrency note in fav.h)");
+        return FAV_EHIP;
+    }
+    return FAV_OK;
+}
 
 extern "C" int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity)
 {
@@ -519,12 +546,14 @@ extern "C" int fav_net_profile_read_host(fav_net* net, int capacity, int* count,
 extern "C" int fav_t7_describe_host(const char* t7_path_host, char* buf_host, size_t capacity)
 {
     FAV_REQUIRE(t7_path_host && buf_host && capacity > 0, "fav_t7_describe_host: null argument");
+    FAV_ABI_TRY
     std::vector<Layer> layers;
     int rc = t7_parse_model(t7_path_host, layers); if (rc) return rc;
     const std::string s = describe_layers(layers);
     FAV_REQUIRE(s.size() + 1 <= capacity, "fav_t7_describe_host: need %zu bytes", s.size() + 1);
     memcpy(buf_host, s.c_str(), s.size() + 1);
     return FAV_OK;
+    FAV_ABI_CATCH("fav_t7_describe_host")
 }
 
 extern "C" long long fav_net_param_count(const fav_net* net) { return net ? net->params : 0; }

@@ -6,6 +6,7 @@
 // nn.SpatialReflectionPadding of train_video.lua:319-325).  Grammar: Torch7 File.lua binary format
 // (not in the reference tree; restated in SURVEY.md Appendix B).  Unknown fields (gradWeight, bn,
 // output, _type, train, ...) are parsed and ignored.
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -20,7 +21,7 @@ struct Val;
 using VP = std::shared_ptr<Val>;
 
 struct Val {
-    enum Kind { NIL, NUM, STR, BOOL, TABLE, OBJECT, TENSOR, STORAGE } kind = NIL;
+    enum Kind { NIL, NUM, STR, BOOL, TABLE, OBJECT, TENSOR, STORAGE, FUNC } kind = NIL;
     double num = 0;
     std::string str;                        // STR value / class name
     bool b = false;
@@ -42,7 +43,8 @@ struct Reader {
     bool ok = true;
     std::string err;
 
-    bool need(size_t k) { if (p + k > n) { ok = false; if (err.empty()) err = "unexpected end of file"; return false; } return true; }
+    // k > n - p, not p + k > n: a crafted 2^62-element storage must not wrap the comparison
+    bool need(size_t k) { if (k > n - p) { ok = false; if (err.empty()) err = "unexpected end of file"; return false; } return true; }
     int i32() { if (!need(4)) return 0; int v; memcpy(&v, d + p, 4); p += 4; return v; }
     long long i64() { if (!need(8)) return 0; long long v; memcpy(&v, d + p, 8); p += 8; return v; }
     double f64() { if (!need(8)) return 0; double v; memcpy(&v, d + p, 8); p += 8; return v; }
@@ -60,7 +62,14 @@ struct Reader {
         if (cls == "torch.ByteStorage") { elem = 1; t = 'b'; return true; }
         if (cls == "torch.CharStorage") { elem = 1; t = 'c'; return true; }
         if (cls == "torch.ShortStorage") { elem = 2; t = 's'; return true; }
+        // cutorch storages are serialised with their host element type (a model saved without :float())
         if (cls == "torch.CudaStorage") { elem = 4; t = 'f'; return true; }
+        if (cls == "torch.CudaDoubleStorage") { elem = 8; t = 'd'; return true; }
+        if (cls == "torch.CudaLongStorage") { elem = 8; t = 'l'; return true; }
+        if (cls == "torch.CudaIntStorage") { elem = 4; t = 'i'; return true; }
+        if (cls == "torch.CudaByteStorage") { elem = 1; t = 'b'; return true; }
+        if (cls == "torch.CudaCharStorage") { elem = 1; t = 'c'; return true; }
+        if (cls == "torch.CudaShortStorage") { elem = 2; t = 's'; return true; }
         return false;
     }
     static bool is_tensor(const std::string& cls) {
@@ -99,7 +108,8 @@ struct Reader {
             if (storage_info(cls, elem, st)) {
                 v->kind = Val::STORAGE; v->elem = elem; v->stype = st;
                 const long long cnt = i64();
-                if (cnt < 0 || !need((size_t)cnt * elem)) { ok = false; if (err.empty()) err = "bad storage size"; return v; }
+                if (!ok) return v;
+                if (cnt < 0 || (unsigned long long)cnt > (unsigned long long)((n - p) / (size_t)elem)) { ok = false; if (err.empty()) err = "bad storage size"; return v; }
                 v->raw.assign(d + p, d + p + (size_t)cnt * elem); p += (size_t)cnt * elem;
                 return v;
             }
@@ -109,7 +119,8 @@ struct Reader {
                 if (nd < 0 || nd > 16) { ok = false; err = "bad tensor rank"; return v; }
                 for (int i = 0; i < nd; ++i) v->size.push_back(i64());
                 for (int i = 0; i < nd; ++i) v->stride.push_back(i64());
-                v->offset = i64() - 1;
+                v->offset = i64();
+                if (v->offset != LLONG_MIN) v->offset -= 1;       // 1-based in the file
                 v->storage = obj(depth + 1);
                 return v;
             }
@@ -117,10 +128,22 @@ struct Reader {
             v->body = obj(depth + 1);
             return v;
         }
+        case 6: case 7: case 8: {
+            // TYPE_FUNCTION / LEGACY_TYPE_RECUR_FUNCTION / TYPE_RECUR_FUNCTION [recalled, File.lua]: index, dumped
+            // bytecode (int32 length + bytes), then the upvalue table.  Closures stored in a checkpoint's `opt` or in a
+            // module field are irrelevant to the forward pass: parsed and ignored.
+            const int idx = i32();
+            auto it = memo.find(idx);
+            if (it != memo.end()) return it->second;
+            v->kind = Val::FUNC; memo[idx] = v;
+            (void)rawstr();
+            (void)obj(depth + 1);
+            return v;
+        }
         default:
             ok = false;
             err = "unsupported .t7 type tag " + std::to_string(t) + " at byte " + std::to_string(p - 4) +
-                  " (functions/upvalues are outside the checkpoint grammar)";
+                  " (not a Torch7 File.lua binary object)";
             return v;
         }
     }
@@ -155,37 +178,58 @@ std::vector<const Val*> array_items(const Val* tab)
     return out;
 }
 
+// strided read of a Float/Double tensor.  Every size, the element count and the extreme reachable storage offsets are
+// validated (overflow-checked) BEFORE anything is allocated: a damaged size field must end in `false`, not in
+// std::length_error / bad_alloc crossing the C ABI.
+constexpr long long MAX_TENSOR_ELEMS = 1ll << 28;      // 1 GiB of fp32: far above any layer of this model family
+
 bool tensor_to_floats(const Val* t, std::vector<float>& out)
 {
     out.clear();
     if (!t || t->kind != Val::TENSOR) return false;
     if (t->size.empty() || !t->storage || t->storage->kind != Val::STORAGE) return true;   // empty tensor
-    long long total = 1;
-    for (auto s : t->size) total *= s;
-    if (total <= 0) return true;
+    if (t->stride.size() != t->size.size()) return false;
     const Val* st = t->storage.get();
-    const long long cap = (long long)(st->raw.size() / st->elem);
+    if (st->stype != 'f' && st->stype != 'd') return false;
+    long long total = 1;
+    for (auto s : t->size) {
+        if (s < 0) return false;
+        if (s == 0) return true;
+        if (total > MAX_TENSOR_ELEMS / s) return false;
+        total *= s;
+    }
+    const long long cap = (long long)(st->raw.size() / (size_t)st->elem);
+    // lowest / highest element offset the index walk can reach
+    __int128 lo = t->offset, hi = t->offset;
+    for (size_t k = 0; k < t->size.size(); ++k) {
+        const __int128 span = (__int128)(t->size[k] - 1) * t->stride[k];
+        if (span < 0) lo += span; else hi += span;
+    }
+    if (lo < 0 || hi >= cap) return false;
     out.resize((size_t)total);
     std::vector<long long> idx(t->size.size(), 0);
     for (long long i = 0; i < total; ++i) {
         long long off = t->offset;
         for (size_t k = 0; k < idx.size(); ++k) off += idx[k] * t->stride[k];
-        if (off < 0 || off >= cap) return false;
         const uint8_t* p = st->raw.data() + (size_t)off * st->elem;
         float v;
         if (st->stype == 'f') memcpy(&v, p, 4);
-        else if (st->stype == 'd') { double d; memcpy(&d, p, 8); v = (float)d; }
-        else return false;
+        else { double d; memcpy(&d, p, 8); v = (float)d; }
         out[(size_t)i] = v;
         for (int k = (int)idx.size() - 1; k >= 0; --k) { if (++idx[k] < t->size[k]) break; idx[k] = 0; }
     }
     return true;
 }
 
-int extract(const Val* seq, std::vector<Layer>& out);
+int extract(const Val* seq, std::vector<Layer>& out, int depth);
 
-int module_to_layers(const Val* m, std::vector<Layer>& out)
+// depth: a memoised table may refer to itself (nn.Sequential listed in its own `modules`); the parser shares the node, so the
+// walk has to be bounded here
+constexpr int MAX_MODULE_DEPTH = 32;
+
+int module_to_layers(const Val* m, std::vector<Layer>& out, int depth)
 {
+    if (depth > MAX_MODULE_DEPTH) { set_error(".t7: modules nested deeper than %d levels (a container that contains itself?)", MAX_MODULE_DEPTH); return FAV_EFORMAT; }
     if (!m || m->kind != Val::OBJECT) { set_error(".t7: expected an nn module object"); return FAV_EFORMAT; }
     const std::string& c = m->str;
     Layer L;
@@ -204,12 +248,12 @@ int module_to_layers(const Val* m, std::vector<Layer>& out)
                 L.shave = 0;
             } else { set_error(".t7: unsupported skip branch"); return FAV_EUNSUPPORTED; }
             if (br[0]->kind != Val::OBJECT || br[0]->str != "nn.Sequential") { set_error(".t7: residual branch must be nn.Sequential"); return FAV_EUNSUPPORTED; }
-            int rc = extract(br[0], L.block);
+            int rc = extract(br[0], L.block, depth + 1);
             if (rc) return rc;
             out.push_back(std::move(L));
             return FAV_OK;
         }
-        return extract(m, out);
+        return extract(m, out, depth + 1);
     }
     if (c == "nn.SpatialReflectionPadding") {
         if (!num_field(m, "pad_l", a) || !num_field(m, "pad_r", b) || !num_field(m, "pad_t", cc) || !num_field(m, "pad_b", d)) {
@@ -281,10 +325,10 @@ int module_to_layers(const Val* m, std::vector<Layer>& out)
     return FAV_OK;
 }
 
-int extract(const Val* seq, std::vector<Layer>& out)
+int extract(const Val* seq, std::vector<Layer>& out, int depth)
 {
     for (const Val* m : array_items(field(seq, "modules"))) {
-        int rc = module_to_layers(m, out);
+        int rc = module_to_layers(m, out, depth);
         if (rc) return rc;
     }
     return FAV_OK;
@@ -361,7 +405,7 @@ int t7_parse_model(const char* path, std::vector<Layer>& out)
     else if (root->kind == Val::OBJECT) model = root.get();               // a bare nn.Sequential
     if (!model || model->kind != Val::OBJECT) { set_error(".t7: %s has no `model` field", path); return FAV_EFORMAT; }
     if (model->str != "nn.Sequential") { set_error(".t7: model is %s, expected nn.Sequential", model->str.c_str()); return FAV_EUNSUPPORTED; }
-    return extract(model, out);
+    return extract(model, out, 0);
 }
 
 int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob)

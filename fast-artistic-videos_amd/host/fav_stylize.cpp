@@ -15,8 +15,21 @@
 // -seed <n> (key of the documented RNG behind -fill_occlusions uniform-random, unseeded in the reference),
 // -writers <n>, -timing <0|1>, -temporal_eval_file <path> (the temporal-consistency number of -evaluate, fav.lua:128-151,
 // with the frame's own flow and certainty: one line of ';'-separated per-frame values, one line with their mean).
+//
+// Several videos on several GPUs (BASELINE config 4; the reference runs one `th` process per video, stylizeVideo_deepflow.sh:87-96,
+// and its only device hook is utils.setup_gpu, fast_artistic_video/utils.lua:43-66):
+//   -streams <a,b,c,...>  independent videos; every path option (-input_pattern, -flow_pattern, -forward_flow_pattern,
+//                         -occlusions_pattern, -output_prefix, -temporal_eval_file) has the token %S replaced by the stream's name
+//   -gpus <n>             one worker PROCESS per GPU (devices -gpu .. -gpu+n-1), stream s -> worker s mod n, streams of a worker run
+//                         back to back.  Rank 0 parses the checkpoint(s) once and broadcasts the packed blob (fav_net_pack_host) with
+//                         RCCL (ncclBroadcast over xGMI; ncclCommInitRank + a unique-id file); no other collective: a stream's
+//                         frame i needs its own frame i-1 only.  Each worker gets host-threads / n PNG writers and loaders.
+//   -force_dist 1         take the worker / RCCL path even for -gpus 1;  -dry_run 1: workers print their assignment and exit
+//                         without touching a device (plumbing test).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -183,6 +196,18 @@ private:
     size_t pending_ = 0; bool stop_ = false;
 };
 
+// Pinned PNG output slots with explicit ownership: a slot is taken before the D2H copy of a frame is enqueued and released by
+// the writer task once the file is on disk.  (Counting pending tasks is not enough: tasks finish out of order, so the oldest
+// slot -- the next one a round-robin hands out -- may still be read by its writer.)
+class Slots {
+public:
+    void add(uint8_t* p) { std::lock_guard<std::mutex> l(m_); free_.push_back(p); }
+    uint8_t* take() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !free_.empty(); }); uint8_t* p = free_.back(); free_.pop_back(); return p; }
+    void give(uint8_t* p) { { std::lock_guard<std::mutex> l(m_); free_.push_back(p); } cv_.notify_one(); }
+private:
+    std::mutex m_; std::condition_variable cv_; std::vector<uint8_t*> free_;
+};
+
 struct FrameIn {           // everything frame i needs from disk
     int index = 0; bool ok = false; bool single = false;
     uint8_t* frame = nullptr; int W = 0, H = 0;
@@ -190,56 +215,21 @@ struct FrameIn {           // everything frame i needs from disk
     void release() { fav_free_host(frame); fav_free_host(bw); fav_free_host(fw); fav_free_host(cert); frame = nullptr; bw = fw = nullptr; cert = nullptr; }
 };
 
-}  // namespace
 
-int main(int argc, char** argv)
+struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0; };
+
+std::string subst_stream(std::string v, const std::string& name)
 {
-    Opt o;
-    // fast_artistic_video.lua:21-67 (defaults as there, except -gpu: the reference defaults to the CPU)
-    o.v = {{"model_img", "self"}, {"model_vid", "models/checkpoint-candy-video.t7"}, {"num_frames", "9999"}, {"continue_with", "1"},
-           {"input_pattern", ""}, {"output_prefix", "out"}, {"flow_pattern", ""}, {"occlusions_pattern", ""},
-           {"occlusions_min_filter", "7"}, {"fill_occlusions", "vgg-mean"}, {"median_filter", "3"}, {"scale_factor", "1"},
-           {"gpu", "0"}, {"backend", "cuda"}, {"use_cudnn", "1"}, {"cudnn_benchmark", "0"},
-           {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""}, {"evaluation_file", "evaluation.txt"},
-           {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"},
-           {"style_image", "images/styles/candy.jpg"}, {"style_image_size", "256"}, {"style_weights", "1.0"},
-           {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
-           // additive
-           {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"}};
-    o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
-           {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
-    for (int a = 1; a < argc; ++a) {
-        if (argv[a][0] != '-') die(std::string("invalid argument: ") + argv[a]);
-        const std::string k = argv[a] + 1;
-        if (o.b.count(k)) { o.b[k] = true; continue; }
-        if (!o.v.count(k)) die("unknown option -" + k);
-        if (a + 1 >= argc) die("missing value for -" + k);
-        o.v[k] = argv[++a];
-    }
-    if (o.s("input_pattern").empty()) die("Must give -input_pattern");                                      // fav.lua:177-179
+    for (size_t p = v.find("%S"); p != std::string::npos; p = v.find("%S", p + name.size())) v.replace(p, 2, name);
+    return v;
+}
+
+// One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
+// `net` / `net_img` live on the current device; `nwriters` PNG threads.
+void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, StreamResult* res)
+{
     const bool fused_check = !o.s("forward_flow_pattern").empty();
-    if (!o.f("create_inconsistent") && (o.s("flow_pattern").empty() || (o.s("occlusions_pattern").empty() && !fused_check)))
-        die("Must give -flow_pattern and -occlusions_pattern");                                              // fav.lua:180-182
-    if (o.i("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement lives in oracle/ and is test infrastructure only)");
-    if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
-    if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
-    if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     const int border = o.s("warp_border") == "cpu" ? FAV_BORDER_CPU : FAV_BORDER_STN;
-
-    if (fav_device_count() <= 0) die(std::string("ERROR: ") + fav_last_error());
-    if (hipSetDevice(o.i("gpu")) != hipSuccess) die("cannot select -gpu " + o.s("gpu"));
-    fav_net* net = nullptr;
-    if (fav_net_create(o.s("model_vid").c_str(), o.i("gpu"), &net)) die(fav_last_error());                   // core.lua:39-43
-    if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
-    check(fav_net_set_precision(net, o.s("precision") == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
-    printf("Model loaded.\n");
-    fav_net* net_img = nullptr;                                                                              // core.lua:59-66
-    if (o.s("model_img") != "self") {
-        if (fav_net_create(o.s("model_img").c_str(), o.i("gpu"), &net_img)) die(fav_last_error());
-        printf("Model loaded.\n");
-    }
-
     const int num_frames = o.i("num_frames");
     const bool backward = o.f("backward");
     const int start = backward ? num_frames - 1 : o.i("continue_with"), end = backward ? 1 : num_frames, inc = backward ? -1 : 1;   // core:189-191
@@ -283,9 +273,6 @@ int main(int argc, char** argv)
         return in;
     };
 
-    // PNG deflate is the slowest host stage (level 1: ~25-100 MB/s per thread depending on the content): size the pool from the host
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nwriters = o.i("writers") > 0 ? o.i("writers") : std::max(4, std::min(32, hw / 8));
     Pool writers(nwriters);
     hipStream_t st, st_copy;                 // compute queue; upload queue (the next frame's inputs travel while this frame computes)
     if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess) die("hipStreamCreate failed");
@@ -300,7 +287,7 @@ int main(int argc, char** argv)
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
-    int slot = 0;
+    Slots slots;
 
     // continue_with > 1: reload the previous stylised PNG as the recurrent state (8-bit; the reference's
     // video CLI does not reload anything and fails, fast_artistic_video.lua:89,153-156)
@@ -358,6 +345,8 @@ int main(int argc, char** argv)
     auto finish = [&](Pending& pd) {
         if (!pd.valid) return;
         if (hipEventSynchronize(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
+        check(fav_net_check(net), "stylising a frame");      // a stream-K hand-off that timed out: fail at THIS frame, before its PNG exists
+        if (net_img) check(fav_net_check(net_img), "stylising a frame");
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd.t0).count();
         if (pd.single) printf("Elapsed time for stylizing frame independently:%g\n", ms / 1000.0);           // core:155
         else printf("Elapsed time for stylizing frame:%g\n", ms / 1000.0);                                   // core:177
@@ -366,7 +355,11 @@ int main(int argc, char** argv)
         mkdirs_for(nm);
         const int lvl = o.i("png_level");
         const std::string path = nm; uint8_t* hb = pd.hb; const int w_ = W, h_ = H;
-        writers.submit([hb, path, w_, h_, lvl] { if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error()); });
+        Slots* sl = &slots;
+        writers.submit([hb, path, w_, h_, lvl, sl] {
+            if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error());
+            sl->give(hb);                                     // only now may the slot receive another frame
+        });
         pd.valid = false;
     };
     auto pop_next = [&](FrameIn& out) {
@@ -395,7 +388,7 @@ int main(int argc, char** argv)
             for (auto& dv : dev)
                 if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
                     hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
-            for (auto& p : h_out) if (hipHostMalloc((void**)&p, n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+            for (auto& p : h_out) { if (hipHostMalloc((void**)&p, n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed"); slots.add(p); }
             for (auto& p : pin)
                 if (hipHostMalloc((void**)&p.frame, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, n * 8, hipHostMallocDefault) ||
                     hipHostMalloc((void**)&p.fw, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&p.cert, n, hipHostMallocDefault)) die("hipHostMalloc failed");
@@ -442,9 +435,8 @@ int main(int argc, char** argv)
             temporal.push_back(tl);
         }
         const auto tw = std::chrono::steady_clock::now();
-        writers.wait_below((size_t)nslots - 2);          // a free pinned output slot (one more is held by the frame in flight)
+        uint8_t* hb = slots.take();                      // a pinned output slot nobody is reading (blocks while the PNG pool is behind)
         t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-        uint8_t* hb = h_out[slot]; slot = (slot + 1) % nslots;
         hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st);     // stream order protects d_out8 from frame i+1
         Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
         hipEventRecord(ev_done[now.ev], st);
@@ -470,15 +462,252 @@ int main(int argc, char** argv)
         fprintf(f, "\n%.9g\n", sum / (double)temporal.size());
         fclose(f);
     }
-    if (o.i("timing")) {
-        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-        printf("{\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f}\n",
-               done, s, done / s, t_wait_load, t_gpu, t_wait_writer);
-    }
-    fav_stream_destroy(fs); fav_net_destroy(net); fav_net_destroy(net_img);
+    res->frames = done;
+    res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
+    fav_stream_destroy(fs);
     hipFree(d_prev); hipFree(d_cur);
     hipFree(d_out8); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
     for (auto p : h_out) hipHostFree(p);
     for (auto& p : pin) { hipHostFree(p.frame); hipHostFree(p.bw); hipHostFree(p.fw); hipHostFree(p.cert); }
+    for (auto& e : ev_up) hipEventDestroy(e);
+    for (auto& e : ev_done) hipEventDestroy(e);
+    hipStreamDestroy(st); hipStreamDestroy(st_copy);
+}
+
+std::vector<std::string> split_list(const std::string& v)
+{
+    std::vector<std::string> out; std::string cur;
+    for (char c : v) { if (c == ',') { if (!cur.empty()) out.push_back(cur); cur.clear(); } else cur += c; }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+
+// PNG writer threads of one worker when `world` workers share the host: deflate is the slowest host stage (level 1: ~55 ms per
+// 1280x720 frame and thread), so a worker gets its share of the hardware threads minus the loaders and the main thread
+int writer_budget(int requested, int world)
+{
+    if (requested > 0) return requested;
+    const int hw = std::max(1, (int)std::thread::hardware_concurrency());
+    return std::max(4, std::min(32, hw / std::max(1, world) - 8));
+}
+
+void ncheck(ncclResult_t r, const char* what) { if (r != ncclSuccess) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(r)); }
+
+// rank 0 holds `blob`; on return every rank holds the same bytes.  ONE collective per model: ncclBroadcast of the packed
+// checkpoint (6.7 MB, latency-bound) preceded by its 8-byte size.
+void broadcast_blob(ncclComm_t comm, int rank, std::vector<uint8_t>& blob, hipStream_t st)
+{
+    unsigned long long n = rank == 0 ? blob.size() : 0, *d_n = nullptr;
+    if (hipMalloc((void**)&d_n, 8) != hipSuccess) die("hipMalloc failed");
+    hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice);
+    ncheck(ncclBroadcast(d_n, d_n, 8, ncclUint8, 0, comm, st), "ncclBroadcast(size)");
+    hipStreamSynchronize(st);
+    hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost); hipFree(d_n);
+    if (n == 0) { blob.clear(); return; }
+    uint8_t* d_b = nullptr;
+    if (hipMalloc((void**)&d_b, n) != hipSuccess) die("hipMalloc failed");
+    if (rank == 0) hipMemcpy(d_b, blob.data(), n, hipMemcpyHostToDevice);
+    ncheck(ncclBroadcast(d_b, d_b, n, ncclUint8, 0, comm, st), "ncclBroadcast(blob)");
+    if (hipStreamSynchronize(st) != hipSuccess) die("RCCL broadcast failed");
+    blob.resize(n);
+    hipMemcpy(blob.data(), d_b, n, hipMemcpyDeviceToHost); hipFree(d_b);
+}
+
+std::vector<uint8_t> pack_model(const std::string& path)
+{
+    size_t bytes = 0;
+    if (fav_net_pack_host(path.c_str(), nullptr, 0, &bytes)) die(fav_last_error());                         // core.lua:39-43
+    std::vector<uint8_t> blob(bytes);
+    if (fav_net_pack_host(path.c_str(), blob.data(), blob.size(), &bytes)) die(fav_last_error());
+    return blob;
+}
+
+std::string json_str(const std::string& v) { std::string o = "\""; for (char c : v) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o + "\""; }
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Opt o;
+    // fast_artistic_video.lua:21-67 (defaults as there, except -gpu: the reference defaults to the CPU, which this build does not have)
+    o.v = {{"model_img", "models/checkpoint-candy-image.t7"}, {"model_vid", "models/checkpoint-candy-video.t7"}, {"num_frames", "9999"}, {"continue_with", "1"},
+           {"input_pattern", ""}, {"output_prefix", "out"}, {"flow_pattern", ""}, {"occlusions_pattern", ""},
+           {"occlusions_min_filter", "7"}, {"fill_occlusions", "vgg-mean"}, {"median_filter", "3"}, {"scale_factor", "1"},
+           {"gpu", "0"}, {"backend", "cuda"}, {"use_cudnn", "1"}, {"cudnn_benchmark", "0"},
+           {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""}, {"evaluation_file", "evaluation.txt"},
+           {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"},
+           {"style_image", "images/styles/candy.jpg"}, {"style_image_size", "256"}, {"style_weights", "1.0"},
+           {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
+           // additive
+           {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
+           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
+           {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"},
+           // internal (set by the launcher for its workers)
+           {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
+    o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
+           {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
+    for (int a = 1; a < argc; ++a) {
+        if (argv[a][0] != '-') die(std::string("invalid argument: ") + argv[a]);
+        const std::string k = argv[a] + 1;
+        if (o.b.count(k)) { o.b[k] = true; continue; }
+        if (!o.v.count(k)) die("unknown option -" + k);
+        if (a + 1 >= argc) die("missing value for -" + k);
+        o.v[k] = argv[++a];
+    }
+    if (o.s("input_pattern").empty()) die("Must give -input_pattern");                                      // fav.lua:177-179
+    const bool fused_check = !o.s("forward_flow_pattern").empty();
+    if (!o.f("create_inconsistent") && (o.s("flow_pattern").empty() || (o.s("occlusions_pattern").empty() && !fused_check)))
+        die("Must give -flow_pattern and -occlusions_pattern");                                              // fav.lua:180-182
+    if (o.i("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement lives in oracle/ and is test infrastructure only)");
+    if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
+    if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
+    if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
+    if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
+    const bool dry = o.i("dry_run") != 0;
+    std::vector<std::string> streams = split_list(o.s("streams"));
+    const bool named = !streams.empty();
+    if (!named) streams.push_back("");
+    int world = std::max(1, o.i("gpus"));
+    const int rank = o.i("worker_rank");
+    static const char* const path_opts[] = {"input_pattern", "flow_pattern", "forward_flow_pattern", "occlusions_pattern", "output_prefix", "temporal_eval_file"};
+    if (named && streams.size() > 1 && o.s("output_prefix").find("%S") == std::string::npos)
+        die("-streams: -output_prefix must contain %S (the streams would overwrite each other's frames)");
+
+    // ------------------------------------------------------------------------------------------ launcher
+    if (rank < 0 && (world > 1 || o.i("force_dist"))) {
+        if (!dry) {
+            const int ndev = fav_device_count();
+            if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
+            if (o.i("gpu") + world > ndev) die("-gpus " + o.s("gpus") + " from -gpu " + o.s("gpu") + ": only " + std::to_string(ndev) + " devices");
+        }
+        char idf[] = "/tmp/fav_rccl_id_XXXXXX";
+        const int fd = mkstemp(idf);
+        if (fd < 0) die("cannot create the RCCL id file");
+        close(fd); unlink(idf);                                   // the name is reused: rank 0 creates <name> atomically
+        std::vector<pid_t> kids;
+        fflush(stdout); fflush(stderr);
+        for (int r = 0; r < world; ++r) {
+            const pid_t pid = fork();                             // before any HIP call in this process
+            if (pid < 0) die("fork failed");
+            if (pid == 0) {
+                std::vector<std::string> args(argv, argv + argc);
+                args.insert(args.end(), {"-worker_rank", std::to_string(r), "-worker_world", std::to_string(world), "-rccl_id_file", idf});
+                std::vector<char*> av;
+                for (auto& a : args) av.push_back(const_cast<char*>(a.c_str()));
+                av.push_back(nullptr);
+                execv("/proc/self/exe", av.data());
+                perror("execv"); _exit(127);
+            }
+            kids.push_back(pid);
+        }
+        int worst = 0;
+        for (pid_t k : kids) { int stt = 0; waitpid(k, &stt, 0); const int rc = WIFEXITED(stt) ? WEXITSTATUS(stt) : 128; if (rc > worst) worst = rc; }
+        // aggregate line: total frames / slowest worker's stylisation time
+        if (o.i("timing") && !dry && worst == 0) {
+            int frames = 0; double secs = 0; std::string per = "";
+            for (int r = 0; r < world; ++r) {
+                const std::string f = std::string(idf) + ".rank" + std::to_string(r);
+                FILE* fp = fopen(f.c_str(), "r");
+                int fr = 0; double sc = 0;
+                if (fp) { if (fscanf(fp, "%d %lf", &fr, &sc) != 2) { fr = 0; sc = 0; } fclose(fp); unlink(f.c_str()); }
+                frames += fr; secs = std::max(secs, sc);
+                per += (r ? ", " : "") + std::to_string(fr ? fr / std::max(sc, 1e-9) : 0.0);
+            }
+            printf("{\"gpus\": %d, \"streams\": %zu, \"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"fps_per_gpu\": [%s], "
+                   "\"weights\": \"rank 0 parsed the .t7, ncclBroadcast of the packed blob\"}\n",
+                   world, streams.size(), frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str());
+        }
+        unlink(idf);
+        return worst;
+    }
+
+    // ------------------------------------------------------------------------------------------ worker / single process
+    const bool dist = rank >= 0;
+    if (dist) world = o.i("worker_world");
+    const int device = o.i("gpu") + (dist ? rank : 0);
+    std::vector<std::string> mine;
+    for (size_t s = 0; s < streams.size(); ++s) if (!dist || (int)(s % (size_t)world) == rank) mine.push_back(streams[s]);     // stream s -> GPU s mod N
+    const int nwriters = writer_budget(o.i("writers"), dist ? world : 1);
+    if (dry) {
+        std::string js = "{\"rank\": " + std::to_string(std::max(rank, 0)) + ", \"world\": " + std::to_string(dist ? world : 1) + ", \"device\": " + std::to_string(device) +
+                         ", \"writers\": " + std::to_string(nwriters) + ", \"streams\": [";
+        for (size_t k = 0; k < mine.size(); ++k) {
+            js += std::string(k ? ", " : "") + "{\"name\": " + json_str(mine[k]);
+            for (const char* po : path_opts) js += std::string(", \"") + po + "\": " + json_str(named ? subst_stream(o.s(po), mine[k]) : o.s(po));
+            js += "}";
+        }
+        printf("%s]}\n", js.c_str());
+        return 0;
+    }
+
+    if (fav_device_count() <= 0) die(std::string("ERROR: ") + fav_last_error());
+    if (hipSetDevice(device) != hipSuccess) die("cannot select GPU " + std::to_string(device));
+    const bool want_img = o.s("model_img") != "self";
+    fav_net* net = nullptr; fav_net* net_img = nullptr;                                                      // core.lua:39-66
+    if (dist) {
+        // rank 0 parses; the other ranks never open the .t7
+        ncclUniqueId id;
+        const std::string idf = o.s("rccl_id_file");
+        if (rank == 0) {
+            ncheck(ncclGetUniqueId(&id), "ncclGetUniqueId");
+            const std::string tmp = idf + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
+            fclose(f);
+            if (rename(tmp.c_str(), idf.c_str())) die("cannot publish " + idf);
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            FILE* f = nullptr;
+            while (!(f = fopen(idf.c_str(), "rb"))) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120) die("timed out waiting for the RCCL id of rank 0");
+                usleep(2000);
+            }
+            if (fread(&id, sizeof id, 1, f) != 1) die("short RCCL id file");
+            fclose(f);
+        }
+        ncclComm_t comm;
+        ncheck(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        hipStream_t bst; if (hipStreamCreate(&bst) != hipSuccess) die("hipStreamCreate failed");
+        std::vector<uint8_t> blob, blob_img;
+        if (rank == 0) { blob = pack_model(o.s("model_vid")); if (want_img) blob_img = pack_model(o.s("model_img")); }
+        const auto tb = std::chrono::steady_clock::now();
+        broadcast_blob(comm, rank, blob, bst);
+        broadcast_blob(comm, rank, blob_img, bst);
+        const double bms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+        if (fav_net_create_from_blob(blob.data(), blob.size(), device, &net)) die(fav_last_error());
+        if (!blob_img.empty() && fav_net_create_from_blob(blob_img.data(), blob_img.size(), device, &net_img)) die(fav_last_error());
+        printf("[rank %d/%d gpu %d] weights: %zu B%s via ncclBroadcast from rank 0 in %.2f ms; %zu stream(s), %d PNG writers\n", rank, world, device,
+               blob.size(), blob_img.empty() ? "" : " (+ image model)", bms, mine.size(), nwriters);
+        hipStreamDestroy(bst);
+        ncclCommDestroy(comm);
+    } else {
+        if (fav_net_create(o.s("model_vid").c_str(), device, &net)) die(fav_last_error());                   // core.lua:39-43
+        if (want_img && fav_net_create(o.s("model_img").c_str(), device, &net_img)) die(fav_last_error());
+    }
+    check(fav_net_set_precision(net, o.s("precision") == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
+    printf("Model loaded.\n");
+    if (net_img) printf("Model loaded.\n");
+
+    int frames = 0; double seconds = 0;
+    for (const std::string& name : mine) {
+        Opt os = o;
+        if (named) for (const char* po : path_opts) os.v[po] = subst_stream(o.s(po), name);
+        StreamResult r;
+        run_stream(os, net, net_img, nwriters, &r);
+        frames += r.frames; seconds += r.seconds;
+        if (o.i("timing"))
+            printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"png_writers\": %d}\n",
+                   named ? ("\"stream\": " + json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
+                   r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, nwriters);
+    }
+    check(fav_net_check(net), "at exit");
+    if (dist && o.i("timing")) {
+        const std::string f = o.s("rccl_id_file") + ".rank" + std::to_string(rank);
+        FILE* fp = fopen(f.c_str(), "w");
+        if (fp) { fprintf(fp, "%d %.6f\n", frames, seconds); fclose(fp); }
+    }
+    fflush(stdout);
+    fav_net_destroy(net); fav_net_destroy(net_img);
     return 0;
 }

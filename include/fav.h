@@ -106,6 +106,12 @@ int fav_net_pack_host(const char* t7_path_host, void* blob_host, size_t capacity
 /* create a net from a packed blob (host memory) */
 int fav_net_create_from_blob(const void* blob_host, size_t bytes, int device, fav_net** out);
 void fav_net_destroy(fav_net* net);
+/* The stream-K convolution grids hand partial tiles between co-resident blocks; a hand-off that cannot complete (another
+ * context holding compute units of the device) times out inside the kernel and sets a host-visible word.  Call this AFTER the
+ * work of a frame has completed (event / stream synchronised): FAV_EHIP means the frames computed since the last check are
+ * wrong.  fav_stylize checks before every PNG is queued and at exit; fav_net_forward / fav_stream_* also fail on their next
+ * call.  Clears the word. */
+int fav_net_check(fav_net* net);
 /* human-readable layer list (one line per layer) -- used to cross-check the .t7 reader */
 int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity);
 /* host-only (no device needed): parse a .t7 checkpoint and write the same layer list text */

@@ -40,6 +40,63 @@ def test_oracle_mask_vs_live_reference_binary(oracle, tmp_path):
         assert np.array_equal(oracle.read_pnm(o), oracle.consistency(bw, fw, img))
 
 
+def test_oracle_mask_extreme_flows_vs_live_reference_binary(oracle, tmp_path):
+    """|flow| >= 2^31, +-inf and NaN (the Middlebury 'unknown flow' marker is 1e10): the reference's (int)floor() gives INT_MIN
+    on x86 and the pixel is written 0.  Pins the oracle -- and through it the GPU kernel's float-domain range test
+    (tests/test_gpu_parity.py::test_consistency_extreme_flows) -- on the compiled reference for those inputs."""
+    if not os.path.exists(oracle.REF_CHECKER):
+        pytest.skip("oracle/_ref/consistencyChecker not built (reference tree absent)")
+    h, w = 24, 40
+    bw = synth.random_flow(h, w, 7, 2.0); fw = synth.random_flow(h, w, 8, 2.0)
+    vals = [1e10, -1e10, np.inf, -np.inf, np.nan, 2147483648.0, 2147483520.0, -2147483904.0, 3e9]
+    rng = np.random.default_rng(2)
+    hit = []
+    for v in vals * 2:
+        y, x, c = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 2))
+        bw[y, x, c] = np.float32(v); hit.append((y, x))
+    a, b, o = (str(tmp_path / n) for n in ("a.flo", "b.flo", "o.pgm"))
+    oracle.write_flo(a, bw); oracle.write_flo(b, fw)
+    subprocess.check_call([oracle.REF_CHECKER, a, b, o], stdout=subprocess.DEVNULL)
+    ref = oracle.read_pnm(o)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(ref, oracle.consistency(bw, fw))
+    assert all(ref[y, x] == 0 for y, x in hit)
+
+
+def test_launcher_shards_streams_across_workers(favlib, tmp_path):
+    """fav_stylize -streams a,b,c,d,e -gpus 2 -dry_run 1: one worker PROCESS per GPU, stream s -> worker s mod N, %S replaced
+    in every path option, per-worker PNG-writer budget = host threads / N.  No device is touched."""
+    import json
+    exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
+    names = ["a", "b", "c", "d", "e"]
+    base = [exe, "-input_pattern", "in/%S/frame_%05d.ppm", "-flow_pattern", "in/%S/flow/backward_[%d]_{%d}.flo",
+            "-forward_flow_pattern", "in/%S/flow/forward_{%d}_[%d].flo", "-output_prefix", "out/%S/out", "-model_vid", "m.t7", "-model_img", "self",
+            "-streams", ",".join(names), "-dry_run", "1"]
+    for world in (2, 3):
+        r = subprocess.run(base + ["-gpus", str(world), "-gpu", "1"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+        assert [d["rank"] for d in recs] == list(range(world)) and all(d["world"] == world for d in recs)
+        assert [d["device"] for d in recs] == [1 + k for k in range(world)]            # devices -gpu .. -gpu + n - 1
+        hw = os.cpu_count()
+        assert all(d["writers"] == max(4, min(32, hw // world - 8)) for d in recs)
+        for d in recs:
+            want = [n for k, n in enumerate(names) if k % world == d["rank"]]
+            assert [s["name"] for s in d["streams"]] == want
+            for s in d["streams"]:
+                assert s["input_pattern"] == f"in/{s['name']}/frame_%05d.ppm" and s["output_prefix"] == f"out/{s['name']}/out"
+                assert s["flow_pattern"] == f"in/{s['name']}/flow/backward_[%d]_{{%d}}.flo"
+                assert s["forward_flow_pattern"] == f"in/{s['name']}/flow/forward_{{%d}}_[%d].flo"
+    # single process (no -gpus): the streams run back to back in this process
+    r = subprocess.run(base, capture_output=True, text=True, timeout=60)
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(recs) == 1 and [s["name"] for s in recs[0]["streams"]] == names and recs[0]["world"] == 1
+    # streams that would overwrite each other are refused
+    bad = [a if a != "out/%S/out" else "out/out" for a in base]
+    r = subprocess.run(bad + ["-gpus", "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "%S" in r.stderr
+
+
 def test_mask_edge_cases(oracle):
     h, w = 8, 12
     z = np.zeros((h, w, 2), np.float32)

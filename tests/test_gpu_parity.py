@@ -397,6 +397,73 @@ def test_canonical_640x360_frame_vs_oracle(favlib, oracle, cuda, canonical):
     oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
 
 
+def test_canonical_1280x720_recurrent_step_vs_oracle(favlib, oracle, cuda, canonical):
+    """BASELINE config 3 -- the configuration bench.py's headline number is quoted on: one recurrent step
+    (fused consistency check + min filter + warp + assembly + network + de-process, core.lua:161-180) at 1280x720 against the
+    oracle (~6 s of CPU).  Gates of BASELINE.md section 4: mask bit-exact, max-abs <= 2e-4 de-processed (= 5e-2 in the
+    150*tanh space), 8-bit PSNR >= 50 dB."""
+    h, w = 720, 1280
+    layers = _layers(canonical)
+    frames, bws, fws = _clip(h, w, 2, 70)
+    net = favlib.Net(canonical, 0)
+    st = favlib.Stream(net, h, w)
+    oracle.set_threads(len(os.sched_getaffinity(0)))
+    try:
+        o0, _ = st.first_frame(T(frames[0], cuda))
+        o1, u1 = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda), want_u8=True)
+        net.check()
+        mask = oracle.consistency(bws[1], fws[1])
+        assert np.array_equal(st.last_mask().cpu().numpy(), mask)
+        ref = oracle.Stylizer(layers)
+        ref.last = o0.cpu().numpy()                 # teacher-forced: the step under test is the recurrent one
+        r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
+        err = float(np.abs(o1.cpu().numpy() - r1).max())
+        assert err <= 2e-4, err
+        assert psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
+        assert np.abs(r1).std() > 0.05              # not a saturated / trivial frame
+    finally:
+        oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+
+
+def test_config1_256x256_two_frames_vs_oracle(favlib, oracle, cuda, canonical):
+    """BASELINE config 1 geometry (2-frame 256x256 clip, precomputed .flo + reliable_*.pgm, the reference's plumbing case):
+    both frames free-running against the oracle, canonical architecture."""
+    h, w = 256, 256
+    layers = _layers(canonical)
+    frames, bws, fws = _clip(h, w, 2, 90)
+    mask = oracle.consistency(bws[1], fws[1])       # what consistencyChecker writes to reliable_2_1.pgm
+    net = favlib.Net(canonical, 0)
+    st = favlib.Stream(net, h, w)
+    o0, u0 = st.first_frame(T(frames[0], cuda), want_u8=True)
+    o1, u1 = st.next_frame_cert(T(frames[1], cuda), T(bws[1], cuda), T(mask, cuda), want_u8=True)
+    net.check()
+    ref = oracle.Stylizer(layers)
+    r0 = ref.first(_f01(frames[0]))
+    r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))     # free-running: the oracle's own frame 1 is the prior
+    assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+    assert np.abs(o1.cpu().numpy() - r1).max() <= 4e-4       # two frames of accumulated rounding
+    assert psnr8(u0.cpu().numpy(), oracle.to_u8_hwc(r0)) >= 50.0 and psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
+
+
+def test_consistency_extreme_flows(favlib, oracle, cuda):
+    """Flows that leave the int range (the Middlebury 'unknown' marker 1e10, +-inf, NaN): the reference's (int)floor() yields
+    INT_MIN there (cvttsd2si) and the pixel is written 0; the GPU's saturating conversion must not turn that into an
+    out-of-bounds gather."""
+    h, w = 40, 56
+    bw = synth.backward_flow(h, w, 5); fw = synth.forward_flow_from_backward(bw, 6)
+    bw = bw.copy(); fw = fw.copy()
+    vals = [1e10, -1e10, np.inf, -np.inf, np.nan, 2147483648.0, 2147483520.0, -2147483904.0, 3e9]
+    rng = np.random.default_rng(1)
+    for k, v in enumerate(vals * 3):
+        y, x, c = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(0, 2))
+        bw[y, x, c] = np.float32(v)
+    fw[3, 4, 0] = np.float32(1e10); fw[7, 9, 1] = np.float32(np.nan)      # poisoned samples of flow2: only the values propagate
+    got = favlib.consistency(T(bw, cuda), T(fw, cuda)).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = oracle.consistency(bw, fw)
+    assert np.array_equal(got, want)
+
+
 def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
     """the temporal-consistency number of -evaluate (fast_artistic_video.lua:128-151)."""
     h, w = 90, 130
