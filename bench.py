@@ -17,7 +17,10 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import hashlib
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -30,25 +33,104 @@ FLOP_PER_FRAME = 305_651_220_480          # useful conv FLOPs of the canonical n
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(layers, frames, bw, fw):
-    """The oracle (a port of the reference's CPU path) timed on this host's cores, bounded sample."""
+def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out_u8, gpu_mask):
+    """The oracle (a port of the reference's CPU path, fast_artistic_video_core.lua:161-180) timed on this host's cores on ONE
+    1280x720 recurrent step (min of 3 runs), and -- since that frame is computed anyway -- compared with what the GPU path
+    produced from the same inputs (teacher-forced: both start from the GPU's previous stylised frame).  Outside the timed
+    region; the oracle is the checker here, never the thing measured as `value`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
-    h, w = H, W                            # one full 1280x720 frame (~20 s on 8 cores)
-    f0 = np.transpose(frames[0][:h, :w], (2, 0, 1)).astype(np.float32) / np.float32(255)
-    f1 = np.transpose(frames[1][:h, :w], (2, 0, 1)).astype(np.float32) / np.float32(255)
-    b, f = np.ascontiguousarray(bw[:h, :w]), np.ascontiguousarray(fw[:h, :w])
-    st = O.Stylizer(layers)
-    st.last = f0                            # any previous output: the timing does not depend on its values
-    t0 = time.perf_counter()
-    mask = O.consistency(b, f)
-    st.next(f1, b, mask.astype(np.float32) / np.float32(255))
-    dt = time.perf_counter() - t0
+    O.build()
+    f1 = np.transpose(frame1, (2, 0, 1)).astype(np.float32) / np.float32(255)
+    b, f = np.ascontiguousarray(bw), np.ascontiguousarray(fw)
+    times = []
+    for _ in range(3):
+        st = O.Stylizer(layers)
+        st.last = prev_state
+        t0 = time.perf_counter()
+        mask = O.consistency(b, f)
+        r1 = st.next(f1, b, mask.astype(np.float32) / np.float32(255))
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     cores = len(os.sched_getaffinity(0))
-    return {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+    base = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"1 frame of 1280x720 (3-arg mask + min-filter + warp + assemble + net + deprocess) through oracle/ "
-                      f"(C, fp64 accumulation, OpenMP) in {dt:.1f} s on {cores} threads"}
+                      f"(C, fp64 accumulation, OpenMP) on {cores} threads, min of 3 runs ({', '.join('%.2f' % t for t in times)} s)"}
+    ref_u8 = O.to_u8_hwc(r1)
+    mse = float(np.mean((ref_u8.astype(np.float64) - gpu_out_u8.astype(np.float64)) ** 2))
+    max_abs = float(np.abs(r1 - gpu_out).max())
+    parity = {"psnr_db": 99.0 if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
+              "max_abs": float("%.3e" % max_abs), "max_abs_tanh150_space": float("%.3e" % (max_abs * 255.0)),
+              "mask_mismatch_bytes": int((mask != gpu_mask).sum()),
+              "vs": "oracle/ (CPU restatement) on the same 1280x720 inputs, one recurrent step, teacher-forced from the GPU's previous frame; "
+                    "max_abs in de-processed [0,1] units (gate 2e-4), PSNR of the 8-bit frames (gate 50 dB), mask bytes (gate 0)"}
+    return base, parity
+
+
+def reference_checker_baseline(bw, fw, frame):
+    """The reference's OWN consistencyChecker (compiled by oracle/Makefile into oracle/_ref, 1 thread as shipped), timed per
+    1280x720 flow pair including its file I/O on RAM-backed files; min of 3."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "consistencyChecker")
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    d = tempfile.mkdtemp(prefix="fav_refchk_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        a, b, i, o = (os.path.join(d, n) for n in ("bw.flo", "fw.flo", "img.ppm", "out.pgm"))
+        O.write_flo(a, bw); O.write_flo(b, fw); O.write_pnm(i, frame)
+        res = {}
+        for name, args in (("3arg", [exe, a, b, o]), ("4arg", [exe, a, b, o, i])):
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); subprocess.check_call(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); ts.append(time.perf_counter() - t0)
+            res[name] = min(ts)
+        return {"kind": "reference", "cores": 1, "unit": "masks/s", "value": round(1.0 / res["3arg"], 3), "value_4arg": round(1.0 / res["4arg"], 3),
+                "sample": "consistencyChecker (reference sources, g++ -O3) on one 1280x720 flow pair incl. .flo read + .pgm write on /dev/shm, "
+                          "min of 3: %.3f s (3-arg) / %.3f s (4-arg, image structure)" % (res["3arg"], res["4arg"])}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300):
+    """File -> PNG rate of the drop-in CLI (fast_artistic_video.lua:93-97,160-170): bin/fav_stylize over `nframes` RAM-backed
+    1280x720 P6 frames + backward/forward .flo, fused on-GPU 3-argument check, PNGs written back to RAM.  Everything the
+    in-HBM `value` leaves out is inside: decode, H2D, D2H, deflate, file writes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
+    if not os.path.exists(exe) or not os.path.isdir("/dev/shm"):
+        return {"error": "bin/fav_stylize or /dev/shm missing"}
+    d = tempfile.mkdtemp(prefix="fav_e2e_", dir="/dev/shm")
+    try:
+        os.makedirs(d + "/src"); os.makedirs(d + "/flow")
+        ring = len(frames_h)
+        for k in range(ring):
+            O.write_pnm(f"{d}/src/f{k}.ppm", frames_h[k]); O.write_flo(f"{d}/src/b{k}.flo", bw_h[k]); O.write_flo(f"{d}/src/w{k}.flo", fw_h[k])
+        for i in range(1, nframes + 1):
+            os.symlink(f"{d}/src/f{i % ring}.ppm", f"{d}/frame_{i:05d}.ppm")
+            if i > 1:
+                os.symlink(f"{d}/src/b{i % ring}.flo", f"{d}/flow/backward_{i}_{i-1}.flo"); os.symlink(f"{d}/src/w{i % ring}.flo", f"{d}/flow/forward_{i-1}_{i}.flo")
+        base = [exe, "-input_pattern", d + "/frame_%05d.ppm", "-flow_pattern", d + "/flow/backward_[%d]_{%d}.flo",
+                "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo", "-structure", "0",
+                "-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1"]
+        out = {"frames": nframes, "host_threads": os.cpu_count(), "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net -> D2H -> PNG to /dev/shm",
+               "h2d_bytes_per_frame": H * W * (3 + 8 + 8), "d2h_bytes_per_frame": H * W * 3}
+        for name, lvl in (("png_level_1", "1"), ("png_level_0", "0")):
+            r = subprocess.run(base + ["-output_prefix", f"{d}/o{lvl}/out", "-png_level", lvl], capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            n_png = len([f for f in os.listdir(f"{d}/o{lvl}") if f.endswith(".png")])
+            out[name] = {"fps": j["fps_end_to_end"], "seconds": j["seconds"], "png_written": n_png, "png_writers": j.get("png_writers"),
+                         "wait_loader_s": j["wait_loader_s"], "wait_png_pool_s": j["wait_png_pool_s"]}
+            shutil.rmtree(f"{d}/o{lvl}", ignore_errors=True)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -59,7 +141,10 @@ def main():
     ap.add_argument("--structure", type=int, default=0, help="1 = 4-argument (image-structure) checker mode")
     ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
                     "(fav_stream_prefetch_mask); default: on for --structure 1, off for the (7 us) 3-argument mask")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle timing + parity block, reference checker)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file->PNG run of bin/fav_stylize after the timed region")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the weight broadcast even at "
+                    "world size 1 (exercises the N>1 launch path on a 1-GPU box)")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational 4-argument-mode pass after the timed region "
                     "(used for the rocprofv3 runs, so that the per-kernel averages cover the timed configuration only)")
     args = ap.parse_args()
@@ -76,19 +161,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfav has no CPU fallback")
     ndev = torch.cuda.device_count()
-    backend = os.environ.get("FAV_BENCH_BACKEND", "nccl")       # "gloo": launch-path smoke test with several ranks on one GPU
-    if backend == "nccl" and world > ndev:
-        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPUs visible (one process per GPU)")
-    local = local % ndev
+    if world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPUs visible (one process per GPU: the persistent convolution "
+                         "grids own the device, include/fav.h)")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    cdev = dev if backend == "nccl" else torch.device("cpu")    # device of the collective buffers
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev                                                  # device of the collective buffers
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # RCCL over xGMI
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.lookahead < 0:
         args.lookahead = 1 if args.structure else 0
@@ -100,7 +182,9 @@ def main():
     if rank == 0:
         t7.make_synthetic_checkpoint(ckpt, seed=1234)
         blob = fav_amd.pack_checkpoint(ckpt)
-    blob = shard.broadcast_blob(blob, cdev)            # RCCL over xGMI: 6.7 MB, once, before the timed region
+    t_b = time.perf_counter()
+    blob = shard.broadcast_blob(blob, cdev, force=args.force_dist)   # RCCL over xGMI: 6.7 MB, once, before the timed region
+    t_b = time.perf_counter() - t_b
     net = fav_amd.Net(blob=blob, device=local)
     stream = fav_amd.Stream(net, H, W)
 
@@ -130,15 +214,16 @@ def main():
         step(i)
     net.profile_enable(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    net.check()                                         # no stream-K hand-off timed out inside the timed region
     net.profile_enable(False)
     prof = net.profile_read()
     dt = shard.max_over_ranks(dt, cdev)
@@ -187,18 +272,28 @@ def main():
         nl = sum(n for ms, n, macs in dom)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         conv_ms = sum(ms for ms, n, macs, kid in prof) / max(1, args.steps)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written by scripts/gpu_pmc.sh from rocprofv3 --pmc passes
+        # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json).  The file records the hash of
+        # the kernel source it was measured on: a stale file (kernel changed since) is refused rather than reported.
+        traffic, traffic_note = None, "profiles/pmc_traffic.json missing"
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        ksrc = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc", "kernels_conv.hip")
+        khash = hashlib.sha256(open(ksrc, "rb").read()).hexdigest()[:16]
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("kernel", "").startswith(dom_name.split(" ")[0]):
-                traffic = tj["hbm_bytes_per_launch"]
+            if not tj.get("kernel", "").startswith(dom_name.split(" ")[0]):
+                traffic_note = "pmc_traffic.json is for another kernel (%s)" % tj.get("kernel")
+            elif tj.get("kernels_conv_sha16") != khash:
+                traffic_note = "stale: measured on kernels_conv.hip %s, current %s -- re-run scripts/gpu_pmc.sh" % (tj.get("kernels_conv_sha16"), khash)
+            else:
+                traffic, traffic_note = tj["hbm_bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE, separate passes, kernels_conv.hip " + khash
         per_kernel = {}
         for ms, n, macs, kid in prof:
             if n:
                 k = per_kernel.setdefault(str(kid), [0.0, 0.0]); k[0] += ms / args.steps; k[1] += 2.0 * macs * n / args.steps
         line = {
-            "metric": "stylized frames/sec end-to-end @1280x720", "value": round(fps, 3), "unit": "frames/s",
+            "metric": "stylized frames/sec @1280x720, per-frame hot path (mask + warp + assembly + net + deprocess) with inputs resident in HBM; "
+                      "file->PNG rate in `e2e`, PSNR vs CPU ref in `parity`",
+            "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "1280x720 fused on-GPU consistency check (%s) + min-filter + warp + assemble + transformer net "
@@ -206,7 +301,7 @@ def main():
                                    "1 independent stream per GPU" % ("4-arg" if args.structure else "3-arg"),
                        "frame": [W, H], "streams": world, "parallelism": f"{world} independent streams, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": dom_name,
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
@@ -215,15 +310,32 @@ def main():
                          "per_kernel_ms_tflops": {k: [round(v[0], 4), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in per_kernel.items()}},
         }
         line["extra"] = extra
+        if use_dist:
+            line["extra"]["weight_broadcast"] = {"backend": "nccl (RCCL)", "world": world, "bytes": len(blob), "seconds_incl_first_call_setup": round(t_b, 4)}
         if world == 1 and not args.no_cpu_baseline:
+            # one more recurrent step on a fresh stream, float outputs kept: GPU result and oracle result of the SAME inputs
             layers = t7.extract_layers(t7.load(ckpt)["model"])
-            line["cpu_baseline"] = cpu_baseline(layers, frames_h, bw_h[1], fw_h[1])
+            pst = fav_amd.Stream(net, H, W)
+            o0, _ = pst.first_frame(frames[0])
+            o1, u1 = pst.next_frame_flow(frames[1], bws[1], fws[1], use_structure=False, want_u8=True)
+            torch.cuda.synchronize(); net.check()
+            base, parity = cpu_baseline_and_parity(layers, frames_h[1], bw_h[1], fw_h[1], o0.cpu().numpy(), o1.cpu().numpy(), u1.cpu().numpy(),
+                                                   pst.last_mask().cpu().numpy())
+            ref = reference_checker_baseline(bw_h[1], fw_h[1], frames_h[1])
+            if ref is not None:
+                base["reference_consistency_checker"] = ref
+            line["cpu_baseline"] = base
+            line["parity"] = parity
+            del pst
+        if world == 1 and not args.no_e2e:
+            del stream; torch.cuda.synchronize()
+            line["e2e"] = e2e_block(ckpt, frames_h, bw_h, fw_h)
         print(json.dumps(line), flush=True)
         try:
             os.remove(ckpt)
         except OSError:
             pass
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

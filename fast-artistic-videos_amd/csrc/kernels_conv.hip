@@ -50,6 +50,14 @@ struct ConvArgs {
     int reserve_cus;
 };
 
+// 16-byte write-through store (sc1): the stream-K partial tiles are published with these + `s_waitcnt vmcnt(0)` + an sc1 flag
+// store, instead of plain stores + an agent-scope release fence (which writes back the whole XCD L2's dirty lines, i.e. also the
+// output tiles other blocks are storing at that moment): MI355X_MICROARCH.md "publish-large" row, 8.2 -> 3.0 us per 64 KB.
+__device__ __forceinline__ void store16_wt(void* p, v4f v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // branch-free form used inside the MFMA loop: lo = 0 for ReLU, -inf for none; identity = scale 1, shift 0
 __device__ __forceinline__ float4 affine4_lo(float4 v, const float* sc, const float* sh, float lo)
 {
@@ -666,6 +674,7 @@ struct H3Args {
     int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
     int stages, relu1, relu2;
     const unsigned short* wgt16;   // bf16 copy of the weights (fast mode) or null
+    int sk_wt;               // 1: publish partial tiles with write-through (sc1) stores; 0: plain stores + release fence
     long long* dbg;          // optional in-kernel timeline (FAV_H3_DBG), 24 slots per block
 };
 
@@ -874,17 +883,29 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         constexpr int NV4 = TN * 4;
         if (k0 > 0) {
             float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
+            if (p.sk_wt) {
+                // write-through payload -> drained -> sc1 flag (no L2 write-back fence)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    slot[(size_t)(j * 4 + q) * NT] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    for (int q = 0; q < 4; ++q)
+                        store16_wt(slot + (size_t)(j * 4 + q) * NT, v4f{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (t == 0) __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        slot[(size_t)(j * 4 + q) * NT] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             __syncthreads();
             DBG_T(); DBG_T();
@@ -1374,6 +1395,8 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
     const bool s2 = c.pre.stages >= 2;
     a.wgt16 = c.wgt16;
+    static const int sk_wt = getenv("FAV_SK_WT") ? atoi(getenv("FAV_SK_WT")) : 1;      // (A/B switch, read once)
+    a.sk_wt = sk_wt;
     if (c.wgt16) {           // fast mode: bf16 operands
         if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, st);
         return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, st);

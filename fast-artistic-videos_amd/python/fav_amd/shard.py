@@ -11,11 +11,12 @@ def streams_for_rank(n_streams: int, rank: int, world: int) -> List[int]:
     return [s for s in range(n_streams) if s % world == rank]
 
 
-def broadcast_blob(blob: Optional[bytes], device) -> bytes:
-    """rank 0 passes the packed checkpoint (fav_net_pack_host), every rank gets the same bytes back."""
+def broadcast_blob(blob: Optional[bytes], device, force: bool = False) -> bytes:
+    """rank 0 passes the packed checkpoint (fav_net_pack_host), every rank gets the same bytes back.
+    force: run the two broadcasts even in a one-rank group (exercises the RCCL path on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         assert blob is not None
         return blob
     rank = dist.get_rank()

@@ -8,7 +8,7 @@ if [ "$2" != "quick" ]; then
 fi
 (python bench.py --steps 40 --warmup 5 2>&1 | tail -2) > $O/bench_$TAG.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra > $O/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-e2e > $O/prof_$TAG.log 2>&1
 cd $R
 for f in $(find $O/prof_$TAG -name "*kernel_stats.csv"); do cp $f $O/kernel_stats_$TAG.csv; done
 cat $O/test_$TAG.log $O/smoke_$TAG.log 2>/dev/null | tail -25

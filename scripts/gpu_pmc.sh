@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_list.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${TAG}_$N -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra > $O/pmc_${TAG}_$N.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${TAG}_$N -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --no-e2e > $O/pmc_${TAG}_$N.log 2>&1
 done
 cd $R
 python - <<PY
@@ -26,7 +26,9 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
     f, w = out[dom[0]]["FETCH_SIZE"]["mean"], out[dom[0]]["WRITE_SIZE"]["mean"]
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of
     # 16-B/lane coalesced streams (this kernel's loads are all 16 B/lane) -> doubled; WRITE_SIZE taken as is (uncalibrated)
-    json.dump({"kernel": "conv3_halo_kernel<128, false>", "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
+    import hashlib
+    sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/kernels_conv.hip", "rb").read()).hexdigest()[:16]
+    json.dump({"kernel": "conv3_halo_kernel<128, false>", "kernels_conv_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
                "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of the kernel in "
                        "bench.py; read side doubled per the gfx950 FETCH_SIZE calibration; algorithmic bytes per launch: ~64 MB "

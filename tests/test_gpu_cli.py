@@ -120,8 +120,12 @@ def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
     # th shim used by the unmodified shell drivers
     shim = os.path.join(ROOT, "fast-artistic-videos_amd", "host", "th")
     r = subprocess.run([shim, "fast_artistic_video.lua", "-input_pattern", str(tmp_path / "no_%05d.ppm"), "-create_inconsistent",
-                        "-model_vid", model, "-gpu", "0"], capture_output=True, text=True)
+                        "-model_vid", model, "-model_img", "self", "-gpu", "0"], capture_output=True, text=True)
     assert r.returncode == 0 and "Model loaded." in r.stdout
+    # -model_img defaults to the reference's models/checkpoint-candy-image.t7 (fast_artistic_video.lua:24): absent here -> core.lua:41's error
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "no_%05d.ppm"), "-create_inconsistent", "-model_vid", model, "-gpu", "0"],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode != 0 and "Could not load model" in r.stderr and "checkpoint-candy-image.t7" in r.stderr
 
 
 def test_fav_stylize_loop_flags(oracle, favlib, tmp_path, golden_dir):
@@ -207,3 +211,33 @@ def test_fav_stylize_vr_matches_oracle(oracle, favlib, tmp_path, golden_dir):
     for bad in (["-gpu", "-1"], ["-evaluate"], ["-continue_with", "2"], ["-backward"]):
         rb = subprocess.run(cmd + bad, capture_output=True, text=True)
         assert rb.returncode != 0 and rb.stderr.strip(), bad
+
+
+def test_fav_stylize_multi_stream_launcher_rccl(oracle, favlib, tmp_path, golden_dir):
+    """BASELINE config 4 plumbing on the one GPU of this box: `-streams a,b -gpus 1 -force_dist 1` takes the worker path -- rank 0
+    parses the .t7, the packed blob goes through ncclCommInitRank + ncclBroadcast (RCCL), the net is created from the blob --
+    and both videos come out byte-identical to two plain single-video runs."""
+    import json
+    h, w, n = 48, 64, 3
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    exe = os.path.join(BIN, "fav_stylize")
+    for k, name in enumerate(("a", "b")):
+        _write_clip(oracle, tmp_path / name, h, w, n, 300 + 50 * k)
+    common = ["-flow_pattern", str(tmp_path / "%S" / "flow" / "backward_[%d]_{%d}.flo"),
+              "-forward_flow_pattern", str(tmp_path / "%S" / "flow" / "forward_{%d}_[%d].flo"), "-structure", "1",
+              "-model_vid", model, "-model_img", "self", "-gpu", "0", "-timing", "1"]
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "%S" / "frame_%05d.ppm"), "-output_prefix", str(tmp_path / "multi_%S" / "out"),
+                        "-streams", "a,b", "-gpus", "1", "-force_dist", "1"] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "via ncclBroadcast from rank 0" in r.stdout and "[rank 0/1 gpu 0]" in r.stdout
+    agg = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"gpus"')]
+    assert len(agg) == 1 and agg[0]["frames"] == 2 * n and agg[0]["streams"] == 2 and agg[0]["fps_end_to_end"] > 0
+    for name in ("a", "b"):
+        single = [a.replace("%S", name) for a in common]
+        r1 = subprocess.run([exe, "-input_pattern", str(tmp_path / name / "frame_%05d.ppm"), "-output_prefix", str(tmp_path / f"single_{name}" / "out")] + single,
+                            capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0, r1.stderr
+        for i in range(1, n + 1):
+            a = open(tmp_path / f"multi_{name}" / f"out-{i:05d}.png", "rb").read()
+            b = open(tmp_path / f"single_{name}" / f"out-{i:05d}.png", "rb").read()
+            assert a == b, (name, i)
