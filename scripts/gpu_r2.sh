@@ -7,7 +7,7 @@ if [ "$2" != "notests" ]; then
   (timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -30) > $O/test_$TAG.log
   (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > $O/smoke_$TAG.log
 fi
-(timeout 900 python bench.py --steps 40 --warmup 5 --force-dist 2>&1 | tail -3) > $O/bench_$TAG.log
+timeout 900 python bench.py --steps 40 --warmup 5 --force-dist > $O/bench_$TAG.log 2> $O/bench_$TAG.err; tail -5 $O/bench_$TAG.err
 for kv in $AB; do
   for rep in 1 2; do
     (env $kv timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-e2e 2>&1 | tail -1 | python -c "

@@ -138,14 +138,14 @@ def test_fav_stylize_loop_flags(oracle, favlib, tmp_path, golden_dir):
     layers = t7.extract_layers(t7.load(model)["model"])
     exe = os.path.join(BIN, "fav_stylize")
     common = ["-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
-              "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "0", "-model_vid", model, "-gpu", "0"]
+              "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "0", "-model_vid", model, "-model_img", "self", "-gpu", "0"]
     f01 = lambda u8: np.transpose(u8, (2, 0, 1)).astype(np.float32) / np.float32(255)
     # -num_frames 2: only two outputs
     r = subprocess.run([exe] + common + ["-output_prefix", str(tmp_path / "a" / "out"), "-num_frames", "2"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.exists(tmp_path / "a" / "out-00002.png") and not os.path.exists(tmp_path / "a" / "out-00003.png")
     # -create_inconsistent: every frame is stylised without a prior (func_is_single_image, fast_artistic_video.lua:172)
-    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-create_inconsistent", "-model_vid", model, "-gpu", "0",
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-create_inconsistent", "-model_vid", model, "-model_img", "self", "-gpu", "0",
                         "-output_prefix", str(tmp_path / "b" / "out")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for i in range(1, n + 1):
