@@ -78,21 +78,10 @@ std::string describe_layers(const std::vector<Layer>& layers, int indent = 0);
 // ------------------------------------------------------------------------------------------------
 // device kernels: launch wrappers (each enqueues on `st` and does not synchronise)
 // ------------------------------------------------------------------------------------------------
-// Deferred InstanceNorm finalize: the producer left per-tile (mean, M2[, count]) partials; the CONSUMING kernel merges them
-// itself in its prologue (every block redundantly, fp64) instead of a dependent 6 us launch per normalisation, and block 0
-// publishes scale/shift to the stage's buffers for any later consumer.  partials == nullptr: the buffers are already final.
-struct FinDesc {
-    const float* partials = nullptr; const int* counts = nullptr;   // [mblocks][ppitch] float2; counts or null (then bp pixels per block)
-    const float* gamma = nullptr; const float* beta = nullptr;
-    int mblocks = 0, M = 0, bp = 0, ppitch = 0; float eps = 0.f;
-};
-
 struct Affine {            // pending per-channel transform t(x) = relu?(x*scale+shift), up to two stages
     const float* scale1 = nullptr; const float* shift1 = nullptr; int relu1 = 0;
     const float* scale2 = nullptr; const float* shift2 = nullptr; int relu2 = 0;
     int stages = 0;
-    FinDesc fin1, fin2;    // pending finalize of stage 1 / 2 (scaleK/shiftK are then the buffers to fill)
-    int in1 = -1, in2 = -1;   // host bookkeeping: index of the normalisation (fav_net::ins) behind each stage
 };
 
 struct ConvLaunch {
@@ -122,12 +111,6 @@ struct ConvLaunch {
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;
     unsigned* sk_err = nullptr;     // host-mapped error word (device pointer): set by a hand-off wait that timed out
     int reserve_cus = 0;            // CUs left to concurrent side-queue work: persistent / stream-K grids shrink by this many
-    int OWp = 0;                    // output row pitch in pixels (0 = OW); halo kernel only
-    // lazy residual join (halo kernel only): the operand is  pre(in[y][x]) + join_t(join_skip[y][x])  -- nn.CAddTable of the
-    // branch and the shaved skip (models_video.lua:41-53) evaluated while the halo is gathered.  join_skip has the geometry
-    // of `in` (same pitch and channels; the caller has already applied the shave offset); join_t has at most one stage.
-    // join_emit (same geometry, or null) receives the joined tensor: the NEXT block's skip.
-    const float* join_skip = nullptr; Affine join_t; float* join_emit = nullptr;
 };
 size_t conv_streamk_workspace_bytes();
 int conv_streamk_grid();
@@ -152,14 +135,13 @@ int launch_conv3_halo(const ConvLaunch& p, int* counts, hipStream_t st);
 int launch_in_finalize(const float* partials, const int* counts, int mblocks, int M, int block_pixels, int C, int Cpitch,
                        const float* gamma, const float* beta, float eps,
                        float* scale, float* shift, hipStream_t st);
-// statistics of t(x) over an NHWC tensor [H][pitch >= W][C] -> partials [ceil(H*W/128)][C] float2
-int launch_stats(const float* x, int H, int W, int pitch, int C, const Affine& t, float* partials, hipStream_t st);
-// residual join  z[oy][ox][c] = y[oy][ox][c]*scale[c]+shift[c] + t(skip[oy+s][ox+s][c])  over OH x OW pixels; y, skip and z
-// have their own row pitches (pixels).  partials != null: additionally the per-row-segment (mean, M2, count) statistics of z
-// ([OH * ceil(OW/128)][C] float2 + counts) for an InstanceNorm that follows the join (directly or after a nearest upsample)
-int launch_res_add(const float* y, int ypitch, const float* scale, const float* shift,
-                   const float* skip, int spitch, int shave, const Affine& skip_t,
-                   int OH, int OW, int C, float* z, int zpitch, float* partials, int* counts, hipStream_t st);
+// statistics of t(x) over an NHWC tensor [M][C] -> partials [ceil(M/128)][C] float2
+int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st);
+// z[oy][ox][c] = y[oy][ox][c]*scale[c]+shift[c] + t(skip[oy+s][ox+s][c]).  partials != null: also the per-row-segment
+// (mean, M2, count) statistics of z ([res_add_stat_blocks(OH, OW)][C] float2 + counts) for an InstanceNorm that follows the join
+int launch_res_add(const float* y, const float* scale, const float* shift,
+                   const float* skip, int SH, int SW, int shave, const Affine& skip_t,
+                   int C, float* z, float* partials, int* counts, hipStream_t st);
 inline int res_add_stat_blocks(int OH, int OW) { return OH * ((OW + 127) / 128); }
 // NCHW [C][H][W] -> NHWC [H+2p][W+2p][Cp] with reflection padding p and zero channels >= C
 int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int Cp, float* out, hipStream_t st);

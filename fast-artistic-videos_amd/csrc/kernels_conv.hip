@@ -36,72 +36,9 @@ constexpr int BM = CONV_BM;   // 128 output pixels per block
 constexpr int BK = 32;        // K elements per step
 constexpr int LDSS = 36;      // LDS row stride in floats (144 B: 16-B aligned, conflict-free b128 reads)
 
-// device view of a FinDesc (fav_internal.h)
-struct FinArgs {
-    const float2* partials; const int* counts; const float* gamma; const float* beta;
-    int mblocks, M, bp, ppitch; float eps;
-};
-inline FinArgs fin_args(const FinDesc& f)
-{
-    FinArgs a;
-    a.partials = reinterpret_cast<const float2*>(f.partials); a.counts = f.counts; a.gamma = f.gamma; a.beta = f.beta;
-    a.mblocks = f.mblocks; a.M = f.M; a.bp = f.bp; a.ppitch = f.ppitch; a.eps = f.eps;
-    return a;
-}
-
-// InstanceNorm finalize inside the CONSUMING kernel's prologue (InstanceNormalization.lua:33-53: biased variance, eps inside
-// the sqrt).  Every block merges the producer's per-tile (mean, M2, count) partials of all C channels itself -- fp64, one
-// pass: var = (sum M2_b + sum n_b mean_b^2) / M - mean^2, all blocks in the same order, hence bit-identical across blocks --
-// and leaves scale = gamma / sqrt(var + eps), shift = beta - mean * scale in LDS; `publish` (one block) also stores them to
-// the stage's global buffers for later consumers.  Replaces a dependent 6 us launch + kernel boundary per normalisation.
-// C <= NT; `scratch` = 16 * NT bytes of LDS that is free at this point; ends with a barrier.
-template <int NT>
-__device__ __forceinline__ void in_finalize_block(const FinArgs& f, int C, float* sc_lds, float* sh_lds, float* sc_glob, float* sh_glob,
-                                                  double* scratch, bool publish)
-{
-    const int t = threadIdx.x;
-    const int P = NT / C;                       // tile subsets per channel
-    const int part = t / C, c = t - part * C;
-    double s1 = 0.0, s2 = 0.0;
-    if (part < P)
-        for (int b = part; b < f.mblocks; b += P) {
-            const float2 pr = f.partials[(size_t)b * f.ppitch + c];
-            const double n = f.counts ? (double)f.counts[b] : (double)min(f.bp, f.M - b * f.bp);
-            const double mu = (double)pr.x;
-            s1 += n * mu; s2 += (double)pr.y + n * mu * mu;
-        }
-    if (part < P) { scratch[2 * t] = s1; scratch[2 * t + 1] = s2; }
-    __syncthreads();
-    if (t < C) {
-        double a = 0.0, q = 0.0;
-        for (int k = 0; k < P; ++k) { a += scratch[2 * (k * C + t)]; q += scratch[2 * (k * C + t) + 1]; }
-        const double mean = a / (double)f.M;
-        double var = q / (double)f.M - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const double g = f.gamma ? (double)f.gamma[t] : 1.0, bt = f.beta ? (double)f.beta[t] : 0.0;
-        const double sc = g / sqrt(var + (double)f.eps);
-        const float scf = (float)sc, shf = (float)(bt - mean * sc);
-        sc_lds[t] = scf; sh_lds[t] = shf;
-        if (publish) { sc_glob[t] = scf; sh_glob[t] = shf; }
-    }
-    __syncthreads();
-}
-
-// fill the [4][CIN] transform table (scale1, shift1, scale2, shift2; identity for absent stages), finalising pending stages
-#define FAV_FILL_AFF(NT_, aff_, CIN_, P_, scratch_, pub_)                                                                \
-    {                                                                                                                   \
-        if ((P_).stages >= 1 && (P_).fin1.partials)                                                                     \
-            in_finalize_block<NT_>((P_).fin1, CIN_, aff_, aff_ + CIN_, const_cast<float*>((P_).scale1), const_cast<float*>((P_).shift1), scratch_, pub_); \
-        else for (int i = threadIdx.x; i < CIN_; i += NT_) { aff_[i] = (P_).stages >= 1 ? (P_).scale1[i] : 1.f; aff_[CIN_ + i] = (P_).stages >= 1 ? (P_).shift1[i] : 0.f; } \
-        if ((P_).stages >= 2 && (P_).fin2.partials)                                                                     \
-            in_finalize_block<NT_>((P_).fin2, CIN_, aff_ + 2 * CIN_, aff_ + 3 * CIN_, const_cast<float*>((P_).scale2), const_cast<float*>((P_).shift2), scratch_, pub_); \
-        else for (int i = threadIdx.x; i < CIN_; i += NT_) { aff_[2 * CIN_ + i] = (P_).stages >= 2 ? (P_).scale2[i] : 1.f; aff_[3 * CIN_ + i] = (P_).stages >= 2 ? (P_).shift2[i] : 0.f; } \
-    }
-
 struct ConvArgs {
     const float* in; const float* wgt; const float* bias;
     const float* scale1; const float* shift1; const float* scale2; const float* shift2;
-    FinArgs fin1, fin2;
     float* out; float2* partials; float* out_planar; float* out_raw;
     int IH, IW, IWp, ups, stuff, CIN;
     int COUT, COUTp, KH, KW, stride, pad, Kpad, OH, OW;
@@ -182,7 +119,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
 
     // transform tables: always two stages in the loop (identity = scale 1, shift 0, no ReLU floor), so the
     // K loop carries no data-dependent or uniform branches and the scheduler can interleave it with the MFMAs
-    FAV_FILL_AFF(NT, aff, CIN, p, reinterpret_cast<double*>(smem), blockIdx.x == 0 && blockIdx.y == 0);
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
     __syncthreads();
@@ -734,9 +674,6 @@ struct H3Args {
     int IH, IW, IWp, ups, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
     int stages, relu1, relu2;
     const unsigned short* wgt16;   // bf16 copy of the weights (fast mode) or null
-    FinArgs fin1, fin2;      // pending InstanceNorm finalize of stage 1 / 2 (partials == null: scale/shift are final)
-    const float* skip; const float* skip_sc; const float* skip_sh; int skip_relu; float* emit;   // lazy residual join (JOIN != 0)
-    int OWp;                 // output row pitch (pixels)
     int sk_wt;               // 1: publish partial tiles with write-through (sc1) stores; 0: plain stores + release fence
     long long* dbg;          // optional in-kernel timeline (FAV_H3_DBG), 24 slots per block
 };
@@ -755,10 +692,7 @@ struct H3Args {
 //   barrier: one per step, between groups 1 and 2 -- it publishes ring slot (s+1)%3 half a step before its first read
 //            and is never followed by a dependent LDS read (three slots make the write-after-read side safe)
 //   end    : the halo piece, transformed, -> the other halo buffer
-// JOIN: 0 = plain operand; 1 = lazy residual join, operand = pre(in) + skip; 2 = the skip carries one pending stage of its own
-// (the first block's skip is the IN+ReLU'd output of the last strided convolution).  With JOIN the joined halo values can
-// also be written out (p.emit): that tensor is the next residual block's skip, so no separate join pass ever runs.
-template <int BN, bool S2, int JOIN>
+template <int BN, bool S2>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
 {
     constexpr int NT = 512;
@@ -772,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                           // [2][HP][LDSS]
     float* Bs = Hs + 2 * HP * LDSS;             // [3][BN][LDSS]
-    float* aff = Bs + 3 * BN * LDSS;            // [6][CIN]: scale1, shift1, scale2, shift2, skip scale, skip shift
+    float* aff = Bs + 3 * BN * LDSS;            // [4][CIN]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int CIN = p.CIN;
@@ -787,11 +721,12 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    FAV_FILL_AFF(NT, aff, CIN, p, reinterpret_cast<double*>(Hs), blockIdx.x == 0);
-    if (JOIN == 2) for (int i = t; i < CIN; i += NT) { aff[4 * CIN + i] = p.skip_sc[i]; aff[5 * CIN + i] = p.skip_sh[i]; }
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
-    const float los = (JOIN == 2 && p.skip_relu) ? 0.f : -INFINITY;
     __syncthreads();
 
     const int c4 = t & 7, r0 = t >> 3;                      // staging: weight row r0 (+64) / halo pixel r0 (+64 i), 16-byte chunk c4
@@ -838,25 +773,17 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         const int c_first = (k0 * 21846) >> 16, ky0 = k0 - c_first * 3;      // k / 3
         const int c_last = ((k1 - 1) * 21846) >> 16;
 
-        float4 hr, hk; float hm; v4f rb[BROWS];
-        v4f sc1, sh1, sc2, sh2, ssc, ssh;   // IN/ReLU stages of the slice being staged (and of the skip), this thread's 4 channels
+        float4 hr; float hm; v4f rb[BROWS];
+        v4f sc1, sh1, sc2, sh2;             // IN/ReLU stages of the slice being staged, this thread's 4 channels
 #define H3_AFF(chunk_)                                                                              \
         { sc1 = *reinterpret_cast<const v4f*>(affr + (chunk_) * 32); sh1 = *reinterpret_cast<const v4f*>(affr + CIN + (chunk_) * 32); \
-          if (S2) { sc2 = *reinterpret_cast<const v4f*>(affr + 2 * CIN + (chunk_) * 32); sh2 = *reinterpret_cast<const v4f*>(affr + 3 * CIN + (chunk_) * 32); } \
-          if (JOIN == 2) { ssc = *reinterpret_cast<const v4f*>(affr + 4 * CIN + (chunk_) * 32); ssh = *reinterpret_cast<const v4f*>(affr + 5 * CIN + (chunk_) * 32); } }
-// operand value of one 16-byte halo piece: stages of the producer's pending transform, + the (transformed) skip, zero outside the image
-#define H3_XFORM(v_, k_, m_)                                                                        \
+          if (S2) { sc2 = *reinterpret_cast<const v4f*>(affr + 2 * CIN + (chunk_) * 32); sh2 = *reinterpret_cast<const v4f*>(affr + 3 * CIN + (chunk_) * 32); } }
+#define H3_XFORM(v_, m_)                                                                            \
         { v_.x = fmaxf(fmaf(v_.x, sc1.x, sh1.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc1.y, sh1.y), lo1);  \
           v_.z = fmaxf(fmaf(v_.z, sc1.z, sh1.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc1.w, sh1.w), lo1);  \
           if (S2) { v_.x = fmaxf(fmaf(v_.x, sc2.x, sh2.x), lo2); v_.y = fmaxf(fmaf(v_.y, sc2.y, sh2.y), lo2); \
                     v_.z = fmaxf(fmaf(v_.z, sc2.z, sh2.z), lo2); v_.w = fmaxf(fmaf(v_.w, sc2.w, sh2.w), lo2); } \
-          if (JOIN == 2) { k_.x = fmaxf(fmaf(k_.x, ssc.x, ssh.x), los); k_.y = fmaxf(fmaf(k_.y, ssc.y, ssh.y), los); \
-                           k_.z = fmaxf(fmaf(k_.z, ssc.z, ssh.z), los); k_.w = fmaxf(fmaf(k_.w, ssc.w, ssh.w), los); } \
-          if (JOIN) { v_.x += k_.x; v_.y += k_.y; v_.z += k_.z; v_.w += k_.w; }                     \
           v_.x *= m_; v_.y *= m_; v_.z *= m_; v_.w *= m_; }
-// the joined values of a valid piece -> p.emit (same geometry as p.in: same byte offset)
-#define H3_EMIT(base_, off_, v_, m_)                                                                \
-        { if (JOIN && (base_) != nullptr && (m_) != 0.f) *reinterpret_cast<float4*>((base_) + (off_)) = v_; }
 #define H3_HLDS(i_) ((i_) == NHV - 1 ? hst_last : 64 * (i_) * LDSS)
 #define H3_LOAD_B(src_)                                                                             \
         { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) rb[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(src_) + (wofs + j * wrow64)); }
@@ -866,27 +793,22 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         {
             // prologue: this slice's whole halo -> buffer 0; the pieces of the next slice that the skipped tap rows would
             // have staged -> buffer 1; all loads in flight before the first store
-            const int cnx = min(c_first + 1, c_last);
             const char* in0 = reinterpret_cast<const char*>(p.in + c_first * 32);
-            const char* in1 = reinterpret_cast<const char*>(p.in + cnx * 32);
-            const char* sk0 = reinterpret_cast<const char*>(p.skip + c_first * 32);
-            const char* sk1 = reinterpret_cast<const char*>(p.skip + cnx * 32);
-            char* em0 = p.emit ? reinterpret_cast<char*>(p.emit + c_first * 32) : nullptr;
-            char* em1 = p.emit ? reinterpret_cast<char*>(p.emit + cnx * 32) : nullptr;
-            float4 q0[NHV], q1[NHV], j0[NHV], j1[NHV];
+            const char* in1 = reinterpret_cast<const char*>(p.in + min(c_first + 1, c_last) * 32);
+            float4 q0[NHV], q1[NHV];
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) { q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]); if (JOIN) j0[i] = *reinterpret_cast<const float4*>(sk0 + hoff[i]); }
+            for (int i = 0; i < NHV; ++i) q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]);
             H3_LOAD_B(p.wgt + k0 * 3 * BK);
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) { q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]); if (JOIN) j1[i] = *reinterpret_cast<const float4*>(sk1 + hoff[i]); }
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) q1[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
             H3_AFF(c_first);
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) { H3_XFORM(q0[i], j0[i], hmask[i]); *reinterpret_cast<float4*>(hst + H3_HLDS(i)) = q0[i]; H3_EMIT(em0, hoff[i], q0[i], hmask[i]); }
+            for (int i = 0; i < NHV; ++i) { H3_XFORM(q0[i], hmask[i]); *reinterpret_cast<float4*>(hst + H3_HLDS(i)) = q0[i]; }
             H3_STORE_B(0);
             H3_LOAD_B(p.wgt + min(k0 * 3 + 1, nsteps - 1) * BK);
-            H3_AFF(cnx);
+            H3_AFF(min(c_first + 1, c_last));
 #pragma unroll
-            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) { H3_XFORM(q1[i], j1[i], hmask[i]); *reinterpret_cast<float4*>(hst + HP * LDSS + H3_HLDS(i)) = q1[i]; H3_EMIT(em1, hoff[i], q1[i], hmask[i]); }
+            for (int i = 0; i < NHV; ++i) if (i < 2 * ky0) { H3_XFORM(q1[i], hmask[i]); *reinterpret_cast<float4*>(hst + HP * LDSS + H3_HLDS(i)) = q1[i]; }
         }
         f32x16 acc[TN];
 #pragma unroll
@@ -915,15 +837,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             H3_FRAG(1, a_cu + (KX) * LDSS + 8, bfr + (KX) * BN * LDSS + 8);                         \
             H3_STORE_B(NB);                                                                         \
             H3_LOAD_B(p.wgt + min(sg + (KX) + 2, nsteps - 1) * BK);                                 \
-            if ((KX) < 2) { hr = *reinterpret_cast<const float4*>(in_n + ((KX) == 0 ? ho0 : ho1)); hm = (KX) == 0 ? hm0 : hm1;      \
-                            if (JOIN) hk = *reinterpret_cast<const float4*>(sk_n + ((KX) == 0 ? ho0 : ho1)); }                   \
+            if ((KX) < 2) { hr = *reinterpret_cast<const float4*>(in_n + ((KX) == 0 ? ho0 : ho1)); hm = (KX) == 0 ? hm0 : hm1; } \
             H3_MFMA(0); H3_GROUP(1 + TN);                                                           \
             H3_FRAG(0, a_cu + (KX) * LDSS + 16, bfr + (KX) * BN * LDSS + 16); H3_MFMA(1); H3_GROUP(1 + TN); \
             __syncthreads();                                                                        \
             H3_FRAG(1, a_cu + (KX) * LDSS + 24, bfr + (KX) * BN * LDSS + 24); H3_MFMA(0); H3_GROUP(1 + TN); \
             H3_FRAG(0, an_, bfr + NB * BN * LDSS);                                                  \
-            if ((KX) < 2) { H3_XFORM(hr, hk, hm); *reinterpret_cast<float4*>(h_nx + ((KX) == 0 ? hl0 : hl1)) = hr;             \
-                            H3_EMIT(em_n, (KX) == 0 ? ho0 : ho1, hr, hm); }                                                    \
+            if ((KX) < 2) { H3_XFORM(hr, hm); *reinterpret_cast<float4*>(h_nx + ((KX) == 0 ? hl0 : hl1)) = hr; } \
             H3_MFMA(1); H3_GROUP(1 + TN);                                                           \
         }
 
@@ -937,8 +857,6 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
             float* h_nx = hst + (par ^ 1) * (HP * LDSS);
             const int cn = min(c + 1, c_last);                              // no next slice: the pieces land in the unused buffer
             const char* in_n = reinterpret_cast<const char*>(p.in + cn * 32);
-            const char* sk_n = reinterpret_cast<const char*>(p.skip + cn * 32);
-            char* em_n = p.emit ? reinterpret_cast<char*>(p.emit + cn * 32) : nullptr;
             const int sg = uu * 3;
             // the two halo pieces of this unit: 2*ky and 2*ky + 1 (uniform selects)
             const int ho0 = ky == 0 ? hoff[0] : (ky == 1 ? hoff[2] : hoff[4]), ho1 = ky == 0 ? hoff[1] : (ky == 1 ? hoff[3] : hoff[5]);
@@ -953,7 +871,6 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         if (p.dbg && t == 0 && k1 - k0 > 6) { p.dbg[blockIdx.x * 24 + 21] = clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] = wall_clock64() - wk0; p.dbg[blockIdx.x * 24 + 20] = (k1 - k0) * 3; }
 #undef H3_AFF
 #undef H3_XFORM
-#undef H3_EMIT
 #undef H3_HLDS
 #undef H3_LOAD_B
 #undef H3_STORE_B
@@ -1038,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                 const float v = acc[j][r] + bv;
                 acc[j][r] = v;
                 if (oy < p.OH && ox < p.OW) {
-                    if (n < p.COUT) p.out[((size_t)oy * p.OWp + ox) * p.COUT + n] = v;
+                    if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
                     sm += v;
                 }
             }
@@ -1346,7 +1263,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_bf16_kernel(const H3Args p)
                 const float v = acc[j][r] + bv;
                 acc[j][r] = v;
                 if (oy < p.OH && ox < p.OW) {
-                    if (n < p.COUT) p.out[((size_t)oy * p.OWp + ox) * p.COUT + n] = v;
+                    if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
                     sm += v;
                 }
             }
@@ -1427,12 +1344,12 @@ static void h3_debug_report(const long long* h, int grid)
             sum[0] / grid, sum[1] / grid, sum[2] / grid, sum[3] / grid, tend);
 }
 
-template <int BN, bool S2, bool BF, int JOIN = 0>
+template <int BN, bool S2, bool BF>
 static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t st)
 {
-    const auto kern = BF ? conv3_halo_bf16_kernel<BN, S2> : conv3_halo_kernel<BN, S2, JOIN>;
+    const auto kern = BF ? conv3_halo_bf16_kernel<BN, S2> : conv3_halo_kernel<BN, S2>;
     const size_t lds = BF ? (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * 40 + 3 * BN * 40) * 2 + (size_t)4 * cin * sizeof(float)
-                          : (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 6 * cin) * sizeof(float);
+                          : (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * LDSS + 3 * BN * LDSS + 4 * cin) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
@@ -1450,7 +1367,7 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t s
     H3Args a = a0; a.dbg = nullptr;
     static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;
-    const bool dbg = dbg_n > 0 && BN == 128 && !BF && JOIN == 0 && --dbg_n == 0;
+    const bool dbg = dbg_n > 0 && BN == 128 && !BF && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), SK_GRID * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, SK_GRID * 24 * 8, st)); a.dbg = dbuf; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_halo_kernel");
@@ -1476,15 +1393,6 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
     a.tiles_x = (c.OW + H3_TW - 1) / H3_TW; a.tiles_y = (c.OH + H3_TH - 1) / H3_TH;
-    a.OWp = c.OWp > 0 ? c.OWp : c.OW;
-    FAV_REQUIRE(a.OWp >= c.OW, "halo conv: output pitch %d < width %d", a.OWp, c.OW);
-    a.fin1 = fin_args(c.pre.fin1); a.fin2 = fin_args(c.pre.fin2);
-    a.skip = c.join_skip; a.emit = c.join_emit; a.skip_sc = c.join_t.scale1; a.skip_sh = c.join_t.shift1; a.skip_relu = c.join_t.relu1;
-    const int join = c.join_skip ? (c.join_t.stages >= 1 ? 2 : 1) : 0;
-    FAV_REQUIRE(!join || (c.wgt16 == nullptr && c.ups == 0 && c.pre.stages == 1 && c.join_t.stages <= 1 && c.join_t.fin1.partials == nullptr && c.COUTp == 128),
-                "halo conv: unsupported lazy join (needs fp32 mode, no upsampling, a one-stage branch transform, a final skip transform, 128 output channels)");
-    FAV_REQUIRE(c.wgt16 == nullptr || (c.pre.fin1.partials == nullptr && c.pre.fin2.partials == nullptr), "halo conv (bf16 mode): pending finalize is not supported");
-    FAV_REQUIRE(c.CIN <= 512, "halo conv: too many input channels for the in-kernel finalize");
     const bool s2 = c.pre.stages >= 2;
     a.wgt16 = c.wgt16;
     static const int sk_wt = getenv("FAV_SK_WT") ? atoi(getenv("FAV_SK_WT")) : 1;      // (A/B switch, read once)
@@ -1493,8 +1401,6 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
         if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, st);
         return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, st);
     }
-    if (join == 1) return launch_h3_t<128, false, false, 1>(a, c.CIN, c.reserve_cus, st);
-    if (join == 2) return launch_h3_t<128, false, false, 2>(a, c.CIN, c.reserve_cus, st);
     if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, false>(a, c.CIN, c.reserve_cus, st);
     return s2 ? launch_h3_t<64, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, false>(a, c.CIN, c.reserve_cus, st);
 }
@@ -1717,9 +1623,6 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.in = c.in; a.wgt = c.wgt; a.bias = c.bias;
     a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
     a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
-    a.fin1 = fin_args(c.pre.fin1); a.fin2 = fin_args(c.pre.fin2);
-    FAV_REQUIRE(c.join_skip == nullptr && (c.OWp == 0 || c.OWp == c.OW), "conv: lazy joins / pitched outputs need the halo-resident kernel");
-    FAV_REQUIRE((c.pre.fin1.partials == nullptr && c.pre.fin2.partials == nullptr) || c.CIN <= 256, "conv: too many input channels for the in-kernel finalize");
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials);
     a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.stuff = c.stuff ? 1 : 0; a.CIN = c.CIN;
@@ -1822,7 +1725,7 @@ __device__ __forceinline__ float4 apply_affine_g(float4 v, const Affine& a, int 
 }
 
 // statistics of t(x) over [M][C]: one block per 128 pixels, two passes (mean, then M2) over the tile
-__global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int W, int pitch, int C, const Affine a, float2* partials)
+__global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C, const Affine a, float2* partials)
 {
     __shared__ float red[1024];
     __shared__ float mean_s[1024];
@@ -1836,8 +1739,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int W
     float4 s = make_float4(0, 0, 0, 0);
     if (active)
         for (int pix = pl; pix < cnt; pix += nl) {
-            const int m = m0 + pix, row = m / W;
-            float4 v = *reinterpret_cast<const float4*>(x + ((size_t)row * pitch + (m - row * W)) * C + 4 * g);
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
             v = apply_affine_g(v, a, 4 * g);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -1853,8 +1755,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int W
     if (active) {
         const float4 mu = *reinterpret_cast<const float4*>(mean_s + 4 * g);
         for (int pix = pl; pix < cnt; pix += nl) {
-            const int m = m0 + pix, row = m / W;
-            float4 v = *reinterpret_cast<const float4*>(x + ((size_t)row * pitch + (m - row * W)) * C + 4 * g);
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
             v = apply_affine_g(v, a, 4 * g);
             const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
             q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
@@ -1869,13 +1770,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int W
     }
 }
 
-// residual join: nn.CAddTable of (IN(conv_b) , ShaveImage(skip))  -- models_video.lua:41-53.  Only joins that no halo-resident
-// convolution can evaluate lazily run here (the last block's, whose result feeds an InstanceNorm through an upsample: STATS
-// then also yields that norm's partial statistics; and the fallbacks).  One block = one row segment of up to 128 pixels.
+// residual join: nn.CAddTable of (IN(conv_b) , ShaveImage(skip))  -- models_video.lua:41-53.  One block = one row segment of up
+// to 128 pixels.  STATS: the join feeds an InstanceNorm (directly or through a nearest upsample, which leaves mean and biased
+// variance unchanged: the R128 -> U2 -> IN tail of models_video.lua:94-98): the same pass yields that norm's per-segment
+// (mean, M2, count) partials instead of a second read-only pass over the joined tensor.
 template <bool STATS>
-__global__ __launch_bounds__(256) void res_add_kernel(const float* y, int ypitch, const float* scale, const float* shift,
-                                                      const float* skip, int spitch, int shave, const Affine sa,
-                                                      int OW, int C, float* z, int zpitch, float2* partials, int* counts)
+__global__ __launch_bounds__(256) void res_add_kernel(const float* y, const float* scale, const float* shift,
+                                                      const float* skip, int SW, int shave, const Affine sa,
+                                                      int OW, int C, float* z, float2* partials, int* counts)
 {
     __shared__ float red[1024];
     __shared__ float mean_s[1024];
@@ -1886,9 +1788,9 @@ __global__ __launch_bounds__(256) void res_add_kernel(const float* y, int ypitch
     const int oy = blockIdx.x / segs, x0 = (blockIdx.x - oy * segs) * 128;
     const int cnt = min(128, OW - x0);
     const bool active = pl < nl;
-    const float* yr = y + ((size_t)oy * ypitch + x0) * C + 4 * g;
-    const float* kr = skip + ((size_t)(oy + shave) * spitch + x0 + shave) * C + 4 * g;
-    float* zr = z + ((size_t)oy * zpitch + x0) * C + 4 * g;
+    const float* yr = y + ((size_t)oy * OW + x0) * C + 4 * g;
+    const float* kr = skip + ((size_t)(oy + shave) * SW + x0 + shave) * C + 4 * g;
+    float* zr = z + ((size_t)oy * OW + x0) * C + 4 * g;
     float4 sm = make_float4(0, 0, 0, 0);
     if (active)
         for (int px = pl; px < cnt; px += nl) {
@@ -1979,28 +1881,26 @@ int launch_in_finalize(const float* partials, const int* counts, int mblocks, in
     return FAV_OK;
 }
 
-int launch_stats(const float* x, int H, int W, int pitch, int C, const Affine& t, float* partials, hipStream_t st)
+int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st)
 {
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "stats: unsupported channel count %d", C);
-    FAV_REQUIRE(t.fin1.partials == nullptr && t.fin2.partials == nullptr, "stats: the transform must be final");
-    const int M = H * W;
-    hipLaunchKernelGGL(stats_kernel, dim3((M + 127) / 128), dim3(256), 0, st, x, M, W, pitch, C, t,
+    hipLaunchKernelGGL(stats_kernel, dim3((M + 127) / 128), dim3(256), 0, st, x, M, C, t,
                        reinterpret_cast<float2*>(partials));
     FAV_LAUNCH_CHECK("stats_kernel");
     return FAV_OK;
 }
 
-int launch_res_add(const float* y, int ypitch, const float* scale, const float* shift, const float* skip, int spitch, int shave,
-                   const Affine& skip_t, int OH, int OW, int C, float* z, int zpitch, float* partials, int* counts, hipStream_t st)
+int launch_res_add(const float* y, const float* scale, const float* shift, const float* skip, int SH, int SW,
+                   int shave, const Affine& skip_t, int C, float* z, float* partials, int* counts, hipStream_t st)
 {
+    const int OH = SH - 2 * shave, OW = SW - 2 * shave;
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && OH > 0 && OW > 0, "res_add: bad shape (C=%d)", C);
-    FAV_REQUIRE(skip_t.fin1.partials == nullptr && skip_t.fin2.partials == nullptr, "res_add: the skip transform must be final");
     const dim3 grid(res_add_stat_blocks(OH, OW));
     if (partials)
-        hipLaunchKernelGGL(res_add_kernel<true>, grid, dim3(256), 0, st, y, ypitch, scale, shift, skip, spitch, shave, skip_t, OW, C, z, zpitch,
+        hipLaunchKernelGGL(res_add_kernel<true>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
                            reinterpret_cast<float2*>(partials), counts);
     else
-        hipLaunchKernelGGL(res_add_kernel<false>, grid, dim3(256), 0, st, y, ypitch, scale, shift, skip, spitch, shave, skip_t, OW, C, z, zpitch,
+        hipLaunchKernelGGL(res_add_kernel<false>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
                            static_cast<float2*>(nullptr), static_cast<int*>(nullptr));
     FAV_LAUNCH_CHECK("res_add_kernel");
     return FAV_OK;

@@ -32,19 +32,12 @@ struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nul
 struct Act {
     float* data = nullptr;
     int Hp = 0, Wp = 0;          // physical size
-    int pitch = 0;               // row pitch in pixels (>= Wp): the residual stage keeps one pitch so that a branch output and its
-                                 // shaved skip differ by a constant offset (lazy join in the next convolution's gather)
     int C = 0;                   // channel pitch
     int ups = 0;                 // pending nearest upsample (log2)
     Affine pre;                  // pending per-channel transform
     float* partials = nullptr;   // (mean, M2) tiles of the raw tensor from the producing conv, or null
     int mblocks = 0, ppitch = 0;
     int* counts = nullptr;       // per-partial pixel counts (first-layer kernel) or null
-    int pblock = 0;              // pixels per partial when counts == null
-    // lazy residual join (models_video.lua:41-53): value = pre(data) + jskip_t(jskip); jskip already points at the shaved origin
-    // and has this tensor's pitch and channel count
-    const float* jskip = nullptr; Affine jskip_t;
-    bool lazy() const { return jskip != nullptr; }
     int H() const { return Hp << ups; }
     int W() const { return Wp << ups; }
 };
@@ -81,16 +74,12 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_lazy_join, no_defer_fin; };
+struct Tuning { bool no_fold, no_c8, no_h3; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr,
-                             getenv("FAV_NO_LAZY_JOIN") != nullptr, getenv("FAV_NO_DEFER_FIN") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr};
     return t;
 }
-// in-kernel InstanceNorm finalize: every consuming block walks mblocks * C / threads partials; beyond this it is cheaper to
-// run the (single) finalize kernel
-constexpr long long DEFER_FIN_MAX_WORK = 160;
 
 bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul)
 {
@@ -119,8 +108,6 @@ struct fav_net {
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
-    std::vector<char> in_final;     // per normalisation (ins[]): scale/shift buffers are final in stream order (this forward)
-    float* pending_emit = nullptr;  // buffer the next (lazily joining) convolution writes the joined tensor to, or null
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -146,9 +133,6 @@ struct fav_net {
     int upload();
     int alloc(size_t bytes, float** out);
     int timed_conv(const ConvLaunch& c, int conv_index, const Layer& L);
-    int resolve(Affine& a, int C, bool capable, int threads);
-    bool lazy_consumable(const Act& a, const Layer& L) const;
-    int materialize(Act& a, const DevIN* stats_for, const Layer* in_layer, int in_index);
     int run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw);
     int forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     void out_size(int H, int W, int* Ho, int* Wo) const;
@@ -292,63 +276,6 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     return rc;
 }
 
-// Make the stages of a pending transform usable by its consumer.  A stage whose InstanceNorm is not finalised yet either stays
-// pending (the consuming kernel merges the partials in its prologue and publishes scale/shift: `capable`, small enough) or is
-// finalised now by the stand-alone kernel.
-int fav_net::resolve(Affine& a, int C, bool capable, int threads)
-{
-    for (int k = 1; k <= 2; ++k) {
-        FinDesc& f = k == 1 ? a.fin1 : a.fin2;
-        const int idx = k == 1 ? a.in1 : a.in2;
-        if (!f.partials) continue;
-        if (idx >= 0 && in_final[idx]) { f = FinDesc(); continue; }            // another consumer already did it (stream order)
-        const bool defer = capable && !tuning().no_defer_fin && C <= threads && (long long)f.mblocks * C <= DEFER_FIN_MAX_WORK * threads;
-        if (!defer) {
-            float* sc = const_cast<float*>(k == 1 ? a.scale1 : a.scale2); float* sh = const_cast<float*>(k == 1 ? a.shift1 : a.shift2);
-            int rc = launch_in_finalize(f.partials, f.counts, f.mblocks, f.M, f.bp, C, f.ppitch, f.gamma, f.beta, f.eps, sc, sh, st);
-            if (rc) return rc;
-            f = FinDesc();
-        }
-        if (idx >= 0) in_final[idx] = 1;          // final once the consumer about to be launched has run
-    }
-    return FAV_OK;
-}
-
-// can the convolution `L` evaluate the lazy join `a` while it gathers its operand? (halo-resident fp32 kernel, 128 channels)
-bool fav_net::lazy_consumable(const Act& a, const Layer& L) const
-{
-    return a.lazy() && L.type == L_CONV && !L.transposed && precision == 0 && !tuning().no_h3 && a.ups == 0 && a.pre.stages == 1 && !a.pre.relu1 &&
-           a.jskip_t.stages <= 1 && L.cin == a.C && conv3_halo_eligible(a.C, (L.cout + 31) / 32 * 32, L.k, L.stride) && (L.cout + 31) / 32 * 32 == 128;
-}
-
-// evaluate a lazy join with the stand-alone kernel (dense result).  in_layer != null: an InstanceNorm follows (possibly through
-// a nearest upsample, which leaves mean and biased variance unchanged): the same pass yields its partial statistics and the
-// norm becomes the tensor's pending stage 1.
-int fav_net::materialize(Act& a, const DevIN* stats_for, const Layer* in_layer, int in_index)
-{
-    int rc = resolve(a.pre, a.C, false, 0); if (rc) return rc;
-    rc = resolve(a.jskip_t, a.C, false, 0); if (rc) return rc;
-    Act z; z.Hp = a.Hp; z.Wp = a.Wp; z.pitch = a.Wp; z.C = a.C; z.ups = a.ups;
-    rc = alloc((size_t)z.Hp * z.Wp * z.C * sizeof(float), &z.data); if (rc) return rc;
-    float* part = nullptr; int* cnts = nullptr;
-    const int nb = res_add_stat_blocks(z.Hp, z.Wp);
-    if (stats_for) {
-        rc = alloc((size_t)nb * z.C * 2 * sizeof(float), &part); if (rc) return rc;
-        float* cp = nullptr; rc = alloc((size_t)nb * sizeof(int), &cp); if (rc) return rc; cnts = reinterpret_cast<int*>(cp);
-    }
-    // the skip pointer already includes the shave offset: shave 0 here
-    rc = launch_res_add(a.data, a.pitch, a.pre.scale1, a.pre.shift1, a.jskip, a.pitch, 0, a.jskip_t, z.Hp, z.Wp, z.C, z.data, z.pitch, part, cnts, st);
-    if (rc) return rc;
-    if (stats_for) {
-        z.pre.scale1 = stats_for->scale; z.pre.shift1 = stats_for->shift; z.pre.relu1 = 0; z.pre.stages = 1; z.pre.in1 = in_index;
-        FinDesc f; f.partials = part; f.counts = cnts; f.gamma = stats_for->gamma; f.beta = stats_for->beta; f.mblocks = nb; f.M = z.Hp * z.Wp;
-        f.bp = 0; f.ppitch = z.C; f.eps = in_layer->eps;
-        z.pre.fin1 = f; in_final[in_index] = 0;
-    }
-    a = z;
-    return FAV_OK;
-}
-
 int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw)
 {
     for (size_t li = 0; li < ls.size(); ++li) {
@@ -358,10 +285,9 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
         case L_CONV: {
             const DevConvW& d = convs[conv_cursor++];
             if (cur.C != d.cinp) { set_error("internal: channel pitch mismatch (%d vs %d)", cur.C, d.cinp); return FAV_EINVAL; }
-            const bool join = lazy_consumable(cur, L);
-            if (cur.lazy() && !join) { int rc = materialize(cur, nullptr, nullptr, -1); if (rc) return rc; }
             ConvLaunch c;
-            c.in = cur.data; c.IH = cur.H(); c.IW = cur.W(); c.IWp = cur.pitch; c.ups = cur.ups; c.CIN = d.cinp;
+            c.in = cur.data; c.IH = cur.H(); c.IW = cur.W(); c.IWp = cur.Wp; c.ups = cur.ups; c.CIN = d.cinp;
+            c.pre = cur.pre;
             c.wgt = d.wgt; c.bias = d.bias; c.COUT = L.cout; c.COUTp = d.coutp; c.KH = c.KW = L.k; c.stride = L.stride;
             c.pad = L.pad; c.Kpad = d.kpad;
             if (L.transposed) {
@@ -377,36 +303,20 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             bool has_tanh = false; float mul = 1.f;
             const bool is_final = top && only_tail(ls, li + 1, has_tanh, mul) && has_tanh && L.cout == 3;
             Act nxt;
-            nxt.Hp = c.OH; nxt.Wp = c.OW; nxt.pitch = c.OW; nxt.C = L.cout;
+            nxt.Hp = c.OH; nxt.Wp = c.OW; nxt.C = L.cout;
             if (is_final && L.transposed) { set_error("network: a transposed convolution as the last layer is unsupported"); return FAV_EUNSUPPORTED; }
             if (is_final) {
-                // row-folded / generic last layer: no in-kernel finalize there
-                int rc = resolve(cur.pre, cur.C, false, 0); if (rc) return rc;
-                c.pre = cur.pre;
                 c.final_mode = 1; c.tanh_mul = mul; c.out_planar = out_planar; c.out_raw_nchw = out_raw;
-                rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
+                int rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
                 cur = nxt;
                 return FAV_OK;        // Tanh / MulConstant / TotalVariation are folded into the epilogue
             }
             if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
+            int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
             const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
             const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
-            // stride-1 halo convolutions keep their input's row pitch (see Act::pitch)
-            if (h3 && cur.ups == 0 && cur.pitch >= c.OW) nxt.pitch = cur.pitch;
-            c.OWp = nxt.pitch;
-            int rc = alloc((size_t)c.OH * nxt.pitch * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
-            // pending transform of the operand: stages whose InstanceNorm is not finalised yet are merged by the kernel itself
-            // (halo fp32 / generic kernels) or by the stand-alone kernel
-            const bool fin_capable = !c8 && !(h3 && precision == 1);
-            rc = resolve(cur.pre, cur.C, fin_capable, h3 ? 512 : 256); if (rc) return rc;
-            c.pre = cur.pre;
-            if (join) {
-                rc = resolve(cur.jskip_t, cur.C, false, 0); if (rc) return rc;
-                c.join_skip = cur.jskip; c.join_t = cur.jskip_t; c.join_emit = pending_emit; pending_emit = nullptr;
-            }
             nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW)); nxt.ppitch = d.coutp;
-            nxt.pblock = CONV_BM;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
@@ -418,24 +328,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             break;
         }
         case L_IN: {
-            const int in_index = (int)in_cursor;
             const DevIN& d = ins[in_cursor++];
             const int C = (int)L.gamma.size();
             const int M = cur.Hp * cur.Wp;
             if (cur.data == nullptr || C != cur.C) { set_error("network: misplaced InstanceNormalization"); return FAV_EUNSUPPORTED; }
-            if (cur.lazy()) {
-                // a residual join feeding a normalisation (the R128 -> U2 -> IN of models_video.lua:94-98): one pass evaluates
-                // the join and the statistics of its result
-                if (cur.pre.stages != 1) { set_error("network: unsupported transform before InstanceNormalization"); return FAV_EUNSUPPORTED; }
-                int rc = materialize(cur, &d, &L, in_index); if (rc) return rc;
-                break;
-            }
             if (cur.partials != nullptr && cur.pre.stages == 0) {
-                // statistics came with the producing convolution: the finalize is left to the consumer (fav_net::resolve)
-                FinDesc f; f.partials = cur.partials; f.counts = cur.counts; f.gamma = d.gamma; f.beta = d.beta; f.mblocks = cur.mblocks; f.M = M;
-                f.bp = cur.pblock; f.ppitch = cur.ppitch; f.eps = L.eps;
-                cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; cur.pre.fin1 = f; cur.pre.in1 = in_index;
-                in_final[in_index] = 0;
+                int rc = launch_in_finalize(cur.partials, cur.counts, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
+                                            d.scale, d.shift, st);
+                if (rc) return rc;
+                cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1;
             } else {
                 if (cur.pre.stages >= 2) { set_error("network: more than two stacked normalisations on one tensor are unsupported"); return FAV_EUNSUPPORTED; }
                 // statistics of the pending-transformed tensor (nearest upsampling replicates every
@@ -443,18 +344,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 float* part = nullptr;
                 const int mb = (M + 127) / 128;
                 int rc = alloc((size_t)mb * C * 2 * sizeof(float), &part); if (rc) return rc;
-                rc = resolve(cur.pre, C, false, 0); if (rc) return rc;
-                rc = launch_stats(cur.data, cur.Hp, cur.Wp, cur.pitch, C, cur.pre, part, st); if (rc) return rc;
-                FinDesc f; f.partials = part; f.counts = nullptr; f.gamma = d.gamma; f.beta = d.beta; f.mblocks = mb; f.M = M; f.bp = 128; f.ppitch = C; f.eps = L.eps;
-                if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; cur.pre.fin1 = f; cur.pre.in1 = in_index; }
-                else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; cur.pre.fin2 = f; cur.pre.in2 = in_index; }
-                in_final[in_index] = 0;
+                rc = launch_stats(cur.data, M, C, cur.pre, part, st); if (rc) return rc;
+                rc = launch_in_finalize(part, nullptr, mb, M, 128, C, C, d.gamma, d.beta, L.eps, d.scale, d.shift, st); if (rc) return rc;
+                if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
+                else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             }
             cur.partials = nullptr; cur.counts = nullptr;
             break;
         }
         case L_BN: {
-            if (cur.lazy()) { int rc = materialize(cur, nullptr, nullptr, -1); if (rc) return rc; }
             const DevIN& d = ins[in_cursor++];
             if (cur.data == nullptr || (int)L.mean.size() != cur.C) { set_error("network: misplaced SpatialBatchNormalization"); return FAV_EUNSUPPORTED; }
             if (cur.pre.stages >= 2) { set_error("network: more than two stacked normalisations on one tensor are unsupported"); return FAV_EUNSUPPORTED; }
@@ -464,7 +362,6 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             break;
         }
         case L_RELU:
-            if (cur.lazy()) { int rc = materialize(cur, nullptr, nullptr, -1); if (rc) return rc; }
             if (cur.pre.stages == 0) { cur.pre.scale1 = ones; cur.pre.shift1 = zeros; cur.pre.relu1 = 1; cur.pre.stages = 1; }
             else if (cur.pre.stages == 1) cur.pre.relu1 = 1;
             else cur.pre.relu2 = 1;
@@ -476,45 +373,30 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             break;
         case L_RES: {
             if (cur.ups != 0) { set_error("network: residual block directly after an upsampling is unsupported"); return FAV_EUNSUPPORTED; }
-            // The block's input may itself be a lazy join (the previous block's output).  If the branch's first convolution can
-            // evaluate it while gathering, it also writes the joined tensor out (pending_emit): that buffer is this block's skip.
-            float* emitted = nullptr;
-            if (cur.lazy()) {
-                if (!L.block.empty() && lazy_consumable(cur, L.block[0])) {
-                    int rc = alloc((size_t)cur.Hp * cur.pitch * cur.C * sizeof(float), &emitted); if (rc) return rc;
-                    pending_emit = emitted;
-                } else { int rc = materialize(cur, nullptr, nullptr, -1); if (rc) return rc; }
-            }
             Act skip = cur;
             Act br = cur;
             br.partials = nullptr;
             int rc = run(L.block, br, false, nullptr, nullptr); if (rc) return rc;
-            if (emitted) {
-                if (pending_emit != nullptr) { set_error("internal: the lazy join was not consumed"); return FAV_EINVAL; }
-                skip.data = emitted; skip.pre = Affine(); skip.jskip = nullptr; skip.jskip_t = Affine();       // materialised by that convolution
-            }
-            if (br.lazy()) { rc = materialize(br, nullptr, nullptr, -1); if (rc) return rc; }
             if (br.pre.stages != 1 || br.pre.relu1 || br.ups != 0) { set_error("network: residual branch must end in conv + InstanceNormalization"); return FAV_EUNSUPPORTED; }
             if (br.Hp != skip.Hp - 2 * L.shave || br.Wp != skip.Wp - 2 * L.shave || br.C != skip.C) {
                 set_error("network: residual branch output %dx%d does not match the shaved skip %dx%d", br.Wp, br.Hp,
                           skip.Wp - 2 * L.shave, skip.Hp - 2 * L.shave);
                 return FAV_EUNSUPPORTED; }
-            if (!tuning().no_lazy_join && precision == 0 && br.pitch == skip.pitch && skip.pre.stages <= 1) {
-                // lazy: nothing runs here; the next consumer adds the shaved skip while it loads the branch
-                Act z = br;
-                z.partials = nullptr; z.counts = nullptr;
-                z.jskip = skip.data + ((size_t)L.shave * skip.pitch + L.shave) * skip.C; z.jskip_t = skip.pre;
-                cur = z;
-            } else {
-                rc = resolve(br.pre, br.C, false, 0); if (rc) return rc;
-                rc = resolve(skip.pre, skip.C, false, 0); if (rc) return rc;
-                Act z; z.Hp = br.Hp; z.Wp = br.Wp; z.pitch = br.Wp; z.C = br.C;
-                rc = alloc((size_t)z.Hp * z.Wp * z.C * sizeof(float), &z.data); if (rc) return rc;
-                rc = launch_res_add(br.data, br.pitch, br.pre.scale1, br.pre.shift1, skip.data, skip.pitch, L.shave, skip.pre, z.Hp, z.Wp, z.C,
-                                    z.data, z.pitch, nullptr, nullptr, st);
-                if (rc) return rc;
-                cur = z;
+            Act z; z.Hp = br.Hp; z.Wp = br.Wp; z.C = br.C;
+            rc = alloc((size_t)z.Hp * z.Wp * z.C * sizeof(float), &z.data); if (rc) return rc;
+            // the join feeds an InstanceNorm (directly, or through the x2 nearest upsample of models_video.lua:94-98, which leaves
+            // mean and biased variance unchanged): take that norm's statistics in the same pass
+            size_t nx = li + 1;
+            if (nx < ls.size() && ls[nx].type == L_UP && ls[nx].scale == 2) ++nx;
+            if (nx < ls.size() && ls[nx].type == L_IN) {
+                z.mblocks = res_add_stat_blocks(z.Hp, z.Wp); z.ppitch = z.C;
+                rc = alloc((size_t)z.mblocks * z.C * 2 * sizeof(float), &z.partials); if (rc) return rc;
+                float* cp = nullptr; rc = alloc((size_t)z.mblocks * sizeof(int), &cp); if (rc) return rc; z.counts = reinterpret_cast<int*>(cp);
             }
+            rc = launch_res_add(br.data, br.pre.scale1, br.pre.shift1, skip.data, skip.Hp, skip.Wp, L.shave, skip.pre, z.C,
+                                z.data, z.partials, z.counts, st);
+            if (rc) return rc;
+            cur = z;
             break;
         }
         case L_TANH: case L_MUL:
@@ -559,10 +441,9 @@ int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, f
         }
         curH = H; curW = W;
     }
-    st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0; pending_emit = nullptr;
-    in_final.assign(ins.size(), 1);
+    st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0;
     Act cur;
-    cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.pitch = cur.Wp; cur.C = 8;
+    cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.C = 8;
     return run(layers, cur, true, out_planar, out_raw);
 }
 
@@ -792,7 +673,6 @@ struct fav_stream {
 extern "C" int fav_net_set_precision(fav_net* net, int mode)
 {
     FAV_REQUIRE(net && (mode == 0 || mode == 1), "fav_net_set_precision: mode must be FAV_PRECISION_FP32 or FAV_PRECISION_BF16_OPERANDS");
-    if (net->precision != mode) net->curH = -1;      // the two modes size the activation arena differently: rebuild it
     net->precision = mode;
     return FAV_OK;
 }
