@@ -1770,14 +1770,32 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C
     }
 }
 
-// residual join: nn.CAddTable of (IN(conv_b) , ShaveImage(skip))  -- models_video.lua:41-53.  One block = one row segment of up
-// to 128 pixels.  STATS: the join feeds an InstanceNorm (directly or through a nearest upsample, which leaves mean and biased
-// variance unchanged: the R128 -> U2 -> IN tail of models_video.lua:94-98): the same pass yields that norm's per-segment
-// (mean, M2, count) partials instead of a second read-only pass over the joined tensor.
-template <bool STATS>
+// residual join: nn.CAddTable of (IN(conv_b) , ShaveImage(skip))  -- models_video.lua:41-53.
+// res_add_stats_kernel: the join feeds an InstanceNorm (directly or through a nearest upsample, which leaves mean and biased
+// variance unchanged: the R128 -> U2 -> IN tail of models_video.lua:94-98): one block = one row segment of up to 128 pixels, and
+// the same pass yields that norm's per-segment (mean, M2, count) partials instead of a second read-only pass over the joined tensor.
 __global__ __launch_bounds__(256) void res_add_kernel(const float* y, const float* scale, const float* shift,
                                                       const float* skip, int SW, int shave, const Affine sa,
-                                                      int OW, int C, float* z, float2* partials, int* counts)
+                                                      int OH, int OW, int C, float* z)
+{
+    const int groups = C >> 2;
+    const size_t total = (size_t)OH * OW * groups;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int g = (int)(idx % groups);
+        const size_t pix = idx / groups;
+        const int oy = (int)(pix / OW), ox = (int)(pix - (size_t)oy * OW);
+        float4 v = *reinterpret_cast<const float4*>(y + pix * C + 4 * g);
+        v = affine4(v, scale + 4 * g, shift + 4 * g, 0);
+        float4 k = *reinterpret_cast<const float4*>(skip + ((size_t)(oy + shave) * SW + ox + shave) * C + 4 * g);
+        k = apply_affine_g(k, sa, 4 * g);
+        v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w;
+        *reinterpret_cast<float4*>(z + pix * C + 4 * g) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void res_add_stats_kernel(const float* y, const float* scale, const float* shift,
+                                                            const float* skip, int SW, int shave, const Affine sa,
+                                                            int OW, int C, float* z, float2* partials, int* counts)
 {
     __shared__ float red[1024];
     __shared__ float mean_s[1024];
@@ -1802,7 +1820,6 @@ __global__ __launch_bounds__(256) void res_add_kernel(const float* y, const floa
             *reinterpret_cast<float4*>(zr + (size_t)px * C) = v;
             sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
         }
-    if (!STATS) return;
     if (active) *reinterpret_cast<float4*>(red + pl * C + 4 * g) = sm;
     __syncthreads();
     for (int c = t; c < C; c += 256) {
@@ -1895,13 +1912,12 @@ int launch_res_add(const float* y, const float* scale, const float* shift, const
 {
     const int OH = SH - 2 * shave, OW = SW - 2 * shave;
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && OH > 0 && OW > 0, "res_add: bad shape (C=%d)", C);
-    const dim3 grid(res_add_stat_blocks(OH, OW));
     if (partials)
-        hipLaunchKernelGGL(res_add_kernel<true>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
+        hipLaunchKernelGGL(res_add_stats_kernel, dim3(res_add_stat_blocks(OH, OW)), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
                            reinterpret_cast<float2*>(partials), counts);
     else
-        hipLaunchKernelGGL(res_add_kernel<false>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
-                           static_cast<float2*>(nullptr), static_cast<int*>(nullptr));
+        hipLaunchKernelGGL(res_add_kernel, dim3(grid_for((size_t)OH * OW * (C / 4))), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t,
+                           OH, OW, C, z);
     FAV_LAUNCH_CHECK("res_add_kernel");
     return FAV_OK;
 }
