@@ -131,6 +131,10 @@ int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
 int conv3_halo_tiles(int OH, int OW);
 int launch_conv3_halo(const ConvLaunch& p, int* counts, hipStream_t st);
+// 3x3 stride-2 layers: halo-resident implicit GEMM with even / odd column planes (stream-K); partials per 4x32 tile
+bool conv3s2_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups);
+int conv3s2_tiles(int OH, int OW);
+int launch_conv3s2(const ConvLaunch& p, int* counts, hipStream_t st);
 // counts: per-partial pixel counts or null (then block b holds min(block_pixels, M - b*block_pixels) pixels)
 int launch_in_finalize(const float* partials, const int* counts, int mblocks, int M, int block_pixels, int C, int Cpitch,
                        const float* gamma, const float* beta, float eps,

@@ -1406,6 +1406,363 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 STRIDE-2 layers (d64: 32 -> 64 at 1360x800, d128: 64 -> 128 at 680x400; models_video.lua:88-92): halo-resident implicit
+// GEMM with even / odd column planes.  The generic kernel re-gathers its operand per tap with 2-5 vector-ALU instructions per
+// MFMA (address arithmetic + the pending transform, nine times per element) and reaches 0.44 / 0.55 of the fp32 MFMA peak on
+// these two layers.  Here a block (8 waves, one per CU, stream-K over (tile, slice, tap row) units like the stride-1 kernel)
+// owns a 4 x 32 pixel output tile: wave = (output row, half of the output channels).  Per 32-channel slice the
+// (2*4+1) x (2*32+1) = 9 x 65 pixel halo is gathered ONCE (IN/ReLU applied, zero padding) into LDS as two planes -- even
+// input columns (33 per row) and odd input columns (32 per row) -- so that for every tap the 32 lanes of a wave (32 consecutive
+// OUTPUT columns = input columns 2m + kx) read 32 CONSECUTIVE pixels of one plane: conflict-free ds_read_b128, immediate tap
+// offsets.  585 pixels x 144 B = 84 KB: one halo buffer only, so the next slice's halo travels through registers (10 pieces of
+// 16 bytes per thread, loaded one per K step) and is written between slices.  Weights stream through the same 3-slot ring as
+// in the stride-1 kernel; one barrier per K step (mid-step), two per slice change.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int S2_TH = 4, S2_TW = 32;                 // output tile
+constexpr int S2_HR = 2 * S2_TH + 1;                 // 9 halo rows
+constexpr int S2_EW = S2_TW + 1, S2_OW = S2_TW;      // even / odd plane widths (33, 32)
+constexpr int S2_EP = S2_HR * S2_EW;                 // 297 pixels in the even plane
+constexpr int S2_HP = S2_EP + S2_HR * S2_OW;         // 585 halo pixels
+constexpr int S2_NHV = 10;                           // 16-byte halo pieces per thread and slice (585 * 8 / 512 = 9.14)
+
+struct S2Args {
+    const float* in; const float* wgt; const float* bias;
+    const float* scale1; const float* shift1;
+    float* out; float2* partials; int* counts;
+    float* sk_ws; unsigned* sk_flags; unsigned sk_epoch; unsigned* sk_err;
+    int IH, IW, IWp, CIN, COUT, COUTp, pad, OH, OW, Kpad, tiles_x, tiles_y;
+    int stages, relu1;
+};
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3s2_halo_kernel(const S2Args p)
+{
+    constexpr int NT = 512;
+    constexpr int TN = BN / 64;                       // 32-channel accumulator tiles per wave (a wave owns BN/2 channels)
+    constexpr int BROWS = BN / 64;                    // weight rows per thread per step
+    constexpr int ALIAS = NT * S2_NHV - S2_HP * 8;    // staging units past the end alias earlier ones (same data, same slot)
+    static_assert(ALIAS % 8 == 0 && ALIAS >= 0 && ALIAS <= NT, "halo aliasing");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                 // [585][LDSS]: even plane, then odd plane
+    float* Bs = Hs + S2_HP * LDSS;                    // [3][BN][LDSS]
+    float* aff = Bs + 3 * BN * LDSS;                  // [2][CIN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave & 3, nh = wave >> 2;          // output row of the tile, channel half
+    const int CIN = p.CIN;
+    const int nchunks = CIN >> 5, nsteps = nchunks * 9;
+    const int ntiles = p.tiles_x * p.tiles_y;
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    for (int i = t; i < CIN; i += NT) { aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f; }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int c4 = t & 7, r0 = t >> 3;
+    const int frag_k = (lane >> 5) * 4, m = lane & 31;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    const unsigned wofs = (unsigned)(r0 * p.Kpad + c4 * 4) * 4u;
+    const unsigned wrow64 = (unsigned)(64 * p.Kpad) * 4u;
+    float* const bst = Bs + r0 * LDSS + c4 * 4;                                        // weight staging slot (ring slot 0)
+    // A fragments: even plane (kx = 0, 2) and odd plane (kx = 1), tap row 0, this wave's output row
+    const float* const afrE = Hs + ((2 * wr) * S2_EW + m) * LDSS + frag_k;
+    const float* const afrO = Hs + (S2_EP + (2 * wr) * S2_OW + m) * LDSS + frag_k;
+    const float* const bfr = Bs + (nh * (BN / 2) + m) * LDSS + frag_k;                 // B fragments: ring slot 0, this wave's channels
+    const float* const affr = aff + c4 * 4;
+
+    const int nunits = nchunks * 3;                   // stream-K unit: one tap row (3 K steps) of one slice of one tile
+    const int U = ntiles * nunits;
+    int u = (int)((long long)U * lb / gridDim.x);
+    const int u_end = (int)((long long)U * (lb + 1) / gridDim.x);
+
+    while (u < u_end) {
+        const int tile = u / nunits;
+        const int k0 = u - tile * nunits;
+        const int k1 = (u_end - u) < nunits - k0 ? k0 + (u_end - u) : nunits;
+        u += k1 - k0;
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int oy0 = ty * S2_TH, ox0 = tx * S2_TW;
+
+        // halo piece i of this thread: staging unit e = t + 512 i -> halo pixel e >> 3 (plane-major), 16-byte chunk c4
+        int hoff[S2_NHV], hlds[S2_NHV]; float hmask[S2_NHV];
+#pragma unroll
+        for (int i = 0; i < S2_NHV; ++i) {
+            int e = t + NT * i; e -= e >= S2_HP * 8 ? ALIAS : 0;
+            const int pe = e >> 3;
+            int hy, hx;
+            if (pe < S2_EP) { hy = pe / S2_EW; hx = 2 * (pe - hy * S2_EW); }
+            else { const int q = pe - S2_EP; hy = q / S2_OW; hx = 2 * (q - hy * S2_OW) + 1; }
+            const int iy = 2 * oy0 - p.pad + hy, ix = 2 * ox0 - p.pad + hx;
+            const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+            hoff[i] = ((v ? (iy * p.IWp + ix) * CIN : 0) + c4 * 4) * 4;
+            hmask[i] = v ? 1.f : 0.f;
+            hlds[i] = pe * LDSS + c4 * 4;
+        }
+        const int c_first = (k0 * 21846) >> 16, ky0 = k0 - c_first * 3;
+        const int c_last = ((k1 - 1) * 21846) >> 16, ky_end = k1 - c_last * 3;       // tap rows [.., ky_end) of the last slice
+
+        v4f rb[BROWS];
+        float4 hq[S2_NHV];                           // the next slice's halo, in flight / parked in registers
+#define S2_XFORM(v_, sc_, sh_, m_)                                                                  \
+        { v_.x = fmaxf(fmaf(v_.x, sc_.x, sh_.x), lo1) * m_; v_.y = fmaxf(fmaf(v_.y, sc_.y, sh_.y), lo1) * m_;  \
+          v_.z = fmaxf(fmaf(v_.z, sc_.z, sh_.z), lo1) * m_; v_.w = fmaxf(fmaf(v_.w, sc_.w, sh_.w), lo1) * m_; }
+#define S2_LOAD_B(gs_)                                                                              \
+        { const float* src_ = p.wgt + min((gs_), nsteps - 1) * BK;                                  \
+          _Pragma("unroll") for (int j = 0; j < BROWS; ++j) rb[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(src_) + (wofs + j * wrow64)); }
+#define S2_STORE_B(slot_)                                                                           \
+        { _Pragma("unroll") for (int j = 0; j < BROWS; ++j) *reinterpret_cast<v4f*>(bst + ((slot_) * BN + 64 * j) * LDSS) = rb[j]; }
+
+        {
+            // prologue: the first slice's whole halo -> LDS; weights of the first step -> ring slot 0; the pieces of the next slice
+            // that the skipped steps of this slice would have fetched -> registers
+            const char* in0 = reinterpret_cast<const char*>(p.in + c_first * 32);
+            const char* in1 = reinterpret_cast<const char*>(p.in + min(c_first + 1, c_last) * 32);
+            float4 q0[S2_NHV];
+#pragma unroll
+            for (int i = 0; i < S2_NHV; ++i) q0[i] = *reinterpret_cast<const float4*>(in0 + hoff[i]);
+            S2_LOAD_B(c_first * 9 + 3 * ky0);
+            if (c_first < c_last) {
+#pragma unroll
+                for (int i = 0; i < S2_NHV; ++i) if (i < 3 * ky0 || (i == 9 && ky0 > 0)) hq[i] = *reinterpret_cast<const float4*>(in1 + hoff[i]);
+            }
+            const v4f sc = *reinterpret_cast<const v4f*>(affr + c_first * 32), sh = *reinterpret_cast<const v4f*>(affr + CIN + c_first * 32);
+#pragma unroll
+            for (int i = 0; i < S2_NHV; ++i) { S2_XFORM(q0[i], sc, sh, hmask[i]); *reinterpret_cast<float4*>(Hs + hlds[i]) = q0[i]; }
+            S2_STORE_B(0);
+            S2_LOAD_B(c_first * 9 + 3 * ky0 + 1);
+        }
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        __syncthreads();
+
+        v4f fa[2], fb[2][TN];
+#define S2_FRAG(set_, ap_, bp_)                                                                     \
+        { fa[set_] = *reinterpret_cast<const v4f*>(ap_);                                            \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[set_][j] = *reinterpret_cast<const v4f*>((bp_) + j * 32 * LDSS); }
+#define S2_MFMA(set_)                                                                               \
+        { _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                          \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].x, fb[set_][j].x, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].y, fb[set_][j].y, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].z, fb[set_][j].z, acc[j], 0, 0, 0); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set_].w, fb[set_][j].w, acc[j], 0, 0, 0); } }
+// A-fragment base of tap T_ (compile time): even plane for kx = 0 / 2 (shifted by one pixel), odd plane for kx = 1
+#define S2_ABASE(T_) (((T_) % 3 == 1 ? afrO + ((T_) / 3) * S2_OW * LDSS : afrE + (((T_) / 3) * S2_EW + ((T_) % 3 == 2 ? 1 : 0)) * LDSS))
+// one K step = tap T_ of the current slice (32 channels); ring slot = T_ % 3; piece T_ (and piece 9 with tap 0) of the next slice is
+// fetched.  PIN_: the group-0 fragments were already read by the previous step; POUT_: read those of tap T_ + 1 (compile time:
+// a run-time flag here makes the compiler shuffle the fragment registers with dozens of v_mov per step)
+#define S2_STEP(T_, PIN_, POUT_)                                                                    \
+        {                                                                                           \
+            const float* a_ = S2_ABASE(T_);                                                         \
+            const float* b_ = bfr + ((T_) % 3) * BN * LDSS;                                         \
+            if (!(PIN_)) S2_FRAG(0, a_, b_);                                                        \
+            S2_FRAG(1, a_ + 8, b_ + 8);                                                             \
+            S2_STORE_B(((T_) + 1) % 3);                                                             \
+            S2_LOAD_B(c * 9 + (T_) + 2);                                                            \
+            if (has_next) { hq[T_] = *reinterpret_cast<const float4*>(in_n + hoff[T_]); if ((T_) == 0) hq[9] = *reinterpret_cast<const float4*>(in_n + hoff[9]); } \
+            S2_MFMA(0);                                                                             \
+            S2_FRAG(0, a_ + 16, b_ + 16); S2_MFMA(1);                                               \
+            __syncthreads();                                                                        \
+            S2_FRAG(1, a_ + 24, b_ + 24); S2_MFMA(0);                                               \
+            if (POUT_) { constexpr int TNX = ((T_) + 1) % 9; S2_FRAG(0, S2_ABASE(TNX), bfr + (TNX % 3) * BN * LDSS); } \
+            S2_MFMA(1);                                                                             \
+        }
+#define S2_STEP_IF(T_) if ((T_) >= t_lo && (T_) < t_hi) S2_STEP(T_, false, false)
+
+        for (int c = c_first; c <= c_last; ++c) {
+            const int t_lo = c == c_first ? 3 * ky0 : 0, t_hi = c == c_last ? 3 * ky_end : 9;
+            const bool has_next = c < c_last;
+            const char* in_n = reinterpret_cast<const char*>(p.in + (c + 1) * 32);
+            if (t_lo == 0 && t_hi == 9) {
+                // whole slice (the common case): fragments of the next tap are read one step ahead
+                S2_STEP(0, false, true) S2_STEP(1, true, true) S2_STEP(2, true, true) S2_STEP(3, true, true) S2_STEP(4, true, true)
+                S2_STEP(5, true, true) S2_STEP(6, true, true) S2_STEP(7, true, true) S2_STEP(8, true, false)
+            } else {
+                // a split tile's partial slice: plain steps
+                S2_STEP_IF(0) S2_STEP_IF(1) S2_STEP_IF(2) S2_STEP_IF(3) S2_STEP_IF(4) S2_STEP_IF(5) S2_STEP_IF(6) S2_STEP_IF(7) S2_STEP_IF(8)
+            }
+            if (has_next) {
+                // slice change: everybody is done reading the halo; the parked pieces (transformed) replace it
+                __syncthreads();
+                const v4f sc = *reinterpret_cast<const v4f*>(affr + (c + 1) * 32), sh = *reinterpret_cast<const v4f*>(affr + CIN + (c + 1) * 32);
+#pragma unroll
+                for (int i = 0; i < S2_NHV; ++i) { S2_XFORM(hq[i], sc, sh, hmask[i]); *reinterpret_cast<float4*>(Hs + hlds[i]) = hq[i]; }
+                __syncthreads();
+            }
+        }
+        __syncthreads();                    // the epilogue reuses the staging memory
+#undef S2_XFORM
+#undef S2_LOAD_B
+#undef S2_STORE_B
+#undef S2_FRAG
+#undef S2_MFMA
+#undef S2_ABASE
+#undef S2_STEP
+#undef S2_STEP_IF
+
+        // ------------------------------------------------------------ stream-K hand-off (as in conv3_halo_kernel)
+        constexpr int NV4 = TN * 4;
+        if (k0 > 0) {
+            float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store16_wt(slot + (size_t)(j * 4 + q) * NT, v4f{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            continue;
+        }
+        if (k1 < nunits) {
+            int covered = k1;
+            for (int nb = lb + 1; covered < nunits && nb < (int)gridDim.x; ++nb) {
+                const int nu0 = (int)((long long)U * nb / gridDim.x), nu1 = (int)((long long)U * (nb + 1) / gridDim.x);
+                const int span = (nu1 - nu0) < (nunits - covered) ? (nu1 - nu0) : (nunits - covered);
+                if (t == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 22)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const float4* slot = reinterpret_cast<const float4*>(p.sk_ws) + (size_t)nb * NV4 * NT + t;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = slot[(size_t)(j * 4 + q) * NT];
+                        acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w;
+                    }
+                covered += span;
+            }
+        }
+
+        // ------------------------------------------------------------ epilogue: wave = (output row, channel half), MFMA rows = columns
+        float* red = smem;                 // [4 rows][BN] + [BN]
+        const int oy = oy0 + wr;
+        const int vh = min(S2_TH, p.OH - oy0), vw = min(S2_TW, p.OW - ox0);
+        const int cnt = vh * vw;
+        float lsum[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nh * (BN / 2) + j * 32 + col;
+            const float bv = p.bias[n];
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                const float v = acc[j][r] + bv;
+                acc[j][r] = v;
+                if (oy < p.OH && ox < p.OW) {
+                    if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
+                    sm += v;
+                }
+            }
+            lsum[j] = sm;
+        }
+        if (p.partials != nullptr) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
+                if (lane < 32) red[wr * BN + nh * (BN / 2) + j * 32 + lane] = sm;
+            }
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < S2_TH; ++w) a += red[w * BN + t];
+                red[S2_TH * BN + t] = a / (float)cnt;
+            }
+            __syncthreads();
+            float lq[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float mu = red[S2_TH * BN + nh * (BN / 2) + j * 32 + col];
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + rbase;
+                    const float d = acc[j][r] - mu;
+                    if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+                }
+                lq[j] = q + __shfl_xor(q, 32);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (lane < 32) red[wr * BN + nh * (BN / 2) + j * 32 + lane] = lq[j];
+            __syncthreads();
+            if (t < BN) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < S2_TH; ++w) a += red[w * BN + t];
+                p.partials[(size_t)tile * p.COUTp + t] = make_float2(red[S2_TH * BN + t], a);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool conv3s2_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups)
+{
+    return k == 3 && stride == 2 && ups == 0 && stages <= 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 && (coutp == 128 || coutp == 64);
+}
+int conv3s2_tiles(int OH, int OW) { return ((OH + S2_TH - 1) / S2_TH) * ((OW + S2_TW - 1) / S2_TW); }
+
+template <int BN>
+static int launch_s2_t(const S2Args& a, int cin, int reserve_cus, hipStream_t st)
+{
+    const auto kern = conv3s2_halo_kernel<BN>;
+    const size_t lds = (size_t)(S2_HP * LDSS + 3 * BN * LDSS + 2 * cin) * sizeof(float);
+    const int dv = cur_dev();
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int occ = 0; hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
+        if (occ < 1) { set_error("stride-2 halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
+        cus[dv] = prop.multiProcessorCount;
+    }
+    int nres = std::max(1, cus[dv] - reserve_cus);
+    if (nres > SK_GRID) nres = SK_GRID;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = tiles * (cin / 32) * 3 < nres ? 1 : nres;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv3s2_halo_kernel");
+    return FAV_OK;
+}
+
+int launch_conv3s2(const ConvLaunch& c, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv3s2_eligible(c.CIN, c.COUTp, c.KH, c.stride, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode && !c.stuff && c.sk_ws && c.sk_flags,
+                "stride-2 halo conv: not eligible");
+    FAV_REQUIRE((long long)(c.IH + 1) * c.IWp * c.CIN < (1ll << 31), "stride-2 halo conv: tensor too large for 32-bit offsets");
+    S2Args a;
+    a.in = c.in; a.wgt = c.wgt; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.stages = c.pre.stages; a.relu1 = c.pre.relu1;
+    a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.sk_err = c.sk_err;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
+    a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
+    a.tiles_x = (c.OW + S2_TW - 1) / S2_TW; a.tiles_y = (c.OH + S2_TH - 1) / S2_TH;
+    return c.COUTp == 128 ? launch_s2_t<128>(a, c.CIN, c.reserve_cus, st) : launch_s2_t<64>(a, c.CIN, c.reserve_cus, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Last layer (c9s1-3: 64 -> 3 channels, 9x9): "row-folded" implicit GEMM.
 // With only 3 output channels a pixels x channels GEMM would waste 29/32 of every MFMA.  Instead the
 // kx taps are folded into the N dimension: for one output row y

@@ -74,10 +74,10 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr};
     return t;
 }
 
@@ -107,7 +107,7 @@ struct fav_net {
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
-    bool use_c8 = false, use_h3 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
+    bool use_c8 = false, use_h3 = false, use_s2 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -261,7 +261,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : launch_conv(cs, st))); };
+    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
@@ -271,8 +271,8 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    // kernel id: 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), else the generic kernel's N tile
-    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 300 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32))));
+    // kernel id: 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
+    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
     return rc;
 }
 
@@ -316,14 +316,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
             const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
             const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
-            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW)); nxt.ppitch = d.coutp;
+            const bool s2 = !L.transposed && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
+            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
-            if (want_stats && (c8 || h3)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
+            if (want_stats && (c8 || h3 || s2)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
-            c8_counts = (c8 || h3) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3;
+            c8_counts = (c8 || h3 || s2) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
-            use_c8 = false; use_h3 = false;
+            use_c8 = false; use_h3 = false; use_s2 = false;
             cur = nxt;
             break;
         }
