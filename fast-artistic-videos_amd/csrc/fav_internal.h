@@ -129,7 +129,7 @@ int conv_c8_tiles(int OH, int OW);
 int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
 // 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
-int conv3_halo_tiles(int OH, int OW);
+int conv3_halo_tiles(int OH, int OW, bool edge_b);      // edge_b: fp32 kernel (16 x 16 tiles on a narrow ragged right edge)
 int launch_conv3_halo(const ConvLaunch& p, int* counts, hipStream_t st);
 // 3x3 stride-2 layers: halo-resident implicit GEMM with even / odd column planes (stream-K); partials per 4x32 tile
 bool conv3s2_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups);

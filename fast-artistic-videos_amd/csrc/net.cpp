@@ -317,7 +317,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
             const bool h3 = !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
             const bool s2 = !L.transposed && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
-            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
+            nxt.mblocks = c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3 || s2)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
@@ -674,6 +674,7 @@ struct fav_stream {
 extern "C" int fav_net_set_precision(fav_net* net, int mode)
 {
     FAV_REQUIRE(net && (mode == 0 || mode == 1), "fav_net_set_precision: mode must be FAV_PRECISION_FP32 or FAV_PRECISION_BF16_OPERANDS");
+    if (net->precision != mode) net->curH = -1;      // the two modes tile (and size the statistics buffers) differently: rebuild the arena
     net->precision = mode;
     return FAV_OK;
 }
