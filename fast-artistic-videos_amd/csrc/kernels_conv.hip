@@ -1844,8 +1844,8 @@ int launch_conv3s2(const ConvLaunch& c, int* counts, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int FOLD_R = 8;        // output rows per block
-constexpr int FOLD_M = 128;      // input columns per block
+constexpr int FOLD_R = 16;       // output rows per tile
+constexpr int FOLD_M = 128;      // input columns per tile
 
 struct FoldArgs {
     const float* in; const float* wfold; const float* bias;
@@ -1854,26 +1854,29 @@ struct FoldArgs {
     int IH, IW, IWp, ups, COUT, KH, KW, pad, OH, OW;
     int stages, relu1, relu2;
     float tanh_mul;
+    int tiles_x, tiles_y;
 };
 
+// 16 output rows per tile (8 accumulators per wave): every staged input row feeds up to 9 output rows, so a taller tile stages
+// (16 + 8) / 16 = 1.5 input rows per output row instead of 2, and the per-tile costs (the first row's latency, the ramp of
+// half-used rows at the top and bottom, the diagonal-sum epilogue) are paid 495 instead of 990 times per 1280x720 frame.
+// Persistent blocks: the nine ky weight slices (78 KB) are loaded into LDS once per block, not once per tile.
 template <int CIN>
 __global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
 {
-    constexpr int NT = 512;                    // 8 waves: waves 0-3 own output rows 0-3, waves 4-7 rows 4-7 (same columns)
+    constexpr int NT = 512;                    // 8 waves: waves 0-3 own output rows 0-7, waves 4-7 rows 8-15 (same columns)
     constexpr int RW = FOLD_R / 2;             // output rows per wave
     constexpr int S = CIN + 4;                 // LDS row stride (floats): odd multiple of 16 B -> conflict-free b128
     constexpr int NV = CIN / 16;               // float4 per thread per staged row (4 threads per column)
     constexpr int KK = CIN / 8;                // fragment steps per row (8 k values each)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                          // [KH][32][S]
-    float* As = Bs + p.KH * 32 * S;            // [2][FOLD_M][S]
-    float* aff = As + 2 * FOLD_M * S;          // [4][CIN]
+    float* aff = Bs + p.KH * 32 * S;           // [4][CIN]
+    float* As = aff + 4 * CIN;                 // [2][FOLD_M][S]; the epilogue's D tile reuses it
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wcol = wave & 3, wrow = wave >> 2;
-    const int XO = FOLD_M - (p.KW - 1);        // output columns per block
-    const int ox0 = blockIdx.x * XO, oy0 = blockIdx.y * FOLD_R;
-    const int xs = ox0 - p.pad;                // first input column of the tile (may be negative)
+    const int XO = FOLD_M - (p.KW - 1);        // output columns per tile
 
     for (int i = t; i < CIN; i += NT) {
         aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
@@ -1881,131 +1884,151 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
     }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
-    // all ky weight slices -> LDS (wfold is [KH][32][CIN], zero rows for n >= COUT*KW)
+    // all ky weight slices -> LDS, once per block (wfold is [KH][32][CIN], zero rows for n >= COUT*KW)
     for (int e = t; e < p.KH * 32 * (CIN / 4); e += NT) {
         const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
         *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(p.wfold + (size_t)row * CIN + c4 * 4);
     }
-
-    const int iy_lo = max(0, oy0 - p.pad), iy_hi = min(p.IH - 1, oy0 + FOLD_R - 1 + p.KH - 1 - p.pad);
-    const int pr_lo = iy_lo >> p.ups, pr_hi = iy_hi >> p.ups;
-
     // staging assignment: column xl = t>>2 of the tile, channel quarter (t&3)
     const int xl = t >> 2, ch0 = (t & 3) * (CIN / 4);
-    const int ix = xs + xl;
-    const bool colv = ix >= 0 && ix < p.IW;
-    const float colm = colv ? 1.f : 0.f;
-    const int coloff = colv ? (ix >> p.ups) * CIN + ch0 : 0;
+    const int frag = (lane & 31) * S + (lane >> 5) * 4;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
     float4 ra[NV];
 
+    for (int tile = blockIdx.x; tile < p.tiles_x * p.tiles_y; tile += gridDim.x) {
+        const int by = tile / p.tiles_x, bx = tile - by * p.tiles_x;
+        const int ox0 = bx * XO, oy0 = by * FOLD_R;
+        const int xs = ox0 - p.pad;                // first input column of the tile (may be negative)
+        const int iy_lo = max(0, oy0 - p.pad), iy_hi = min(p.IH - 1, oy0 + FOLD_R - 1 + p.KH - 1 - p.pad);
+        const int pr_lo = iy_lo >> p.ups, pr_hi = iy_hi >> p.ups;
+        const int ix = xs + xl;
+        const bool colv = ix >= 0 && ix < p.IW;
+        const float colm = colv ? 1.f : 0.f;
+        const int coloff = colv ? (ix >> p.ups) * CIN + ch0 : 0;
+
 #define FOLD_LOAD(pr_)                                                                              \
-    {                                                                                               \
-        const float* src_ = p.in + (size_t)(pr_) * p.IWp * CIN + coloff;                            \
-        _Pragma("unroll") for (int i = 0; i < NV; ++i) ra[i] = *reinterpret_cast<const float4*>(src_ + 4 * i); \
-    }
+        {                                                                                           \
+            const float* src_ = p.in + (size_t)(pr_) * p.IWp * CIN + coloff;                        \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) ra[i] = *reinterpret_cast<const float4*>(src_ + 4 * i); \
+        }
 #define FOLD_STORE(buf_)                                                                            \
-    {                                                                                               \
-        float* dst_ = As + (buf_) * FOLD_M * S + xl * S + ch0;                                      \
-        _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                            \
-            float4 v_ = affine4_lo(ra[i], aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, lo1);         \
-            v_ = affine4_lo(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, lo2);     \
-            v_.x *= colm; v_.y *= colm; v_.z *= colm; v_.w *= colm;                                 \
-            *reinterpret_cast<float4*>(dst_ + 4 * i) = v_;                                          \
-        }                                                                                           \
-    }
+        {                                                                                           \
+            float* dst_ = As + (buf_) * FOLD_M * S + xl * S + ch0;                                  \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                        \
+                float4 v_ = affine4_lo(ra[i], aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, lo1);     \
+                v_ = affine4_lo(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, lo2); \
+                v_.x *= colm; v_.y *= colm; v_.z *= colm; v_.w *= colm;                             \
+                *reinterpret_cast<float4*>(dst_ + 4 * i) = v_;                                      \
+            }                                                                                       \
+        }
 
-    f32x16 acc[RW];
+        f32x16 acc[RW];
 #pragma unroll
-    for (int y = 0; y < RW; ++y)
+        for (int y = 0; y < RW; ++y)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
 
-    FOLD_LOAD(pr_lo);
-    __syncthreads();               // affine tables + weights visible
-    FOLD_STORE(0);
-    __syncthreads();
+        FOLD_LOAD(pr_lo);
+        __syncthreads();               // affine tables + weights visible; the previous tile's epilogue is done with the staging memory
+        FOLD_STORE(0);
+        __syncthreads();
 
-    const int frag = (lane & 31) * S + (lane >> 5) * 4;
-    int cur = 0;
-    for (int pr = pr_lo; pr <= pr_hi; ++pr) {
-        const bool more = pr < pr_hi;
-        if (more) FOLD_LOAD(pr + 1);
-        const float* a_base = As + cur * FOLD_M * S + wcol * 32 * S + frag;
-        const int iy_first = max(iy_lo, pr << p.ups), iy_last = min(iy_hi, ((pr + 1) << p.ups) - 1);
-        for (int iy = iy_first; iy <= iy_last; ++iy) {
-            const int kyb = iy - oy0 + p.pad - wrow * RW;      // ky for this wave's output row yy is kyb - yy
-#pragma unroll 2
-            for (int kk = 0; kk < KK; ++kk) {
-                const float4 af = *reinterpret_cast<const float4*>(a_base + kk * 8);
+        int cur = 0;
+        for (int pr = pr_lo; pr <= pr_hi; ++pr) {
+            const bool more = pr < pr_hi;
+            if (more) FOLD_LOAD(pr + 1);
+            const float* a_base = As + cur * FOLD_M * S + wcol * 32 * S + frag;
+            const int iy_first = max(iy_lo, pr << p.ups), iy_last = min(iy_hi, ((pr + 1) << p.ups) - 1);
+            for (int iy = iy_first; iy <= iy_last; ++iy) {
+                const int kyb = iy - oy0 + p.pad - wrow * RW;      // ky for this wave's output row yy is kyb - yy
+                // the row's A fragments are read once and serve every output row it feeds; per output row one wave-uniform test,
+                // then a straight-line block of KK weight-fragment reads and 4 KK MFMAs (LDS latency hides inside it)
+                float4 af[KK];
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) af[kk] = *reinterpret_cast<const float4*>(a_base + kk * 8);
 #pragma unroll
                 for (int yy = 0; yy < RW; ++yy) {
                     const int ky = kyb - yy;
-                    if (ky >= 0 && ky < p.KH) {        // wave-uniform
-                        const float4 bf = *reinterpret_cast<const float4*>(Bs + ky * 32 * S + frag + kk * 8);
-                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[yy], 0, 0, 0);
-                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[yy], 0, 0, 0);
-                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[yy], 0, 0, 0);
-                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[yy], 0, 0, 0);
+                    if (ky >= 0 && ky < p.KH) {            // wave-uniform
+                        const float* b_base = Bs + ky * 32 * S + frag;
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk) {
+                            const float4 bf = *reinterpret_cast<const float4*>(b_base + kk * 8);
+                            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc[yy], 0, 0, 0);
+                            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc[yy], 0, 0, 0);
+                            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc[yy], 0, 0, 0);
+                            acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc[yy], 0, 0, 0);
+                        }
                     }
                 }
             }
+            if (more) FOLD_STORE(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
-        if (more) FOLD_STORE(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
 #undef FOLD_LOAD
 #undef FOLD_STORE
 
-    // ---- epilogue: D tiles -> LDS [R][128][33], then the diagonal sum over kx
-    float* D = smem;
-    const int col = lane & 31, rbase = 4 * (lane >> 5);
+        // ---- epilogue in four passes of 4 output rows (2 of each row half): D tiles -> LDS [4][128][33] in the staging area (the
+        // weights stay resident), then the diagonal sum over kx
+        float* D = As;
+        const size_t MO = (size_t)p.OH * p.OW;
+        const int per_row = XO * p.COUT;
+        constexpr int PR = 2;              // rows of each half per pass
 #pragma unroll
-    for (int yy = 0; yy < RW; ++yy)
+        for (int h = 0; h < RW / PR; ++h) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int xr = wcol * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-            D[((wrow * RW + yy) * FOLD_M + xr) * 33 + col] = acc[yy][r];
-        }
-    __syncthreads();
-    const size_t MO = (size_t)p.OH * p.OW;
-    const int per_row = XO * p.COUT;
-    for (int e = t; e < FOLD_R * per_row; e += NT) {
-        const int yy = e / per_row, rem = e - yy * per_row;
-        const int c = rem / XO, xo = rem - c * XO;
-        const int oy = oy0 + yy, ox = ox0 + xo;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        float v = p.bias[c];
-        const float* d = D + (yy * FOLD_M + xo) * 33 + c * p.KW;
-        for (int kx = 0; kx < p.KW; ++kx) v += d[kx * 33 + kx];
-        v = tanhf(v) * p.tanh_mul;                                              // models_video.lua:135-136
-        const size_t o = (size_t)oy * p.OW + ox;
-        if (p.out_raw) p.out_raw[(size_t)c * MO + o] = v;
-        if (p.out_planar) {
-            const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
-            p.out_planar[(size_t)(2 - c) * MO + o] = (v + mean) / 255.f;          // preprocess.lua:66-71
+            for (int y2 = 0; y2 < PR; ++y2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xr = wcol * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                    D[((wrow * PR + y2) * FOLD_M + xr) * 33 + col] = acc[h * PR + y2][r];
+                }
+            __syncthreads();
+            for (int e = t; e < 2 * PR * per_row; e += NT) {
+                const int yl = e / per_row, rem = e - yl * per_row;            // D row: half = yl / PR, y2 = yl % PR
+                const int c = rem / XO, xo = rem - c * XO;
+                const int oy = oy0 + (yl / PR) * RW + h * PR + (yl % PR), ox = ox0 + xo;
+                if (oy >= p.OH || ox >= p.OW) continue;
+                float v = p.bias[c];
+                const float* d = D + (yl * FOLD_M + xo) * 33 + c * p.KW;
+                for (int kx = 0; kx < p.KW; ++kx) v += d[kx * 33 + kx];
+                v = tanhf(v) * p.tanh_mul;                                              // models_video.lua:135-136
+                const size_t o = (size_t)oy * p.OW + ox;
+                if (p.out_raw) p.out_raw[(size_t)c * MO + o] = v;
+                if (p.out_planar) {
+                    const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+                    p.out_planar[(size_t)(2 - c) * MO + o] = (v + mean) / 255.f;          // preprocess.lua:66-71
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
 template <int CIN>
-int launch_fold_t(const FoldArgs& a, hipStream_t st)
+int launch_fold_t(FoldArgs a, hipStream_t st)
 {
     const int S = CIN + 4;
-    size_t lds = (size_t)(a.KH * 32 * S + 2 * FOLD_M * S + 4 * CIN) * sizeof(float);
-    const size_t epi = (size_t)FOLD_R * FOLD_M * 33 * sizeof(float);
-    if (epi > lds) lds = epi;
+    const size_t wbytes = (size_t)(a.KH * 32 * S + 4 * CIN) * sizeof(float);      // resident: weights + transform table
+    size_t stage = (size_t)(2 * FOLD_M * S) * sizeof(float);
+    const size_t epi = (size_t)4 * FOLD_M * 33 * sizeof(float);                   // D tile of one epilogue pass
+    if (epi > stage) stage = epi;
+    const size_t lds = wbytes + stage;
     if (lds > 160 * 1024) { set_error("row-folded conv: %zu bytes of LDS needed", lds); return FAV_EUNSUPPORTED; }
     const int dv = cur_dev();
-    static bool attr_done[MAX_DEVICES] = {};
-    if (!attr_done[dv]) {
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_kernel<CIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done[dv] = true;
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        cus[dv] = prop.multiProcessorCount;
     }
     const int XO = FOLD_M - (a.KW - 1);
-    dim3 grid((a.OW + XO - 1) / XO, (a.OH + FOLD_R - 1) / FOLD_R);
-    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), grid, dim3(512), lds, st, a);
+    a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
+    const int tiles = a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), dim3(tiles < cus[dv] ? tiles : cus[dv]), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_rowfold_kernel");
     return FAV_OK;
 }
