@@ -219,6 +219,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enq = time.perf_counter() - t0                    # host time to ENQUEUE the steps (the GPU runs behind)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -310,6 +311,9 @@ def main():
                          "per_kernel_ms_tflops": {k: [round(v[0], 4), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in per_kernel.items()}},
         }
         line["extra"] = extra
+        # the launch path is not the limiter: host enqueue time per frame vs GPU time per frame (why a HIP graph would not help:
+        # kernel boundaries cost the same GPU-side in a replayed graph, MI355X_MICROARCH.md "boundary" row)
+        line["extra"]["host_enqueue_ms_per_frame"] = round(t_enq / args.steps * 1e3, 4)
         if use_dist:
             line["extra"]["weight_broadcast"] = {"backend": "nccl (RCCL)", "world": world, "bytes": len(blob), "seconds_incl_first_call_setup": round(t_b, 4)}
         if world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,35 @@
 
 #include "fav_internal.h"
 
+#include <dlfcn.h>
+
 namespace fav {
+
+namespace {
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const Roctx& roctx()
+{
+    static const Roctx r = [] {
+        Roctx x;
+        if (!getenv("FAV_ROCTX")) return x;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (x.push && x.pop) return x;
+                x = Roctx();
+            }
+        }
+        return x;
+    }();
+    return r;
+}
+}  // namespace
+
+bool TraceRange::enabled() { return roctx().push != nullptr; }
+TraceRange::TraceRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+TraceRange::~TraceRange() { if (on) roctx().pop(); }
+
 
 static thread_local char g_err[1024] = "";
 

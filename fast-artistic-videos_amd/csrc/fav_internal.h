@@ -47,6 +47,15 @@ int hip_fail(hipError_t e, const char* what);
 
 int ensure_device();   // FAV_OK or FAV_ENODEVICE
 
+// roctx ranges around the stages of a frame (mask / certainty + input assembly / network, and every convolution inside it) for
+// rocprofv3 --marker-trace.  Off unless FAV_ROCTX=1: the marker library is then dlopen'ed (libfav itself does not link it).
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    static bool enabled();
+    bool on;
+};
+
 // ------------------------------------------------------------------------------------------------
 // host-side description of a parsed checkpoint (t7_reader.cpp)
 // ------------------------------------------------------------------------------------------------
@@ -111,6 +120,7 @@ struct ConvLaunch {
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;
     unsigned* sk_err = nullptr;     // host-mapped error word (device pointer): set by a hand-off wait that timed out
     int reserve_cus = 0;            // CUs left to concurrent side-queue work: persistent / stream-K grids shrink by this many
+    int no_sk = 0;                  // shared device: data-parallel grids only (no hand-off between blocks, no co-residency assumption)
 };
 size_t conv_streamk_workspace_bytes();
 int conv_streamk_grid();

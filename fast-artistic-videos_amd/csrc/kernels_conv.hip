@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // bounded, and reported to the host
+                        if (++spins > (1u << 22)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // bounded, and reported to the host
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        if (++spins > (1u << 22)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_bf16_kernel(const H3Args p)
                     unsigned spins = 0;
                     while (__hip_atomic_load(p.sk_flags + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 26)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                        if (++spins > (1u << 22)) { if (p.sk_err) __hip_atomic_store(p.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
@@ -1376,7 +1376,7 @@ static void h3_debug_report(const long long* h, int grid)
 }
 
 template <int BN, bool S2, bool BF>
-static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t st)
+static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, bool no_sk, hipStream_t st)
 {
     const auto kern = BF ? conv3_halo_bf16_kernel<BN, S2> : conv3_halo_kernel<BN, S2>;
     const size_t lds = BF ? (size_t)(2 * (H3_TH + 2) * (H3_TW + 2) * 40 + 3 * BN * 40) * 2 + (size_t)4 * cin * sizeof(float)
@@ -1394,7 +1394,9 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, hipStream_t s
     int nres = std::max(1, cus[dv] - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
     const int tiles = a0.tiles_x * a0.tiles_y + a0.nb;
-    const int grid = tiles * (cin / 32) * 3 < nres ? 1 : nres;      // (stream-K units: tap rows)
+    // no_sk (shared device): one block per tile -- the unit range of block b is then exactly tile b, nothing is handed between blocks
+    // and nothing needs to be co-resident
+    const int grid = no_sk ? tiles : (tiles * (cin / 32) * 3 < nres ? 1 : nres);      // (stream-K units: tap rows)
     H3Args a = a0; a.dbg = nullptr;
     static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;
@@ -1429,11 +1431,11 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     static const int sk_wt = getenv("FAV_SK_WT") ? atoi(getenv("FAV_SK_WT")) : 1;      // (A/B switch, read once)
     a.sk_wt = sk_wt;
     if (c.wgt16) {           // fast mode: bf16 operands
-        if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, st);
-        return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, st);
+        if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
+        return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
     }
-    if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<128, false, false>(a, c.CIN, c.reserve_cus, st);
-    return s2 ? launch_h3_t<64, true, false>(a, c.CIN, c.reserve_cus, st) : launch_h3_t<64, false, false>(a, c.CIN, c.reserve_cus, st);
+    if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, false>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<128, false, false>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
+    return s2 ? launch_h3_t<64, true, false>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<64, false, false>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1791,7 +1793,7 @@ bool conv3s2_eligible(int cin_pitch, int coutp, int k, int stride, int stages, i
 int conv3s2_tiles(int OH, int OW) { return ((OH + S2_TH - 1) / S2_TH) * ((OW + S2_TW - 1) / S2_TW); }
 
 template <int BN>
-static int launch_s2_t(const S2Args& a, int cin, int reserve_cus, hipStream_t st)
+static int launch_s2_t(const S2Args& a, int cin, int reserve_cus, bool no_sk, hipStream_t st)
 {
     const auto kern = conv3s2_halo_kernel<BN>;
     const size_t lds = (size_t)(S2_HP * LDSS + 3 * BN * LDSS + 2 * cin) * sizeof(float);
@@ -1808,7 +1810,7 @@ static int launch_s2_t(const S2Args& a, int cin, int reserve_cus, hipStream_t st
     int nres = std::max(1, cus[dv] - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int grid = tiles * (cin / 32) * 3 < nres ? 1 : nres;
+    const int grid = no_sk ? tiles : (tiles * (cin / 32) * 3 < nres ? 1 : nres);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3s2_halo_kernel");
     return FAV_OK;
@@ -1826,7 +1828,7 @@ int launch_conv3s2(const ConvLaunch& c, int* counts, hipStream_t st)
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.COUT = c.COUT; a.COUTp = c.COUTp; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
     a.tiles_x = (c.OW + S2_TW - 1) / S2_TW; a.tiles_y = (c.OH + S2_TH - 1) / S2_TH;
-    return launch_s2_t<64>(a, c.CIN, c.reserve_cus, st);
+    return launch_s2_t<64>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2081,7 +2083,7 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;   // tuning only: results are wrong for 1-4,6-8
     // stream-K when the tile count is within a few waves of the 512 resident blocks (imbalance matters there)
     const long long tiles = (long long)((c.OH * c.OW + BM - 1) / BM) * (c.COUTp / (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));
-    const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && abl != 13 && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID &&
+    const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && !c.no_sk && abl != 13 && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID &&
                     c.Kpad / BK >= 4;
     if (c.COUTp % 128 == 0) {
 #ifdef FAV_ABLATIONS          // tuning builds only (make CXXEXTRA=-DFAV_ABLATIONS; scripts/abl.sh): the instances below give wrong results

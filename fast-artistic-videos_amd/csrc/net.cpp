@@ -105,6 +105,7 @@ struct fav_net {
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
+    bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false, use_s2 = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
@@ -258,10 +259,14 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     const float* wfold = (c.final_mode && !tuning().no_fold) ? convs[conv_index].wfold : nullptr;
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
+    cs.no_sk = shared_device ? 1 : 0;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
     auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
+    char tag[96] = "";
+    if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
+    TraceRange tr(tag);
     if (!profiling) return go();
     ProfRec r; r.conv = conv_index;
     FAV_HIP(hipEventCreate(&r.a)); FAV_HIP(hipEventCreate(&r.b));
@@ -430,6 +435,7 @@ int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, f
     FAV_HIP(hipSetDevice(device));
     if (sk_err_host && *reinterpret_cast<volatile unsigned*>(sk_err_host)) {      // reported by an earlier launch of this net
         *sk_err_host = 0;
+        shared_device = true;
         set_error("a stream-K hand-off between convolution blocks timed out in an earlier launch of this network: its result was "
                   "wrong (two networks running concurrently on one device? see the concurrency note in fav.h)");
         return FAV_EHIP;
@@ -509,10 +515,19 @@ extern "C" int fav_net_check(fav_net* net)
     FAV_REQUIRE(net, "fav_net_check: null net");
     if (net->sk_err_host && *reinterpret_cast<volatile unsigned*>(net->sk_err_host)) {
         *net->sk_err_host = 0;
+        net->shared_device = true;      // from now on: data-parallel grids, which need no co-resident blocks
         set_error("a stream-K hand-off between convolution blocks timed out: the frame(s) computed since the last check are wrong "
-                  "(another context holding compute units of this device? see the concurrency note in fav.h)");
+                  "(another context holding compute units of this device? see the concurrency note in fav.h); this network now runs "
+                  "with data-parallel grids (fav_net_set_shared_device)");
         return FAV_EHIP;
     }
+    return FAV_OK;
+}
+
+extern "C" int fav_net_set_shared_device(fav_net* net, int shared)
+{
+    FAV_REQUIRE(net, "fav_net_set_shared_device: null net");
+    net->shared_device = shared != 0;
     return FAV_OK;
 }
 
@@ -778,14 +793,19 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
                        hipStream_t st)
 {
     FAV_REQUIRE(s->has_state, "fav_stream_next_frame: no previous stylised frame (call fav_stream_first_frame or fav_stream_set_state first)");
-    int rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+    int rc;
+    {
+        TraceRange tr_pre("fav:certainty+warp+assemble");
+        rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
                                  s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
+        if (rc) return rc;
+        ++s->frame_counter;
+        rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
+                               s->opts.fill_random, s->opts.seed, s->frame_counter);
+        if (rc) return rc;
+    }
+    { TraceRange tr_net("fav:network"); rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); }
     if (rc) return rc;
-    ++s->frame_counter;
-    rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
-                           s->opts.fill_random, s->opts.seed, s->frame_counter);
-    if (rc) return rc;
-    rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
     return stream_finish(s, out_f32, out_u8, st);
 }
 
@@ -817,6 +837,7 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
             return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
         }
     // not prefetched: compute inline on the caller's stream (own workspace)
+    TraceRange tr_mask("fav:consistency mask");
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->ws, s->ws_bytes, &structure, &avg, st); if (rc) return rc;

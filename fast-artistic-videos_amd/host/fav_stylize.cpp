@@ -24,6 +24,7 @@
 //                         back to back.  Rank 0 parses the checkpoint(s) once and broadcasts the packed blob (fav_net_pack_host) with
 //                         RCCL (ncclBroadcast over xGMI; ncclCommInitRank + a unique-id file); no other collective: a stream's
 //                         frame i needs its own frame i-1 only.  Each worker gets host-threads / n PNG writers and loaders.
+//   -shared_gpu 1         the GPU is shared with other processes: data-parallel convolution grids (fav_net_set_shared_device)
 //   -force_dist 1         take the worker / RCCL path even for -gpus 1;  -dry_run 1: workers print their assignment and exit
 //                         without touching a device (plumbing test).
 #include <hip/hip_runtime.h>
@@ -542,7 +543,7 @@ int main(int argc, char** argv)
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
            {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
-           {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"},
+           {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"},
            // internal (set by the launcher for its workers)
            {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
@@ -686,6 +687,7 @@ int main(int argc, char** argv)
         if (want_img && fav_net_create(o.s("model_img").c_str(), device, &net_img)) die(fav_last_error());
     }
     check(fav_net_set_precision(net, o.s("precision") == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
+    if (o.i("shared_gpu")) { check(fav_net_set_shared_device(net, 1), "fav_net_set_shared_device"); if (net_img) check(fav_net_set_shared_device(net_img, 1), "fav_net_set_shared_device"); }
     printf("Model loaded.\n");
     if (net_img) printf("Model loaded.\n");
 

@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check",
+    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device",
 ]
 
 
@@ -178,6 +178,10 @@ class Net:
         """fav_net_check: raises if a stream-K hand-off timed out since the last check (call after synchronising)"""
         _torch().cuda.synchronize()
         _check(lib().fav_net_check(self.h))
+
+    def set_shared_device(self, shared: bool):
+        """True: data-parallel convolution grids only (no stream-K hand-offs): for a GPU this process does not own exclusively"""
+        _check(lib().fav_net_set_shared_device(self.h, 1 if shared else 0))
 
     def set_precision(self, bf16_operands: bool):
         """False: fp32 parity mode (default); True: bf16 operands in the 3x3 halo convolutions (fast mode, not bit-compatible)."""

@@ -112,6 +112,10 @@ void fav_net_destroy(fav_net* net);
  * wrong.  fav_stylize checks before every PNG is queued and at exit; fav_net_forward / fav_stream_* also fail on their next
  * call.  Clears the word. */
 int fav_net_check(fav_net* net);
+/* shared != 0: the device is NOT exclusively this network's (other processes / contexts compute on it).  The convolutions then
+ * use data-parallel grids only -- one block per tile, nothing handed between blocks, no co-residency assumed -- at some cost in
+ * load balance.  fav_net_check switches a network to this mode by itself after a hand-off has timed out. */
+int fav_net_set_shared_device(fav_net* net, int shared);
 /* human-readable layer list (one line per layer) -- used to cross-check the .t7 reader */
 int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity);
 /* host-only (no device needed): parse a .t7 checkpoint and write the same layer list text */

@@ -464,6 +464,35 @@ def test_consistency_extreme_flows(favlib, oracle, cuda):
     assert np.array_equal(got, want)
 
 
+def test_shared_device_mode_matches_oracle(favlib, oracle, cuda, canonical):
+    """fav_net_set_shared_device: data-parallel convolution grids (one block per tile, no stream-K hand-off, no co-residency
+    assumption) -- the mode for a GPU this process does not own, and what fav_net_check falls back to after a timed-out
+    hand-off.  Same arithmetic per tile up to the order in which split tiles are summed: same tolerance as the default mode."""
+    layers = _layers(canonical)
+    h, w = 96, 128
+    frames, bws, fws = _clip(h, w, 2, 120)
+    net = favlib.Net(canonical, 0)
+    net.set_shared_device(True)
+    st = favlib.Stream(net, h, w)
+    o0, _ = st.first_frame(T(frames[0], cuda))
+    o1, _ = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda))
+    net.check()
+    ref = oracle.Stylizer(layers)
+    r0 = ref.first(_f01(frames[0]))
+    assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+    ref.last = o0.cpu().numpy()
+    m = oracle.consistency(bws[1], fws[1])
+    r1 = ref.next(_f01(frames[1]), bws[1], m.astype(np.float32) / np.float32(255))
+    assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+    # and at a size where the default mode splits tiles between blocks (more tiles than CUs): both modes agree closely
+    net2 = favlib.Net(canonical, 0)
+    x = (np.random.default_rng(7).standard_normal((7, 360, 640)) * 40).astype(np.float32)
+    a = net2.forward(T(x, cuda)).cpu().numpy()
+    net2.set_shared_device(True)
+    b = net2.forward(T(x, cuda)).cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-2            # 150*tanh space; summation order of split tiles only
+
+
 def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
     """the temporal-consistency number of -evaluate (fast_artistic_video.lua:128-151)."""
     h, w = 90, 130
