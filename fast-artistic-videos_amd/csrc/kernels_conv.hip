@@ -2009,7 +2009,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
 }
 
 template <int CIN>
-int launch_fold_t(FoldArgs a, hipStream_t st)
+int launch_fold_t(FoldArgs a, int reserve_cus, hipStream_t st)
 {
     const int S = CIN + 4;
     const size_t wbytes = (size_t)(a.KH * 32 * S + 4 * CIN) * sizeof(float);      // resident: weights + transform table
@@ -2030,7 +2030,8 @@ int launch_fold_t(FoldArgs a, hipStream_t st)
     const int XO = FOLD_M - (a.KW - 1);
     a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
     const int tiles = a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), dim3(tiles < cus[dv] ? tiles : cus[dv]), dim3(512), lds, st, a);
+    const int nres = std::max(1, cus[dv] - reserve_cus);       // persistent blocks: leave the side queues their CUs
+    hipLaunchKernelGGL((conv_rowfold_kernel<CIN>), dim3(tiles < nres ? tiles : nres), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_rowfold_kernel");
     return FAV_OK;
 }
@@ -2052,9 +2053,9 @@ int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
     a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.COUT = c.COUT; a.KH = c.KH; a.KW = c.KW; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.tanh_mul = c.tanh_mul;
-    if (c.CIN == 64) return launch_fold_t<64>(a, st);
-    if (c.CIN == 32) return launch_fold_t<32>(a, st);
-    return launch_fold_t<16>(a, st);
+    if (c.CIN == 64) return launch_fold_t<64>(a, c.reserve_cus, st);
+    if (c.CIN == 32) return launch_fold_t<32>(a, c.reserve_cus, st);
+    return launch_fold_t<16>(a, c.reserve_cus, st);
 }
 
 int launch_conv(const ConvLaunch& c, hipStream_t st)
@@ -2124,39 +2125,32 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ double block_sum_d(double v, double* sh)
-{
-    const int t = threadIdx.x;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((t & 63) == 0) sh[t >> 6] = v;
-    __syncthreads();
-    double r = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
-    return r;
-}
-
+// One pass over the per-tile (mean, M2, count) partials in fp64:  mean = sum n_b mean_b / M,  var = (sum M2_b + sum n_b mean_b^2) / M
+// - mean^2 (biased).  The cancellation in the last step costs (mean^2 / var) ulps of fp64 -- far below the fp32 result's own
+// rounding -- and saves the second dependent sweep + block reduction of the textbook two-pass merge: this kernel is pure
+// latency (16 launches per frame), not bandwidth.
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials, const int* counts, int mblocks, int M, int bp,
                                                           int Cpitch, const float* gamma, const float* beta,
                                                           float eps, float* scale, float* shift)
 {
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     const int c = blockIdx.x, t = threadIdx.x;
-    double s = 0;
+    double s1 = 0, s2 = 0;
     for (int b = t; b < mblocks; b += 256) {
-        const int nb = counts ? counts[b] : min(bp, M - b * bp);
-        s += (double)nb * (double)partials[(size_t)b * Cpitch + c].x;
-    }
-    const double mean = block_sum_d(s, sh) / (double)M;
-    double q = 0;
-    for (int b = t; b < mblocks; b += 256) {
-        const int nb = counts ? counts[b] : min(bp, M - b * bp);
+        const double n = (double)(counts ? counts[b] : min(bp, M - b * bp));
         const float2 pr = partials[(size_t)b * Cpitch + c];
-        const double d = (double)pr.x - mean;
-        q += (double)pr.y + (double)nb * d * d;
+        const double mu = (double)pr.x;
+        s1 += n * mu;
+        s2 += (double)pr.y + n * mu * mu;
     }
-    const double var = block_sum_d(q, sh) / (double)M;
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((t & 63) == 0) { sh[2 * (t >> 6)] = s1; sh[2 * (t >> 6) + 1] = s2; }
+    __syncthreads();
     if (t == 0) {
+        const double a = ((sh[0] + sh[2]) + sh[4]) + sh[6], q = ((sh[1] + sh[3]) + sh[5]) + sh[7];
+        const double mean = a / (double)M;
+        double var = q / (double)M - mean * mean;
+        var = var > 0.0 ? var : 0.0;
         const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
         const double sc = g / sqrt(var + (double)eps);
         scale[c] = (float)sc;

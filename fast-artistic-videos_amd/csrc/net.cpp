@@ -263,7 +263,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(c, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
+    auto go = [&]() { return wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
