@@ -33,6 +33,18 @@ FLOP_PER_FRAME = 305_651_220_480          # useful conv FLOPs of the canonical n
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def effective_cpus():
+    """usable CPUs: scheduler affinity capped by the cgroup CPU quota (the GPU box shows 256 threads under a 16-CPU quota)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out_u8, gpu_mask):
     """The oracle (a port of the reference's CPU path, fast_artistic_video_core.lua:161-180) timed on this host's cores on ONE
     1280x720 recurrent step (min of 3 runs), and -- since that frame is computed anyway -- compared with what the GPU path
@@ -42,6 +54,8 @@ def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out
     import numpy as np
     import oracle as O
     O.build()
+    cores = effective_cpus()
+    O.set_threads(cores)            # one OpenMP thread per usable CPU (not per visible hardware thread)
     f1 = np.transpose(frame1, (2, 0, 1)).astype(np.float32) / np.float32(255)
     b, f = np.ascontiguousarray(bw), np.ascontiguousarray(fw)
     times = []
@@ -53,10 +67,9 @@ def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out
         r1 = st.next(f1, b, mask.astype(np.float32) / np.float32(255))
         times.append(time.perf_counter() - t0)
     dt = min(times)
-    cores = len(os.sched_getaffinity(0))
     base = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"1 frame of 1280x720 (3-arg mask + min-filter + warp + assemble + net + deprocess) through oracle/ "
-                      f"(C, fp64 accumulation, OpenMP) on {cores} threads, min of 3 runs ({', '.join('%.2f' % t for t in times)} s)"}
+                      f"(C, fp64 accumulation, OpenMP) on {cores} threads (= usable CPUs: {len(os.sched_getaffinity(0))} visible, cgroup quota applied), min of 3 runs ({', '.join('%.2f' % t for t in times)} s)"}
     ref_u8 = O.to_u8_hwc(r1)
     mse = float(np.mean((ref_u8.astype(np.float64) - gpu_out_u8.astype(np.float64)) ** 2))
     max_abs = float(np.abs(r1 - gpu_out).max())
@@ -115,7 +128,7 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300):
         base = [exe, "-input_pattern", d + "/frame_%05d.ppm", "-flow_pattern", d + "/flow/backward_[%d]_{%d}.flo",
                 "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo", "-structure", "0",
                 "-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1"]
-        out = {"frames": nframes, "host_threads": os.cpu_count(), "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net -> D2H -> PNG to /dev/shm",
+        out = {"frames": nframes, "host_threads": os.cpu_count(), "usable_cpus": effective_cpus(), "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net -> D2H -> PNG to /dev/shm",
                "h2d_bytes_per_frame": H * W * (3 + 8 + 8), "d2h_bytes_per_frame": H * W * 3}
         for name, lvl in (("png_level_1", "1"), ("png_level_0", "0")):
             r = subprocess.run(base + ["-output_prefix", f"{d}/o{lvl}/out", "-png_level", lvl], capture_output=True, text=True, timeout=600)

@@ -484,13 +484,31 @@ std::vector<std::string> split_list(const std::string& v)
     return out;
 }
 
-// PNG writer threads of one worker when `world` workers share the host: deflate is the slowest host stage (level 1: ~55 ms per
-// 1280x720 frame and thread), so a worker gets its share of the hardware threads minus the loaders and the main thread
+// CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (containers: the GPU box of this project
+// shows 256 hardware threads under a 16-CPU quota -- 32 deflate threads there only fight each other)
+int effective_cpus()
+{
+    int n = std::max(1, (int)std::thread::hardware_concurrency());
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+        char q[64] = "";
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1ll, (quota + period - 1) / period));
+    return n;
+}
+
+// PNG writer threads of one worker when `world` workers share the host: deflate is the slowest host stage (~25 ms per 1280x720
+// frame and core at the default -png_level 1), so a worker gets its share of the usable CPUs (the loaders mostly wait on I/O)
 int writer_budget(int requested, int world)
 {
     if (requested > 0) return requested;
-    const int hw = std::max(1, (int)std::thread::hardware_concurrency());
-    return std::max(4, std::min(32, hw / std::max(1, world) - 8));
+    return std::max(4, std::min(32, effective_cpus() / std::max(1, world)));
 }
 
 void ncheck(ncclResult_t r, const char* what) { if (r != ncclSuccess) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(r)); }
