@@ -442,49 +442,6 @@ __global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, f
     if (t == 0) { const float s = s_sum; if (sum_out) *sum_out = s; if (avg_out) *avg_out = s / (float)n; }
 }
 
-// (the previous implementation, kept as the reference for the unit test and as documentation of the plain chain)
-__global__ __launch_bounds__(64) void avg_kernel(const float* v, int n, float* avg_out)
-{
-    constexpr int CH = 2048;                        // elements per chunk (8 float4 per lane)
-    __shared__ __attribute__((aligned(16))) float buf[2][CH];
-    const int lane = threadIdx.x;
-    float acc = 0.f;
-    const int nfull = n / CH;
-    const float4* v4 = reinterpret_cast<const float4*>(v);      // v is 256-byte aligned (workspace carve)
-    float4 r[8];
-    if (nfull > 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = v4[i * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&buf[0][(i * 64 + lane) * 4]) = r[i];
-    }
-    int cur = 0;
-    for (int c = 0; c < nfull; ++c) {
-        const bool more = c + 1 < nfull;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = v4[(size_t)(c + 1) * (CH / 4) + i * 64 + lane];
-        }
-        const float4* b4 = reinterpret_cast<const float4*>(buf[cur]);
-#pragma unroll 16
-        for (int i = 0; i < CH / 4; ++i) {
-            const float4 q = b4[i];                 // same address in every lane: LDS broadcast
-            acc += q.x; acc += q.y; acc += q.z; acc += q.w;
-        }
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&buf[cur ^ 1][(i * 64 + lane) * 4]) = r[i];
-        }
-        cur ^= 1;
-    }
-    for (int base = nfull * CH; base < n; base += 64) {
-        const float x = base + lane < n ? v[base + lane] : 0.f;
-        const int m = n - base < 64 ? n - base : 64;
-        for (int j = 0; j < m; ++j) acc += __shfl(x, j);
-    }
-    if (lane == 0) *avg_out = acc / (float)n;
-}
-
 // recursiveSmoothX through LDS: a block owns 64 rows; 64x64 tiles are moved with coalesced row-major accesses and each
 // lane walks ITS row inside the tile (LDS pitch 65: conflict-free column walk), so the sequential recurrences of
 // CFilter.h:1426-1437 keep their exact order while global memory sees full lines.
@@ -561,8 +518,7 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     hipLaunchKernelGGL(quirkmin_kernel, dim3(nb), dim3(256), 0, st, corners, n, bpre, bmin);
     hipLaunchKernelGGL(minreduce_kernel, dim3(1), dim3(256), 0, st, bmin, nb, mm);
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, corners, n, mm);
-    if (getenv("FAV_AVG_CHAIN")) hipLaunchKernelGGL(avg_kernel, dim3(1), dim3(64), 0, st, corners, (int)n, mm + 2);
-    else hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, corners, (int)n, mm + 2, static_cast<float*>(nullptr));
+    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, corners, (int)n, mm + 2, static_cast<float*>(nullptr));
     FAV_LAUNCH_CHECK("structure kernels");
     *structure_out = corners;
     *avg_out = mm + 2;

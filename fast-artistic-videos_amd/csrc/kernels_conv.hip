@@ -86,7 +86,7 @@ __device__ __forceinline__ float4 affine4(float4 v, const float* sc, const float
 //               write their partial accumulators FIRST in their timelines, publish a flag (agent-scope
 //               release), and the owner picks them up after an agent-scope acquire.  This removes the
 //               "515 tiles on 512 slots" quantisation that cost the residual layers ~20 %.
-template <int BN, int WM, int WN, int ABL = 0, bool SK = false>   // ABL: tuning ablations (FAV_ABL env), 0 = product
+template <int BN, int WM, int WN, bool SK = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfma_kernel(const ConvArgs p)   // 2 blocks per CU
 {
     constexpr int NT = 64 * WM * WN;           // threads per block (4 or 8 waves)
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
 // global -> registers (set X), chunk q_ of 4: A row q_ and B row q_ of K-step s_ (raw values; the transform
 // is applied when they are written to LDS)
 #define FAV_LOAD_CHUNK(X, s_, q_)                                                                           \
-        if (ABL != 1 && ABL != 2 && ABL != 3) {                                                             \
+        {                                                                                                   \
             if ((q_) < AROWS) {                                                                             \
                 constexpr int i_ = (q_) < AROWS ? (q_) : 0;                                                 \
                 const int iy_ = iy0[i_] + ky##X, ix_ = ix0[i_] + kx##X;                                     \
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
 // registers (set X) -> LDS buffer buf_, chunk q_ of 4: A row q_ (pending transform of the producer: IN
 // scale/shift [+ReLU], two stages; then zero for padding / out-of-range rows) and B row q_
 #define FAV_STORE_CHUNK(X, buf_, q_)                                                                        \
-        if (ABL != 2 && ABL != 3) {                                                                         \
+        {                                                                                                   \
             if ((q_) < AROWS) {                                                                             \
                 float4 v_ = ra##X[(q_) < AROWS ? (q_) : 0];                                                 \
                 v_ = affine4_lo(v_, aff + ci##X, aff + CIN + ci##X, lo1);                                   \
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
 #define FAV_MFMA_GROUP(kk_)                                                                                 \
         {                                                                                                   \
             float4 af[TM], bf[TN];                                                                          \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = ABL == 3 ? make_float4(1.f + i, 2.f, 3.f, 4.f + (kk_)) : *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = ABL == 3 ? make_float4(1.f, 2.f + j, 3.f, 4.f) : *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LDSS + (kk_) * 8); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LDSS + (kk_) * 8); \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0); \
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
             FAV_MFMA_GROUP(1); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 1); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 1); \
             FAV_MFMA_GROUP(2); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 2); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 2); \
             FAV_MFMA_GROUP(3); if (do_load_) FAV_LOAD_CHUNK(L, s + 2, 3); if (do_store_) FAV_STORE_CHUNK(S, cur ^ 1, 3); \
-            if (ABL != 4) __syncthreads();                                                                  \
+            __syncthreads();                                                                                \
             cur ^= 1; ++s;                                                                                  \
         }
 
@@ -427,16 +427,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 4 : 2) void conv_mfm
 
 constexpr int SK_GRID = 512;            // stream-K grid: 2 blocks on each of the 256 CUs, all co-resident
 
-template <int BN, int WM, int WN, int ABL = 0, bool SK = false>
+template <int BN, int WM, int WN, bool SK = false>
 int launch_conv_t(const ConvArgs& a, hipStream_t st)
 {
     const int M = a.OH * a.OW;
-    size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
-    if (ABL == 5) lds = 100 * 1024;      // force one block per CU
+    const size_t lds = (size_t)(2 * (BM + BN) * LDSS + 4 * a.CIN) * sizeof(float);
     const int dv = cur_dev();
     static bool attr_done[MAX_DEVICES] = {};   // per instantiation and device
     if (!attr_done[dv]) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, ABL, SK>),
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<BN, WM, WN, SK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dv] = true;
     }
@@ -448,7 +447,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
         if (!sk_per_cu[dv]) {
             int occ = 0; hipDeviceProp_t prop;
             FAV_HIP(hipGetDeviceProperties(&prop, dv));
-            FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, ABL, SK>, 64 * WM * WN, lds));
+            FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, SK>, 64 * WM * WN, lds));
             if (occ < 1) { set_error("stream-K conv: kernel does not fit on a CU"); return FAV_EHIP; }
             sk_per_cu[dv] = occ >= 2 ? 2 : 1; sk_cus[dv] = prop.multiProcessorCount;
         }
@@ -456,7 +455,7 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
         if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
         grid = dim3(sk_blocks, 1);
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, ABL, SK>), grid, dim3(64 * WM * WN), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<BN, WM, WN, SK>), grid, dim3(64 * WM * WN), lds, st, a);
     FAV_LAUNCH_CHECK("conv_mfma_kernel");
     return FAV_OK;
 }
@@ -675,7 +674,6 @@ struct H3Args {
     int nb;                  // number of 16 x 16 edge tiles (fp32 kernel; see conv3_halo_tiles)
     int stages, relu1, relu2;
     const unsigned short* wgt16;   // bf16 copy of the weights (fast mode) or null
-    int sk_wt;               // 1: publish partial tiles with write-through (sc1) stores; 0: plain stores + release fence
     long long* dbg;          // optional in-kernel timeline (FAV_H3_DBG), 24 slots per block
 };
 
@@ -898,30 +896,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
         constexpr int NV4 = TN * 4;
         if (k0 > 0) {
             float4* slot = reinterpret_cast<float4*>(p.sk_ws) + (size_t)lb * NV4 * NT + t;
-            if (p.sk_wt) {
-                // write-through payload -> drained -> sc1 flag (no L2 write-back fence)
+            // write-through payload -> drained -> sc1 flag (no L2 write-back fence)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        store16_wt(slot + (size_t)(j * 4 + q) * NT, v4f{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]});
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (t == 0) __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        slot[(size_t)(j * 4 + q) * NT] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (t == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+                for (int q = 0; q < 4; ++q)
+                    store16_wt(slot + (size_t)(j * 4 + q) * NT, v4f{acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(p.sk_flags + lb, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             DBG_T(); DBG_T();
             continue;
@@ -1428,8 +1411,6 @@ int launch_conv3_halo(const ConvLaunch& c, int* counts, hipStream_t st)
     h3_tiling(c.OH, c.OW, c.wgt16 == nullptr, &a.tiles_x, &a.tiles_y, &a.nb);      // (the bf16 fast-mode kernel keeps 8 x 32 tiles only)
     const bool s2 = c.pre.stages >= 2;
     a.wgt16 = c.wgt16;
-    static const int sk_wt = getenv("FAV_SK_WT") ? atoi(getenv("FAV_SK_WT")) : 1;      // (A/B switch, read once)
-    a.sk_wt = sk_wt;
     if (c.wgt16) {           // fast mode: bf16 operands
         if (c.COUTp == 128) return s2 ? launch_h3_t<128, true, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<128, false, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
         return s2 ? launch_h3_t<64, true, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st) : launch_h3_t<64, false, true>(a, c.CIN, c.reserve_cus, c.no_sk != 0, st);
@@ -2081,41 +2062,13 @@ int launch_conv(const ConvLaunch& c, hipStream_t st)
     a.cin_shift = __builtin_ctz((unsigned)c.CIN); a.kw_magic = (65536 + c.KW - 1) / c.KW;
     a.ntaps_magic = (65536 + c.KH * c.KW - 1) / (c.KH * c.KW);
     a.sk_ws = c.sk_ws; a.sk_flags = c.sk_flags; a.sk_epoch = c.sk_epoch; a.sk_err = c.sk_err; a.reserve_cus = c.reserve_cus;
-    static const int abl = getenv("FAV_ABL") ? atoi(getenv("FAV_ABL")) : 0;   // tuning only: results are wrong for 1-4,6-8
     // stream-K when the tile count is within a few waves of the 512 resident blocks (imbalance matters there)
     const long long tiles = (long long)((c.OH * c.OW + BM - 1) / BM) * (c.COUTp / (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)));
-    const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && !c.no_sk && abl != 13 && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID &&
-                    c.Kpad / BK >= 4;
-    if (c.COUTp % 128 == 0) {
-#ifdef FAV_ABLATIONS          // tuning builds only (make CXXEXTRA=-DFAV_ABLATIONS; scripts/abl.sh): the instances below give wrong results
-        switch (abl) {
-        case 21: if (sk) return launch_conv_t<128, 2, 2, 1, true>(a, st); break;
-        case 22: if (sk) return launch_conv_t<128, 2, 2, 2, true>(a, st); break;
-        case 23: if (sk) return launch_conv_t<128, 2, 2, 3, true>(a, st); break;
-        case 1: return launch_conv_t<128, 2, 2, 1>(a, st);
-        case 2: return launch_conv_t<128, 2, 2, 2>(a, st);
-        case 3: return launch_conv_t<128, 2, 2, 3>(a, st);
-        case 4: return launch_conv_t<128, 2, 2, 4>(a, st);
-        case 5: return launch_conv_t<128, 2, 2, 5>(a, st);
-        case 6: return launch_conv_t<128, 2, 2, 6>(a, st);
-        case 7: return launch_conv_t<128, 2, 2, 7>(a, st);
-        case 8: return launch_conv_t<128, 2, 2, 8>(a, st);
-        case 12: return launch_conv_t<128, 2, 2>(a, st);      // 4 waves: 64x64 per wave
-        default: break;
-        }
-#endif
-        // product: 8 waves (32x64 per wave), 4 waves per SIMD with two blocks per CU
-        // product: stream-K with 4-wave blocks (64x64 per wave, no spills at 2 blocks/CU); FAV_SK=1 selects the
-        // 8-wave stream-K instance, FAV_SK=0 the data-parallel 8-wave instance (measured: 177.8 / 179.8 / 182.2 us)
-        static const int skmode = getenv("FAV_SK") ? atoi(getenv("FAV_SK")) : 2;
-        if (sk && skmode == 1) return launch_conv_t<128, 4, 2, 0, true>(a, st);
-        if (sk && skmode == 2) return launch_conv_t<128, 2, 2, 0, true>(a, st);
-        return launch_conv_t<128, 4, 2>(a, st);
-    }
-    if (c.COUTp % 64 == 0) {
-        static const int skmode = getenv("FAV_SK") ? atoi(getenv("FAV_SK")) : 2;
-        return (sk && skmode) ? launch_conv_t<64, 2, 2, 0, true>(a, st) : launch_conv_t<64, 2, 2>(a, st);
-    }
+    const bool sk = c.sk_ws != nullptr && c.sk_flags != nullptr && !c.no_sk && tiles >= SK_GRID / 2 && tiles <= 6 * SK_GRID && c.Kpad / BK >= 4;
+    // 128-wide layers: stream-K with 4-wave blocks (64x64 per wave, two blocks per CU; measured 177.8 us against 179.8 us for the
+    // 8-wave stream-K instance and 182.2 us for the data-parallel 8-wave instance on the residual layers), else 8 waves data-parallel
+    if (c.COUTp % 128 == 0) return sk ? launch_conv_t<128, 2, 2, true>(a, st) : launch_conv_t<128, 4, 2>(a, st);
+    if (c.COUTp % 64 == 0) return sk ? launch_conv_t<64, 2, 2, true>(a, st) : launch_conv_t<64, 2, 2>(a, st);
     return launch_conv_t<32, 4, 1>(a, st);
 }
 

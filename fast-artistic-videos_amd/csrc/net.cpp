@@ -709,13 +709,7 @@ int net_forward_padded(fav_net* n, const float* in8, int H, int W, float* out_pl
 static constexpr int SIDE_CUS = 8;
 static hipError_t create_side_stream(hipStream_t* st)
 {
-    if (getenv("FAV_SIDE_CUMASK")) {          // experiment: confine the side queues with a CU mask (measured: slower)
-        uint32_t mask[16] = {0};
-        mask[0] = (1u << SIDE_CUS) - 1;
-        hipError_t e = hipExtStreamCreateWithCUMask(st, 16, mask);
-        if (e == hipSuccess) return e;
-        (void)hipGetLastError();
-    }
+    // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free)
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
@@ -852,8 +846,7 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && forward_flo, "fav_stream_prefetch_mask: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int side_cus = getenv("FAV_SIDE_CUS") ? atoi(getenv("FAV_SIDE_CUS")) : SIDE_CUS;   // (tuning knob)
-    s->net->reserve_cus = side_cus;      // from now on the network's persistent grids leave the side queues' CUs alone
+    s->net->reserve_cus = SIDE_CUS;      // from now on the network's persistent grids leave the side queues' CUs alone
     fav_stream::Pref& pf = s->pref[s->pref_next];
     s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
     const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;
