@@ -28,7 +28,6 @@
 //   -force_dist 1         take the worker / RCCL path even for -gpus 1;  -dry_run 1: workers print their assignment and exit
 //                         without touching a device (plumbing test).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -49,6 +48,7 @@
 #include <vector>
 
 #include "../../include/fav.h"
+#include "fav_launcher.h"
 
 namespace {
 
@@ -61,11 +61,7 @@ struct Opt {
     bool f(const char* k) const { return b.at(k); }
 };
 
-[[noreturn]] void die(const std::string& m)
-{
-    fprintf(stderr, "%s\n", m.c_str());
-    exit(1);
-}
+using favl::die;
 
 void check(int rc, const char* what)
 {
@@ -218,12 +214,6 @@ struct FrameIn {           // everything frame i needs from disk
 
 
 struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0; };
-
-std::string subst_stream(std::string v, const std::string& name)
-{
-    for (size_t p = v.find("%S"); p != std::string::npos; p = v.find("%S", p + name.size())) v.replace(p, 2, name);
-    return v;
-}
 
 // One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
 // `net` / `net_img` live on the current device; `nwriters` PNG threads.
@@ -476,74 +466,6 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipStreamDestroy(st); hipStreamDestroy(st_copy);
 }
 
-std::vector<std::string> split_list(const std::string& v)
-{
-    std::vector<std::string> out; std::string cur;
-    for (char c : v) { if (c == ',') { if (!cur.empty()) out.push_back(cur); cur.clear(); } else cur += c; }
-    if (!cur.empty()) out.push_back(cur);
-    return out;
-}
-
-// CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (containers: the GPU box of this project
-// shows 256 hardware threads under a 16-CPU quota -- 32 deflate threads there only fight each other)
-int effective_cpus()
-{
-    int n = std::max(1, (int)std::thread::hardware_concurrency());
-    long long quota = -1, period = 0;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
-        char q[64] = "";
-        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-        fclose(f);
-    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
-        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-        fclose(g);
-        if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
-    }
-    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1ll, (quota + period - 1) / period));
-    return n;
-}
-
-// PNG writer threads of one worker when `world` workers share the host: deflate is the slowest host stage (~25 ms per 1280x720
-// frame and core at the default -png_level 1), so a worker gets its share of the usable CPUs (the loaders mostly wait on I/O)
-int writer_budget(int requested, int world)
-{
-    if (requested > 0) return requested;
-    return std::max(4, std::min(32, effective_cpus() / std::max(1, world)));
-}
-
-void ncheck(ncclResult_t r, const char* what) { if (r != ncclSuccess) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(r)); }
-
-// rank 0 holds `blob`; on return every rank holds the same bytes.  ONE collective per model: ncclBroadcast of the packed
-// checkpoint (6.7 MB, latency-bound) preceded by its 8-byte size.
-void broadcast_blob(ncclComm_t comm, int rank, std::vector<uint8_t>& blob, hipStream_t st)
-{
-    unsigned long long n = rank == 0 ? blob.size() : 0, *d_n = nullptr;
-    if (hipMalloc((void**)&d_n, 8) != hipSuccess) die("hipMalloc failed");
-    hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice);
-    ncheck(ncclBroadcast(d_n, d_n, 8, ncclUint8, 0, comm, st), "ncclBroadcast(size)");
-    hipStreamSynchronize(st);
-    hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost); hipFree(d_n);
-    if (n == 0) { blob.clear(); return; }
-    uint8_t* d_b = nullptr;
-    if (hipMalloc((void**)&d_b, n) != hipSuccess) die("hipMalloc failed");
-    if (rank == 0) hipMemcpy(d_b, blob.data(), n, hipMemcpyHostToDevice);
-    ncheck(ncclBroadcast(d_b, d_b, n, ncclUint8, 0, comm, st), "ncclBroadcast(blob)");
-    if (hipStreamSynchronize(st) != hipSuccess) die("RCCL broadcast failed");
-    blob.resize(n);
-    hipMemcpy(blob.data(), d_b, n, hipMemcpyDeviceToHost); hipFree(d_b);
-}
-
-std::vector<uint8_t> pack_model(const std::string& path)
-{
-    size_t bytes = 0;
-    if (fav_net_pack_host(path.c_str(), nullptr, 0, &bytes)) die(fav_last_error());                         // core.lua:39-43
-    std::vector<uint8_t> blob(bytes);
-    if (fav_net_pack_host(path.c_str(), blob.data(), blob.size(), &bytes)) die(fav_last_error());
-    return blob;
-}
-
-std::string json_str(const std::string& v) { std::string o = "\""; for (char c : v) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o + "\""; }
-
 }  // namespace
 
 int main(int argc, char** argv)
@@ -584,7 +506,7 @@ int main(int argc, char** argv)
     if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
     const bool dry = o.i("dry_run") != 0;
-    std::vector<std::string> streams = split_list(o.s("streams"));
+    std::vector<std::string> streams = favl::split_list(o.s("streams"));
     const bool named = !streams.empty();
     if (!named) streams.push_back("");
     int world = std::max(1, o.i("gpus"));
@@ -600,44 +522,9 @@ int main(int argc, char** argv)
             if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
             if (o.i("gpu") + world > ndev) die("-gpus " + o.s("gpus") + " from -gpu " + o.s("gpu") + ": only " + std::to_string(ndev) + " devices");
         }
-        char idf[] = "/tmp/fav_rccl_id_XXXXXX";
-        const int fd = mkstemp(idf);
-        if (fd < 0) die("cannot create the RCCL id file");
-        close(fd); unlink(idf);                                   // the name is reused: rank 0 creates <name> atomically
-        std::vector<pid_t> kids;
-        fflush(stdout); fflush(stderr);
-        for (int r = 0; r < world; ++r) {
-            const pid_t pid = fork();                             // before any HIP call in this process
-            if (pid < 0) die("fork failed");
-            if (pid == 0) {
-                std::vector<std::string> args(argv, argv + argc);
-                args.insert(args.end(), {"-worker_rank", std::to_string(r), "-worker_world", std::to_string(world), "-rccl_id_file", idf});
-                std::vector<char*> av;
-                for (auto& a : args) av.push_back(const_cast<char*>(a.c_str()));
-                av.push_back(nullptr);
-                execv("/proc/self/exe", av.data());
-                perror("execv"); _exit(127);
-            }
-            kids.push_back(pid);
-        }
-        int worst = 0;
-        for (pid_t k : kids) { int stt = 0; waitpid(k, &stt, 0); const int rc = WIFEXITED(stt) ? WEXITSTATUS(stt) : 128; if (rc > worst) worst = rc; }
-        // aggregate line: total frames / slowest worker's stylisation time
-        if (o.i("timing") && !dry && worst == 0) {
-            int frames = 0; double secs = 0; std::string per = "";
-            for (int r = 0; r < world; ++r) {
-                const std::string f = std::string(idf) + ".rank" + std::to_string(r);
-                FILE* fp = fopen(f.c_str(), "r");
-                int fr = 0; double sc = 0;
-                if (fp) { if (fscanf(fp, "%d %lf", &fr, &sc) != 2) { fr = 0; sc = 0; } fclose(fp); unlink(f.c_str()); }
-                frames += fr; secs = std::max(secs, sc);
-                per += (r ? ", " : "") + std::to_string(fr ? fr / std::max(sc, 1e-9) : 0.0);
-            }
-            printf("{\"gpus\": %d, \"streams\": %zu, \"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"fps_per_gpu\": [%s], "
-                   "\"weights\": \"rank 0 parsed the .t7, ncclBroadcast of the packed blob\"}\n",
-                   world, streams.size(), frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str());
-        }
-        unlink(idf);
+        std::string idf;
+        const int worst = favl::spawn_workers(argc, argv, world, &idf);
+        if (o.i("timing") && !dry && worst == 0) favl::print_aggregate(idf, world, streams.size());
         return worst;
     }
 
@@ -647,13 +534,13 @@ int main(int argc, char** argv)
     const int device = o.i("gpu") + (dist ? rank : 0);
     std::vector<std::string> mine;
     for (size_t s = 0; s < streams.size(); ++s) if (!dist || (int)(s % (size_t)world) == rank) mine.push_back(streams[s]);     // stream s -> GPU s mod N
-    const int nwriters = writer_budget(o.i("writers"), dist ? world : 1);
+    const int nwriters = favl::writer_budget(o.i("writers"), dist ? world : 1);
     if (dry) {
         std::string js = "{\"rank\": " + std::to_string(std::max(rank, 0)) + ", \"world\": " + std::to_string(dist ? world : 1) + ", \"device\": " + std::to_string(device) +
                          ", \"writers\": " + std::to_string(nwriters) + ", \"streams\": [";
         for (size_t k = 0; k < mine.size(); ++k) {
-            js += std::string(k ? ", " : "") + "{\"name\": " + json_str(mine[k]);
-            for (const char* po : path_opts) js += std::string(", \"") + po + "\": " + json_str(named ? subst_stream(o.s(po), mine[k]) : o.s(po));
+            js += std::string(k ? ", " : "") + "{\"name\": " + favl::json_str(mine[k]);
+            for (const char* po : path_opts) js += std::string(", \"") + po + "\": " + favl::json_str(named ? favl::subst_stream(o.s(po), mine[k]) : o.s(po));
             js += "}";
         }
         printf("%s]}\n", js.c_str());
@@ -666,40 +553,8 @@ int main(int argc, char** argv)
     fav_net* net = nullptr; fav_net* net_img = nullptr;                                                      // core.lua:39-66
     if (dist) {
         // rank 0 parses; the other ranks never open the .t7
-        ncclUniqueId id;
-        const std::string idf = o.s("rccl_id_file");
-        if (rank == 0) {
-            ncheck(ncclGetUniqueId(&id), "ncclGetUniqueId");
-            const std::string tmp = idf + ".tmp";
-            FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
-            fclose(f);
-            if (rename(tmp.c_str(), idf.c_str())) die("cannot publish " + idf);
-        } else {
-            const auto t0 = std::chrono::steady_clock::now();
-            FILE* f = nullptr;
-            while (!(f = fopen(idf.c_str(), "rb"))) {
-                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120) die("timed out waiting for the RCCL id of rank 0");
-                usleep(2000);
-            }
-            if (fread(&id, sizeof id, 1, f) != 1) die("short RCCL id file");
-            fclose(f);
-        }
-        ncclComm_t comm;
-        ncheck(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
-        hipStream_t bst; if (hipStreamCreate(&bst) != hipSuccess) die("hipStreamCreate failed");
-        std::vector<uint8_t> blob, blob_img;
-        if (rank == 0) { blob = pack_model(o.s("model_vid")); if (want_img) blob_img = pack_model(o.s("model_img")); }
-        const auto tb = std::chrono::steady_clock::now();
-        broadcast_blob(comm, rank, blob, bst);
-        broadcast_blob(comm, rank, blob_img, bst);
-        const double bms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
-        if (fav_net_create_from_blob(blob.data(), blob.size(), device, &net)) die(fav_last_error());
-        if (!blob_img.empty() && fav_net_create_from_blob(blob_img.data(), blob_img.size(), device, &net_img)) die(fav_last_error());
-        printf("[rank %d/%d gpu %d] weights: %zu B%s via ncclBroadcast from rank 0 in %.2f ms; %zu stream(s), %d PNG writers\n", rank, world, device,
-               blob.size(), blob_img.empty() ? "" : " (+ image model)", bms, mine.size(), nwriters);
-        hipStreamDestroy(bst);
-        ncclCommDestroy(comm);
+        favl::load_models_dist(rank, world, o.s("rccl_id_file"), device, o.s("model_vid"), want_img ? o.s("model_img") : std::string(), &net, &net_img,
+                               mine.size(), nwriters);
     } else {
         if (fav_net_create(o.s("model_vid").c_str(), device, &net)) die(fav_last_error());                   // core.lua:39-43
         if (want_img && fav_net_create(o.s("model_img").c_str(), device, &net_img)) die(fav_last_error());
@@ -712,21 +567,17 @@ int main(int argc, char** argv)
     int frames = 0; double seconds = 0;
     for (const std::string& name : mine) {
         Opt os = o;
-        if (named) for (const char* po : path_opts) os.v[po] = subst_stream(o.s(po), name);
+        if (named) for (const char* po : path_opts) os.v[po] = favl::subst_stream(o.s(po), name);
         StreamResult r;
         run_stream(os, net, net_img, nwriters, &r);
         frames += r.frames; seconds += r.seconds;
         if (o.i("timing"))
             printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"png_writers\": %d}\n",
-                   named ? ("\"stream\": " + json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
+                   named ? ("\"stream\": " + favl::json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
                    r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, nwriters);
     }
     check(fav_net_check(net), "at exit");
-    if (dist && o.i("timing")) {
-        const std::string f = o.s("rccl_id_file") + ".rank" + std::to_string(rank);
-        FILE* fp = fopen(f.c_str(), "w");
-        if (fp) { fprintf(fp, "%d %.6f\n", frames, seconds); fclose(fp); }
-    }
+    if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds);
     fflush(stdout);
     fav_net_destroy(net); fav_net_destroy(net_img);
     return 0;

@@ -5,7 +5,11 @@
 // "<prefix>-%05d_equi.png" / "<prefix>-%05d_cubemap.png" (:541,552).  All compute goes through libfav's C ABI (fav_vr_*);
 // there is no CPU backend.  Not provided (rejected with a message): -evaluate, -backward, -smooth_certainty and
 // -continue_with > 1 (in the reference that option reloads per-face PNGs which func_save_image no longer writes, :521-523).
-// Additive flags: -precision <fp32|bf16>, -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>.
+// Additive flags: -precision <fp32|bf16>, -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>,
+// and -- several 360-degree videos on several GPUs (BASELINE config 5; the faces of one frame depend on each other through the
+// border priors, so the unit of sharding is the video) -- -streams <a,b,...> / -gpus <n> / -force_dist / -dry_run exactly as in
+// fav_stylize (host/fav_launcher.h): %S in -input_pattern, -flow_pattern, -occlusions_pattern and -output_prefix is the stream's
+// name, stream s -> worker process s mod n, rank 0 parses the checkpoints and ncclBroadcast (RCCL) hands the packed blobs on.
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -20,10 +24,11 @@
 #include <vector>
 
 #include "../../include/fav.h"
+#include "fav_launcher.h"
 
 namespace {
 
-[[noreturn]] void die(const std::string& m) { fprintf(stderr, "%s\n", m.c_str()); exit(1); }
+using favl::die;
 void check(int rc, const char* what) { if (rc) die(std::string(what) + ": " + fav_last_error()); }
 void hipc(hipError_t e, const char* what) { if (e != hipSuccess) die(std::string(what) + ": " + hipGetErrorString(e)); }
 bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
@@ -65,54 +70,12 @@ void mkdirs_for(const std::string& path)
     for (size_t p = 1; p < path.size(); ++p) if (path[p] == '/') mkdir(path.substr(0, p).c_str(), 0777);
 }
 
-}  // namespace
-
-int main(int argc, char** argv)
+// one 360-degree video: the loop of run_fast_neural_video with fast_artistic_video_vr.lua's callbacks (:103-302,454-591)
+int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>& b, fav_net* vid, fav_net* img, double* seconds_out)
 {
-    std::map<std::string, std::string> v = {
-        {"input_pattern", ""}, {"flow_pattern", ""}, {"occlusions_pattern", ""}, {"model_img", ""}, {"model_vid", ""},
-        {"start_frame", "1"}, {"continue_with", "1"}, {"num_frames", "9999"}, {"occlusions_min_filter", "7"},
-        {"fill_occlusions", "vgg-mean"}, {"overlap_pixel_w", "20"}, {"overlap_pixel_h", "20"}, {"output_prefix", "out"},
-        {"out_equi_w", "768"}, {"out_equi_h", "768"}, {"median_filter", "3"}, {"gpu", "-1"}, {"backend", "cuda"}, {"use_cudnn", "1"},
-        {"cudnn_benchmark", "0"}, {"evaluation_file", "evaluation.txt"}, {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""},
-        {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
-        {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
-        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"}};
-    std::map<std::string, bool> b = {
-        {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},
-        {"create_inconsistent_border", false}, {"backward", false}, {"out_equi", false}, {"out_cubemap", false}, {"evaluate", false},
-        {"no_consistency_eval", false}, {"invert_occlusions_eval", false}, {"backward_eval", false}, {"fix_occlusions_eval", false}};
-    for (int a = 1; a < argc; ++a) {                       // torch.CmdLine: -flag value | -boolflag
-        std::string k = argv[a];
-        if (k.size() < 2 || k[0] != '-') die("unknown argument " + k);
-        k = k.substr(1);
-        if (b.count(k)) { b[k] = true; continue; }
-        if (!v.count(k)) die("unknown option -" + k);
-        if (a + 1 >= argc) die("missing value for -" + k);
-        v[k] = argv[++a];
-    }
     auto I = [&](const char* k) { return atoi(v[k].c_str()); };
-    if (v["input_pattern"].empty()) die("Must give -input_pattern");                                               // :564-566
-    if (!b["create_inconsistent"] && (v["flow_pattern"].empty() || v["occlusions_pattern"].empty()))
-        die("Must give -flow_pattern and -occlusions_pattern");                                                     // :567-569
-    if (I("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement under oracle/ is test infrastructure); pass -gpu <id>");
-    if (b["evaluate"]) die("-evaluate (perceptual / edge losses) is outside the hot-path scope");
-    if (b["backward"]) die("-backward is not provided for the cube-map pipeline");
-    if (b["smooth_certainty"]) die("-smooth_certainty is not provided");
-    if (I("continue_with") != 1) die("-continue_with > 1 reloads per-face PNGs that the reference no longer writes (fast_artistic_video_vr.lua:521-523); not provided");
-    if (v["model_vid"].empty()) die("Must give -model_vid");
-    if (v["fill_occlusions"] != "vgg-mean" && v["fill_occlusions"] != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     const bool timing = I("timing") != 0;
     static const int proc_order[6] = {6, 1, 2, 5, 3, 4};                                                           // :103
-
-    hipc(hipSetDevice(I("gpu")), "hipSetDevice");
-    fav_net* vid = nullptr; fav_net* img = nullptr;
-    if (fav_net_create(v["model_vid"].c_str(), I("gpu"), &vid)) die(std::string("ERROR: Could not load model from ") + v["model_vid"] + " (" + fav_last_error() + ")");
-    if (v["precision"] != "fp32" && v["precision"] != "bf16") die("-precision must be fp32 or bf16");
-    check(fav_net_set_precision(vid, v["precision"] == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
-    if (!v["model_img"].empty() && v["model_img"] != "self")
-        if (fav_net_create(v["model_img"].c_str(), I("gpu"), &img)) die(std::string("ERROR: Could not load model from ") + v["model_img"] + " (" + fav_last_error() + ")");
-
     hipStream_t st; hipc(hipStreamCreate(&st), "hipStreamCreate");
     fav_vr* vr = nullptr;
     int W = 0, H = 0, ew = 0, eh = 0, cw = 0, ch = 0;
@@ -194,8 +157,108 @@ int main(int argc, char** argv)
         printf("%d frames (x6 faces) in %.3f s: %.2f frames/s\n", frames_done, s, frames_done / s);
     }
     if (vr) fav_vr_destroy(vr);
+    check(fav_net_check(vid), "stylising the video");
+    (void)hipFree(d_frame); (void)hipFree(d_cert); (void)hipFree(d_flow); (void)hipFree(d_equi); (void)hipFree(d_cube);
+    hipStreamDestroy(st);
+    *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
+    return frames_done;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::map<std::string, std::string> v = {
+        {"input_pattern", ""}, {"flow_pattern", ""}, {"occlusions_pattern", ""}, {"model_img", ""}, {"model_vid", ""},
+        {"start_frame", "1"}, {"continue_with", "1"}, {"num_frames", "9999"}, {"occlusions_min_filter", "7"},
+        {"fill_occlusions", "vgg-mean"}, {"overlap_pixel_w", "20"}, {"overlap_pixel_h", "20"}, {"output_prefix", "out"},
+        {"out_equi_w", "768"}, {"out_equi_h", "768"}, {"median_filter", "3"}, {"gpu", "-1"}, {"backend", "cuda"}, {"use_cudnn", "1"},
+        {"cudnn_benchmark", "0"}, {"evaluation_file", "evaluation.txt"}, {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""},
+        {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
+        {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
+        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
+        {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
+    std::map<std::string, bool> b = {
+        {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},
+        {"create_inconsistent_border", false}, {"backward", false}, {"out_equi", false}, {"out_cubemap", false}, {"evaluate", false},
+        {"no_consistency_eval", false}, {"invert_occlusions_eval", false}, {"backward_eval", false}, {"fix_occlusions_eval", false}};
+    for (int a = 1; a < argc; ++a) {                       // torch.CmdLine: -flag value | -boolflag
+        std::string k = argv[a];
+        if (k.size() < 2 || k[0] != '-') die("unknown argument " + k);
+        k = k.substr(1);
+        if (b.count(k)) { b[k] = true; continue; }
+        if (!v.count(k)) die("unknown option -" + k);
+        if (a + 1 >= argc) die("missing value for -" + k);
+        v[k] = argv[++a];
+    }
+    auto I = [&](const char* k) { return atoi(v[k].c_str()); };
+    if (v["input_pattern"].empty()) die("Must give -input_pattern");                                               // :564-566
+    if (!b["create_inconsistent"] && (v["flow_pattern"].empty() || v["occlusions_pattern"].empty()))
+        die("Must give -flow_pattern and -occlusions_pattern");                                                     // :567-569
+    if (I("gpu") < 0) die("-gpu -1: this build has no CPU backend (the CPU restatement under oracle/ is test infrastructure); pass -gpu <id>");
+    if (b["evaluate"]) die("-evaluate (perceptual / edge losses) is outside the hot-path scope");
+    if (b["backward"]) die("-backward is not provided for the cube-map pipeline");
+    if (b["smooth_certainty"]) die("-smooth_certainty is not provided");
+    if (I("continue_with") != 1) die("-continue_with > 1 reloads per-face PNGs that the reference no longer writes (fast_artistic_video_vr.lua:521-523); not provided");
+    if (v["model_vid"].empty()) die("Must give -model_vid");
+    if (v["fill_occlusions"] != "vgg-mean" && v["fill_occlusions"] != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
+    if (v["precision"] != "fp32" && v["precision"] != "bf16") die("-precision must be fp32 or bf16");
+    const bool timing = I("timing") != 0, dry = I("dry_run") != 0;
+    std::vector<std::string> streams = favl::split_list(v["streams"]);
+    const bool named = !streams.empty();
+    if (!named) streams.push_back("");
+    int world = std::max(1, I("gpus"));
+    const int rank = I("worker_rank");
+    static const char* const path_opts[] = {"input_pattern", "flow_pattern", "occlusions_pattern", "output_prefix"};
+    if (named && streams.size() > 1 && v["output_prefix"].find("%S") == std::string::npos)
+        die("-streams: -output_prefix must contain %S (the videos would overwrite each other's frames)");
+    if (rank < 0 && (world > 1 || I("force_dist"))) {                                   // launcher: one worker process per GPU
+        if (!dry) {
+            const int ndev = fav_device_count();
+            if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
+            if (I("gpu") + world > ndev) die("-gpus " + v["gpus"] + " from -gpu " + v["gpu"] + ": only " + std::to_string(ndev) + " devices");
+        }
+        std::string idf;
+        const int worst = favl::spawn_workers(argc, argv, world, &idf);
+        if (timing && !dry && worst == 0) favl::print_aggregate(idf, world, streams.size());
+        return worst;
+    }
+    const bool dist = rank >= 0;
+    if (dist) world = I("worker_world");
+    const int device = I("gpu") + (dist ? rank : 0);
+    std::vector<std::string> mine;
+    for (size_t s_ = 0; s_ < streams.size(); ++s_) if (!dist || (int)(s_ % (size_t)world) == rank) mine.push_back(streams[s_]);
+    if (dry) {
+        std::string js = "{\"rank\": " + std::to_string(std::max(rank, 0)) + ", \"world\": " + std::to_string(dist ? world : 1) + ", \"device\": " + std::to_string(device) + ", \"streams\": [";
+        for (size_t k = 0; k < mine.size(); ++k) {
+            js += std::string(k ? ", " : "") + "{\"name\": " + favl::json_str(mine[k]);
+            for (const char* po : path_opts) js += std::string(", \"") + po + "\": " + favl::json_str(named ? favl::subst_stream(v[po], mine[k]) : v[po]);
+            js += "}";
+        }
+        printf("%s]}\n", js.c_str());
+        return 0;
+    }
+
+    hipc(hipSetDevice(device), "hipSetDevice");
+    fav_net* vid = nullptr; fav_net* img = nullptr;
+    const bool want_img = !v["model_img"].empty() && v["model_img"] != "self";
+    if (dist) {
+        favl::load_models_dist(rank, world, v["rccl_id_file"], device, v["model_vid"], want_img ? v["model_img"] : std::string(), &vid, &img, mine.size(), 1);
+    } else {
+        if (fav_net_create(v["model_vid"].c_str(), device, &vid)) die(std::string("ERROR: Could not load model from ") + v["model_vid"] + " (" + fav_last_error() + ")");
+        if (want_img && fav_net_create(v["model_img"].c_str(), device, &img)) die(std::string("ERROR: Could not load model from ") + v["model_img"] + " (" + fav_last_error() + ")");
+    }
+    check(fav_net_set_precision(vid, v["precision"] == "bf16" ? FAV_PRECISION_BF16_OPERANDS : FAV_PRECISION_FP32), "fav_net_set_precision");
+    int frames = 0; double seconds = 0;
+    for (const std::string& name : mine) {
+        std::map<std::string, std::string> vs = v;
+        if (named) for (const char* po : path_opts) vs[po] = favl::subst_stream(v[po], name);
+        double sec = 0;
+        frames += run_video(vs, b, vid, img, &sec);
+        seconds += sec;
+    }
+    if (dist && timing) favl::write_worker_result(v["rccl_id_file"], rank, frames, seconds);
     if (img) fav_net_destroy(img);
     fav_net_destroy(vid);
-    (void)hipFree(d_frame); (void)hipFree(d_cert); (void)hipFree(d_flow); (void)hipFree(d_equi); (void)hipFree(d_cube);
     return 0;
 }

@@ -102,6 +102,20 @@ def test_launcher_shards_streams_across_workers(favlib, tmp_path):
     assert r.returncode != 0 and "%S" in r.stderr
 
 
+def test_vr_launcher_shards_videos_across_workers(favlib):
+    """fav_stylize_vr shares the launcher (host/fav_launcher.h): 360-degree videos are the unit of sharding (BASELINE config 5)"""
+    import json
+    exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize_vr")
+    r = subprocess.run([exe, "-input_pattern", "v/%S/f_%05d-%d.ppm", "-flow_pattern", "v/%S/flow-%d/backward_[%d]_{%d}.flo",
+                        "-occlusions_pattern", "v/%S/flow-%d/reliable_[%d]_{%d}.pgm", "-output_prefix", "o/%S/out", "-model_vid", "m.t7", "-gpu", "2",
+                        "-streams", "x,y,z", "-gpus", "2", "-dry_run", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["device"] for d in recs] == [2, 3]
+    assert [[s["name"] for s in d["streams"]] for d in recs] == [["x", "z"], ["y"]]
+    assert recs[1]["streams"][0]["occlusions_pattern"] == "v/y/flow-%d/reliable_[%d]_{%d}.pgm" and recs[1]["streams"][0]["output_prefix"] == "o/y/out"
+
+
 def test_mask_edge_cases(oracle):
     h, w = 8, 12
     z = np.zeros((h, w, 2), np.float32)

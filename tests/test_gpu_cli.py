@@ -241,3 +241,36 @@ def test_fav_stylize_multi_stream_launcher_rccl(oracle, favlib, tmp_path, golden
             a = open(tmp_path / f"multi_{name}" / f"out-{i:05d}.png", "rb").read()
             b = open(tmp_path / f"single_{name}" / f"out-{i:05d}.png", "rb").read()
             assert a == b, (name, i)
+
+
+def test_fav_stylize_vr_multi_stream_launcher_rccl(oracle, favlib, tmp_path, golden_dir):
+    """BASELINE config 5 plumbing: two 360-degree videos through `fav_stylize_vr -streams a,b -gpus 1 -force_dist 1` (worker process,
+    RCCL broadcast of the packed weights, videos back to back) give the same PNG bytes as two plain runs."""
+    hp = wp = 64
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    exe = os.path.join(BIN, "fav_stylize_vr")
+    rng = np.random.default_rng(11)
+    for k, name in enumerate(("a", "b")):
+        d = tmp_path / name
+        os.makedirs(d, exist_ok=True)
+        for fr in (1, 2):
+            for face in (6, 1, 2, 5, 3, 4):
+                oracle.write_pnm(str(d / f"frame_{fr:05d}-{face}.ppm"), synth.smooth_frame(hp, wp, 900 + 100 * k + 10 * fr + face))
+                if fr > 1:
+                    os.makedirs(d / f"flow-{face}", exist_ok=True)
+                    oracle.write_flo(str(d / f"flow-{face}" / f"backward_{fr}_{fr-1}.flo"), synth.backward_flow(hp, wp, 950 + 100 * k + face))
+                    oracle.write_pnm(str(d / f"flow-{face}" / f"reliable_{fr}_{fr-1}.pgm"), ((rng.random((hp, wp)) > 0.2) * 255).astype(np.uint8))
+    common = ["-flow_pattern", str(tmp_path / "%S" / "flow-%d" / "backward_[%d]_{%d}.flo"), "-occlusions_pattern", str(tmp_path / "%S" / "flow-%d" / "reliable_[%d]_{%d}.pgm"),
+              "-gpu", "0", "-model_vid", model, "-model_img", "self", "-overlap_pixel_h", "24", "-overlap_pixel_w", "24",
+              "-out_equi", "-out_equi_w", "96", "-out_equi_h", "48", "-fill_occlusions", "uniform-random", "-seed", "4", "-timing", "1"]
+    r = subprocess.run([exe, "-input_pattern", str(tmp_path / "%S" / "frame_%05d-%d.ppm"), "-output_prefix", str(tmp_path / "multi_%S" / "out"),
+                        "-streams", "a,b", "-gpus", "1", "-force_dist", "1"] + common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "via ncclBroadcast from rank 0" in r.stdout and '"frames": 4' in r.stdout
+    for name in ("a", "b"):
+        single = [a.replace("%S", name) for a in common]
+        r1 = subprocess.run([exe, "-input_pattern", str(tmp_path / name / "frame_%05d-%d.ppm"), "-output_prefix", str(tmp_path / f"single_{name}" / "out")] + single,
+                            capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0, r1.stderr
+        for fr in (1, 2):
+            assert open(tmp_path / f"multi_{name}" / f"out-{fr:05d}_equi.png", "rb").read() == open(tmp_path / f"single_{name}" / f"out-{fr:05d}_equi.png", "rb").read(), (name, fr)
