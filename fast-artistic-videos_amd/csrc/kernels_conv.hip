@@ -1379,7 +1379,12 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, bool no_sk, h
     const int tiles = a0.tiles_x * a0.tiles_y + a0.nb;
     // no_sk (shared device): one block per tile -- the unit range of block b is then exactly tile b, nothing is handed between blocks
     // and nothing needs to be co-resident
-    const int grid = no_sk ? tiles : (tiles * (cin / 32) * 3 < nres ? 1 : nres);      // (stream-K units: tap rows)
+    // Almost exactly one tile per CU (the 16x16 edge tiles bring six of the ten residual layers to 242 / 252 tiles for 256 CUs): one
+    // whole tile per block beats stream-K there -- the 12/11.8 longer K range costs less than the second prologue and the
+    // hand-off of a split tile (measured: timeline in DESIGN.md section 4)
+    // (threshold swept on the MI355X: 165.1 us without, 161.3 at 96 %, 159.6 at 94 %, 159.8 at 89 %)
+    const bool one_per_cu = tiles <= nres && tiles * 100 >= nres * 94;
+    const int grid = (no_sk || one_per_cu) ? tiles : (tiles * (cin / 32) * 3 < nres ? 1 : nres);      // (stream-K units: tap rows)
     H3Args a = a0; a.dbg = nullptr;
     static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;
