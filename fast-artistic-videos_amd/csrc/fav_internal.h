@@ -137,6 +137,11 @@ int launch_conv_fold(const ConvLaunch& p, const float* wfold, hipStream_t st);
 bool conv_c8_eligible(int cin_pitch, int coutp, int k, int stride, int stages, int ups);
 int conv_c8_tiles(int OH, int OW);
 int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
+// the same layer with dense K for 7 (video model) or 3 (image model) real input channels: taps paired so that no zero channel is
+// multiplied; wc8d = conv_c8d_pack() of the [cout][cin][9][9] weights
+bool conv_c8d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups);
+void conv_c8d_pack(const float* w, int cin, int cout, std::vector<float>& out);
+int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* counts, hipStream_t st);
 // 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
 int conv3_halo_tiles(int OH, int OW, bool edge_b);      // edge_b: fp32 kernel (16 x 16 tiles on a narrow ragged right edge)

@@ -650,6 +650,219 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------
+// First layer with DENSE K (round 2).  conv_c8_kernel feeds one filter tap = 8 channels = 4 MFMAs, of which the 8th channel
+// (7 real ones: content BGR, prior BGR, mask; 3 for an image model) is a zero: 12.5 % (62.5 %) of the matrix work multiplies
+// zeros.  A 32x32x2 MFMA takes ONE k per half-wave, and any two k may share an instruction, so the taps of one channel are
+// PAIRED such that the second half-wave's operand sits at a constant offset from the first's:
+//     (ky, 2q) + (ky, 2q+1)   -> +1 halo pixel      (36 pairs per channel)
+//     (2p, 8)  + (2p+1, 8)    -> +1 halo row        ( 4 pairs)
+//     (8, 8)   + nothing                            ( 1, zero weight in the second half)
+// = 41 MFMAs per channel, 287 (123) instead of 324 per tile.  The halo lives in LDS as one PLANE per channel (lanes = 32
+// consecutive pixels: conflict-free ds_read_b32), the weights as [pair][half][32 output channels]; every operand address is a
+// per-lane base (pixel + the half-wave's +1 pixel / +1 row / +32 floats) plus an immediate.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int C8D_PAIRS = 41;                         // MFMAs per real input channel (9x9 taps)
+
+template <int CR>
+__global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
+{
+    constexpr int KS = 9;
+    constexpr int HW = C8_TW + KS - 1;            // halo width (40)
+    constexpr int HP = (C8_TH + KS - 1) * HW;     // halo pixels per plane (16 x 40 = 640)
+    constexpr int NJ = CR * C8D_PAIRS;            // MFMAs per tile
+    constexpr int NH = (HP + 511) / 512;          // halo pixels per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;                             // [NJ][2][32]
+    float* Hs = Ws + NJ * 64;                     // [2 buffers][CR planes][HP] (+ HW + 1 floats of slack: the unpaired tap reads one pixel on)
+    float* red = Hs + 2 * CR * HP + 64;           // [8 waves][32] + [32]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int e = t; e < NJ * 16; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wgt + e * 4);
+    for (int e = t; e < 64; e += 512) Hs[2 * CR * HP + e] = 0.f;
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    float4 hlo[NH], hhi[NH];
+#define C8D_LOAD_HALO(tile_)                                                                        \
+    {                                                                                               \
+        const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
+        _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                            \
+            const int pix_ = t + 512 * i, hy_ = pix_ / HW, hx_ = pix_ - hy_ * HW;                   \
+            const int iy_ = ty_ * C8_TH - p.pad + hy_, ix_ = tx_ * C8_TW - p.pad + hx_;             \
+            const bool v_ = (pix_ < HP) & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+            const int off_ = v_ ? (iy_ * p.IWp + ix_) * 8 : 0;                                      \
+            const float4 a_ = *reinterpret_cast<const float4*>(p.in + off_);                        \
+            const float4 b_ = CR > 4 ? *reinterpret_cast<const float4*>(p.in + off_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            hlo[i] = v_ ? a_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            hhi[i] = v_ ? b_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+        }                                                                                           \
+    }
+#define C8D_STORE_HALO(buf_)                                                                        \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                            \
+            const int pix_ = t + 512 * i;                                                           \
+            if (pix_ < HP) {                                                                        \
+                float* d_ = Hs + (buf_) * CR * HP + pix_;                                           \
+                const float c_[8] = {hlo[i].x, hlo[i].y, hlo[i].z, hlo[i].w, hhi[i].x, hhi[i].y, hhi[i].z, hhi[i].w}; \
+                _Pragma("unroll") for (int c = 0; c < CR; ++c) d_[c * HP] = c_[c];                  \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) C8D_LOAD_HALO(tile);
+    C8D_STORE_HALO(0);
+    __syncthreads();
+
+    const int m = lane & 31, half = lane >> 5;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    // per-lane bases: pixel (wave row, m); second half-wave one pixel / one row further; weights of this lane's output channel
+    const float* const a_px = Hs + wave * HW + m + half;
+    const float* const a_row = Hs + (wave + half) * HW + m;
+    const float* const b_lo = Ws + half * 32 + m;
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) C8D_LOAD_HALO(nxt);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* apx = a_px + cur * CR * HP;
+        const float* arw = a_row + cur * CR * HP;
+#pragma unroll
+        for (int c = 0; c < CR; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int j = c * C8D_PAIRS + ky * 4 + q;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(apx[c * HP + ky * HW + 2 * q], b_lo[j * 64], acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int j = c * C8D_PAIRS + 36 + pp;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arw[c * HP + 2 * pp * HW + 8], b_lo[j * 64], acc, 0, 0, 0);
+            }
+            {
+                const int j = c * C8D_PAIRS + 40;      // tap (8, 8) alone: the second half-wave's weight is zero
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(apx[c * HP + 8 * HW + 8], b_lo[j * 64], acc, 0, 0, 0);
+            }
+        }
+        if (nxt < ntiles) C8D_STORE_HALO(cur ^ 1);
+
+        // epilogue: as conv_c8_kernel (MFMA rows = 32 pixels of this wave's tile row, columns = channels)
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const float bv = p.bias[col];
+        float sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mi = (r & 3) + 8 * (r >> 2) + rbase;
+            const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
+            const float v = acc[r] + bv;
+            acc[r] = v;
+            if (oy < p.OH && ox < p.OW) {
+                if (col < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + col] = v;
+                sm += v;
+            }
+        }
+        if (p.partials != nullptr) {
+            const int vh = min(C8_TH, p.OH - ty * C8_TH), vw = min(C8_TW, p.OW - tx * C8_TW);
+            const int cnt = vh * vw;
+            sm += __shfl_xor(sm, 32);
+            if (lane < 32) red[wave * 32 + lane] = sm;
+            __syncthreads();
+            if (t < 32) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
+                red[256 + t] = a / (float)cnt;
+            }
+            __syncthreads();
+            const float mu = red[256 + col];
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mi = (r & 3) + 8 * (r >> 2) + rbase;
+                const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
+                const float d = acc[r] - mu;
+                if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+            }
+            q += __shfl_xor(q, 32);
+            __syncthreads();
+            if (lane < 32) red[wave * 32 + lane] = q;
+            __syncthreads();
+            if (t < 32) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
+                p.partials[(size_t)tile * 32 + t] = make_float2(red[256 + t], a);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+        }
+        __syncthreads();            // next halo buffer written by every thread; red scratch free again
+        cur ^= 1;
+    }
+#undef C8D_LOAD_HALO
+#undef C8D_STORE_HALO
+}
+
+}  // namespace
+
+bool conv_c8d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups)
+{
+    return conv_c8_eligible(cin_pitch, coutp, k, stride, stages, ups) && (cin_real == 7 || cin_real == 3);
+}
+
+// weights [cout][cin][9][9] -> [pair j][half][32]: the pairing of conv_c8d_kernel
+void conv_c8d_pack(const float* w, int cin, int cout, std::vector<float>& out)
+{
+    out.assign((size_t)cin * C8D_PAIRS * 64, 0.f);
+    auto W = [&](int n, int c, int ky, int kx) { return w[(((size_t)n * cin + c) * 9 + ky) * 9 + kx]; };
+    for (int c = 0; c < cin; ++c)
+        for (int n = 0; n < cout && n < 32; ++n) {
+            float* o = out.data() + (size_t)c * C8D_PAIRS * 64 + n;
+            for (int ky = 0; ky < 9; ++ky)
+                for (int q = 0; q < 4; ++q) { o[(ky * 4 + q) * 64] = W(n, c, ky, 2 * q); o[(ky * 4 + q) * 64 + 32] = W(n, c, ky, 2 * q + 1); }
+            for (int pp = 0; pp < 4; ++pp) { o[(36 + pp) * 64] = W(n, c, 2 * pp, 8); o[(36 + pp) * 64 + 32] = W(n, c, 2 * pp + 1, 8); }
+            o[40 * 64] = W(n, c, 8, 8);
+        }
+}
+
+template <int CR>
+static int launch_c8d_t(const C8Args& a, int reserve_cus, hipStream_t st)
+{
+    constexpr int HPc = (C8_TH + 8) * (C8_TW + 8);
+    const size_t lds = (size_t)(CR * C8D_PAIRS * 64 + 2 * CR * HPc + 64 + 8 * 32 + 32) * sizeof(float);
+    const int dv = cur_dev();
+    static int nblocks[MAX_DEVICES] = {};
+    if (!nblocks[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8d_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        nblocks[dv] = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = std::max(1, nblocks[dv] - reserve_cus);
+    hipLaunchKernelGGL((conv_c8d_kernel<CR>), dim3(tiles < grid ? tiles : grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_c8d_kernel");
+    return FAV_OK;
+}
+
+int launch_conv_c8d(const ConvLaunch& c, int cin_real, const float* wc8d, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv_c8d_eligible(c.CIN, cin_real, c.COUTp, c.KH, c.stride, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode && wc8d,
+                "first-layer conv (dense K): not eligible");
+    FAV_REQUIRE((long long)c.IH * c.IWp * 8 < (1ll << 31), "first-layer conv: bad shape");
+    C8Args a;
+    a.in = c.in; a.wgt = wc8d; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW; a.Kpad = c.Kpad;
+    a.tiles_x = (c.OW + C8_TW - 1) / C8_TW; a.tiles_y = (c.OH + C8_TH - 1) / C8_TH;
+    return cin_real == 7 ? launch_c8d_t<7>(a, c.reserve_cus, st) : launch_c8d_t<3>(a, c.reserve_cus, st);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3 stride-1 layers (the ten 128->128 residual convolutions and c3s1-64: 71 % of the network's FLOPs):
 // halo-resident implicit GEMM.  The generic kernel re-gathers (and re-transforms) its activation operand
 // for every tap; measured, that global gather costs ~20 % of the kernel.  Here a block (8 waves, one per

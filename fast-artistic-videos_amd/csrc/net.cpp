@@ -26,7 +26,7 @@ using namespace fav;
 namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
-struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
 struct Act {
@@ -74,10 +74,10 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_s2; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr};
     return t;
 }
 
@@ -125,7 +125,7 @@ struct fav_net {
     {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
-        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wgt16); }
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
@@ -164,6 +164,11 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             if (L.transposed && (L.stride != 2 || L.adj != 1 || L.pad > L.k - 1)) {
                 set_error("network: SpatialFullConvolution is supported for stride 2, adj 1 (models_video.lua:99-102), got s=%d adj=%d", L.stride, L.adj);
                 return FAV_EUNSUPPORTED; }
+            if (!L.transposed && conv_c8d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, 0, 0)) {      // first layer: dense-K pairing
+                std::vector<float> wd;
+                conv_c8d_pack(L.w.data(), L.cin, L.cout, wd);
+                rc = dev_upload(wd, 0, &d.wc8d); if (rc) return rc;
+            }
             if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
                 // [ky][n = c*k + kx][ci] for the row-folded last-layer kernel
                 std::vector<float> wf((size_t)L.k * 32 * d.cinp, 0.f);
@@ -257,13 +262,14 @@ int fav_net::alloc(size_t bytes, float** out)
 int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
     const float* wfold = (c.final_mode && !tuning().no_fold) ? convs[conv_index].wfold : nullptr;
+    const float* c8d_w = (use_c8 && !tuning().no_c8d && conv_c8d_eligible(c.CIN, L.cin, c.COUTp, L.k, c.stride, c.pre.stages, c.ups)) ? convs[conv_index].wc8d : nullptr;
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
     cs.no_sk = shared_device ? 1 : 0;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? launch_conv_c8(cs, c8_counts, st) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
+    auto go = [&]() { return wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
@@ -277,7 +283,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
     // kernel id: 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
-    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? 8 : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
+    prof_tile[conv_index] = wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
     return rc;
 }
 
