@@ -126,12 +126,13 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300):
             if i > 1:
                 os.symlink(f"{d}/src/b{i % ring}.flo", f"{d}/flow/backward_{i}_{i-1}.flo"); os.symlink(f"{d}/src/w{i % ring}.flo", f"{d}/flow/forward_{i-1}_{i}.flo")
         base = [exe, "-input_pattern", d + "/frame_%05d.ppm", "-flow_pattern", d + "/flow/backward_[%d]_{%d}.flo",
-                "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo", "-structure", "0",
+                "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo",
                 "-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1"]
         out = {"frames": nframes, "host_threads": os.cpu_count(), "usable_cpus": effective_cpus(), "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net -> D2H -> PNG to /dev/shm",
                "h2d_bytes_per_frame": H * W * (3 + 8 + 8), "d2h_bytes_per_frame": H * W * 3}
-        for name, lvl in (("png_level_1", "1"), ("png_level_0", "0")):
-            r = subprocess.run(base + ["-output_prefix", f"{d}/o{lvl}/out", "-png_level", lvl], capture_output=True, text=True, timeout=600)
+        # 3-argument check = the workload of `value`; the 4-argument (image-structure) check is what makeOptFlow_deepflow.sh:59 runs
+        for name, lvl, structure in (("png_level_1", "1", "0"), ("png_level_0", "0", "0"), ("png_level_1_4arg_check", "1", "1")):
+            r = subprocess.run(base + ["-structure", structure, "-output_prefix", f"{d}/o{lvl}/out", "-png_level", lvl], capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
                 out[name] = {"error": (r.stderr or r.stdout)[-300:]}
