@@ -58,6 +58,21 @@ __device__ __forceinline__ void store16_wt(void* p, v4f v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// Per-tile InstanceNorm partials with ONE barrier: every wave reduces its own 32 pixels x 32 channels accumulator tile(s) to
+// (mean, M2, count) in registers (two half-wave shuffles), the NW waves' results meet in LDS, and thread c merges the waves of
+// channel c exactly (Chan et al.): mean = sum n_w mean_w / n, M2 = sum M2_w + n_w (mean_w - mean)^2.  (Before: block-wide
+// sum -> barrier -> mean -> barrier -> M2 -> barrier -> barrier, four barriers per tile on an 8-wave block.)
+__device__ __forceinline__ float2 merge_wave_stats(const float2* st, const int* wn, int NW, int pitch, int c, int* n_out)
+{
+    int n = 0; float s = 0.f;
+    for (int w = 0; w < NW; ++w) { n += wn[w]; s += (float)wn[w] * st[w * pitch + c].x; }
+    const float mean = n ? s / (float)n : 0.f;
+    float m2 = 0.f;
+    for (int w = 0; w < NW; ++w) { const float d = st[w * pitch + c].x - mean; m2 += st[w * pitch + c].y + (float)wn[w] * d * d; }
+    *n_out = n;
+    return make_float2(mean, m2);
+}
+
 // branch-free form used inside the MFMA loop: lo = 0 for ReLU, -inf for none; identity = scale 1, shift 0
 __device__ __forceinline__ float4 affine4_lo(float4 v, const float* sc, const float* sh, float lo)
 {
@@ -574,37 +589,27 @@ __global__ __launch_bounds__(512, 2) void conv_c8_kernel(const C8Args p)
             }
         }
         if (p.partials != nullptr) {
-            const int vh = min(C8_TH, p.OH - ty * C8_TH), vw = min(C8_TW, p.OW - tx * C8_TW);
-            const int cnt = vh * vw;
+            float2* st = reinterpret_cast<float2*>(red);          // [8 waves][32]
+            int* wn = reinterpret_cast<int*>(red + 8 * 64);         // [8]
+            const int oyw = ty * C8_TH + wave;
+            const int nw = oyw < p.OH ? min(C8_TW, p.OW - tx * C8_TW) : 0;      // valid pixels of this wave's row
             sm += __shfl_xor(sm, 32);
-            if (lane < 32) red[wave * 32 + lane] = sm;
-            __syncthreads();
-            if (t < 32) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
-                red[256 + t] = a / (float)cnt;
-            }
-            __syncthreads();
-            const float mu = red[256 + col];
+            const float mu = nw ? sm / (float)nw : 0.f;
             float q = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mi = (r & 3) + 8 * (r >> 2) + rbase;
-                const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
                 const float d = acc[r] - mu;
-                if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+                if (oyw < p.OH && tx * C8_TW + mi < p.OW) q = fmaf(d, d, q);
             }
             q += __shfl_xor(q, 32);
-            __syncthreads();
-            if (lane < 32) red[wave * 32 + lane] = q;
+            if (lane < 32) st[wave * 32 + lane] = make_float2(mu, q);
+            if (lane == 0) wn[wave] = nw;
             __syncthreads();
             if (t < 32) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
-                p.partials[(size_t)tile * 32 + t] = make_float2(red[256 + t], a);
-                if (t == 0) p.counts[tile] = cnt;
+                int n;
+                p.partials[(size_t)tile * 32 + t] = merge_wave_stats(st, wn, 8, 32, t, &n);
+                if (t == 0) p.counts[tile] = n;
             }
         }
         (void)nvalid;
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ws = smem;                             // [NJ][2][32]
     float* Hs = Ws + NJ * 64;                     // [2 buffers][CR planes][HP] (+ HW + 1 floats of slack: the unpaired tap reads one pixel on)
-    float* red = Hs + 2 * CR * HP + 64;           // [8 waves][32] + [32]
+    float* red = Hs + 2 * CR * HP + 64;           // [8 waves][32] float2 + [8] int
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     for (int e = t; e < NJ * 16; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wgt + e * 4);
@@ -768,37 +773,27 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
             }
         }
         if (p.partials != nullptr) {
-            const int vh = min(C8_TH, p.OH - ty * C8_TH), vw = min(C8_TW, p.OW - tx * C8_TW);
-            const int cnt = vh * vw;
+            float2* st = reinterpret_cast<float2*>(red);          // [8 waves][32]
+            int* wn = reinterpret_cast<int*>(red + 8 * 64);         // [8]
+            const int oyw = ty * C8_TH + wave;
+            const int nw = oyw < p.OH ? min(C8_TW, p.OW - tx * C8_TW) : 0;      // valid pixels of this wave's row
             sm += __shfl_xor(sm, 32);
-            if (lane < 32) red[wave * 32 + lane] = sm;
-            __syncthreads();
-            if (t < 32) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
-                red[256 + t] = a / (float)cnt;
-            }
-            __syncthreads();
-            const float mu = red[256 + col];
+            const float mu = nw ? sm / (float)nw : 0.f;
             float q = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mi = (r & 3) + 8 * (r >> 2) + rbase;
-                const int oy = ty * C8_TH + wave, ox = tx * C8_TW + mi;
                 const float d = acc[r] - mu;
-                if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
+                if (oyw < p.OH && tx * C8_TW + mi < p.OW) q = fmaf(d, d, q);
             }
             q += __shfl_xor(q, 32);
-            __syncthreads();
-            if (lane < 32) red[wave * 32 + lane] = q;
+            if (lane < 32) st[wave * 32 + lane] = make_float2(mu, q);
+            if (lane == 0) wn[wave] = nw;
             __syncthreads();
             if (t < 32) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * 32 + t];
-                p.partials[(size_t)tile * 32 + t] = make_float2(red[256 + t], a);
-                if (t == 0) p.counts[tile] = cnt;
+                int n;
+                p.partials[(size_t)tile * 32 + t] = merge_wave_stats(st, wn, 8, 32, t, &n);
+                if (t == 0) p.counts[tile] = n;
             }
         }
         __syncthreads();            // next halo buffer written by every thread; red scratch free again
@@ -834,7 +829,7 @@ template <int CR>
 static int launch_c8d_t(const C8Args& a, int reserve_cus, hipStream_t st)
 {
     constexpr int HPc = (C8_TH + 8) * (C8_TW + 8);
-    const size_t lds = (size_t)(CR * C8D_PAIRS * 64 + 2 * CR * HPc + 64 + 8 * 32 + 32) * sizeof(float);
+    const size_t lds = (size_t)(CR * C8D_PAIRS * 64 + 2 * CR * HPc + 64 + 8 * 64 + 8) * sizeof(float);
     const int dv = cur_dev();
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
@@ -1150,16 +1145,14 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
 
         DBG_T();   /* fixup end */
         // ------------------------------------------------------------ epilogue: wave = output row, MFMA rows = columns
-        float* red = smem;                 // [8][BN] + [BN]
-        const int vh = min(tb ? 16 : H3_TH, p.OH - oy0), vw = min(tb ? 16 : H3_TW, p.OW - ox0);
-        const int cnt = vh * vw;
+        float* red = smem;                 // [8][BN] float2 + [8] int
         // output pixel of MFMA row mi: A tiles (oy0 + wave, ox0 + mi); B tiles (oy0 + 2 wave + mi / 16, ox0 + un-rotated column)
 #define H3_OPIX(r_)                                                                                 \
         const int mi_ = ((r_) & 3) + 8 * ((r_) >> 2) + rbase;                                       \
         const int oy = tb ? oy0 + 2 * wave + (mi_ >> 4) : oy0 + wave;                               \
         const int ox = tb ? ox0 + (mi_ < 16 ? mi_ : ((mi_ + 14) & 15)) : ox0 + mi_;                 \
         const bool ok_ = tb ? (oy < p.OH) & (ox < p.OW) & ((mi_ < 16 ? mi_ : ((mi_ + 14) & 15)) < 16) : (oy < p.OH) & (ox < p.OW);
-        float lsum[TN];
+        float lsum[TN]; int lcnt = 0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = j * 32 + col;
@@ -1173,28 +1166,19 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                 if (ok_) {
                     if (n < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + n] = v;
                     sm += v;
+                    if (j == 0) ++lcnt;
                 }
             }
             lsum[j] = sm;
         }
         if (p.partials != nullptr) {
+            float2* st = reinterpret_cast<float2*>(red);          // [8 waves][BN]
+            int* wn = reinterpret_cast<int*>(red + 16 * BN);        // [8]
+            const int nw = lcnt + __shfl_xor(lcnt, 32);             // valid pixels of this wave's 32
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
-                if (lane < 32) red[wave * BN + j * 32 + lane] = sm;
-            }
-            __syncthreads();
-            if (t < BN) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
-                red[8 * BN + t] = a / (float)cnt;
-            }
-            __syncthreads();
-            float lq[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float mu = red[8 * BN + j * 32 + col];
+                const float mu = nw ? sm / (float)nw : 0.f;
                 float q = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1202,19 +1186,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const H3Args p)
                     const float d = acc[j][r] - mu;
                     if (ok_) q = fmaf(d, d, q);
                 }
-                lq[j] = q + __shfl_xor(q, 32);
+                q += __shfl_xor(q, 32);
+                if (lane < 32) st[wave * BN + j * 32 + lane] = make_float2(mu, q);
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (lane < 32) red[wave * BN + j * 32 + lane] = lq[j];
+            if (lane == 0) wn[wave] = nw;
             __syncthreads();
             if (t < BN) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) a += red[w * BN + t];
-                p.partials[(size_t)tile * p.COUTp + t] = make_float2(red[8 * BN + t], a);
-                if (t == 0) p.counts[tile] = cnt;
+                int n;
+                p.partials[(size_t)tile * p.COUTp + t] = merge_wave_stats(st, wn, 8, BN, t, &n);
+                if (t == 0) p.counts[tile] = n;
             }
         }
 #undef H3_OPIX
@@ -1891,10 +1871,8 @@ __global__ __launch_bounds__(512, 2) void conv3s2_halo_kernel(const S2Args p)
             }
             if (owner) {
                 // -------------------------------------------------------- epilogue: wave = (output row, channel half), MFMA rows = columns
-                float* red = smem;                 // [4 rows][BN] + [BN]
+                float* red = smem;                 // [8 waves][BN/2] float2 + [8] int
                 const int oy = oy0 + wr;
-                const int vh = min(S2_TH, p.OH - oy0), vw = min(S2_TW, p.OW - ox0);
-                const int cnt = vh * vw;
                 float lsum[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -1914,23 +1892,13 @@ __global__ __launch_bounds__(512, 2) void conv3s2_halo_kernel(const S2Args p)
                     lsum[j] = sm;
                 }
                 if (p.partials != nullptr) {
+                    float2* st = reinterpret_cast<float2*>(red);      // [4 rows][BN]: the two channel halves of a row sit side by side
+                    int* wn = reinterpret_cast<int*>(red + 2 * S2_TH * BN);
+                    const int nw = oy < p.OH ? min(S2_TW, p.OW - ox0) : 0;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const float sm = lsum[j] + __shfl_xor(lsum[j], 32);
-                        if (lane < 32) red[wr * BN + nh * (BN / 2) + j * 32 + lane] = sm;
-                    }
-                    __syncthreads();
-                    if (t < BN) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int w = 0; w < S2_TH; ++w) a += red[w * BN + t];
-                        red[S2_TH * BN + t] = a / (float)cnt;
-                    }
-                    __syncthreads();
-                    float lq[TN];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float mu = red[S2_TH * BN + nh * (BN / 2) + j * 32 + col];
+                        const float mu = nw ? sm / (float)nw : 0.f;
                         float q = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -1938,19 +1906,15 @@ __global__ __launch_bounds__(512, 2) void conv3s2_halo_kernel(const S2Args p)
                             const float d = acc[j][r] - mu;
                             if (oy < p.OH && ox < p.OW) q = fmaf(d, d, q);
                         }
-                        lq[j] = q + __shfl_xor(q, 32);
+                        q += __shfl_xor(q, 32);
+                        if (lane < 32) st[wr * BN + nh * (BN / 2) + j * 32 + lane] = make_float2(mu, q);
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (lane < 32) red[wr * BN + nh * (BN / 2) + j * 32 + lane] = lq[j];
+                    if (lane == 0 && nh == 0) wn[wr] = nw;
                     __syncthreads();
                     if (t < BN) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int w = 0; w < S2_TH; ++w) a += red[w * BN + t];
-                        p.partials[(size_t)tile * p.COUTp + t] = make_float2(red[S2_TH * BN + t], a);
-                        if (t == 0) p.counts[tile] = cnt;
+                        int n;
+                        p.partials[(size_t)tile * p.COUTp + t] = merge_wave_stats(st, wn, S2_TH, BN, t, &n);
+                        if (t == 0) p.counts[tile] = n;
                     }
                 }
             }
