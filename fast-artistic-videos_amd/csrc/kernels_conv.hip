@@ -680,12 +680,11 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
     constexpr int NH = (HP + 511) / 512;          // halo pixels per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ws = smem;                             // [NJ][2][32]
-    float* Hs = Ws + NJ * 64;                     // [2 buffers][CR planes][HP] (+ HW + 1 floats of slack: the unpaired tap reads one pixel on)
-    float* red = Hs + 2 * CR * HP + 64;           // [8 waves][32] float2 + [8] int
+    float* Hs = Ws + NJ * 64;                     // [2 buffers][CR planes][HP]
+    float* red = Hs + 2 * CR * HP;                // [8 waves][32] float2 + [8] int
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     for (int e = t; e < NJ * 16; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wgt + e * 4);
-    for (int e = t; e < 64; e += 512) Hs[2 * CR * HP + e] = 0.f;
 
     const int ntiles = p.tiles_x * p.tiles_y;
     float4 hlo[NH], hhi[NH];
@@ -725,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
     // per-lane bases: pixel (wave row, m); second half-wave one pixel / one row further; weights of this lane's output channel
     const float* const a_px = Hs + wave * HW + m + half;
     const float* const a_row = Hs + (wave + half) * HW + m;
+    const float* const a_one = Hs + wave * HW + m;     // the unpaired tap: both half-waves read the SAME (valid) pixel; the second one's weight is 0
     const float* const b_lo = Ws + half * 32 + m;
     int cur = 0;
     for (; tile < ntiles; tile += gridDim.x) {
@@ -735,6 +735,7 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* apx = a_px + cur * CR * HP;
         const float* arw = a_row + cur * CR * HP;
+        const float* aon = a_one + cur * CR * HP;
 #pragma unroll
         for (int c = 0; c < CR; ++c) {
 #pragma unroll
@@ -751,8 +752,11 @@ __global__ __launch_bounds__(512, 2) void conv_c8d_kernel(const C8Args p)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arw[c * HP + 2 * pp * HW + 8], b_lo[j * 64], acc, 0, 0, 0);
             }
             {
-                const int j = c * C8D_PAIRS + 40;      // tap (8, 8) alone: the second half-wave's weight is zero
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(apx[c * HP + 8 * HW + 8], b_lo[j * 64], acc, 0, 0, 0);
+                // tap (8, 8) alone: the second half-wave's weight is zero -- but 0 x NaN is NaN, so its operand must still be a
+                // value this kernel wrote (one pixel further would leave the plane and, for the last plane of the first tile,
+                // read LDS that nobody initialised: stale NaN patterns there zeroed a whole frame through the IN statistics)
+                const int j = c * C8D_PAIRS + 40;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aon[c * HP + 8 * HW + 8], b_lo[j * 64], acc, 0, 0, 0);
             }
         }
         if (nxt < ntiles) C8D_STORE_HALO(cur ^ 1);
@@ -829,7 +833,7 @@ template <int CR>
 static int launch_c8d_t(const C8Args& a, int reserve_cus, hipStream_t st)
 {
     constexpr int HPc = (C8_TH + 8) * (C8_TW + 8);
-    const size_t lds = (size_t)(CR * C8D_PAIRS * 64 + 2 * CR * HPc + 64 + 8 * 64 + 8) * sizeof(float);
+    const size_t lds = (size_t)(CR * C8D_PAIRS * 64 + 2 * CR * HPc + 8 * 64 + 8) * sizeof(float);
     const int dv = cur_dev();
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {

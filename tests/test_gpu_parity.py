@@ -493,6 +493,41 @@ def test_shared_device_mode_matches_oracle(favlib, oracle, cuda, canonical):
     assert np.abs(a - b).max() <= 2e-2            # 150*tanh space; summation order of split tiles only
 
 
+def test_results_do_not_depend_on_stale_lds_or_memory(favlib, oracle, cuda, golden_dir, canonical, tmp_path):
+    """A GPU handed over by another tenant holds arbitrary bit patterns in LDS and HBM.  NaN-poison every CU's LDS and a gigabyte
+    of device memory (tests/util/lds_poison.hip, compiled here), then run the tiny and the canonical network: an operand the
+    kernels never wrote, multiplied by a zero weight, would turn into NaN and -- through the InstanceNorm statistics and the ReLU's
+    fmaxf -- into a finite but wrong frame (seen once on a fresh box with the dense-K first layer's unpaired tap)."""
+    import ctypes, subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "util", "lds_poison.hip")
+    so = str(tmp_path / "liblds_poison.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, src])
+    P = ctypes.CDLL(so)
+    for path, (h, w) in ((os.path.join(golden_dir, "tiny_model.t7"), (48, 64)), (canonical, (64, 96))):
+        layers = _layers(path)
+        frames, bws, fws = _clip(h, w, 2, 140)
+        assert P.poison_lds(3) == 0
+        net = favlib.Net(path, 0)
+        st = favlib.Stream(net, h, w)
+        assert P.poison_lds(3) == 0
+        o0, _ = st.first_frame(T(frames[0], cuda))
+        import torch
+        torch.cuda.synchronize()
+        assert P.poison_lds(3) == 0
+        o1, _ = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda))
+        ref = oracle.Stylizer(layers)
+        r0 = ref.first(_f01(frames[0]))
+        assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+        ref.last = o0.cpu().numpy()
+        m = oracle.consistency(bws[1], fws[1])
+        r1 = ref.next(_f01(frames[1]), bws[1], m.astype(np.float32) / np.float32(255))
+        assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+        # the structure-aware (4-argument) mask: order-preserving scans through LDS
+        assert P.poison_lds(2) == 0
+        got = favlib.consistency(T(bws[1], cuda), T(fws[1], cuda), T(frames[1], cuda)).cpu().numpy()
+        assert np.array_equal(got, oracle.consistency(bws[1], fws[1], frames[1]))
+
+
 def test_temporal_loss_vs_oracle(favlib, oracle, cuda):
     """the temporal-consistency number of -evaluate (fast_artistic_video.lua:128-151)."""
     h, w = 90, 130
