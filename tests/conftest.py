@@ -42,3 +42,18 @@ def cuda():
     import torch
     assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def poison(tmp_path_factory):
+    """NaN-poison every CU's LDS and 1 GB of device memory (tests/util/lds_poison.hip, compiled once per session with hipcc): the
+    state a GPU may be handed over in.  Kernels must not depend on anything they did not write (0 x NaN = NaN)."""
+    import ctypes, subprocess
+    src = os.path.join(ROOT, "tests", "util", "lds_poison.hip")
+    so = str(tmp_path_factory.mktemp("poison") / "liblds_poison.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+
+    def run(repeats=3):
+        assert lib.poison_lds(repeats) == 0
+    return run
