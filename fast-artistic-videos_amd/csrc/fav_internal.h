@@ -142,6 +142,11 @@ int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
 bool conv_c8d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups);
 void conv_c8d_pack(const float* w, int cin, int cout, std::vector<float>& out);
 int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* counts, hipStream_t st);
+// 3x3 stride-1 UNPADDED 128-channel layers (the residual blocks): Winograd F(2x2,3x3), kernels_wino.hip; wpk = conv_wino_pack()
+// of the [cout][cin][3][3] weights (wino_pack.h); partials per 8x16-pixel unit with explicit counts
+bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
+int conv3_wino_tiles(int OH, int OW);
+int launch_conv3_wino(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
 int conv3_halo_tiles(int OH, int OW, bool edge_b);      // edge_b: fp32 kernel (16 x 16 tiles on a narrow ragged right edge)

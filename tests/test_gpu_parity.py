@@ -561,6 +561,29 @@ def test_halo_kernel_variants_in_networks(favlib, oracle, cuda, tmp_path, arch, 
     assert np.abs(ref).std() > 5
 
 
+@pytest.mark.parametrize("arch,size", [
+    ("c3s1-128,R128,R128,c9s1-3", (45, 61)),                 # 2 blocks: inputs with and without a pending InstanceNorm; 6 x 4 / 5 x 4 units, ragged both ways
+    ("c9s1-32,d64,d128,R128,U2,c3s1-64,U2,c9s1-3", (72, 136)),  # one unit row, fewer units than CUs
+    ("c3s1-128,R128,R128,R128,c9s1-3", (150, 330)),           # more units than CUs (persistent blocks take two)
+], ids=["two-blocks", "canonical-small", "multi-round"])
+def test_winograd_residual_layers_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
+    """The residual 128 -> 128 convolutions run as Winograd F(2x2,3x3) (conv3_wino_kernel; lane-level restatement in
+    tests/test_cpu_wino.py): against the oracle's direct convolution, same tolerance as the direct-form kernels."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=78)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    h, w = size
+    x = (np.random.default_rng(12).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    net.check()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-2, err
+    assert np.abs(ref).std() > 5
+
+
 def _seq_sum(x):
     return np.add.accumulate(x.astype(np.float32), dtype=np.float32)[-1]     # sequential, one rounding per element
 
