@@ -2175,6 +2175,184 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
     }
 }
 
+// The same layer when its input is a x2 nearest-upsampled tensor (U2 before c9s1-3, models_video.lua:129-133): the upsampled
+// image holds every physical pixel four times, so three quarters of the products above are repeats.
+//   * columns: D[x'][(c,kx)] is identical for the logical columns 2v and 2v+1 -- it is computed once per PHYSICAL column and the
+//     diagonal sum reads it at (x + kx - p) >> 1: half the GEMM rows, no change to the weights;
+//   * rows: the logical input rows 2r and 2r+1 are the same data and reach output row y through ky0 = 2r - y + p and ky0 + 1, so the
+//     physical row is multiplied ONCE by the merged slice  Wm[ky0 + 1] = W[ky0] + W[ky0 + 1]  (W[-1] = W[KH] = 0; KH + 1 merged
+//     slices, summed on the host in double): five merged slices per output row instead of nine.
+// 3.6x fewer MFMAs than on the upsampled image, same operands otherwise (the merged weights are the only re-association).
+// Tile = 16 output rows x 120 output columns = 64 physical input columns: waves = 2 column groups x 4 row groups, a row group
+// owning the output rows g, g+4, g+8, g+12 -- a physical row feeds ten CONSECUTIVE output rows, so the interleave gives every
+// wave two or three 32-MFMA blocks per staged row (consecutive rows per wave would leave half the waves idle at each barrier).
+constexpr int FOLD2_M = 64;      // physical input columns per tile
+
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs p)
+{
+    constexpr int NT = 512;
+    constexpr int RW = FOLD_R / 4;             // output rows per wave (rows g + 4 yy)
+    constexpr int S = CIN + 4;
+    constexpr int NV = CIN / 32;               // float4 per thread per staged row (8 threads per column)
+    constexpr int KK = CIN / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bs = smem;                          // [KH + 1][32][S] merged slices
+    float* aff = Bs + (p.KH + 1) * 32 * S;     // [4][CIN]
+    float* As = aff + 4 * CIN;                 // [2][FOLD2_M][S]; the epilogue's D tile [4][FOLD2_M][33] reuses it
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wcol = wave & 1, wrow = wave >> 1;
+    const int XO = 2 * FOLD2_M - (p.KW - 1);   // output columns per tile (120)
+    const int PH = p.IH >> 1, PW = p.IW >> 1;  // physical input size
+
+    for (int i = t; i < CIN; i += NT) {
+        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
+        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
+    }
+    const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
+    const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
+    const float* wm = p.wfold + (size_t)p.KH * 32 * CIN;           // merged slices follow the plain ones
+    for (int e = t; e < (p.KH + 1) * 32 * (CIN / 4); e += NT) {
+        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
+        *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(wm + (size_t)row * CIN + c4 * 4);
+    }
+    const int xl = t >> 3, ch0 = (t & 7) * (CIN / 8);
+    const int frag = (lane & 31) * S + (lane >> 5) * 4;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    float4 ra[NV];
+
+    for (int tile = blockIdx.x; tile < p.tiles_x * p.tiles_y; tile += gridDim.x) {
+        const int by = tile / p.tiles_x, bx = tile - by * p.tiles_x;
+        const int ox0 = bx * XO, oy0 = by * FOLD_R;
+        const int pxs = (ox0 - p.pad) >> 1;        // first physical column of the tile (ox0 - pad is even; may be negative)
+        const int iy_lo = max(0, oy0 - p.pad), iy_hi = min(p.IH - 1, oy0 + FOLD_R - 1 + p.KH - 1 - p.pad);
+        const int pr_lo = iy_lo >> 1, pr_hi = min(iy_hi >> 1, PH - 1);
+        const int pc = pxs + xl;
+        const bool colv = pc >= 0 && pc < PW;
+        const float colm = colv ? 1.f : 0.f;
+        const int coloff = colv ? pc * CIN + ch0 : 0;
+
+#define FOLD_LOAD(pr_)                                                                              \
+        {                                                                                           \
+            const float* src_ = p.in + (size_t)(pr_) * p.IWp * CIN + coloff;                        \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) ra[i] = *reinterpret_cast<const float4*>(src_ + 4 * i); \
+        }
+#define FOLD_STORE(buf_)                                                                            \
+        {                                                                                           \
+            float* dst_ = As + (buf_) * FOLD2_M * S + xl * S + ch0;                                 \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                        \
+                float4 v_ = affine4_lo(ra[i], aff + ch0 + 4 * i, aff + CIN + ch0 + 4 * i, lo1);     \
+                v_ = affine4_lo(v_, aff + 2 * CIN + ch0 + 4 * i, aff + 3 * CIN + ch0 + 4 * i, lo2); \
+                v_.x *= colm; v_.y *= colm; v_.z *= colm; v_.w *= colm;                             \
+                *reinterpret_cast<float4*>(dst_ + 4 * i) = v_;                                      \
+            }                                                                                       \
+        }
+
+        f32x16 acc[RW];
+#pragma unroll
+        for (int y = 0; y < RW; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+
+        FOLD_LOAD(pr_lo);
+        __syncthreads();               // affine tables + weights visible; the previous tile's epilogue is done with the staging memory
+        FOLD_STORE(0);
+        __syncthreads();
+
+        int cur = 0;
+        for (int pr = pr_lo; pr <= pr_hi; ++pr) {
+            const bool more = pr < pr_hi;
+            if (more) FOLD_LOAD(pr + 1);
+            const float* a_base = As + cur * FOLD2_M * S + wcol * 32 * S + frag;
+            float4 af[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) af[kk] = *reinterpret_cast<const float4*>(a_base + kk * 8);
+            const int msb = 2 * pr - (oy0 + wrow) + p.pad + 1;      // merged slice of this wave's output row yy: msb - 4 yy
+#pragma unroll
+            for (int yy = 0; yy < RW; ++yy) {
+                const int ms = msb - 4 * yy;
+                if (ms >= 0 && ms <= p.KH) {               // wave-uniform
+                    const float* b_base = Bs + ms * 32 * S + frag;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+                        const float4 bf = *reinterpret_cast<const float4*>(b_base + kk * 8);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].x, bf.x, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].y, bf.y, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].z, bf.z, acc[yy], 0, 0, 0);
+                        acc[yy] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk].w, bf.w, acc[yy], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) FOLD_STORE(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+#undef FOLD_LOAD
+#undef FOLD_STORE
+
+        // ---- epilogue in four passes (pass hh: output rows oy0 + g + 4 hh of the four row groups): D tiles -> LDS [4][64][33],
+        // then the diagonal sum over kx with the logical -> physical column map
+        float* D = As;
+        const size_t MO = (size_t)p.OH * p.OW;
+        const int per_row = XO * p.COUT;
+#pragma unroll
+        for (int hh = 0; hh < RW; ++hh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xr = wcol * 32 + (r & 3) + 8 * (r >> 2) + rbase;
+                D[(wrow * FOLD2_M + xr) * 33 + col] = acc[hh][r];
+            }
+            __syncthreads();
+            for (int e = t; e < 4 * per_row; e += NT) {
+                const int g = e / per_row, rem = e - g * per_row;
+                const int c = rem / XO, xo = rem - c * XO;
+                const int oy = oy0 + g + 4 * hh, ox = ox0 + xo;
+                if (oy >= p.OH || ox >= p.OW) continue;
+                float v = p.bias[c];
+                const float* d = D + g * FOLD2_M * 33 + c * p.KW;
+                for (int kx = 0; kx < p.KW; ++kx) v += d[((xo + kx) >> 1) * 33 + kx];
+                v = tanhf(v) * p.tanh_mul;                                              // models_video.lua:135-136
+                const size_t o = (size_t)oy * p.OW + ox;
+                if (p.out_raw) p.out_raw[(size_t)c * MO + o] = v;
+                if (p.out_planar) {
+                    const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+                    p.out_planar[(size_t)(2 - c) * MO + o] = (v + mean) / 255.f;          // preprocess.lua:66-71
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CIN>
+int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
+{
+    const int S = CIN + 4;
+    const size_t wbytes = (size_t)((a.KH + 1) * 32 * S + 4 * CIN) * sizeof(float);
+    size_t stage = (size_t)(2 * FOLD2_M * S) * sizeof(float);
+    const size_t epi = (size_t)4 * FOLD2_M * 33 * sizeof(float);
+    if (epi > stage) stage = epi;
+    const size_t lds = wbytes + stage;
+    if (lds > 160 * 1024) { set_error("row-folded conv: %zu bytes of LDS needed", lds); return FAV_EUNSUPPORTED; }
+    const int dv = cur_dev();
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_up2_kernel<CIN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        cus[dv] = prop.multiProcessorCount;
+    }
+    const int XO = 2 * FOLD2_M - (a.KW - 1);
+    a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int nres = std::max(1, cus[dv] - reserve_cus);
+    hipLaunchKernelGGL((conv_rowfold_up2_kernel<CIN>), dim3(tiles < nres ? tiles : nres), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_rowfold_up2_kernel");
+    return FAV_OK;
+}
+
 template <int CIN>
 int launch_fold_t(FoldArgs a, int reserve_cus, hipStream_t st)
 {
@@ -2220,6 +2398,12 @@ int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
     a.out_planar = c.out_planar; a.out_raw = c.out_raw_nchw;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.COUT = c.COUT; a.KH = c.KH; a.KW = c.KW; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.tanh_mul = c.tanh_mul;
+    // x2 nearest-upsampled input: physical columns, merged ky slices (wfold carries them after the plain slices)
+    static const bool no_up2 = getenv("FAV_NO_FOLD_UP2") != nullptr;
+    if (c.ups == 1 && !no_up2 && (c.pad & 1) == 0 && (c.KW & 1) == 1 && (c.IH & 1) == 0 && (c.IW & 1) == 0 && c.KH + 1 <= 10) {
+        if (c.CIN == 64) return launch_fold_up2_t<64>(a, c.reserve_cus, st);
+        if (c.CIN == 32) return launch_fold_up2_t<32>(a, c.reserve_cus, st);
+    }
     if (c.CIN == 64) return launch_fold_t<64>(a, c.reserve_cus, st);
     if (c.CIN == 32) return launch_fold_t<32>(a, c.reserve_cus, st);
     return launch_fold_t<16>(a, c.reserve_cus, st);

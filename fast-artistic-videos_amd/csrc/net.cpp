@@ -177,12 +177,22 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             }
             if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
                 // [ky][n = c*k + kx][ci] for the row-folded last-layer kernel
-                std::vector<float> wf((size_t)L.k * 32 * d.cinp, 0.f);
+                // followed by the K+1 merged slices Wm[m] = W[m-1] + W[m] (W[-1] = W[K] = 0) for a x2-upsampled input
+                // (conv_rowfold_up2_kernel: the logical rows 2r and 2r+1 are the same physical row)
+                std::vector<float> wf((size_t)(2 * L.k + 1) * 32 * d.cinp, 0.f);
                 for (int co = 0; co < L.cout; ++co)
                     for (int ci = 0; ci < L.cin; ++ci)
                         for (int ky = 0; ky < L.k; ++ky)
                             for (int kx = 0; kx < L.k; ++kx)
                                 wf[((size_t)ky * 32 + co * L.k + kx) * d.cinp + ci] = L.w[(((size_t)co * L.cin + ci) * L.k + ky) * L.k + kx];
+                for (int co = 0; co < L.cout; ++co)
+                    for (int ci = 0; ci < L.cin; ++ci)
+                        for (int m = 0; m <= L.k; ++m)
+                            for (int kx = 0; kx < L.k; ++kx) {
+                                const float* wr = &L.w[((size_t)co * L.cin + ci) * L.k * L.k + kx];
+                                const double a = m >= 1 ? (double)wr[(size_t)(m - 1) * L.k] : 0.0, b = m < L.k ? (double)wr[(size_t)m * L.k] : 0.0;
+                                wf[((size_t)(L.k + m) * 32 + co * L.k + kx) * d.cinp + ci] = (float)(a + b);
+                            }
                 rc = dev_upload(wf, 0, &d.wfold); if (rc) return rc;
             }
             params += (long long)L.w.size() + (long long)L.b.size();

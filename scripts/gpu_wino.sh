@@ -4,7 +4,7 @@ TAG=${1:-w}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 (timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 600 -x -k "${KEXPR:-winograd or canonical or stale or tiny_network}" 2>&1 | tail -15) > $O/wtest_$TAG.log
 cat $O/wtest_$TAG.log
-for kv in FAV_NO_WINO=1 FAV_WINO_DBG=7 FAV_NO_WINO=1 FAV_WINO_DBG=18; do
+for kv in ${ABS:-FAV_NO_WINO=1 FAV_WINO_DBG=7 FAV_NO_WINO=1 FAV_WINO_DBG=18}; do
   (env $kv timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-e2e 2>$O/werr_$TAG.log | tail -1 | python -c "
 import sys, json
 try:

@@ -584,6 +584,28 @@ def test_winograd_residual_layers_in_networks(favlib, oracle, cuda, tmp_path, ar
     assert np.abs(ref).std() > 5
 
 
+@pytest.mark.parametrize("arch,size", [
+    ("c3s1-32,U2,c9s1-3", (37, 45)),           # 32 input channels, ragged tiles, one pending InstanceNorm
+    ("c3s1-64,U2,c9s1-3", (41, 70)),           # 64 input channels, two column tiles (120 + 20), six row tiles
+    ("c3s1-32,U2,c3s1-64,U2,c9s1-3", (24, 31)),  # the canonical tail: upsample, conv, upsample, last conv
+], ids=["cin32", "cin64", "tail"])
+def test_last_layer_on_upsampled_input(favlib, oracle, cuda, tmp_path, arch, size):
+    """U2 + c9s1-3 (models_video.lua:129-136) runs on the PHYSICAL pixels with merged ky weight slices (conv_rowfold_up2_kernel)
+    instead of the four-fold repeated upsampled image: same result as the oracle's upsample-then-convolve."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=79)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    h, w = size
+    x = (np.random.default_rng(13).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-2, err
+    assert np.abs(ref).std() > 5
+
+
 def _seq_sum(x):
     return np.add.accumulate(x.astype(np.float32), dtype=np.float32)[-1]     # sequential, one rounding per element
 
