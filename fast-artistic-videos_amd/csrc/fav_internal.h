@@ -147,6 +147,11 @@ int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* c
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
 int conv3_wino_tiles(int OH, int OW);
 int launch_conv3_wino(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
+// 3x3 stride-1 pad-1 64-channel layer on a x2 nearest-upsampled materialised input (U2 + c3s1-64): four 2x2 convolutions on the
+// physical pixels with merged weights, kernels_up2.hip; wpk = conv_up2_pack() (up2_pack.h); partials per 8x32 physical-pixel tile
+bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
+int conv3_up2_tiles(int OH, int OW);
+int launch_conv3_up2(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
 int conv3_halo_tiles(int OH, int OW, bool edge_b);      // edge_b: fp32 kernel (16 x 16 tiles on a narrow ragged right edge)

@@ -1,0 +1,251 @@
+// kernels_up2.hip -- U2 + c3s1-64 (nn.SpatialUpSamplingNearest(2) followed by the 3x3 128 -> 64 convolution, models_video.lua:123-128)
+// computed on the PHYSICAL pixels of its input.
+//
+// The upsampled image holds every pixel 2 x 2 times, so a 3x3 window covers only 2 x 2 distinct input pixels: for each of the four
+// output phases (py, px) = (row parity, column parity) the layer is a 2x2 convolution on the physical image with merged weights
+// (up2_pack.h) -- 4 multiply-adds per output and channel pair instead of 9, i.e. 2.25x fewer matrix instructions than the
+// halo-resident kernel spends on the upsampled image, with the same operands (only the weight sums are re-associated).
+//
+// Block = 8 waves on one CU, tile = 8 x 32 physical pixels (-> 16 x 64 output pixels x 64 channels):
+//   * wave = (phase, 32-channel tile): 4 phases x 2 = 8 waves.  A wave owns ALL 256 pixels of the tile for its phase and channel
+//     tile: 8 accumulators (one per tile row, 128 registers).  Every weight fragment is then used by 8 MFMAs in a row and by no
+//     other wave, so weights go global -> registers (packed in fragment order on the host, one 1 KiB load per 32 MFMAs, prefetched
+//     one step ahead): no LDS ring, no barrier for weights
+//   * input: per 32-channel slice the (8+2) x (32+2) halo sits in LDS (pixel pitch 36 floats, two buffers); a wave's four taps are
+//     the halo shifted by (py + a, px + b): all fragment addresses are one per-lane base + immediates.  The layer's input is a
+//     materialised tensor (the residual join), so staging is a plain copy: raw buffer loads return zero outside the image (the
+//     zero padding), six 16-byte pieces per thread and slice, one in flight at a time
+//   * ONE barrier per slice (512 MFMAs per wave)
+//   * epilogue: bias, NHWC stores to (2y + py, 2x + px), per-tile InstanceNorm partials (mean, M2, count) merged over the four
+//     phase waves of a channel tile
+#include <algorithm>
+#include <cstdlib>
+
+#include "fav_internal.h"
+#include "up2_pack.h"
+
+namespace fav {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+
+constexpr int LDSS = 36;                     // pixel pitch in floats
+constexpr int U2_HW = 34, U2_HP = 10 * 34;   // halo: 10 rows x 34 pixels
+constexpr int U2_HPP = 384;                  // padded to 6 pieces x 512 threads / 8 chunks (pixels 340..383 are scratch)
+constexpr int U2_HB = U2_HPP * LDSS;         // floats per halo buffer (55 296 B)
+
+struct Up2Args {
+    const float* in; const float* wpk; const float* bias;
+    float* out; float2* partials; int* counts;
+    int PH, PW, IWp, CIN, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Hs = smem;                  // [2][U2_HB]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int py = wave >> 2, px = (wave >> 1) & 1, nt = wave & 1;
+    const int CIN = p.CIN, nslices = CIN >> 5, nsteps = nslices * 16;      // a step = (tap, group of 8 channels): 32 MFMAs per wave
+    const int m = lane & 31, h = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, nsteps * 8192, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.PH * p.IWp * CIN * 4, 0x00020000);
+    const int wlo = lane * 16, wso = wave * 1024;                          // weights: lane * 16 + [step * 8192 + wave * 1024]
+
+    // fragments: tile row j, tap (a, b), channel group kg -> halo pixel (py + a + j, px + b + m), channels kg * 8 + 4 h ..
+    const float* const ab = Hs + ((py * U2_HW) + px + m) * LDSS + 4 * h;
+    // staging pieces e = t + 512 i: halo pixel e >> 3 (row-major 10 x 34; pixels >= 340 are scratch), 16-byte chunk e & 7
+    const int c4 = t & 7;
+    float* const hst = Hs + (t >> 3) * LDSS + c4 * 4;                      // piece i: + 64 i pixels
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int sy0 = ty * 8, sx0 = tx * 32;
+        int ho[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pix = (t >> 3) + 64 * i, hy = (pix * 1928) >> 16, hx = pix - hy * U2_HW;      // pix / 34 (pix < 384)
+            const int sy = sy0 - 1 + hy, sx = sx0 - 1 + hx;
+            const bool v = pix < U2_HP && (unsigned)sy < (unsigned)p.PH && (unsigned)sx < (unsigned)p.PW;
+            ho[i] = v ? ((sy * p.IWp + sx) * CIN + c4 * 4) * 4 : -16;                               // -16: past the buffer -> reads as zero
+        }
+
+        v4f hq;                            // the halo piece in flight
+        v4f fa[2][4], fb[2];
+#define U2_LOAD_H(i_, slice_) { hq = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i_], (slice_) * 128, 0)); }
+#define U2_STORE_H(i_, buf_) { *reinterpret_cast<v4f*>(hst + (buf_) * U2_HB + (i_) * 64 * LDSS) = hq; }
+#define U2_LOAD_B(set_, step_) { fb[set_] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, wso + (step_) * 8192, 0)); }
+        // A fragments of half-step (tap TP_, group KG_, row half HF_) from halo buffer par_
+#define U2_READ_A(set_, par_, TP_, KG_, HF_)                                                        \
+        { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                          \
+              fa[set_][jj] = *reinterpret_cast<const v4f*>(ab + (par_) * U2_HB + ((((TP_) >> 1) + 4 * (HF_) + jj) * U2_HW + ((TP_) & 1)) * LDSS + (KG_) * 8); }
+#define U2_MFMA(aset_, bset_, HF_)                                                                  \
+        { _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) acc[4 * (HF_) + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[aset_][jj].x, fb[bset_].x, acc[4 * (HF_) + jj], 0, 0, 0); \
+          _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) acc[4 * (HF_) + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[aset_][jj].y, fb[bset_].y, acc[4 * (HF_) + jj], 0, 0, 0); \
+          _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) acc[4 * (HF_) + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[aset_][jj].z, fb[bset_].z, acc[4 * (HF_) + jj], 0, 0, 0); \
+          _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) acc[4 * (HF_) + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[aset_][jj].w, fb[bset_].w, acc[4 * (HF_) + jj], 0, 0, 0); }
+#define U2_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+        // prologue: slice 0 -> buffer 0 (all six pieces in flight at once: the accumulators are not live yet)
+        {
+            v4f q0[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) q0[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i], 0, 0));
+            U2_LOAD_B(0, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>(hst + i * 64 * LDSS) = q0[i];
+        }
+        f32x16 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        __syncthreads();
+
+        // K loop.  Per slice 16 steps (4 taps x 4 channel groups) of two half-steps (tile rows 0-3, 4-7), 16 MFMAs each:
+        //   half-step q: the A fragments of q + 1 are read while q's MFMAs run; at the first half of a step the NEXT step's weight
+        //   fragment is requested; pieces of the next slice's halo: piece i requested at step 2 i, first half, stored at step 2 i + 1,
+        //   second half (buffer par ^ 1, last read before the previous slice's barrier)
+        for (int s = 0; s < nslices; ++s) {
+            const int par = s & 1;
+            const int sn = min(s + 1, nslices - 1);
+            U2_READ_A(0, par, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int tp = st >> 2, kg = st & 3;
+                const int gstep = s * 16 + st;
+                // first half
+                U2_READ_A(1, par, tp, kg, 1);
+                U2_LOAD_B((st + 1) & 1, min(gstep + 1, nsteps - 1));
+                if ((st & 1) == 0 && st < 12) U2_LOAD_H(st >> 1, sn);
+                U2_FENCE(); U2_MFMA(0, st & 1, 0); U2_FENCE();
+                // second half
+                if (st < 15) U2_READ_A(0, par, (st + 1) >> 2, (st + 1) & 3, 0);
+                if ((st & 1) == 1 && st < 12) U2_STORE_H(st >> 1, par ^ 1);
+                U2_FENCE(); U2_MFMA(1, st & 1, 1); U2_FENCE();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#undef U2_LOAD_H
+#undef U2_STORE_H
+#undef U2_LOAD_B
+#undef U2_READ_A
+#undef U2_MFMA
+#undef U2_FENCE
+
+        // ---- epilogue: acc[j][r] = output (2 (sy0 + j) + py, 2 (sx0 + mi) + px), channel nt * 32 + n;  mi = (r & 3) + 8 (r >> 2) + 4 h
+        const int n = lane & 31, co = nt * 32 + n;
+        const float bv = p.bias[co];
+        const int OW = 2 * p.PW;
+        float sm = 0.f; int nv = 0;
+        const bool full = sy0 + 8 <= p.PH && sx0 + 32 <= p.PW;             // (220 of the 230 tiles at 1280x720)
+        char* const ob = reinterpret_cast<char*>(p.out + ((size_t)(2 * sy0 + py) * OW + 2 * (sx0 + 4 * h) + px) * 64 + co);
+        const size_t jpitch = (size_t)2 * OW * 256;                        // two output rows, 64 channels of 4 bytes
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[j][r] + bv;
+                    acc[j][r] = v;
+                    *reinterpret_cast<float*>(ob + j * jpitch + ((r & 3) + 8 * (r >> 2)) * 512) = v;
+                    sm += v;
+                }
+            nv = 128;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sy = sy0 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sx = sx0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = acc[j][r] + bv;
+                    acc[j][r] = v;
+                    if (sy < p.PH && sx < p.PW) { *reinterpret_cast<float*>(ob + j * jpitch + ((r & 3) + 8 * (r >> 2)) * 512) = v; sm += v; ++nv; }
+                }
+            }
+        }
+        if (p.partials != nullptr) {
+            float2* stt = reinterpret_cast<float2*>(Hs);             // [8 waves][32]
+            int* wn = reinterpret_cast<int*>(Hs + 2 * 8 * 32);         // [8]
+            const int nw = nv + __shfl_xor(nv, 32);
+            const float ssum = sm + __shfl_xor(sm, 32);
+            const float mu = nw ? ssum / (float)nw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sy = sy0 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sx = sx0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float d = acc[j][r] - mu;
+                    if (sy < p.PH && sx < p.PW) q = fmaf(d, d, q);
+                }
+            }
+            q += __shfl_xor(q, 32);
+            if (lane < 32) stt[wave * 32 + lane] = make_float2(mu, q);
+            if (lane == 0) wn[wave] = nw;
+            __syncthreads();
+            if (t < 64) {
+                // channel t = ntc * 32 + nn: exact merge (Chan et al.) of the four phase waves 2 ph + ntc
+                const int ntc = t >> 5, nn = t & 31;
+                int cnt = 0; float s1 = 0.f;
+                for (int ph = 0; ph < 4; ++ph) { const int w = 2 * ph + ntc; cnt += wn[w]; s1 += (float)wn[w] * stt[w * 32 + nn].x; }
+                const float mean = cnt ? s1 / (float)cnt : 0.f;
+                float m2 = 0.f;
+                for (int ph = 0; ph < 4; ++ph) { const int w = 2 * ph + ntc; const float d = stt[w * 32 + nn].x - mean; m2 += stt[w * 32 + nn].y + (float)wn[w] * d * d; }
+                p.partials[(size_t)tile * 64 + t] = make_float2(mean, m2);
+                if (t == 0) p.counts[tile] = cnt;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
+{
+    return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 0 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&
+           cout == 64 && coutp == 64;
+}
+int conv3_up2_tiles(int OH, int OW) { return ((OH / 2 + 7) / 8) * ((OW / 2 + 31) / 32); }
+
+int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv3_up2_eligible(c.CIN, c.COUT, c.COUTp, c.KH, c.stride, c.pad, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode && !c.stuff && wpk,
+                "upsampled 3x3 conv: not eligible");
+    FAV_REQUIRE((c.IH & 1) == 0 && (c.IW & 1) == 0 && c.OH == c.IH && c.OW == c.IW, "upsampled 3x3 conv: bad geometry");
+    FAV_REQUIRE((long long)(c.IH / 2 + 1) * c.IWp * c.CIN < (1ll << 29), "upsampled 3x3 conv: tensor too large for 32-bit byte offsets");
+    Up2Args a;
+    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.PH = c.IH / 2; a.PW = c.IW / 2; a.IWp = c.IWp; a.CIN = c.CIN;
+    a.tiles_x = (a.PW + 31) / 32; a.tiles_y = (a.PH + 7) / 8;
+    const size_t lds = (size_t)2 * U2_HB * sizeof(float);
+    const int dv = cur_dev();
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        cus[dv] = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));
+    hipLaunchKernelGGL(conv3_up2_kernel, dim3(grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv3_up2_kernel");
+    return FAV_OK;
+}
+
+}  // namespace fav

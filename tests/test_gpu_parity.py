@@ -606,6 +606,27 @@ def test_last_layer_on_upsampled_input(favlib, oracle, cuda, tmp_path, arch, siz
     assert np.abs(ref).std() > 5
 
 
+@pytest.mark.parametrize("arch,size", [
+    ("c3s1-64,R64,U2,c3s1-64,c9s1-3", (29, 43)),                    # 64 input channels, 25 x 39 physical pixels: ragged tiles both ways
+    ("c9s1-32,d64,d128,R128,U2,c3s1-64,U2,c9s1-3", (88, 152)),      # the canonical tail behind one residual block (128 input channels)
+], ids=["cin64-ragged", "canonical-tail"])
+def test_conv_on_upsampled_join_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
+    """U2 + c3s1-64 behind a residual join runs as four 2x2 convolutions with merged weights on the physical pixels
+    (conv3_up2_kernel, csrc/up2_pack.h): same result as the oracle's upsample-then-convolve."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=80)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    h, w = size
+    x = (np.random.default_rng(14).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-2, err
+    assert np.abs(ref).std() > 5
+
+
 def _seq_sum(x):
     return np.add.accumulate(x.astype(np.float32), dtype=np.float32)[-1]     # sequential, one rounding per element
 
