@@ -12,9 +12,9 @@
 //     other wave, so weights go global -> registers (packed in fragment order on the host, one 1 KiB load per 32 MFMAs, prefetched
 //     one step ahead): no LDS ring, no barrier for weights
 //   * input: per 32-channel slice the (8+2) x (32+2) halo sits in LDS (pixel pitch 36 floats, two buffers); a wave's four taps are
-//     the halo shifted by (py + a, px + b): all fragment addresses are one per-lane base + immediates.  The layer's input is a
-//     materialised tensor (the residual join), so staging is a plain copy: raw buffer loads return zero outside the image (the
-//     zero padding), six 16-byte pieces per thread and slice, one in flight at a time
+//     the halo shifted by (py + a, px + b): all fragment addresses are one per-lane base + immediates.  Staging: six 16-byte
+//     pieces per thread and slice, one in flight at a time; raw buffer loads return zero outside the image, the pending
+//     InstanceNorm/ReLU of the input is applied on the way (0.14 vector-ALU instructions per MFMA) and masked there
 //   * ONE barrier per slice (512 MFMAs per wave)
 //   * epilogue: bias, NHWC stores to (2y + py, 2x + px), per-tile InstanceNorm partials (mean, M2, count) merged over the four
 //     phase waves of a channel tile
@@ -41,15 +41,20 @@ constexpr int U2_HPP = 384;                  // padded to 6 pieces x 512 threads
 constexpr int U2_HB = U2_HPP * LDSS;         // floats per halo buffer (55 296 B)
 
 struct Up2Args {
-    const float* in; const float* wpk; const float* bias;
+    const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
     float* out; float2* partials; int* counts;
-    int PH, PW, IWp, CIN, tiles_x, tiles_y;
+    int PH, PW, IWp, CIN, tiles_x, tiles_y, relu1;
 };
 
+// AFF: the input carries a pending per-channel scale/shift (+ReLU) -- U2 is followed by InstanceNormalization + ReLU in the reference's
+// architecture strings (models_video.lua:94-98,119-131), so the canonical layer sees IN(join) through the upsampling.  Zero padding
+// applies AFTER that transform: out-of-image pieces are masked, not transformed.
+template <bool AFF>
 __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Hs = smem;                  // [2][U2_HB]
+    float* const aff = smem + 2 * U2_HB;     // [2][CIN]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -67,6 +72,10 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
     const int c4 = t & 7;
     float* const hst = Hs + (t >> 3) * LDSS + c4 * 4;                      // piece i: + 64 i pixels
 
+    if (AFF) { for (int i = t; i < CIN; i += 512) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; } __syncthreads(); }
+    const float lo1 = (AFF && p.relu1) ? 0.f : -INFINITY;
+    const float* const affr = aff + c4 * 4;
+
     const int ntiles = p.tiles_x * p.tiles_y;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
@@ -83,7 +92,12 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
         v4f hq;                            // the halo piece in flight
         v4f fa[2][4], fb[2];
 #define U2_LOAD_H(i_, slice_) { hq = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i_], (slice_) * 128, 0)); }
-#define U2_STORE_H(i_, buf_) { *reinterpret_cast<v4f*>(hst + (buf_) * U2_HB + (i_) * 64 * LDSS) = hq; }
+#define U2_XF(v_, i_, slice_)                                                                       \
+        { if (AFF) { const v4f sc_ = *reinterpret_cast<const v4f*>(affr + (slice_) * 32), sh_ = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 32); \
+                     const float mk_ = ho[i_] >= 0 ? 1.f : 0.f;                                      \
+                     v_.x = fmaxf(fmaf(v_.x, sc_.x, sh_.x), lo1) * mk_; v_.y = fmaxf(fmaf(v_.y, sc_.y, sh_.y), lo1) * mk_; \
+                     v_.z = fmaxf(fmaf(v_.z, sc_.z, sh_.z), lo1) * mk_; v_.w = fmaxf(fmaf(v_.w, sc_.w, sh_.w), lo1) * mk_; } }
+#define U2_STORE_H(i_, buf_, slice_) { U2_XF(hq, i_, slice_); *reinterpret_cast<v4f*>(hst + (buf_) * U2_HB + (i_) * 64 * LDSS) = hq; }
 #define U2_LOAD_B(set_, step_) { fb[set_] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, wso + (step_) * 8192, 0)); }
         // A fragments of half-step (tap TP_, group KG_, row half HF_) from halo buffer par_
 #define U2_READ_A(set_, par_, TP_, KG_, HF_)                                                        \
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
             for (int i = 0; i < 6; ++i) q0[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i], 0, 0));
             U2_LOAD_B(0, 0);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>(hst + i * 64 * LDSS) = q0[i];
+            for (int i = 0; i < 6; ++i) { U2_XF(q0[i], i, 0); *reinterpret_cast<v4f*>(hst + i * 64 * LDSS) = q0[i]; }
         }
         f32x16 acc[8];
 #pragma unroll
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
                 U2_FENCE(); U2_MFMA(0, st & 1, 0); U2_FENCE();
                 // second half
                 if (st < 15) U2_READ_A(0, par, (st + 1) >> 2, (st + 1) & 3, 0);
-                if ((st & 1) == 1 && st < 12) U2_STORE_H(st >> 1, par ^ 1);
+                if ((st & 1) == 1 && st < 12) U2_STORE_H(st >> 1, par ^ 1, sn);
                 U2_FENCE(); U2_MFMA(1, st & 1, 1); U2_FENCE();
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
         }
 #undef U2_LOAD_H
 #undef U2_STORE_H
+#undef U2_XF
 #undef U2_LOAD_B
 #undef U2_READ_A
 #undef U2_MFMA
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
 
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
 {
-    return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 0 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&
+    return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&
            cout == 64 && coutp == 64;
 }
 int conv3_up2_tiles(int OH, int OW) { return ((OH / 2 + 7) / 8) * ((OW / 2 + 31) / 32); }
@@ -229,21 +244,21 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     FAV_REQUIRE((c.IH & 1) == 0 && (c.IW & 1) == 0 && c.OH == c.IH && c.OW == c.IW, "upsampled 3x3 conv: bad geometry");
     FAV_REQUIRE((long long)(c.IH / 2 + 1) * c.IWp * c.CIN < (1ll << 29), "upsampled 3x3 conv: tensor too large for 32-bit byte offsets");
     Up2Args a;
-    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.relu1 = c.pre.relu1; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.PH = c.IH / 2; a.PW = c.IW / 2; a.IWp = c.IWp; a.CIN = c.CIN;
     a.tiles_x = (a.PW + 31) / 32; a.tiles_y = (a.PH + 7) / 8;
-    const size_t lds = (size_t)2 * U2_HB * sizeof(float);
+    const size_t lds = (size_t)(2 * U2_HB + 2 * c.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipDeviceProp_t prop;
         FAV_HIP(hipGetDeviceProperties(&prop, dv));
         cus[dv] = prop.multiProcessorCount;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));
-    hipLaunchKernelGGL(conv3_up2_kernel, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv3_up2_kernel<true>, dim3(grid), dim3(512), lds, st, a);      // (every U2 of the reference's builder is followed by a normalisation: stages == 1)
     FAV_LAUNCH_CHECK("conv3_up2_kernel");
     return FAV_OK;
 }

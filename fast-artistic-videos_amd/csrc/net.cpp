@@ -176,7 +176,7 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 conv_wino_pack(L.w.data(), L.cin, L.cout, ww);
                 rc = dev_upload(ww, 0, &d.wwino); if (rc) return rc;
             }
-            if (!L.transposed && L.cin == d.cinp && conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 0, 1)) {      // 3x3 after a x2 upsampling: merged 2x2 taps
+            if (!L.transposed && L.cin == d.cinp && conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 1)) {      // 3x3 after a x2 upsampling: merged 2x2 taps
                 std::vector<float> wu;
                 conv_up2_pack(L.w.data(), L.cin, wu);
                 rc = dev_upload(wu, 0, &d.wup2); if (rc) return rc;
