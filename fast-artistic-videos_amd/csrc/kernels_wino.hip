@@ -29,6 +29,7 @@
 // Units are independent (no stream-K hand-off, nothing co-resident assumed): persistent blocks walk the units round-robin.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fav_internal.h"
 #include "wino_pack.h"
@@ -55,6 +56,7 @@ struct WinoArgs {
     const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
     float* out; float2* partials; int* counts;
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
+    int nfull;               // units 0 .. nfull-1 are computed whole, the rest in four quarters (32 output channels each)
     long long* dbg;          // optional in-kernel timeline (FAV_WINO_DBG), 24 slots per block
 };
 
@@ -121,9 +123,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * CIN * 4, 0x00020000);
     const int wlo = lane * 16, wso = wave * 8192;
 
-    const int U = p.units_x * p.units_y;
     if (AFF) __syncthreads();
-    for (int u = lb; u < U; u += gridDim.x) {
+    // One work item: NTW = 4: a whole unit (128 output channels); NTW = 1: a quarter of one (output channels 32 nq .. 32 nq + 31) --
+    // the units of a thin last round are cut in four so that the round takes a quarter of the time (see launch_wino_t)
+    auto work = [&](auto ntw_c, const int u, const int nq) {
+        constexpr int NTW = decltype(ntw_c)::value;
+        constexpr int NC = 32 * NTW;               // output channels of the item
         const int uy = u / p.units_x, ux = u - uy * p.units_x;
         const int oy0 = uy * 8, ox0 = ux * 16;
         DBG_T();   /* unit start */
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
           *reinterpret_cast<v4f*>((dst_) + 2 * WG_TROW) = qr[2] - qr[1];                             \
           *reinterpret_cast<v4f*>((dst_) + 3 * WG_TROW) = qr[1] - qr[3]; }
 
-        v4f R0, R1, R2, A0, A1, fb[2][4];
+        v4f R0, R1, R2, A0, A1, fb[2][NTW];
+        const int wlq = wlo + nq * 1024;
 #define WG_READ_T(par_, kg_)                                                                        \
         { R0 = *reinterpret_cast<const v4f*>(ap0 + (par_) * WG_TBUF + (kg_) * 8);                   \
           R1 = *reinterpret_cast<const v4f*>(ap1 + (par_) * WG_TBUF + (kg_) * 8);                   \
@@ -165,15 +171,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         { A0 = R0 - R2; A1.x = fmaf(sg, R2.x, R1.x); A1.y = fmaf(sg, R2.y, R1.y); A1.z = fmaf(sg, R2.z, R1.z); A1.w = fmaf(sg, R2.w, R1.w); }
 #define WG_LOAD_B(set_, kgg_, q_)                                                                   \
         { const int so_ = wso + (kgg_) * 65536 + (q_) * 4096;                                      \
-          fb[set_][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so_, 0));            \
-          fb[set_][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 1024, so_, 0));     \
-          fb[set_][2] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 2048, so_, 0));     \
-          fb[set_][3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 3072, so_, 0)); }
+          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                        \
+              fb[set_][nt] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlq + nt * 1024, so_, 0)); }
 #define WG_MFMA(set_, a_, q_)                                                                       \
-        { _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, fb[set_][nt].x, acc[q_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, fb[set_][nt].y, acc[q_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, fb[set_][nt].z, acc[q_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, fb[set_][nt].w, acc[q_][nt], 0, 0, 0); }
+        { _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, fb[set_][nt].x, acc[q_][nt], 0, 0, 0); \
+          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, fb[set_][nt].y, acc[q_][nt], 0, 0, 0); \
+          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, fb[set_][nt].z, acc[q_][nt], 0, 0, 0); \
+          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[q_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, fb[set_][nt].w, acc[q_][nt], 0, 0, 0); }
 
         // ---- prologue: slice 0 -> halo buffer 0
         {
@@ -185,11 +189,11 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
             WG_COMMIT(qr, tstA);
             if (wave == 0) { WG_COMMIT(qb, tstB); }
         }
-        f32x16 acc[2][4];
+        f32x16 acc[2][NTW];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][nt][r] = 0.f;
         __syncthreads();
@@ -255,17 +259,19 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         //                                                                odd wave   P0 = M2,      P1 = -(M2 + M3).
         // Row fold across the waves through LDS, one pass per output column parity b:
         //   Z_i = P(wave 2i) + P(wave 2i+1);   Y[0][b] = Z0 + Z1 + Z2,   Y[1][b] = Z1 - Z2 - Z3
-        // Reduction thread: output channel c = t & 127, tile row qq = t >> 7 (tiles 8 qq .. 8 qq + 7 = tx 0..7).
+        // Reduction thread (4 NC of them): output channel c = t % NC, tile row qq = t / NC (tiles 8 qq .. 8 qq + 7 = tx 0..7).
         const int n = lane & 31;
-        const int c = t & 127, qq = t >> 7;
-        const float bv = p.bias[c];
+        const int c = t & (NC - 1), qq = (t / NC) & 3;
+        const bool red = t < 4 * NC;
+        const int co = nq * 32 + c;
+        const float bv = p.bias[co];
         float yk[2][2][8];                 // [b][a][tx]
-        float* const pw = Ts + (wave * 128 + n) * LDSS + 4 * h;
+        float* const pw = Ts + (wave * NC + n) * LDSS + 4 * h;
         const float* const pr = Ts + c * LDSS + 8 * qq;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     v4f v;
@@ -277,22 +283,25 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
                     *reinterpret_cast<v4f*>(pw + nt * 32 * LDSS + 8 * g) = v;
                 }
             __syncthreads();
+            if (red) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 v4f z[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    z[i] = *reinterpret_cast<const v4f*>(pr + (2 * i) * 128 * LDSS + 4 * hf) + *reinterpret_cast<const v4f*>(pr + (2 * i + 1) * 128 * LDSS + 4 * hf);
+                    z[i] = *reinterpret_cast<const v4f*>(pr + (2 * i) * NC * LDSS + 4 * hf) + *reinterpret_cast<const v4f*>(pr + (2 * i + 1) * NC * LDSS + 4 * hf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     yk[b][0][4 * hf + e] = (z[0][e] + z[1][e]) + z[2][e] + bv;
                     yk[b][1][4 * hf + e] = (z[1][e] - z[2][e]) - z[3][e] + bv;
                 }
             }
+            }
             __syncthreads();
         }
         // store + per-thread statistics of the 32 outputs (2 rows x 16 columns) of channel c
         int nv = 0; float sm = 0.f;
+        if (red) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int oy = oy0 + 2 * qq + a;
@@ -301,8 +310,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int ox = ox0 + 2 * k + b;
-                    if (oy < p.OH && ox < p.OW) { p.out[((size_t)oy * p.OW + ox) * 128 + c] = yk[b][a][k]; sm += yk[b][a][k]; ++nv; }
+                    if (oy < p.OH && ox < p.OW) { p.out[((size_t)oy * p.OW + ox) * 128 + co] = yk[b][a][k]; sm += yk[b][a][k]; ++nv; }
                 }
+        }
         }
         if (p.partials != nullptr) {
             const float mu = nv ? sm / (float)nv : 0.f;
@@ -319,19 +329,23 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
                         if (oy < p.OH && ox < p.OW) m2 = fmaf(d, d, m2);
                     }
             }
-            float2* st = reinterpret_cast<float2*>(Ts);           // [4][128]
+            float2* st = reinterpret_cast<float2*>(Ts);           // [4][NC]
             int* wn = reinterpret_cast<int*>(Ts + 2 * 4 * 128);     // [4]
-            st[qq * 128 + c] = make_float2(mu, m2);
-            if (c == 0) wn[qq] = nv;
+            if (red) { st[qq * NC + c] = make_float2(mu, m2); if (c == 0) wn[qq] = nv; }
             __syncthreads();
-            if (t < 128) {
+            if (t < NC) {
                 int nn;
-                p.partials[(size_t)u * 128 + t] = merge_group_stats(st, wn, 4, 128, t, &nn);
-                if (t == 0) p.counts[u] = nn;
+                p.partials[(size_t)u * 128 + nq * 32 + t] = merge_group_stats(st, wn, 4, NC, t, &nn);
+                if (t == 0) p.counts[u] = nn;          // (the four quarters of a unit write the same count)
             }
             __syncthreads();
         }
         DBG_T();   /* epilogue end */
+    };
+    const int nitems = p.nfull + 4 * (p.units_x * p.units_y - p.nfull);
+    for (int it = lb; it < nitems; it += gridDim.x) {
+        if (it < p.nfull) work(std::integral_constant<int, 4>{}, it, 0);
+        else work(std::integral_constant<int, 1>{}, p.nfull + ((it - p.nfull) >> 2), (it - p.nfull) & 3);
     }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
 #undef DBG_T
@@ -373,6 +387,13 @@ int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
     const int units = a0.units_x * a0.units_y;
     const int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
     WinoArgs a = a0; a.dbg = nullptr;
+    // A CU holds one unit at a time (the accumulators fill the register file), so a launch takes ceil(units / grid) rounds of one
+    // unit time.  When the last round has at most grid / 4 units (the first three residual layers at 1280x720: 550, 525, 525 units
+    // on 256 CUs) its units are cut into quarters of 32 output channels: four times as many CUs work on that round and it takes
+    // roughly a third of a unit time instead of a whole one.
+    static const bool no_quarters = getenv("FAV_WINO_NO_QUARTERS") != nullptr;
+    const int rounds = (units + grid - 1) / grid, rem = units - (rounds - 1) * grid;
+    a.nfull = (rounds >= 2 && rem * 4 <= grid && !no_quarters) ? (rounds - 1) * grid : units;
     static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
