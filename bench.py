@@ -276,13 +276,21 @@ def main():
 
     if rank == 0:
         fps = world * args.steps / dt
-        # roofline of the dominant kernel: the halo-resident 3x3 128->128 instance (the ten residual convolutions,
-        # 91.7 of the 152.8 GMAC per frame), fp32 MFMA.  achieved = useful FLOPs / HIP-event time of those launches.
-        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 428 and n > 0]
-        dom_name = "conv3_halo_kernel<128, false> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
+        # roofline of the dominant kernel: the ten 3x3 128->128 residual convolutions (91.7 of the 152.8 GMAC per frame).  Round 2:
+        # Winograd F(2x2,3x3) on the fp32 matrix cores (kernels_wino.hip, kernel id 528).  `achieved` = ALGORITHMIC FLOPs (the direct
+        # convolution's 2 * MACs) / HIP-event time of those launches; the kernel EXECUTES 16/36 of them, so
+        # `achieved` may exceed the fp32 MFMA peak -- `executed_tflops` / `executed_frac` give the matrix-pipe view.
+        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 528 and n > 0]
+        dom_name = "conv3_wino_kernel (ten 3x3 128->128 residual convolutions, Winograd F(2x2,3x3), fp32 MFMA 32x32x2)"
+        exec_ratio = 16.0 / 36.0
+        if not dom:     # FAV_NO_WINO: the halo-resident direct form
+            dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 428 and n > 0]
+            dom_name = "conv3_halo_kernel<128, false> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
+            exec_ratio = 1.0
         if not dom:     # FAV_NO_H3: fall back to the generic 128-wide instance
             dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 128 and n > 0]
             dom_name = "conv_mfma_kernel<128,2,2,0,true> (3x3 128->128 residual convolutions + 64->128 stride-2)"
+            exec_ratio = 1.0
         flops = sum(2.0 * macs * n for ms, n, macs in dom); secs = sum(ms for ms, n, macs in dom) / 1e3
         nl = sum(n for ms, n, macs in dom)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
@@ -291,16 +299,17 @@ def main():
         # the kernel source it was measured on: a stale file (kernel changed since) is refused rather than reported.
         traffic, traffic_note = None, "profiles/pmc_traffic.json missing"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        ksrc = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc", "kernels_conv.hip")
-        khash = hashlib.sha256(open(ksrc, "rb").read()).hexdigest()[:16]
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if not tj.get("kernel", "").startswith(dom_name.split(" ")[0]):
+            ksrc = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc", tj.get("source", "kernels_conv.hip"))
+            khash = hashlib.sha256(open(ksrc, "rb").read()).hexdigest()[:16] if os.path.exists(ksrc) else "?"
+            if not tj.get("kernel", "").startswith(dom_name.split(" ")[0].split("<")[0]):
                 traffic_note = "pmc_traffic.json is for another kernel (%s)" % tj.get("kernel")
-            elif tj.get("kernels_conv_sha16") != khash:
-                traffic_note = "stale: measured on kernels_conv.hip %s, current %s -- re-run scripts/gpu_pmc.sh" % (tj.get("kernels_conv_sha16"), khash)
+            elif tj.get("source_sha16") != khash:
+                traffic_note = "stale: measured on %s %s, current %s -- re-run scripts/gpu_pmc.sh" % (tj.get("source"), tj.get("source_sha16"), khash)
             else:
-                traffic, traffic_note = tj["hbm_bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE, separate passes, kernels_conv.hip " + khash
+                traffic, traffic_note = tj["hbm_bytes_per_launch"], ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE, separate passes, %s %s"
+                                                                     % (tj.get("source"), khash))
         per_kernel = {}
         for ms, n, macs, kid in prof:
             if n:
@@ -318,6 +327,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": dom_name,
+                         "executed_tflops": round(achieved * exec_ratio, 3), "executed_frac": round(achieved * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "note": "achieved = algorithmic (direct-convolution) FLOPs / time; the Winograd kernel executes 16/36 of them on the matrix pipe, "
+                                 "so frac > 1 means faster than any direct fp32 convolution could run" if exec_ratio < 1 else "direct form: executed = algorithmic",
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
                          "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None,

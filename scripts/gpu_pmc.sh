@@ -21,18 +21,20 @@ for f in sorted(glob.glob("$O/pmc_${TAG}_*/*counter_collection.csv")):
         for c, v in d.items():
             out.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
 json.dump(out, open("$O/pmc_$TAG.json", "w"), indent=1, sort_keys=True)
-dom = [k for k in out if k.startswith("fav::conv3_halo_kernel<128, false>")]
-if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
-    f, w = out[dom[0]]["FETCH_SIZE"]["mean"], out[dom[0]]["WRITE_SIZE"]["mean"]
+dom = [k for k in out if k.startswith("fav::conv3_wino_kernel")]
+if dom and all("FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k] for k in dom):
+    nl = sum(out[k]["FETCH_SIZE"]["n"] for k in dom)
+    f = sum(out[k]["FETCH_SIZE"]["mean"] * out[k]["FETCH_SIZE"]["n"] for k in dom) / nl
+    w = sum(out[k]["WRITE_SIZE"]["mean"] * out[k]["WRITE_SIZE"]["n"] for k in dom) / nl
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of
     # 16-B/lane coalesced streams (this kernel's loads are all 16 B/lane) -> doubled; WRITE_SIZE taken as is (uncalibrated)
     import hashlib
-    sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/kernels_conv.hip", "rb").read()).hexdigest()[:16]
-    json.dump({"kernel": "conv3_halo_kernel<128, false>", "kernels_conv_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
-               "hbm_bytes_per_launch": int((2 * f + w) * 1024),
-               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of the kernel in "
-                       "bench.py; read side doubled per the gfx950 FETCH_SIZE calibration; algorithmic bytes per launch: ~64 MB "
-                       "(32 MB in + 31 MB out + 0.6 MB weights) + ~65 MB of stream-K partial-tile hand-off"},
+    sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/kernels_wino.hip", "rb").read()).hexdigest()[:16]
+    json.dump({"kernel": "conv3_wino_kernel", "source": "kernels_wino.hip", "source_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
+               "launches_averaged": nl, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of both instances "
+                       "(with / without a pending InstanceNorm on the input) in bench.py; read side doubled per the gfx950 FETCH_SIZE "
+                       "calibration; algorithmic bytes per launch: ~68 MB (33-35 MB in + 32-34 MB out + 1 MB packed weights)"},
               open("$O/pmc_traffic_$TAG.json", "w"), indent=1)
 for k in sorted(out):
     print(k[:80], {c: round(v["mean"], 1) for c, v in out[k].items()})
