@@ -124,14 +124,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     if (AFF) __syncthreads();
     // One work item: NTW = 4: a whole unit (128 output channels); NTW = 1: a quarter of one (output channels 32 nq .. 32 nq + 31) --
     // the units of a thin last round are cut in four so that the round takes a quarter of the time (see launch_wino_t)
-    // The raw halo rows of the NEXT item's first slice are requested from inside this item's epilogue (the accumulators are dead by
-    // then), so that only the first item of a block pays the load latency in its prologue.
-    v4f qn[4], qbn[4];
-    bool pre = false;
-    auto work = [&](auto ntw_c, const int u, const int nq, const int un) {
+    auto work = [&](auto ntw_c, const int u, const int nq) {
         constexpr int NTW = decltype(ntw_c)::value;
         constexpr int NC = 32 * NTW;               // output channels of the item
-        // (descriptors are built here from kernel arguments: captured ones are not provably wave-uniform and get a waterfall loop)
+        // (descriptors are built here from kernel arguments: captured ones are not provably wave-uniform and get a waterfall loop.
+        //  Measured and dropped: requesting the NEXT item's first halo rows from inside this epilogue -- the 32 registers it keeps
+        //  alive between items cost 6 % in the K loop, against 0.4 us of prologue it hides)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 3) * 65536, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const int uy = u / p.units_x, ux = u - uy * p.units_x;
@@ -187,13 +185,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         // ---- prologue: slice 0 -> halo buffer 0
         {
             v4f qb[4];
-            if (pre) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { qr[a] = qn[a]; qb[a] = qbn[a]; }
-            } else {
-                WG_LOAD_RAW(qr, 0, hoA);
-                if (wave == 0) { WG_LOAD_RAW(qb, 0, hoB); }
-            }
+            WG_LOAD_RAW(qr, 0, hoA);
+            if (wave == 0) { WG_LOAD_RAW(qb, 0, hoB); }
             WG_LOAD_B(0, 0, 0);
             WG_AFF(0);
             WG_COMMIT(qr, tstA);
@@ -255,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         DBG_T();   /* loop end */
         if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
         DBG_T();   /* (no fix-up) */
+#undef WG_LOAD_RAW
 #undef WG_AFF
 #undef WG_XF
 #undef WG_COMMIT
@@ -291,21 +285,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
                     }
                     *reinterpret_cast<v4f*>(pw + nt * 32 * LDSS + 8 * g) = v;
                 }
-            if (b == 1) {            // accumulators dead: request the next item's first halo rows
-                pre = un >= 0;
-                if (pre) {
-                    const int uyn = un / p.units_x, uxn = un - uyn * p.units_x;
-                    const int ixa = min(uxn * 16 + xA, p.IW - 1), ixb = min(uxn * 16 + xB, p.IW - 1);
-                    int hn[4], hbn[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        hn[a] = ((min(uyn * 8 + 2 * tyA + a, p.IH - 1) * p.IWp + ixa) * CIN + c4 * 4) * 4;
-                        hbn[a] = ((min(uyn * 8 + 6 + a, p.IH - 1) * p.IWp + ixb) * CIN + c4 * 4) * 4;
-                    }
-                    WG_LOAD_RAW(qn, 0, hn);
-                    if (wave == 0) { WG_LOAD_RAW(qbn, 0, hbn); }
-                }
-            }
             __syncthreads();
             if (red) {
 #pragma unroll
@@ -365,14 +344,11 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
             __syncthreads();
         }
         DBG_T();   /* epilogue end */
-#undef WG_LOAD_RAW
     };
     const int nitems = p.nfull + 4 * (p.units_x * p.units_y - p.nfull);
     for (int it = lb; it < nitems; it += gridDim.x) {
-        const int itn = it + (int)gridDim.x;
-        const int un = itn < nitems ? (itn < p.nfull ? itn : p.nfull + ((itn - p.nfull) >> 2)) : -1;
-        if (it < p.nfull) work(std::integral_constant<int, 4>{}, it, 0, un);
-        else work(std::integral_constant<int, 1>{}, p.nfull + ((it - p.nfull) >> 2), (it - p.nfull) & 3, un);
+        if (it < p.nfull) work(std::integral_constant<int, 4>{}, it, 0);
+        else work(std::integral_constant<int, 1>{}, p.nfull + ((it - p.nfull) >> 2), (it - p.nfull) & 3);
     }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
 #undef DBG_T
