@@ -375,7 +375,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     // XCD a block runs on, so a group's rows sit in one L2); the block that arrives last in its group folds the group's rows
     // (<= 64 x 2 KB) in fp64, the group that finishes last folds the eight group rows and writes scale = gamma / sqrt(var + eps),
     // shift = beta - mean * scale -- what in_finalize_kernel did in a launch of its own (4.8 us + a kernel boundary, 16 times
-    // per frame).  Write-through stores + agent-scope counters order the hand-over, as in the stream-K kernels.
+    // per frame).  Ordering as in the stream-K kernels: write-through (sc1) stores, drained (vmcnt 0) before a RELAXED agent-scope
+    // counter increment -- a release fence there would write back the whole L2's dirty lines, i.e. the output tiles, once per
+    // block (measured: +17 us per launch) -- and an acquire fence in the last arriver only.
     if (p.fin_ws != nullptr) {
         volatile int& s_last = *reinterpret_cast<volatile int*>(bst + 128);       // (dynamic LDS: a static would shift its base)
         v4f* const rows = reinterpret_cast<v4f*>(p.fin_ws + FIN_ROWS);
@@ -386,40 +388,60 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned old = __hip_atomic_fetch_add(cnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)(nb - 1);
             if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        // folds: 512 threads = 128 channels x 4 parts, all loads of a thread in flight at once, parts summed through LDS in fp64
+        double* const red = reinterpret_cast<double*>(Ts);           // [3][4][128]
+        const int ch = t & 127, part = t >> 7;
         if (s_last) {
-            if (t < 128) {
+            {
+                v4f r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int b = grp + 8 * (part + 4 * k); r[k] = b < (int)gridDim.x ? rows[(size_t)b * 128 + ch] : v4f{0.f, 0.f, 0.f, 0.f}; }
                 double s1 = 0.0, s2 = 0.0, nn = 0.0;
-                for (int b = grp; b < (int)gridDim.x; b += 8) {
-                    const v4f r = rows[(size_t)b * 128 + t];
-                    const double n = (double)r.x, mu = (double)r.y;
-                    s1 += n * mu; s2 += (double)r.z + n * mu * mu; nn += n;
-                }
-                double2 a; a.x = s1; a.y = s2;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const double n = (double)r[k].x, mu = (double)r[k].y; s1 += n * mu; s2 += (double)r[k].z + n * mu * mu; nn += n; }
+                red[part * 128 + ch] = s1; red[512 + part * 128 + ch] = s2; red[1024 + part * 128 + ch] = nn;
+            }
+            __syncthreads();
+            if (t < 128) {
+                double2 a, c2;
+                a.x = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+                a.y = (red[512 + t] + red[640 + t]) + (red[768 + t] + red[896 + t]);
+                c2.x = (red[1024 + t] + red[1152 + t]) + (red[1280 + t] + red[1408 + t]); c2.y = 0.0;
                 store16_wt(xrows + (size_t)(grp * 128 + t) * 2, __builtin_bit_cast(v4f, a));
-                double2 c2; c2.x = nn; c2.y = 0.0;
                 store16_wt(xrows + (size_t)(grp * 128 + t) * 2 + 1, __builtin_bit_cast(v4f, c2));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
-                const unsigned old = __hip_atomic_fetch_add(cnt + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned old = __hip_atomic_fetch_add(cnt + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_last = old == (unsigned)(ngrp - 1);
                 if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             if (s_last) {
-                if (t < 128) {
+                {
                     double s1 = 0.0, s2 = 0.0, nn = 0.0;
-                    for (int g = 0; g < ngrp; ++g) {
-                        const double2 a = __builtin_bit_cast(double2, xrows[(size_t)(g * 128 + t) * 2]);
-                        const double2 c2 = __builtin_bit_cast(double2, xrows[(size_t)(g * 128 + t) * 2 + 1]);
-                        s1 += a.x; s2 += a.y; nn += c2.x;
+                    v4f xa[2], xc[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int g = part + 4 * k;
+                        xa[k] = g < ngrp ? xrows[(size_t)(g * 128 + ch) * 2] : v4f{0.f, 0.f, 0.f, 0.f};
+                        xc[k] = g < ngrp ? xrows[(size_t)(g * 128 + ch) * 2 + 1] : v4f{0.f, 0.f, 0.f, 0.f};
                     }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) { const double2 a = __builtin_bit_cast(double2, xa[k]), c2 = __builtin_bit_cast(double2, xc[k]); s1 += a.x; s2 += a.y; nn += c2.x; }
+                    red[part * 128 + ch] = s1; red[512 + part * 128 + ch] = s2; red[1024 + part * 128 + ch] = nn;
+                }
+                __syncthreads();
+                if (t < 128) {
+                    const double s1 = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+                    const double s2 = (red[512 + t] + red[640 + t]) + (red[768 + t] + red[896 + t]);
+                    const double nn = (red[1024 + t] + red[1152 + t]) + (red[1280 + t] + red[1408 + t]);
                     const double mean = nn > 0.0 ? s1 / nn : 0.0;
                     double var = nn > 0.0 ? s2 / nn - mean * mean : 0.0;
                     var = var > 0.0 ? var : 0.0;
