@@ -120,11 +120,6 @@ struct ConvLaunch {
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;
     unsigned* sk_err = nullptr;     // host-mapped error word (device pointer): set by a hand-off wait that timed out
     int reserve_cus = 0;            // CUs left to concurrent side-queue work: persistent / stream-K grids shrink by this many
-    // InstanceNorm finalize inside the producing launch (kernels that support it: the Winograd kernel): workspace of
-    // conv3_wino_finalize_workspace_bytes() zero-initialised bytes (reused by stream-ordered launches), the norm's parameters and
-    // outputs; fin_ws == nullptr: per-tile partials are written for in_finalize_kernel instead
-    void* fin_ws = nullptr; const float* fin_gamma = nullptr; const float* fin_beta = nullptr; float fin_eps = 1e-5f;
-    float* fin_scale = nullptr; float* fin_shift = nullptr;
     int no_sk = 0;                  // shared device: data-parallel grids only (no hand-off between blocks, no co-residency assumption)
 };
 size_t conv_streamk_workspace_bytes();
@@ -151,7 +146,6 @@ int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* c
 // of the [cout][cin][3][3] weights (wino_pack.h); partials per 8x16-pixel unit with explicit counts
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
 int conv3_wino_tiles(int OH, int OW);
-size_t conv3_wino_finalize_workspace_bytes();
 int launch_conv3_wino(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 pad-1 64-channel layer on a x2 nearest-upsampled materialised input (U2 + c3s1-64): four 2x2 convolutions on the
 // physical pixels with merged weights, kernels_up2.hip; wpk = conv_up2_pack() (up2_pack.h); partials per 8x32 physical-pixel tile

@@ -58,14 +58,7 @@ struct WinoArgs {
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
     int nfull;               // units 0 .. nfull-1 are computed whole, the rest in four quarters (32 output channels each)
     long long* dbg;          // optional in-kernel timeline (FAV_WINO_DBG), 24 slots per block
-    // InstanceNorm finalize inside this launch (see the end of the kernel): workspace + the norm's parameters, or fin_ws == nullptr
-    char* fin_ws; const float* fin_gamma; const float* fin_beta; float fin_eps; float* fin_scale; float* fin_shift;
 };
-
-// workspace of the in-launch finalize: [512 blocks][128] float4 (n, mean, M2, -) | [8 groups][128] 2 x 16 B (s1, s2 | n) | 9 counters
-constexpr size_t FIN_ROWS = 0, FIN_XROWS = (size_t)512 * 128 * 16, FIN_CNT = FIN_XROWS + (size_t)8 * 128 * 32, FIN_BYTES = FIN_CNT + 64;
-
-__device__ __forceinline__ void store16_wt(void* p, v4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
 // exact merge of NW groups' (mean, M2) with per-group counts (Chan et al.); same as kernels_conv.hip
 __device__ __forceinline__ float2 merge_group_stats(const float2* st, const int* wn, int NW, int pitch, int c, int* n_out)
@@ -87,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ts = smem;                       // [2][WG_TBUF] in the K loop, [8][128][LDSS] in the epilogue
     float* const aff = smem + WG_PS;              // [2][CIN]
-    v4f* const bst = reinterpret_cast<v4f*>(smem + WG_PS + 2 * p.CIN);   // [128] this block's running (n, mean, M2) per output channel
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -103,7 +95,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
-    if (t < 128) bst[t] = v4f{0.f, 0.f, 0.f, 0.f};
     const float lo1 = (AFF && p.relu1) ? 0.f : -INFINITY;
 
     // staging items: (tile row ty, raw column x, 16-byte channel chunk c4) -> raw rows 2 ty .. 2 ty + 3 of column x, four transformed
@@ -130,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     // vector address arithmetic in the loop.  Weights: lane * 16 + [wave * 8192 + kg * 65536 + q * 4096] + nt * 1024
     const int wlo = lane * 16, wso = wave * 8192;
 
-    __syncthreads();
+    if (AFF) __syncthreads();
     // One work item: NTW = 4: a whole unit (128 output channels); NTW = 1: a quarter of one (output channels 32 nq .. 32 nq + 31) --
     // the units of a thin last round are cut in four so that the round takes a quarter of the time (see launch_wino_t)
     auto work = [&](auto ntw_c, const int u, const int nq) {
@@ -347,16 +338,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
             __syncthreads();
             if (t < NC) {
                 int nn;
-                const float2 ms = merge_group_stats(st, wn, 4, NC, t, &nn);
-                if (p.fin_ws == nullptr) {
-                    p.partials[(size_t)u * 128 + nq * 32 + t] = ms;
-                    if (t == 0) p.counts[u] = nn;          // (the four quarters of a unit write the same count)
-                } else if (nn > 0) {
-                    // Chan merge into the block's running statistics of channel 32 nq + t (one thread per channel and item)
-                    const v4f b = bst[nq * 32 + t];
-                    const float n2 = (float)nn, n = b.x + n2, d = ms.x - b.y;
-                    bst[nq * 32 + t] = v4f{n, b.y + d * (n2 / n), b.z + ms.y + d * d * (b.x * n2 / n), 0.f};
-                }
+                p.partials[(size_t)u * 128 + nq * 32 + t] = merge_group_stats(st, wn, 4, NC, t, &nn);
+                if (t == 0) p.counts[u] = nn;          // (the four quarters of a unit write the same count)
             }
             __syncthreads();
         }
@@ -369,91 +352,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
     }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
 #undef DBG_T
-
-    // ---- InstanceNorm finalize inside the launch ("last arriver" pattern: no block ever waits for another one).
-    // Every block publishes one row of per-channel (n, mean, M2) for all its items.  The blocks are grouped by blockIdx % 8 (= the
-    // XCD a block runs on, so a group's rows sit in one L2); the block that arrives last in its group folds the group's rows
-    // (<= 64 x 2 KB) in fp64, the group that finishes last folds the eight group rows and writes scale = gamma / sqrt(var + eps),
-    // shift = beta - mean * scale -- what in_finalize_kernel did in a launch of its own (4.8 us + a kernel boundary, 16 times
-    // per frame).  Ordering as in the stream-K kernels: write-through (sc1) stores, drained (vmcnt 0) before a RELAXED agent-scope
-    // counter increment -- a release fence there would write back the whole L2's dirty lines, i.e. the output tiles, once per
-    // block (measured: +17 us per launch) -- and an acquire fence in the last arriver only.
-    if (p.fin_ws != nullptr) {
-        volatile int& s_last = *reinterpret_cast<volatile int*>(bst + 128);       // (dynamic LDS: a static would shift its base)
-        v4f* const rows = reinterpret_cast<v4f*>(p.fin_ws + FIN_ROWS);
-        v4f* const xrows = reinterpret_cast<v4f*>(p.fin_ws + FIN_XROWS);
-        unsigned* const cnt = reinterpret_cast<unsigned*>(p.fin_ws + FIN_CNT);
-        const int grp = blockIdx.x & 7, ngrp = min((int)gridDim.x, 8), nb = ((int)gridDim.x - grp + 7) >> 3;
-        if (t < 128) store16_wt(rows + (size_t)blockIdx.x * 128 + t, bst[t]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) {
-            const unsigned old = __hip_atomic_fetch_add(cnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)(nb - 1);
-            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        // folds: 512 threads = 128 channels x 4 parts, all loads of a thread in flight at once, parts summed through LDS in fp64
-        double* const red = reinterpret_cast<double*>(Ts);           // [3][4][128]
-        const int ch = t & 127, part = t >> 7;
-        if (s_last) {
-            {
-                v4f r[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const int b = grp + 8 * (part + 4 * k); r[k] = b < (int)gridDim.x ? rows[(size_t)b * 128 + ch] : v4f{0.f, 0.f, 0.f, 0.f}; }
-                double s1 = 0.0, s2 = 0.0, nn = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const double n = (double)r[k].x, mu = (double)r[k].y; s1 += n * mu; s2 += (double)r[k].z + n * mu * mu; nn += n; }
-                red[part * 128 + ch] = s1; red[512 + part * 128 + ch] = s2; red[1024 + part * 128 + ch] = nn;
-            }
-            __syncthreads();
-            if (t < 128) {
-                double2 a, c2;
-                a.x = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
-                a.y = (red[512 + t] + red[640 + t]) + (red[768 + t] + red[896 + t]);
-                c2.x = (red[1024 + t] + red[1152 + t]) + (red[1280 + t] + red[1408 + t]); c2.y = 0.0;
-                store16_wt(xrows + (size_t)(grp * 128 + t) * 2, __builtin_bit_cast(v4f, a));
-                store16_wt(xrows + (size_t)(grp * 128 + t) * 2 + 1, __builtin_bit_cast(v4f, c2));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0) {
-                const unsigned old = __hip_atomic_fetch_add(cnt + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = old == (unsigned)(ngrp - 1);
-                if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-            if (s_last) {
-                {
-                    double s1 = 0.0, s2 = 0.0, nn = 0.0;
-                    v4f xa[2], xc[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int g = part + 4 * k;
-                        xa[k] = g < ngrp ? xrows[(size_t)(g * 128 + ch) * 2] : v4f{0.f, 0.f, 0.f, 0.f};
-                        xc[k] = g < ngrp ? xrows[(size_t)(g * 128 + ch) * 2 + 1] : v4f{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) { const double2 a = __builtin_bit_cast(double2, xa[k]), c2 = __builtin_bit_cast(double2, xc[k]); s1 += a.x; s2 += a.y; nn += c2.x; }
-                    red[part * 128 + ch] = s1; red[512 + part * 128 + ch] = s2; red[1024 + part * 128 + ch] = nn;
-                }
-                __syncthreads();
-                if (t < 128) {
-                    const double s1 = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
-                    const double s2 = (red[512 + t] + red[640 + t]) + (red[768 + t] + red[896 + t]);
-                    const double nn = (red[1024 + t] + red[1152 + t]) + (red[1280 + t] + red[1408 + t]);
-                    const double mean = nn > 0.0 ? s1 / nn : 0.0;
-                    double var = nn > 0.0 ? s2 / nn - mean * mean : 0.0;
-                    var = var > 0.0 ? var : 0.0;
-                    const double g = p.fin_gamma ? (double)p.fin_gamma[t] : 1.0, bt = p.fin_beta ? (double)p.fin_beta[t] : 0.0;
-                    const double sc = g / sqrt(var + (double)p.fin_eps);
-                    p.fin_scale[t] = (float)sc;
-                    p.fin_shift[t] = (float)(bt - mean * sc);
-                }
-                if (t < 9) cnt[t] = 0u;              // ready for the next launch (stream-ordered)
-            }
-        }
-    }
 }
 
 // FAV_WINO_DBG=n: print the in-kernel timeline of the n-th launch
@@ -478,7 +376,7 @@ template <bool AFF>
 int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
 {
     const auto kern = conv3_wino_kernel<AFF>;
-    const size_t lds = (size_t)(WG_PS + 2 * a0.CIN + 128 * 4 + 4) * sizeof(float);
+    const size_t lds = (size_t)(WG_PS + 2 * a0.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
@@ -522,8 +420,6 @@ bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, 
 }
 int conv3_wino_tiles(int OH, int OW) { return ((OH + 7) / 8) * ((OW + 15) / 16); }
 
-size_t conv3_wino_finalize_workspace_bytes() { return FIN_BYTES; }
-
 int launch_conv3_wino(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
 {
     FAV_REQUIRE(conv3_wino_eligible(c.CIN, c.COUT, c.COUTp, c.KH, c.stride, c.pad, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode && !c.stuff && wpk,
@@ -536,9 +432,6 @@ int launch_conv3_wino(const ConvLaunch& c, const float* wpk, int* counts, hipStr
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW;
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 7) / 8;
     a.dbg = nullptr;
-    a.fin_ws = static_cast<char*>(c.fin_ws); a.fin_gamma = c.fin_gamma; a.fin_beta = c.fin_beta; a.fin_eps = c.fin_eps;
-    a.fin_scale = c.fin_scale; a.fin_shift = c.fin_shift;
-    FAV_REQUIRE(a.fin_ws == nullptr || (c.partials != nullptr && a.fin_scale && a.fin_shift), "winograd conv: finalize without statistics");
     return c.pre.stages >= 1 ? launch_wino_t<true>(a, c.reserve_cus, st) : launch_wino_t<false>(a, c.reserve_cus, st);
 }
 

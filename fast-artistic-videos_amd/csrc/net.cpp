@@ -40,7 +40,6 @@ struct Act {
     float* partials = nullptr;   // (mean, M2) tiles of the raw tensor from the producing conv, or null
     int mblocks = 0, ppitch = 0;
     int* counts = nullptr;       // per-partial pixel counts (first-layer kernel) or null
-    bool fin_done = false;       // the producing launch has already written the following InstanceNorm's scale / shift
     int H() const { return Hp << ups; }
     int W() const { return Wp << ups; }
 };
@@ -77,10 +76,10 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_fin; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_WINO_NO_FIN") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr};
     return t;
 }
 
@@ -107,7 +106,6 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
-    void* fin_ws = nullptr;        // workspace of the in-launch InstanceNorm finalize (Winograd kernel)
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
@@ -132,7 +130,7 @@ struct fav_net {
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wup2); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
-        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); (void)hipFree(fin_ws); if (sk_err_host) (void)hipHostFree(sk_err_host);
+        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
     }
     int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
     int upload();
@@ -259,8 +257,6 @@ int fav_net::upload()
     std::vector<float> o((size_t)maxc, 1.f), z((size_t)maxc, 0.f);
     rc = dev_upload(o, 0, &ones); if (rc) return rc;
     rc = dev_upload(z, 0, &zeros); if (rc) return rc;
-    FAV_HIP(hipMalloc(&fin_ws, conv3_wino_finalize_workspace_bytes()));
-    FAV_HIP(hipMemset(fin_ws, 0, conv3_wino_finalize_workspace_bytes()));
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_ws), conv_streamk_workspace_bytes()));
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_flags), conv_streamk_grid() * sizeof(unsigned)));
     FAV_HIP(hipMemset(sk_flags, 0, conv_streamk_grid() * sizeof(unsigned)));
@@ -362,12 +358,6 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3 || s2 || wino || up2)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
-            if (wino && want_stats && !tuning().no_fin && in_cursor < ins.size()) {
-                // the Winograd launch finishes the following InstanceNorm itself (last-arriver fold of per-block statistics)
-                const DevIN& dn = ins[in_cursor];
-                c.fin_ws = fin_ws; c.fin_gamma = dn.gamma; c.fin_beta = dn.beta; c.fin_eps = ls[li + 1].eps; c.fin_scale = dn.scale; c.fin_shift = dn.shift;
-                nxt.fin_done = true;
-            }
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
             c8_counts = (c8 || h3 || s2 || wino || up2) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_up2 = up2;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
@@ -380,9 +370,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const int C = (int)L.gamma.size();
             const int M = cur.Hp * cur.Wp;
             if (cur.data == nullptr || C != cur.C) { set_error("network: misplaced InstanceNormalization"); return FAV_EUNSUPPORTED; }
-            if (cur.fin_done && cur.pre.stages == 0) {
-                cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1;      // written by the producing launch
-            } else if (cur.partials != nullptr && cur.pre.stages == 0) {
+            if (cur.partials != nullptr && cur.pre.stages == 0) {
                 int rc = launch_in_finalize(cur.partials, cur.counts, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
                                             d.scale, d.shift, st);
                 if (rc) return rc;
@@ -399,7 +387,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
                 else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             }
-            cur.partials = nullptr; cur.counts = nullptr; cur.fin_done = false;
+            cur.partials = nullptr; cur.counts = nullptr;
             break;
         }
         case L_BN: {
