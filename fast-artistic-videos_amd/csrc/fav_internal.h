@@ -142,6 +142,10 @@ int launch_conv_c8(const ConvLaunch& p, int* counts, hipStream_t st);
 bool conv_c8d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups);
 void conv_c8d_pack(const float* w, int cin, int cout, std::vector<float>& out);
 int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* counts, hipStream_t st);
+// the same first layer with 1-D minimal filtering F(2,3) along x (kernels_first.hip); wpk = conv_first_pack() (first_pack.h);
+// eligibility as conv_c8d_eligible; partials per 8x64 tile with explicit counts
+int conv_first_tiles(int OH, int OW);
+int launch_conv_first(const ConvLaunch& p, int cin_real, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 UNPADDED 128-channel layers (the residual blocks): Winograd F(2x2,3x3), kernels_wino.hip; wpk = conv_wino_pack()
 // of the [cout][cin][3][3] weights (wino_pack.h); partials per 8x16-pixel unit with explicit counts
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);

@@ -1,0 +1,247 @@
+// kernels_first.hip -- the first layer (c9s1-32: 9x9, 7 real input channels of the NHWC8 network input -> 32 channels, full
+// resolution; models_video.lua:57-80; 3 channels for first-frame image models) with 1-D minimal filtering along x.
+//
+// The direct form (conv_c8d_kernel, kernels_conv.hip) is a dense-K implicit GEMM at 0.78 of the fp32 MFMA peak: K = 7 x 81,
+// N = 32 -- too few output channels for a 2-D Winograd transform to pay (its vector-ALU work is per input element).  Along ONE
+// axis it does: the 9 taps of a filter row are three blocks of three, each block a 3-tap correlation computed as F(2,3) -- 4
+// multiplies per output pair instead of 6 (first_pack.h) -- so a tile needs 4 x 95 instead of 2 x 287 matrix instructions
+// per 64 pixels and 32 channels, for ONE extra vector-ALU instruction per MFMA (the input difference / sum), and the output
+// transform stays inside a lane (all four positions of a tile are accumulators of the same wave).
+//
+// Block = 8 waves, persistent, tile = 8 rows x 64 columns: wave = one output row = 32 tiles of two pixels.  LDS: the four
+// transformed weight sets [position][pair][half][32] (97 KB, resident) + ONE halo buffer, 16 x 72 pixels as an even-column and an
+// odd-column plane per channel (32 KB): tile t reads columns 2t + e, i.e. consecutive words of one plane -- conflict-free
+// ds_read_b32, every address = one of five per-lane bases (the pairing types of first_pack.h) + an immediate.  The next tile's
+// halo travels through registers while this one is computed.
+#include <algorithm>
+#include <cstdlib>
+
+#include "fav_internal.h"
+#include "first_pack.h"
+
+namespace fav {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+
+constexpr int F_TH = 8, F_TW = 64;                 // output tile
+constexpr int F_HR = F_TH + 8, F_HC = F_TW + 8;    // halo 16 x 72
+constexpr int F_RP = F_HC / 2;                     // 36 words per plane row
+constexpr int F_PLN = F_HR * F_RP;                 // 576 words per plane
+constexpr int F_CPL = 2 * F_PLN;                   // 1152 words per channel (even plane | odd plane)
+constexpr int F_HP = F_HR * F_HC;                  // 1152 halo pixels
+constexpr int F_NH = (F_HP + 511) / 512;           // 3 halo pixels per thread
+
+struct FirstArgs {
+    const float* in; const float* wpk; const float* bias;
+    float* out; float2* partials; int* counts;
+    int IH, IW, IWp, COUT, pad, OH, OW, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float2 merge_rows(const float2* st, const int* wn, int c, int* n_out)
+{
+    int n = 0; float s = 0.f;
+    for (int w = 0; w < 8; ++w) { n += wn[w]; s += (float)wn[w] * st[w * 32 + c].x; }
+    const float mean = n ? s / (float)n : 0.f;
+    float m2 = 0.f;
+    for (int w = 0; w < 8; ++w) { const float d = st[w * 32 + c].x - mean; m2 += st[w * 32 + c].y + (float)wn[w] * d * d; }
+    *n_out = n;
+    return make_float2(mean, m2);
+}
+
+constexpr int f_off(int e) { return (e & 1) * F_PLN + (e >> 1); }       // word offset of halo column 2t + e relative to tile t's base
+
+template <int CR>
+__global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
+{
+    constexpr int NCC = (CR / 2) * 27, NJ = NCC + 14, LAST = CR - 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ws = smem;                       // [4][NJ][2][32]
+    float* const Hs = Ws + 4 * NJ * 64;           // [CR][2 planes][16][36]
+    float* const red = Hs + CR * F_CPL;           // [8][32] float2 + [8] int
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int e = t; e < 4 * NJ * 16; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wpk + e * 4);
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    float4 hlo[F_NH], hhi[F_NH];
+#define FL_LOAD_HALO(tile_)                                                                         \
+    {                                                                                               \
+        const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
+        _Pragma("unroll") for (int i = 0; i < F_NH; ++i) {                                          \
+            const int pix_ = t + 512 * i, hy_ = pix_ / F_HC, hx_ = pix_ - hy_ * F_HC;               \
+            const int iy_ = ty_ * F_TH - p.pad + hy_, ix_ = tx_ * F_TW - p.pad + hx_;               \
+            const bool v_ = (pix_ < F_HP) & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+            const int off_ = v_ ? (iy_ * p.IWp + ix_) * 8 : 0;                                      \
+            const float4 a_ = *reinterpret_cast<const float4*>(p.in + off_);                        \
+            const float4 b_ = CR > 4 ? *reinterpret_cast<const float4*>(p.in + off_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            hlo[i] = v_ ? a_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            hhi[i] = v_ ? b_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+        }                                                                                           \
+    }
+#define FL_STORE_HALO()                                                                             \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < F_NH; ++i) {                                          \
+            const int pix_ = t + 512 * i;                                                           \
+            if (pix_ < F_HP) {                                                                      \
+                const int hy_ = pix_ / F_HC, hx_ = pix_ - hy_ * F_HC;                               \
+                float* d_ = Hs + (hx_ & 1) * F_PLN + hy_ * F_RP + (hx_ >> 1);                       \
+                const float c_[8] = {hlo[i].x, hlo[i].y, hlo[i].z, hlo[i].w, hhi[i].x, hhi[i].y, hhi[i].z, hhi[i].w}; \
+                _Pragma("unroll") for (int c = 0; c < CR; ++c) d_[c * F_CPL] = c_[c];               \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) FL_LOAD_HALO(tile);
+    FL_STORE_HALO();
+    __syncthreads();
+
+    const int m = lane & 31, half = lane >> 5;
+    const int col = lane & 31, rbase = 4 * (lane >> 5);
+    // per-lane bases (tile m of output row `wave`); the second half-wave's operand of a pair sits at a constant offset
+    const float* const a_one = Hs + wave * F_RP + m;
+    const float* const a_cc = a_one + half * F_CPL;                      // type 0: next channel
+    const float* const a_ky = a_one + half * F_RP;                       // type 1: next halo row
+    const float* const a_be = a_one + half * (F_PLN + 1);                // type 2, even column offsets: + 3 columns = odd plane, + 1
+    const float* const a_bo = a_one + half * (2 - F_PLN);                // type 2, odd column offsets: + 3 columns = even plane, + 2
+    const float* const b_lo = Ws + half * 32 + m;
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) FL_LOAD_HALO(nxt);
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+        // four reads (halo columns 2t + 3b + j, j = 0..3) -> the four position operands -> four MFMAs
+#define FL_COMBO(j_, r0_, r1_, r2_, r3_)                                                            \
+        {   const float R0 = (r0_), R1 = (r1_), R2 = (r2_), R3 = (r3_);                             \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(R0 - R2, b_lo[((0 * NJ) + (j_)) * 64], acc[0], 0, 0, 0); \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(R1 + R2, b_lo[((1 * NJ) + (j_)) * 64], acc[1], 0, 0, 0); \
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(R2 - R1, b_lo[((2 * NJ) + (j_)) * 64], acc[2], 0, 0, 0); \
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(R1 - R3, b_lo[((3 * NJ) + (j_)) * 64], acc[3], 0, 0, 0); }
+#pragma unroll
+        for (int cc = 0; cc < CR / 2; ++cc)
+#pragma unroll
+            for (int ky = 0; ky < 9; ++ky)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float* a = a_cc + 2 * cc * F_CPL + ky * F_RP;
+                    FL_COMBO(cc * 27 + ky * 3 + b, a[f_off(3 * b)], a[f_off(3 * b + 1)], a[f_off(3 * b + 2)], a[f_off(3 * b + 3)]);
+                }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float* a = a_ky + LAST * F_CPL + 2 * q * F_RP;
+                FL_COMBO(NCC + q * 3 + b, a[f_off(3 * b)], a[f_off(3 * b + 1)], a[f_off(3 * b + 2)], a[f_off(3 * b + 3)]);
+            }
+        {
+            const float* ae = a_be + LAST * F_CPL + 8 * F_RP;
+            const float* ao = a_bo + LAST * F_CPL + 8 * F_RP;
+            FL_COMBO(NCC + 12, ae[f_off(0)], ao[f_off(1)], ae[f_off(2)], ao[f_off(3)]);
+        }
+        {
+            const float* a = a_one + LAST * F_CPL + 8 * F_RP;
+            FL_COMBO(NCC + 13, a[f_off(6)], a[f_off(7)], a[f_off(8)], a[f_off(9)]);
+        }
+#undef FL_COMBO
+        __syncthreads();                    // every wave is done with the halo
+        if (nxt < ntiles) FL_STORE_HALO();
+
+        // ---- output transform + epilogue: tile mi of row `wave` -> output columns 2 mi, 2 mi + 1; MFMA columns = channels
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int oy = ty * F_TH + wave, ox0 = tx * F_TW;
+        const float bv = p.bias[col];
+        float sm = 0.f;
+        float y0[16], y1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mi = (r & 3) + 8 * (r >> 2) + rbase;
+            y0[r] = (acc[0][r] + acc[1][r]) + acc[2][r] + bv;
+            y1[r] = (acc[1][r] - acc[2][r]) - acc[3][r] + bv;
+            const int ox = ox0 + 2 * mi;
+            if (oy < p.OH && ox < p.OW) {
+                if (col < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + col] = y0[r];
+                sm += y0[r];
+            }
+            if (oy < p.OH && ox + 1 < p.OW) {
+                if (col < p.COUT) p.out[((size_t)oy * p.OW + ox + 1) * p.COUT + col] = y1[r];
+                sm += y1[r];
+            }
+        }
+        if (p.partials != nullptr) {
+            float2* st = reinterpret_cast<float2*>(red);          // [8 waves][32]
+            int* wn = reinterpret_cast<int*>(red + 8 * 64);         // [8]
+            const int nw = oy < p.OH ? min(F_TW, p.OW - ox0) : 0;   // valid pixels of this wave's row
+            sm += __shfl_xor(sm, 32);
+            const float mu = nw ? sm / (float)nw : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + 2 * ((r & 3) + 8 * (r >> 2) + rbase);
+                const float d0 = y0[r] - mu, d1 = y1[r] - mu;
+                if (oy < p.OH && ox < p.OW) q = fmaf(d0, d0, q);
+                if (oy < p.OH && ox + 1 < p.OW) q = fmaf(d1, d1, q);
+            }
+            q += __shfl_xor(q, 32);
+            if (lane < 32) st[wave * 32 + lane] = make_float2(mu, q);
+            if (lane == 0) wn[wave] = nw;
+            __syncthreads();
+            if (t < 32) {
+                int n;
+                p.partials[(size_t)tile * 32 + t] = merge_rows(st, wn, t, &n);
+                if (t == 0) p.counts[tile] = n;
+            }
+        }
+        __syncthreads();            // the halo of the next tile is complete; red scratch free again
+    }
+#undef FL_LOAD_HALO
+#undef FL_STORE_HALO
+}
+
+template <int CR>
+int launch_first_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
+{
+    const size_t lds = (size_t)(4 * conv_first_pairs(CR) * 64 + CR * F_CPL + 8 * 64 + 8) * sizeof(float);
+    const int dv = cur_dev();
+    static int nblocks[MAX_DEVICES] = {};
+    if (!nblocks[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        nblocks[dv] = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = std::max(1, nblocks[dv] - reserve_cus);
+    hipLaunchKernelGGL((conv_first_kernel<CR>), dim3(tiles < grid ? tiles : grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_first_kernel");
+    return FAV_OK;
+}
+
+}  // namespace
+
+int conv_first_tiles(int OH, int OW) { return ((OH + F_TH - 1) / F_TH) * ((OW + F_TW - 1) / F_TW); }
+
+// eligibility = conv_c8d_eligible (8-channel input pitch, 7 or 3 real channels, 9x9, stride 1, <= 32 output channels, no pending transform)
+int launch_conv_first(const ConvLaunch& c, int cin_real, const float* wpk, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(c.CIN == 8 && (cin_real == 7 || cin_real == 3) && c.COUTp == 32 && c.KH == 9 && c.KW == 9 && c.stride == 1 && c.pre.stages == 0 &&
+                c.ups == 0 && !c.final_mode && wpk, "first-layer conv (F(2,3) along x): not eligible");
+    FAV_REQUIRE((long long)c.IH * c.IWp * 8 < (1ll << 31), "first-layer conv: bad shape");
+    FirstArgs a;
+    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW;
+    a.tiles_x = (c.OW + F_TW - 1) / F_TW; a.tiles_y = (c.OH + F_TH - 1) / F_TH;
+    return cin_real == 7 ? launch_first_t<7>(a, c.reserve_cus, st) : launch_first_t<3>(a, c.reserve_cus, st);
+}
+
+}  // namespace fav
