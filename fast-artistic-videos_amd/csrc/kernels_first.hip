@@ -110,7 +110,9 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
     const float* const a_ky = a_one + half * F_RP;                       // type 1: next halo row
     const float* const a_be = a_one + half * (F_PLN + 1);                // type 2, even column offsets: + 3 columns = odd plane, + 1
     const float* const a_bo = a_one + half * (2 - F_PLN);                // type 2, odd column offsets: + 3 columns = even plane, + 2
-    const float* const b_lo = Ws + half * 32 + m;
+    const float* const b_lo = Ws + half * 32 + m;                        // positions 0, 1
+    const float* b_hi = b_lo + 2 * NJ * 64;                              // positions 2, 3 (their offsets would not fit a DS immediate)
+    asm volatile("" : "+v"(b_hi));                                       // (keep it a register of its own: folded into b_lo + constant it costs an add per read)
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
@@ -121,39 +123,54 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-        // four reads (halo columns 2t + 3b + j, j = 0..3) -> the four position operands -> four MFMAs
-#define FL_COMBO(j_, r0_, r1_, r2_, r3_)                                                            \
-        {   const float R0 = (r0_), R1 = (r1_), R2 = (r2_), R3 = (r3_);                             \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(R0 - R2, b_lo[((0 * NJ) + (j_)) * 64], acc[0], 0, 0, 0); \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(R1 + R2, b_lo[((1 * NJ) + (j_)) * 64], acc[1], 0, 0, 0); \
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(R2 - R1, b_lo[((2 * NJ) + (j_)) * 64], acc[2], 0, 0, 0); \
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(R1 - R3, b_lo[((3 * NJ) + (j_)) * 64], acc[3], 0, 0, 0); }
+        // A "group" = the three blocks b of one (pair, filter row): ten reads (halo columns 2t + e, e = 0..9; block b uses e = 3b .. 3b+3)
+        // + twelve weight reads -> twelve operands -> twelve MFMAs.  The reads of group g + 1 are issued before the MFMAs of group
+        // g (two register sets, pinned with scheduling fences): LDS latency never sits in front of a matrix instruction.
+        float R[2][10], B[2][12];
+#define FL_READ(set_, abase_, j0_)                                                                  \
+        {   _Pragma("unroll") for (int e = 0; e < 10; ++e) R[set_][e] = (abase_)[f_off(e)];         \
+            _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                         \
+                B[set_][4 * b + 0] = b_lo[((0 * NJ) + (j0_) + b) * 64]; B[set_][4 * b + 1] = b_lo[((1 * NJ) + (j0_) + b) * 64]; \
+                B[set_][4 * b + 2] = b_hi[((0 * NJ) + (j0_) + b) * 64]; B[set_][4 * b + 3] = b_hi[((1 * NJ) + (j0_) + b) * 64]; } }
+#define FL_COMP(set_)                                                                               \
+        {   float V[12];                                                                            \
+            _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                         \
+                V[4 * b + 0] = R[set_][3 * b] - R[set_][3 * b + 2]; V[4 * b + 1] = R[set_][3 * b + 1] + R[set_][3 * b + 2]; \
+                V[4 * b + 2] = R[set_][3 * b + 2] - R[set_][3 * b + 1]; V[4 * b + 3] = R[set_][3 * b + 1] - R[set_][3 * b + 3]; } \
+            _Pragma("unroll") for (int b = 0; b < 3; ++b)                                           \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                       \
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[4 * b + q], B[set_][4 * b + q], acc[q], 0, 0, 0); }
+#define FL_FENCE() __builtin_amdgcn_sched_barrier(0)
+        constexpr int NG = (CR / 2) * 9 + 4;           // groups: (pair, ky) of type 0, then the row pairs q of type 1
+        // base pointer and first pair index of group g
+#define FL_GBASE(g_) ((g_) < (CR / 2) * 9 ? a_cc + 2 * ((g_) / 9) * F_CPL + ((g_) % 9) * F_RP : a_ky + LAST * F_CPL + 2 * ((g_) - (CR / 2) * 9) * F_RP)
+        FL_READ(0, FL_GBASE(0), 0);
 #pragma unroll
-        for (int cc = 0; cc < CR / 2; ++cc)
-#pragma unroll
-            for (int ky = 0; ky < 9; ++ky)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const float* a = a_cc + 2 * cc * F_CPL + ky * F_RP;
-                    FL_COMBO(cc * 27 + ky * 3 + b, a[f_off(3 * b)], a[f_off(3 * b + 1)], a[f_off(3 * b + 2)], a[f_off(3 * b + 3)]);
-                }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float* a = a_ky + LAST * F_CPL + 2 * q * F_RP;
-                FL_COMBO(NCC + q * 3 + b, a[f_off(3 * b)], a[f_off(3 * b + 1)], a[f_off(3 * b + 2)], a[f_off(3 * b + 3)]);
-            }
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) { FL_READ((g + 1) & 1, FL_GBASE(g + 1), 3 * (g + 1)); }
+            FL_FENCE(); FL_COMP(g & 1); FL_FENCE();
+        }
         {
+            // type 2 (ky = 8, blocks 0 | 1) and type 3 (block 2 alone): one combo each
             const float* ae = a_be + LAST * F_CPL + 8 * F_RP;
             const float* ao = a_bo + LAST * F_CPL + 8 * F_RP;
-            FL_COMBO(NCC + 12, ae[f_off(0)], ao[f_off(1)], ae[f_off(2)], ao[f_off(3)]);
+            const float* a1 = a_one + LAST * F_CPL + 8 * F_RP;
+            const float r0 = ae[f_off(0)], r1 = ao[f_off(1)], r2 = ae[f_off(2)], r3 = ao[f_off(3)];
+            const float s0 = a1[f_off(6)], s1 = a1[f_off(7)], s2 = a1[f_off(8)], s3 = a1[f_off(9)];
+            constexpr int J2 = NCC + 12, J3 = NCC + 13;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 - r2, b_lo[((0 * NJ) + J2) * 64], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1 + r2, b_lo[((1 * NJ) + J2) * 64], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r2 - r1, b_hi[((0 * NJ) + J2) * 64], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1 - r3, b_hi[((1 * NJ) + J2) * 64], acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0 - s2, b_lo[((0 * NJ) + J3) * 64], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1 + s2, b_lo[((1 * NJ) + J3) * 64], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s2 - s1, b_hi[((0 * NJ) + J3) * 64], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1 - s3, b_hi[((1 * NJ) + J3) * 64], acc[3], 0, 0, 0);
         }
-        {
-            const float* a = a_one + LAST * F_CPL + 8 * F_RP;
-            FL_COMBO(NCC + 13, a[f_off(6)], a[f_off(7)], a[f_off(8)], a[f_off(9)]);
-        }
-#undef FL_COMBO
+#undef FL_READ
+#undef FL_COMP
+#undef FL_FENCE
+#undef FL_GBASE
         __syncthreads();                    // every wave is done with the halo
         if (nxt < ntiles) FL_STORE_HALO();
 
