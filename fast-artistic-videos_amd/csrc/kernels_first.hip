@@ -111,8 +111,9 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
     const float* const a_be = a_one + half * (F_PLN + 1);                // type 2, even column offsets: + 3 columns = odd plane, + 1
     const float* const a_bo = a_one + half * (2 - F_PLN);                // type 2, odd column offsets: + 3 columns = even plane, + 2
     const float* const b_lo = Ws + half * 32 + m;                        // positions 0, 1
-    const float* b_hi = b_lo + 2 * NJ * 64;                              // positions 2, 3 (their offsets would not fit a DS immediate)
-    asm volatile("" : "+v"(b_hi));                                       // (keep it a register of its own: folded into b_lo + constant it costs an add per read)
+    int hi_words = 2 * NJ * 64;                                          // positions 2, 3 (their offsets would not fit a DS immediate)
+    asm volatile("" : "+v"(hi_words));                                   // (an opaque OFFSET keeps b_hi a register of its own AND an LDS pointer;
+    const float* const b_hi = b_lo + hi_words;                           //  laundering the pointer itself turns the reads into flat loads)
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
