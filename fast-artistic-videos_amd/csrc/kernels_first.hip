@@ -9,8 +9,8 @@
 // transform stays inside a lane (all four positions of a tile are accumulators of the same wave).
 //
 // Block = 8 waves, persistent, tile = 8 rows x 64 columns: wave = one output row = 32 tiles of two pixels.  LDS: the four
-// transformed weight sets [position][pair][half][32] (97 KB, resident) + ONE halo buffer, 16 x 72 pixels as an even-column and an
-// odd-column plane per channel (32 KB): tile t reads columns 2t + e, i.e. consecutive words of one plane -- conflict-free
+// transformed weight sets [position][pair][half][32] (97 KB, resident) + ONE halo buffer, 16 x 72 pixels per channel with every row
+// stored as [even columns | odd columns] (32 KB): tile t reads columns 2t + e, i.e. consecutive words of one half -- conflict-free
 // ds_read_b32, every address = one of five per-lane bases (the pairing types of first_pack.h) + an immediate.  The next tile's
 // halo travels through registers while this one is computed.
 #include <algorithm>
@@ -31,9 +31,9 @@ inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < 
 
 constexpr int F_TH = 8, F_TW = 64;                 // output tile
 constexpr int F_HR = F_TH + 8, F_HC = F_TW + 8;    // halo 16 x 72
-constexpr int F_RP = F_HC / 2;                     // 36 words per plane row
-constexpr int F_PLN = F_HR * F_RP;                 // 576 words per plane
-constexpr int F_CPL = 2 * F_PLN;                   // 1152 words per channel (even plane | odd plane)
+constexpr int F_HALF = F_HC / 2;                   // 36 words: the even (then the odd) columns of a halo row
+constexpr int F_RP = F_HC;                         // 72 words per halo row: [even columns | odd columns] -- the ten reads of a group sit within 42 words
+constexpr int F_CPL = F_HR * F_RP;                 // 1152 words per channel
 constexpr int F_HP = F_HR * F_HC;                  // 1152 halo pixels
 constexpr int F_NH = (F_HP + 511) / 512;           // 3 halo pixels per thread
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ float2 merge_rows(const float2* st, const int* wn, in
     return make_float2(mean, m2);
 }
 
-constexpr int f_off(int e) { return (e & 1) * F_PLN + (e >> 1); }       // word offset of halo column 2t + e relative to tile t's base
+constexpr int f_off(int e) { return (e & 1) * F_HALF + (e >> 1); }       // word offset of halo column 2t + e relative to tile t's base
 
 template <int CR>
 __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
             const int pix_ = t + 512 * i;                                                           \
             if (pix_ < F_HP) {                                                                      \
                 const int hy_ = pix_ / F_HC, hx_ = pix_ - hy_ * F_HC;                               \
-                float* d_ = Hs + (hx_ & 1) * F_PLN + hy_ * F_RP + (hx_ >> 1);                       \
+                float* d_ = Hs + hy_ * F_RP + (hx_ & 1) * F_HALF + (hx_ >> 1);                       \
                 const float c_[8] = {hlo[i].x, hlo[i].y, hlo[i].z, hlo[i].w, hhi[i].x, hhi[i].y, hhi[i].z, hhi[i].w}; \
                 _Pragma("unroll") for (int c = 0; c < CR; ++c) d_[c * F_CPL] = c_[c];               \
             }                                                                                       \
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
     const float* const a_one = Hs + wave * F_RP + m;
     const float* const a_cc = a_one + half * F_CPL;                      // type 0: next channel
     const float* const a_ky = a_one + half * F_RP;                       // type 1: next halo row
-    const float* const a_be = a_one + half * (F_PLN + 1);                // type 2, even column offsets: + 3 columns = odd plane, + 1
-    const float* const a_bo = a_one + half * (2 - F_PLN);                // type 2, odd column offsets: + 3 columns = even plane, + 2
+    const float* const a_be = a_one + half * (F_HALF + 1);               // type 2, even column offsets: + 3 columns = odd half, + 1
+    const float* const a_bo = a_one + half * (2 - F_HALF);               // type 2, odd column offsets: + 3 columns = even half, + 2
     const float* const b_lo = Ws + half * 32 + m;                        // positions 0, 1
     int hi_words = 2 * NJ * 64;                                          // positions 2, 3 (their offsets would not fit a DS immediate)
     asm volatile("" : "+v"(hi_words));                                   // (an opaque OFFSET keeps b_hi a register of its own AND an LDS pointer;
@@ -128,8 +128,10 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
         // + twelve weight reads -> twelve operands -> twelve MFMAs.  The reads of group g + 1 are issued before the MFMAs of group
         // g (two register sets, pinned with scheduling fences): LDS latency never sits in front of a matrix instruction.
         float R[2][10], B[2][12];
-#define FL_READ(set_, abase_, j0_)                                                                  \
-        {   _Pragma("unroll") for (int e = 0; e < 10; ++e) R[set_][e] = (abase_)[f_off(e)];         \
+#define FL_READ(set_, abase_, goff_, j0_)                                                           \
+        {   int go_ = (goff_); asm volatile("" : "+s"(go_));    /* opaque scalar: ONE address add per group, then 8-bit read2 offsets */ \
+            const float* gb_ = (abase_) + go_;                                                      \
+            _Pragma("unroll") for (int e = 0; e < 10; ++e) R[set_][e] = gb_[f_off(e)];              \
             _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                         \
                 B[set_][4 * b + 0] = b_lo[((0 * NJ) + (j0_) + b) * 64]; B[set_][4 * b + 1] = b_lo[((1 * NJ) + (j0_) + b) * 64]; \
                 B[set_][4 * b + 2] = b_hi[((0 * NJ) + (j0_) + b) * 64]; B[set_][4 * b + 3] = b_hi[((1 * NJ) + (j0_) + b) * 64]; } }
@@ -140,15 +142,17 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
                 V[4 * b + 2] = R[set_][3 * b + 2] - R[set_][3 * b + 1]; V[4 * b + 3] = R[set_][3 * b + 1] - R[set_][3 * b + 3]; } \
             _Pragma("unroll") for (int b = 0; b < 3; ++b)                                           \
                 _Pragma("unroll") for (int q = 0; q < 4; ++q)                                       \
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[4 * b + q], B[set_][4 * b + q], acc[q], 0, 0, 0); }
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[4 * b + q], B[set_][4 * b + q], acc[q], 0, 0, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0); }
 #define FL_FENCE() __builtin_amdgcn_sched_barrier(0)
         constexpr int NG = (CR / 2) * 9 + 4;           // groups: (pair, ky) of type 0, then the row pairs q of type 1
         // base pointer and first pair index of group g
-#define FL_GBASE(g_) ((g_) < (CR / 2) * 9 ? a_cc + 2 * ((g_) / 9) * F_CPL + ((g_) % 9) * F_RP : a_ky + LAST * F_CPL + 2 * ((g_) - (CR / 2) * 9) * F_RP)
-        FL_READ(0, FL_GBASE(0), 0);
+#define FL_GBASE(g_) ((g_) < (CR / 2) * 9 ? a_cc : a_ky)
+#define FL_GOFF(g_) ((g_) < (CR / 2) * 9 ? 2 * ((g_) / 9) * F_CPL + ((g_) % 9) * F_RP : LAST * F_CPL + 2 * ((g_) - (CR / 2) * 9) * F_RP)
+        FL_READ(0, FL_GBASE(0), FL_GOFF(0), 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) { FL_READ((g + 1) & 1, FL_GBASE(g + 1), 3 * (g + 1)); }
+            if (g + 1 < NG) { FL_READ((g + 1) & 1, FL_GBASE(g + 1), FL_GOFF(g + 1), 3 * (g + 1)); }
             FL_FENCE(); FL_COMP(g & 1); FL_FENCE();
         }
         {
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void conv_first_kernel(const FirstArgs p)
 #undef FL_COMP
 #undef FL_FENCE
 #undef FL_GBASE
+#undef FL_GOFF
         __syncthreads();                    // every wave is done with the halo
         if (nxt < ntiles) FL_STORE_HALO();
 
