@@ -170,3 +170,69 @@ def test_fragment_reads_are_bank_conflict_free():
     addr = ((lanes & 31) * LDSS + 4 * h) * 4
     for g0 in range(0, 64, 8):
         assert len(set((addr[g0:g0 + 8] // 16) % 8)) == 8
+
+
+# ---------------------------------------------------------------------------------------------- first layer: F(2,3) along x
+@pytest.fixture(scope="module")
+def first_packer(tmp_path_factory):
+    d = tmp_path_factory.mktemp("first")
+    src = d / "pack.cpp"
+    src.write_text('#include "first_pack.h"\n#include <cstring>\n'
+                   'extern "C" long pack(const float* w, int cin, int cout, float* out) {\n'
+                   '  std::vector<float> v; fav::conv_first_pack(w, cin, cout, v); if (out) memcpy(out, v.data(), v.size() * 4); return (long)v.size(); }\n'
+                   'extern "C" void combo(int cr, int j, int h, int* c) { fav::conv_first_combo(cr, j, h, c, c + 1, c + 2); }\n'
+                   'extern "C" int pairs(int cr) { return fav::conv_first_pairs(cr); }\n')
+    so = d / "libfirst.so"
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", CSRC, "-o", str(so), str(src)])
+    lib = ctypes.CDLL(str(so))
+    lib.pack.restype = ctypes.c_long
+    lib.pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("cin", [7, 3])
+def test_first_layer_pairing_and_transform_match_direct_convolution(first_packer, cin):
+    """csrc/first_pack.h: every (channel, filter row, block) appears in exactly one pair half, and the four GEMMs over the packed
+    weights with the operands the kernel builds (d0-d2, d1+d2, d2-d1, d1-d3 of halo columns 2t+3b+j) give the 9x9 correlation."""
+    lib = first_packer
+    NJ = lib.pairs(cin)
+    assert NJ == (cin // 2) * 27 + 14
+    seen = {}
+    combos = np.zeros((NJ, 2, 3), np.int32)
+    for j in range(NJ):
+        for h in range(2):
+            c = (ctypes.c_int * 3)()
+            lib.combo(cin, j, h, c)
+            combos[j, h] = list(c)
+            if c[0] >= 0:
+                assert (c[0], c[1], c[2]) not in seen
+                seen[(c[0], c[1], c[2])] = (j, h)
+    assert len(seen) == cin * 27
+    rng = np.random.default_rng(cin)
+    cout, H, W = 32, 3, 14                                  # 3 output rows, 14 output columns = 7 tiles
+    w = (rng.standard_normal((cout, cin, 9, 9)) / 20).astype(np.float32)
+    x = rng.uniform(-120, 150, (cin, H + 8, W + 8)).astype(np.float32)          # the halo (pad already applied)
+    n = lib.pack(w.ctypes.data, cin, cout, None)
+    wpk = np.empty(n, np.float32)
+    lib.pack(w.ctypes.data, cin, cout, wpk.ctypes.data)
+    wpk = wpk.reshape(4, NJ, 2, 32)
+    ref = np.zeros((H, W, cout))
+    for ky in range(9):
+        for kx in range(9):
+            ref += np.einsum("chw,oc->hwo", x[:, ky:ky + H, kx:kx + W].astype(np.float64), w[:, :, ky, kx].astype(np.float64))
+    out = np.zeros((H, W, cout), np.float32)
+    for oy in range(H):
+        for t in range(W // 2):
+            M = np.zeros((4, cout), np.float32)
+            for j in range(NJ):
+                for h in range(2):
+                    c, ky, b = combos[j, h]
+                    if c < 0:
+                        continue
+                    d = x[c, oy + ky, 2 * t + 3 * b: 2 * t + 3 * b + 4]
+                    V = np.array([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]], np.float32)
+                    M += V[:, None] * wpk[:, j, h, :]
+            out[oy, 2 * t] = (M[0] + M[1]) + M[2]
+            out[oy, 2 * t + 1] = (M[1] - M[2]) - M[3]
+    err = np.abs(out - ref).max()
+    assert err < 2e-3 * max(1.0, np.abs(ref).max() / 100), err
