@@ -743,7 +743,7 @@ int net_forward_padded(fav_net* n, const float* in8, int H, int W, float* out_pl
 // While look-ahead masks are in flight the persistent / stream-K convolution grids leave SIDE_CUS CUs unclaimed
 // (fav_net::reserve_cus): the side queues' kernels (among them a ~3 ms single-wave sequential chain) find free CUs, and a
 // statically scheduled network block is never kept off the chip by them.
-static constexpr int SIDE_CUS = 8;
+static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FAV_SIDE_CUS"))) : 8;      // (tuning: read once)
 static hipError_t create_side_stream(hipStream_t* st)
 {
     // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free)
