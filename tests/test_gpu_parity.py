@@ -565,7 +565,8 @@ def test_halo_kernel_variants_in_networks(favlib, oracle, cuda, tmp_path, arch, 
     ("c3s1-128,R128,R128,c9s1-3", (45, 61)),                 # 2 blocks: inputs with and without a pending InstanceNorm; 6 x 4 / 5 x 4 units, ragged both ways
     ("c9s1-32,d64,d128,R128,U2,c3s1-64,U2,c9s1-3", (72, 136)),  # one unit row, fewer units than CUs
     ("c3s1-128,R128,R128,R128,c9s1-3", (150, 330)),           # more units than CUs (persistent blocks take two)
-], ids=["two-blocks", "canonical-small", "multi-round"])
+    ("c3s1-128,R128,c9s1-3", (138, 258)),                     # 272 and 256 units on 256 CUs: the thin second round runs as quarter units
+], ids=["two-blocks", "canonical-small", "multi-round", "quarter-units"])
 def test_winograd_residual_layers_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
     """The residual 128 -> 128 convolutions run as Winograd F(2x2,3x3) (conv3_wino_kernel; lane-level restatement in
     tests/test_cpu_wino.py): against the oracle's direct convolution, same tolerance as the direct-form kernels."""
