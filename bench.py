@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--structure", type=int, default=0, help="1 = 4-argument (image-structure) checker mode")
+    ap.add_argument("--no-profile", action="store_true", help="no per-convolution HIP events in the timed region (A/B of their cost; the roofline block is then empty)")
+    ap.add_argument("--profile-every", type=int, default=4, help="HIP events around the convolutions on every n-th step of the timed region")
     ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
                     "(fav_stream_prefetch_mask); default: on for --structure 1, off for the (7 us) 3-argument mask")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle timing + parity block, reference checker)")
@@ -226,12 +228,20 @@ def main():
         stream.prefetch_mask(frames[1 % ring], bws[1 % ring], fws[1 % ring], use_structure=bool(args.structure))
     for i in range(args.warmup):
         step(i)
-    net.profile_enable(True)
+    # HIP events around every convolution launch (the roofline block) on every `--profile-every`-th step of the timed region: the
+    # events are not free -- with their default system-scope fence they cost 0.18 ms per frame (6 us on either side of every
+    # convolution in the rocprofv3 trace), without it (hipEventDisableSystemFence) still 2 % of a frame when placed on every launch
+    # of every step (A/B: scripts/ab_profile_events.sh) -- and the product path (bin/fav_stylize) records none
+    pe = 0 if args.no_profile else max(1, args.profile_every)
+    n_prof_steps = 0
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        on = pe > 0 and i % pe == 0
+        net.profile_enable(on)
+        n_prof_steps += 1 if on else 0
         step(i)
     t_enq = time.perf_counter() - t0                    # host time to ENQUEUE the steps (the GPU runs behind)
     torch.cuda.synchronize()
@@ -294,7 +304,7 @@ def main():
         flops = sum(2.0 * macs * n for ms, n, macs in dom); secs = sum(ms for ms, n, macs in dom) / 1e3
         nl = sum(n for ms, n, macs in dom)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
-        conv_ms = sum(ms for ms, n, macs, kid in prof) / max(1, args.steps)
+        conv_ms = sum(ms for ms, n, macs, kid in prof) / max(1, n_prof_steps)
         # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json).  The file records the hash of
         # the kernel source it was measured on: a stale file (kernel changed since) is refused rather than reported.
         traffic, traffic_note = None, "profiles/pmc_traffic.json missing"
@@ -313,7 +323,7 @@ def main():
         per_kernel = {}
         for ms, n, macs, kid in prof:
             if n:
-                k = per_kernel.setdefault(str(kid), [0.0, 0.0]); k[0] += ms / args.steps; k[1] += 2.0 * macs * n / args.steps
+                k = per_kernel.setdefault(str(kid), [0.0, 0.0]); k[0] += ms / max(1, n_prof_steps); k[1] += 2.0 * macs * n / max(1, n_prof_steps)
         line = {
             "metric": "stylized frames/sec @1280x720, per-frame hot path (mask + warp + assembly + net + deprocess) with inputs resident in HBM; "
                       "file->PNG rate in `e2e`, PSNR vs CPU ref in `parity`",
@@ -331,6 +341,7 @@ def main():
                          "note": "achieved = algorithmic (direct-convolution) FLOPs / time; the Winograd kernel executes 16/36 of them on the matrix pipe, "
                                  "so frac > 1 means faster than any direct fp32 convolution could run" if exec_ratio < 1 else "direct form: executed = algorithmic",
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
+                         "timed_with": "HIP events (no system fence) around every convolution launch of every %d-th step of the timed region (%d of %d steps)" % (max(1, pe), n_prof_steps, args.steps),
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
                          "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None,
                          "conv_stack_frac": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms > 0 else None,

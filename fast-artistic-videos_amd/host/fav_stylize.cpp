@@ -268,7 +268,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipStream_t st, st_copy;                 // compute queue; upload queue (the next frame's inputs travel while this frame computes)
     if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess) die("hipStreamCreate failed");
     hipEvent_t ev_up[3], ev_done[2];
-    for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
+    for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
     fav_stream* fs = nullptr;
     int W = 0, H = 0;
