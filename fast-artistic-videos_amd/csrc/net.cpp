@@ -712,7 +712,8 @@ struct fav_stream {
     // (each 4-argument mask contains a ~3 ms sequential fp32 chain, CMatrix::avg), three look-ahead slots
     static constexpr int NSIDE = 2, NPREF = 3;
     hipStream_t side[NSIDE] = {nullptr, nullptr}; void* side_ws[NSIDE] = {nullptr, nullptr}; hipEvent_t ev_in = nullptr;
-    struct Pref { uint8_t* mask = nullptr; hipEvent_t done = nullptr; bool valid = false;
+    float* side_cert_tmp[NSIDE] = {nullptr, nullptr};      // scratch of the certainty preparation (erosion input) on each side queue
+    struct Pref { uint8_t* mask = nullptr; float* cert = nullptr; hipEvent_t done = nullptr; bool valid = false;
                   const void *frame = nullptr, *bw = nullptr, *fw = nullptr; int structure = 0; };
     Pref pref[NPREF]; int pref_next = 0, side_next = 0;
     ~fav_stream()
@@ -720,7 +721,8 @@ struct fav_stream {
         if (net) (void)hipSetDevice(net->device);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); } (void)hipFree(side_ws[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
-        for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); }
+        for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); (void)hipFree(pf.cert); }
+        for (int i = 0; i < NSIDE; ++i) (void)hipFree(side_cert_tmp[i]);
         (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws);
     }
 };
@@ -773,10 +775,11 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) { delete s; return hip_fail(hipErrorOutOfMemory, "hipMalloc(stream buffers)"); }
     for (auto& pf : s->pref)
-        if (hipMalloc(reinterpret_cast<void**>(&pf.mask), n) != hipSuccess || hipEventCreateWithFlags(&pf.done, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&pf.mask), n) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&pf.cert), n * 4) != hipSuccess || hipEventCreateWithFlags(&pf.done, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
             delete s; return hip_fail(hipErrorOutOfMemory, "look-ahead slots"); }
     for (int i = 0; i < fav_stream::NSIDE; ++i)
-        if (create_side_stream(&s->side[i]) != hipSuccess || hipMalloc(&s->side_ws[i], s->ws_bytes) != hipSuccess) {
+        if (create_side_stream(&s->side[i]) != hipSuccess || hipMalloc(&s->side_ws[i], s->ws_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->side_cert_tmp[i]), n * 4) != hipSuccess) {
             delete s; return hip_fail(hipErrorOutOfMemory, "side queues"); }
     *out = s;
     return FAV_OK;
@@ -822,15 +825,17 @@ extern "C" int fav_stream_set_image_net(fav_stream* s, fav_net* image_net)
     return FAV_OK;
 }
 
+// cert_ready: the certainty (mask options + erosion applied) is already in s->cert (computed ahead on a side queue)
 static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, const uint8_t* mask, float* out_f32, uint8_t* out_u8,
-                       hipStream_t st)
+                       hipStream_t st, bool cert_ready = false)
 {
     FAV_REQUIRE(s->has_state, "fav_stream_next_frame: no previous stylised frame (call fav_stream_first_frame or fav_stream_set_state first)");
-    int rc;
+    int rc = FAV_OK;
     {
         TraceRange tr_pre("fav:certainty+warp+assemble");
-        rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
-                                 s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
+        if (!cert_ready)
+            rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+                                     s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
         if (rc) return rc;
         ++s->frame_counter;
         rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
@@ -867,7 +872,8 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
             pf.valid = false;
             FAV_HIP(hipStreamWaitEvent(st, pf.done, 0));
             std::swap(s->mask, pf.mask);
-            return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+            std::swap(s->cert, pf.cert);          // mask -> certainty (options, erosion) was done on the side queue as well
+            return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st, true);
         }
     // not prefetched: compute inline on the caller's stream (own workspace)
     TraceRange tr_mask("fav:consistency mask");
@@ -885,7 +891,9 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     FAV_REQUIRE(s && frame_rgb_hwc && backward_flo && forward_flo, "fav_stream_prefetch_mask: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->net->reserve_cus = SIDE_CUS;      // from now on the network's persistent grids leave the side queues' CUs alone
+    // the 4-argument mask holds long sequential chains: from now on the network's persistent grids leave the side queues their CUs;
+    // the 3-argument mask + certainty (25 us of small kernels) fits into the grids' own tails
+    if (use_structure) s->net->reserve_cus = SIDE_CUS;
     fav_stream::Pref& pf = s->pref[s->pref_next];
     s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
     const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;
@@ -897,6 +905,10 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
     }
     int rc = launch_consistency(backward_flo, forward_flo, structure, avg, pf.mask, s->W, s->H, sd); if (rc) return rc;
+    // certainty of the frame (mask options, fix_occlusions warp of ones, erosion): depends on the mask, the flow and the stream's options only
+    rc = launch_cert_prepare(pf.mask, backward_flo, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+                             s->opts.occlusions_min_filter, s->side_cert_tmp[q], pf.cert, s->H, s->W, sd);
+    if (rc) return rc;
     FAV_HIP(hipEventRecord(pf.done, sd));
     pf.valid = true; pf.frame = frame_rgb_hwc; pf.bw = backward_flo; pf.fw = forward_flo; pf.structure = use_structure != 0;
     return FAV_OK;
