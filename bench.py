@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no per-convolution HIP events in the timed region (A/B of their cost; the roofline block is then empty)")
     ap.add_argument("--profile-every", type=int, default=4, help="HIP events around the convolutions on every n-th step of the timed region")
     ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
-                    "(fav_stream_prefetch_mask: mask + certainty erosion, off the critical path); default: on")
+                    "(fav_stream_prefetch_mask: mask + certainty erosion, off the critical path); default: on for --structure 1 only")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (oracle timing + parity block, reference checker)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file->PNG run of bin/fav_stylize after the timed region")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the weight broadcast even at "
@@ -189,7 +189,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # RCCL over xGMI
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.lookahead < 0:
-        args.lookahead = 1
+        args.lookahead = 1 if args.structure else 0      # (3-argument mode: 544 with, 548 frames/s without the look-ahead -- scripts/ab_lookahead.sh)
 
     # ---- weights: rank 0 parses the (synthetic, canonical-architecture) .t7 and broadcasts the packed blob
     ckpt = os.path.join(tempfile.gettempdir(), f"fav_bench_canonical_{os.getpid()}.t7")
