@@ -16,6 +16,8 @@ import pytest
 
 from fav_amd import synth, t7
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -190,6 +192,26 @@ def test_canonical_network_vs_oracle(favlib, oracle, cuda, canonical):
     err = np.abs(got - ref).max()
     assert err <= 5e-2, err
     assert np.abs(ref).max() > 100 and np.abs(ref).std() > 20     # not saturated / not trivial
+
+
+def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_ones(favlib, oracle, cuda, canonical, tmp_path):
+    """FAV_NO_WINO / FAV_NO_UP2 / FAV_NO_FOLD_UP2 / FAV_NO_FIRST select the direct-form kernels of the same layers (read once per process, so
+    a child process runs them): both builds of the canonical network agree with the oracle, and with each other far inside the tolerance."""
+    import subprocess, sys
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((7, 88, 120)) * 60).astype(np.float32)
+    np.save(tmp_path / "x.npy", x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
+             "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "direct.npy")))
+    env = dict(os.environ, FAV_NO_WINO="1", FAV_NO_UP2="1", FAV_NO_FOLD_UP2="1", FAV_NO_FIRST="1")
+    subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
+    direct = np.load(tmp_path / "direct.npy")
+    ref = oracle.net_forward(_layers(canonical), x)
+    got = favlib.Net(canonical, 0).forward(T(x, cuda)).cpu().numpy()
+    assert np.abs(direct - ref).max() <= 5e-2 and np.abs(got - ref).max() <= 5e-2
+    assert np.abs(got - direct).max() <= 2e-2, np.abs(got - direct).max()
 
 
 @pytest.mark.parametrize("inorm", [True, False])
