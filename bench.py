@@ -140,7 +140,9 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300):
             j = json.loads(line[-1])
             n_png = len([f for f in os.listdir(f"{d}/o{lvl}") if f.endswith(".png")])
             out[name] = {"fps": j["fps_end_to_end"], "seconds": j["seconds"], "png_written": n_png, "png_writers": j.get("png_writers"),
-                         "wait_loader_s": j["wait_loader_s"], "wait_png_pool_s": j["wait_png_pool_s"]}
+                         "wait_loader_s": j["wait_loader_s"], "wait_png_pool_s": j["wait_png_pool_s"],
+                             "setup_s": j.get("setup_s"), "png_tail_s": j.get("png_tail_s"),
+                             "steady_state_fps": round(j["frames"] / max(1e-9, j["seconds"] - (j.get("setup_s") or 0.0) - (j.get("png_tail_s") or 0.0)), 3)}
             shutil.rmtree(f"{d}/o{lvl}", ignore_errors=True)
         return out
     finally:

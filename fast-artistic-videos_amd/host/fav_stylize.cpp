@@ -213,7 +213,7 @@ struct FrameIn {           // everything frame i needs from disk
 };
 
 
-struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0; };
+struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0; };
 
 // One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
 // `net` / `net_img` live on the current device; `nwriters` PNG threads.
@@ -394,6 +394,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             upload(cur, dset);
             hipStreamSynchronize(st_copy);               // the first frame's host buffers are malloc'ed: release them now
             first = false;
+            res->setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();     // first frame read + every allocation
         } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
         issue();                                         // keep DEPTH loads in flight
         const auto t0 = std::chrono::steady_clock::now();
@@ -441,6 +442,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         cur = nxt; dset = (dset + 1) % 3;
     }
     finish(pend);
+    const auto t_tail = std::chrono::steady_clock::now();       // the GPU is done: what follows is the PNG pool draining
     for (auto& pr : inflight) pr.second.join();
     for (auto& r : ready) if (r.index >= 0) r.release();
     fflush(stdout);
@@ -455,6 +457,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     }
     res->frames = done;
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    res->tail = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count();
     res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
     fav_stream_destroy(fs);
     hipFree(d_prev); hipFree(d_cur);
@@ -572,9 +575,9 @@ int main(int argc, char** argv)
         run_stream(os, net, net_img, nwriters, &r);
         frames += r.frames; seconds += r.seconds;
         if (o.i("timing"))
-            printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"png_writers\": %d}\n",
+            printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"setup_s\": %.3f, \"png_tail_s\": %.3f, \"png_writers\": %d}\n",
                    named ? ("\"stream\": " + favl::json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
-                   r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, nwriters);
+                   r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, r.setup, r.tail, nwriters);
     }
     check(fav_net_check(net), "at exit");
     if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds);
