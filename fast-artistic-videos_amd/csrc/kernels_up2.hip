@@ -228,6 +228,223 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer with F(2x2,3x3) minimal filtering on top of the upsampling identity (up2_pack.h, second half): the transform line
+// i = 2 vanishes on repeated rows, NINE positions remain, each a [pixels] x [CIN] x [64] GEMM whose operand is a difference of
+// neighbouring physical pixels -- 2.25 multiply-adds per output instead of 4 (phase merge above) or 9 (direct form).
+//
+// Block = 12 waves (three per SIMD, 168 registers each), tile = 4 rows x 32 physical pixels: wave = (transform row i in {0, 1, 3},
+// tile row) owning the three positions (i, 0), (i, 1), (i, 3) for the row's 32 pixels and all 64 output channels: 6 accumulator
+// tiles.  The three waves of a SIMD (w, w + 4, w + 8) are one of each kind.  Per 8-channel group a wave reads two halo rows x
+// three columns, forms its line  L = Ra - kappa Rb  (kappa = 0 for i = 1) and the three column operands (5 vector instructions
+// per register, 0.83 per MFMA); weights are packed per position in fragment order and go global -> registers, reloaded in place
+// right after their last use (the four waves of a kind share the L1 lines).  Output transform: every wave folds its columns
+// (Z_i0 = M_i0 + M_i1, Z_i1 = M_i1 - M_i3), the kinds 0 and 3 hand their two folds over through LDS, the kind-1 wave adds
+// Y_0b = Z_0b + Z_1b, Y_1b = Z_1b - Z_3b, bias, stores the 2 x 2 output pixels and takes the statistics.
+// ------------------------------------------------------------------------------------------------
+constexpr int UW_HW = 34, UW_HP = 6 * 34;      // halo 6 x 34 pixels
+constexpr int UW_HPP = 288;                    // padded to 3 pieces x 768 threads / 8 chunks
+constexpr int UW_HB = UW_HPP * LDSS;
+constexpr int UW_ZS = 8 * 64 * 2 * LDSS;       // exchange: [kind 0|3 x 4 rows][64 channels][2 folds][36] floats (147 KB)
+
+__global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Hs = smem;                  // [2][UW_HB]; the epilogue's exchange area overlays it
+    float* const aff = smem + UW_ZS;         // [2][CIN]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kind = wave >> 2, row = wave & 3;                            // kind 0, 1, 2 <-> transform row i = 0, 1, 3
+    const int CIN = p.CIN, nslices = CIN >> 5, nkg = CIN >> 3;
+    const int m = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, nkg * 18 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.PH * p.IWp * CIN * 4, 0x00020000);
+    const int wlo = lane * 16, wso = kind * 3 * 2048;                      // weights: lane * 16 + [kg * 18432 + (3 kind + jj) * 2048 + nt * 1024]
+    // operand rows: kind 0: halo rows (row, row + 1), L = Ra - Rb;  kind 1: (row + 1, row + 1), L = Ra;  kind 2: (row + 1, row + 2), L = Ra - Rb
+    const float kap = kind == 1 ? 0.f : 1.f;
+    const float* const ra = Hs + ((row + (kind == 0 ? 0 : 1)) * UW_HW + m) * LDSS + 4 * h;
+    const float* const rb = Hs + ((row + (kind == 0 ? 1 : kind == 1 ? 1 : 2)) * UW_HW + m) * LDSS + 4 * h;
+    const int c4 = t & 7;
+    float* const hst = Hs + (t >> 3) * LDSS + c4 * 4;                       // piece i: + 96 i pixels
+    for (int i = t; i < CIN; i += 768) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
+    __syncthreads();
+    const float lo1 = p.relu1 ? 0.f : -INFINITY;
+    const float* const affr = aff + c4 * 4;
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int sy0 = ty * 4, sx0 = tx * 32;
+        int ho[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pix = (t >> 3) + 96 * i, hy = (pix * 1928) >> 16, hx = pix - hy * UW_HW;      // pix / 34 (pix < 288)
+            const int sy = sy0 - 1 + hy, sx = sx0 - 1 + hx;
+            const bool v = pix < UW_HP && (unsigned)sy < (unsigned)p.PH && (unsigned)sx < (unsigned)p.PW;
+            ho[i] = v ? ((sy * p.IWp + sx) * CIN + c4 * 4) * 4 : -16;
+        }
+#define UW_XF(v_, i_, slice_)                                                                       \
+        { const v4f sc_ = *reinterpret_cast<const v4f*>(affr + (slice_) * 32), sh_ = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 32); \
+          const float mk_ = ho[i_] >= 0 ? 1.f : 0.f;                                                \
+          v_.x = fmaxf(fmaf(v_.x, sc_.x, sh_.x), lo1) * mk_; v_.y = fmaxf(fmaf(v_.y, sc_.y, sh_.y), lo1) * mk_; \
+          v_.z = fmaxf(fmaf(v_.z, sc_.z, sh_.z), lo1) * mk_; v_.w = fmaxf(fmaf(v_.w, sc_.w, sh_.w), lo1) * mk_; }
+#define UW_LOAD_B(jj_, kg_)                                                                         \
+        { const int so_ = wso + (kg_) * 18432 + (jj_) * 2048;                                       \
+          fb[jj_][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so_, 0)); \
+          fb[jj_][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 1024, so_, 0)); }
+#define UW_READ_R(par_, kg_)                                                                        \
+        { _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                        \
+              Ra[dx] = *reinterpret_cast<const v4f*>(ra + (par_) * UW_HB + dx * LDSS + (kg_) * 8);  \
+              Rb[dx] = *reinterpret_cast<const v4f*>(rb + (par_) * UW_HB + dx * LDSS + (kg_) * 8); } }
+
+        v4f fb[3][2], Ra[3], Rb[3], V[3];
+        f32x16 acc[3][2];
+        // prologue: slice 0 -> buffer 0
+        {
+            v4f q0[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q0[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i], 0, 0));
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) UW_LOAD_B(jj, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { UW_XF(q0[i], i, 0); *reinterpret_cast<v4f*>(hst + i * 96 * LDSS) = q0[i]; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jj][nt][r] = 0.f;
+        __syncthreads();
+        UW_READ_R(0, 0);
+
+        for (int s = 0; s < nslices; ++s) {
+            const int par = s & 1;
+            const int sn = min(s + 1, nslices - 1);
+            v4f hq;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const int kgg = s * 4 + kg;
+                {   // this wave's line, then its three column operands
+                    v4f L[3];
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        L[dx].x = fmaf(-kap, Rb[dx].x, Ra[dx].x); L[dx].y = fmaf(-kap, Rb[dx].y, Ra[dx].y);
+                        L[dx].z = fmaf(-kap, Rb[dx].z, Ra[dx].z); L[dx].w = fmaf(-kap, Rb[dx].w, Ra[dx].w);
+                    }
+                    V[0] = L[0] - L[1]; V[1] = L[1]; V[2] = L[1] - L[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kg < 3) { UW_READ_R(par, kg + 1); }
+                if (kg < 3) hq = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[kg], sn * 128, 0));   // one halo piece of the next slice per group
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[jj][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[jj][st], fb[jj][nt][st], acc[jj][nt], 0, 0, 0);
+                    UW_LOAD_B(jj, min(kgg + 1, nkg - 1));      // reloaded in place: needed again one group from now
+                }
+                if (kg < 3) { UW_XF(hq, kg, sn); *reinterpret_cast<v4f*>(hst + (par ^ 1) * UW_HB + kg * 96 * LDSS) = hq; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            UW_READ_R(par ^ 1, 0);
+        }
+#undef UW_XF
+#undef UW_LOAD_B
+#undef UW_READ_R
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                    // (the prefetched reads above are done: the exchange area may overwrite the halo buffers)
+
+        // ---- output transform.  acc[jj][nt][r] = M[i][j] of physical pixel (sy0 + row, sx0 + mi), channel nt * 32 + n.
+        // Column fold in every wave: Z0 = M_i0 + M_i1, Z1 = M_i1 - M_i3.  Kinds 0 and 2 publish [slot = (kind ? 4 : 0) + row][channel][fold][pixel]
+        const int n = lane & 31;
+        if (kind != 1) {
+            float* const zw = Hs + (((kind ? 4 : 0) + row) * 64 + n) * 2 * LDSS + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4f z0, z1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        z0[e] = acc[0][nt][r] + acc[1][nt][r]; z1[e] = acc[1][nt][r] - acc[2][nt][r];
+                    }
+                    *reinterpret_cast<v4f*>(zw + nt * 32 * 2 * LDSS + 8 * g) = z0;
+                    *reinterpret_cast<v4f*>(zw + nt * 32 * 2 * LDSS + LDSS + 8 * g) = z1;
+                }
+        }
+        __syncthreads();
+        const int OW = 2 * p.PW, sy = sy0 + row;
+        float2* stt = reinterpret_cast<float2*>(smem + UW_ZS + 2 * CIN);      // [4 rows][64] (behind the affine table)
+        int* wn = reinterpret_cast<int*>(smem + UW_ZS + 2 * CIN + 2 * 4 * 64);  // [4]
+        if (kind == 1) {
+            const float* const z0r = Hs + ((0 + row) * 64 + n) * 2 * LDSS + 4 * h;      // kind 0 (i = 0)
+            const float* const z3r = Hs + ((4 + row) * 64 + n) * 2 * LDSS + 4 * h;      // kind 2 (i = 3)
+            float sm[2] = {0.f, 0.f}; int nv = 0;
+            float y3[2][16];                   // the fourth output of every pixel (the other three replace the accumulators)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = nt * 32 + n;
+                const float bv = p.bias[co];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4f a0 = *reinterpret_cast<const v4f*>(z0r + nt * 32 * 2 * LDSS + 8 * g), a1 = *reinterpret_cast<const v4f*>(z0r + nt * 32 * 2 * LDSS + LDSS + 8 * g);
+                    const v4f c0 = *reinterpret_cast<const v4f*>(z3r + nt * 32 * 2 * LDSS + 8 * g), c1 = *reinterpret_cast<const v4f*>(z3r + nt * 32 * 2 * LDSS + LDSS + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const int sx = sx0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float b0 = acc[0][nt][r] + acc[1][nt][r], b1 = acc[1][nt][r] - acc[2][nt][r];      // Z_1b of this wave
+                        const float y00 = a0[e] + b0 + bv, y01 = a1[e] + b1 + bv, y10 = b0 - c0[e] + bv, y11 = b1 - c1[e] + bv;
+                        acc[0][nt][r] = y00; acc[1][nt][r] = y01; acc[2][nt][r] = y10; y3[nt][r] = y11;      // kept for the statistics
+                        if (sy < p.PH && sx < p.PW) {
+                            float* o = p.out + ((size_t)(2 * sy) * OW + 2 * sx) * 64 + co;
+                            o[0] = y00; o[64] = y01; o[(size_t)OW * 64] = y10; o[(size_t)OW * 64 + 64] = y11;
+                            sm[nt] += (y00 + y01) + (y10 + y11);
+                            if (nt == 0) nv += 4;
+                        }
+                    }
+                }
+            }
+            if (p.partials != nullptr) {
+                const int nw = nv + __shfl_xor(nv, 32);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float ssum = sm[nt] + __shfl_xor(sm[nt], 32);
+                    const float mu = nw ? ssum / (float)nw : 0.f;
+                    float q = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int sx = sx0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (sy < p.PH && sx < p.PW) {
+                            const float d0 = acc[0][nt][r] - mu, d1 = acc[1][nt][r] - mu, d2 = acc[2][nt][r] - mu, d3 = y3[nt][r] - mu;
+                            q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+                        }
+                    }
+                    q += __shfl_xor(q, 32);
+                    if (lane < 32) stt[row * 64 + nt * 32 + lane] = make_float2(mu, q);
+                }
+                if (lane == 0) wn[row] = nw;
+            }
+        }
+        __syncthreads();
+        if (p.partials != nullptr && t < 64) {
+            int cnt = 0; float s1 = 0.f;
+            for (int w = 0; w < 4; ++w) { cnt += wn[w]; s1 += (float)wn[w] * stt[w * 64 + t].x; }
+            const float mean = cnt ? s1 / (float)cnt : 0.f;
+            float m2 = 0.f;
+            for (int w = 0; w < 4; ++w) { const float d = stt[w * 64 + t].x - mean; m2 += stt[w * 64 + t].y + (float)wn[w] * d * d; }
+            p.partials[(size_t)tile * 64 + t] = make_float2(mean, m2);
+            if (t == 0) p.counts[tile] = cnt;
+        }
+        __syncthreads();            // the exchange area / statistics scratch are free for the next tile's halo
+    }
+}
+
 }  // namespace
 
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
@@ -235,7 +452,8 @@ bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, i
     return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&
            cout == 64 && coutp == 64;
 }
-int conv3_up2_tiles(int OH, int OW) { return ((OH / 2 + 7) / 8) * ((OW / 2 + 31) / 32); }
+static bool up2_winograd() { static const bool w = getenv("FAV_UP2_PHASES") == nullptr; return w; }      // (tuning: read once)
+int conv3_up2_tiles(int OH, int OW) { return ((OH / 2 + (up2_winograd() ? 3 : 7)) / (up2_winograd() ? 4 : 8)) * ((OW / 2 + 31) / 32); }
 
 int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
 {
@@ -246,19 +464,23 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     Up2Args a;
     a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.relu1 = c.pre.relu1; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.PH = c.IH / 2; a.PW = c.IW / 2; a.IWp = c.IWp; a.CIN = c.CIN;
-    a.tiles_x = (a.PW + 31) / 32; a.tiles_y = (a.PH + 7) / 8;
-    const size_t lds = (size_t)(2 * U2_HB + 2 * c.CIN) * sizeof(float);
+    const bool wg = up2_winograd();
+    a.tiles_x = (a.PW + 31) / 32; a.tiles_y = wg ? (a.PH + 3) / 4 : (a.PH + 7) / 8;
+    const size_t lds = (size_t)(2 * (wg ? UW_HB : U2_HB) + 2 * c.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipDeviceProp_t prop;
         FAV_HIP(hipGetDeviceProperties(&prop, dv));
         cus[dv] = prop.multiProcessorCount;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));
-    hipLaunchKernelGGL(conv3_up2_kernel<true>, dim3(grid), dim3(512), lds, st, a);      // (every U2 of the reference's builder is followed by a normalisation: stages == 1)
+    // (every U2 of the reference's builder is followed by a normalisation: stages == 1)
+    if (wg) { a.wpk = wpk + conv_up2_packed_floats(c.CIN); hipLaunchKernelGGL(conv3_up2w_kernel, dim3(grid), dim3(256), lds, st, a); }
+    else hipLaunchKernelGGL(conv3_up2_kernel<true>, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_up2_kernel");
     return FAV_OK;
 }

@@ -181,8 +181,10 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 rc = dev_upload(ww, 0, &d.wwino); if (rc) return rc;
             }
             if (!L.transposed && L.cin == d.cinp && conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 1)) {      // 3x3 after a x2 upsampling: merged 2x2 taps
-                std::vector<float> wu;
+                std::vector<float> wu, wu9;
                 conv_up2_pack(L.w.data(), L.cin, wu);
+                conv_up2w_pack(L.w.data(), L.cin, wu9);                            // the nine-position form follows the phase-merged one
+                wu.insert(wu.end(), wu9.begin(), wu9.end());
                 rc = dev_upload(wu, 0, &d.wup2); if (rc) return rc;
             }
             if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {

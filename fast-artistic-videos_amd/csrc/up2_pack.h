@@ -43,4 +43,36 @@ inline void conv_up2_pack(const float* w, int cin, std::vector<float>& out)
         }
 }
 
+// ---- the same layer through F(2x2,3x3) minimal filtering (conv3_up2w_kernel).  On the upsampled image the 4x4 input patch of the
+// output block (2u..2u+1, 2v..2v+1) has the rows (u-1, u, u, u+1): B^T d gives  l0 = x[u-1] - x[u],  l1 = 2 x[u],  l2 = 0,
+// l3 = x[u] - x[u+1]  (same along the columns) -- the line i = 2 vanishes, 9 of the 16 transform positions remain: 9 multiplies
+// per 4 outputs (2.25 per output against 4 for the phase merge above and 9 for the direct form).  With the factor 2 of l1 moved
+// into the weights, G g G^T becomes a plain tap sum again:
+//     U[i][j] = sum_{a in S_i} sum_{b in S_j} g[a][b],   S_0 = {0}, S_1 = {0, 1, 2}, S_3 = {2}            (i, j in {0, 1, 3})
+//     M[i][j] = sum_ci V[i][j] U[i][j],   V = the row / column differences (x[u-1] - x[u], x[u], x[u] - x[u+1]) of the 3x3 neighbourhood
+//     Y[0][0] = M00 + M01 + M10 + M11     Y[0][1] = (M01 - M03) + (M11 - M13)
+//     Y[1][0] = (M10 + M11) - (M30 + M31) Y[1][1] = (M11 - M13) - (M31 - M33)
+// Packed for the kernel's waves (each wave = one row of 32 physical pixels, all 64 output channels, all 9 positions):
+//   out[(((kg * 9 + p) * 2 + nt) * 64 + lane) * 4 + st]    kg = group of 8 input channels, p = 3 * ii + jj (ii, jj = 0, 1, 2 for i, j = 0, 1, 3),
+//   nt = tile of 32 output channels, lane = h * 32 + n, step st multiplies input channels kg*8 + st (h = 0) and kg*8 + 4 + st (h = 1)
+inline size_t conv_up2w_packed_floats(int cin) { return (size_t)(cin / 8) * 9 * 2 * 64 * 4; }
+
+inline void conv_up2w_pack(const float* w, int cin, std::vector<float>& out)
+{
+    static const int lo[3] = {0, 0, 2}, hi[3] = {0, 2, 2};       // S_0, S_1, S_3
+    out.assign(conv_up2w_packed_floats(cin), 0.f);
+    for (int co = 0; co < 64; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            const int kg = ci >> 3, h = (ci >> 2) & 1, st = ci & 3, nt = co >> 5, n = co & 31;
+            for (int ii = 0; ii < 3; ++ii)
+                for (int jj = 0; jj < 3; ++jj) {
+                    double sum = 0.0;
+                    for (int a = lo[ii]; a <= hi[ii]; ++a)
+                        for (int b = lo[jj]; b <= hi[jj]; ++b) sum += (double)g[a * 3 + b];
+                    out[((((size_t)kg * 9 + ii * 3 + jj) * 2 + nt) * 64 + h * 32 + n) * 4 + st] = (float)sum;
+                }
+        }
+}
+
 }  // namespace fav
