@@ -245,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv3_up2_kernel(const Up2Args p)
 constexpr int UW_HW = 34, UW_HP = 6 * 34;      // halo 6 x 34 pixels
 constexpr int UW_HPP = 288;                    // padded to 3 pieces x 768 threads / 8 chunks
 constexpr int UW_HB = UW_HPP * LDSS;
+static_assert(2 * 288 * LDSS <= 8 * 64 * 2 * LDSS, "halo buffers inside the exchange area");
 constexpr int UW_ZS = 8 * 64 * 2 * LDSS;       // exchange: [kind 0|3 x 4 rows][64 channels][2 folds][36] floats (147 KB)
 
 __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
@@ -466,7 +467,8 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     a.PH = c.IH / 2; a.PW = c.IW / 2; a.IWp = c.IWp; a.CIN = c.CIN;
     const bool wg = up2_winograd();
     a.tiles_x = (a.PW + 31) / 32; a.tiles_y = wg ? (a.PH + 3) / 4 : (a.PH + 7) / 8;
-    const size_t lds = (size_t)(2 * (wg ? UW_HB : U2_HB) + 2 * c.CIN) * sizeof(float);
+    const size_t lds = wg ? (size_t)(UW_ZS + 2 * c.CIN + 2 * 4 * 64 + 8) * sizeof(float)          // exchange area (the halo buffers live inside it) | affine table | statistics
+                          : (size_t)(2 * U2_HB + 2 * c.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
