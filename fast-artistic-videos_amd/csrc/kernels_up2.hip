@@ -481,7 +481,7 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));
     // (every U2 of the reference's builder is followed by a normalisation: stages == 1)
-    if (wg) { a.wpk = wpk + conv_up2_packed_floats(c.CIN); hipLaunchKernelGGL(conv3_up2w_kernel, dim3(grid), dim3(256), lds, st, a); }
+    if (wg) { a.wpk = wpk + conv_up2_packed_floats(c.CIN); hipLaunchKernelGGL(conv3_up2w_kernel, dim3(grid), dim3(768), lds, st, a); }
     else hipLaunchKernelGGL(conv3_up2_kernel<true>, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_up2_kernel");
     return FAV_OK;
