@@ -236,3 +236,188 @@ def test_first_layer_pairing_and_transform_match_direct_convolution(first_packer
             out[oy, 2 * t + 1] = (M[1] - M[2]) - M[3]
     err = np.abs(out - ref).max()
     assert err < 2e-3 * max(1.0, np.abs(ref).max() / 100), err
+
+
+# ---------------------------------------------------------------------------------------------- U2 + c3s1-64: nine-position form
+UW_HW, UW_HP, UW_HPP = 34, 6 * 34, 288
+UW_HB = UW_HPP * LDSS
+
+
+@pytest.fixture(scope="module")
+def up2w_packer(tmp_path_factory):
+    d = tmp_path_factory.mktemp("up2w")
+    src = d / "pack.cpp"
+    src.write_text('#include "up2_pack.h"\n#include <cstring>\n'
+                   'extern "C" long pack(const float* w, int cin, float* out) {\n'
+                   '  std::vector<float> v; fav::conv_up2w_pack(w, cin, v); if (out) memcpy(out, v.data(), v.size() * 4); return (long)v.size(); }\n')
+    so = d / "libup2w.so"
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", CSRC, "-o", str(so), str(src)])
+    lib = ctypes.CDLL(str(so))
+    lib.pack.restype = ctypes.c_long
+    lib.pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+
+    def pack(w):
+        w = np.ascontiguousarray(w, np.float32)
+        n = lib.pack(w.ctypes.data, w.shape[1], None)
+        out = np.empty(n, np.float32)
+        lib.pack(w.ctypes.data, w.shape[1], out.ctypes.data)
+        return out
+    return pack
+
+
+def emulate_up2w_tile(x, wpk_bytes, bias, scale, shift, relu, sy0, sx0, f=np.float32):
+    """One tile (4 x 32 physical pixels -> 8 x 64 outputs x 64 channels) the way conv3_up2w_kernel computes it: byte offsets into the
+    packed weights, the staging threads' halo pieces, the fragment addresses of the 12 waves, the 32x32x2 MFMA operand / result
+    layout and the LDS exchange of the output transform are the kernel's formulas.  Returns Y[8][64][64] (rows/columns past the
+    image are left NaN) and the per-channel (mean, M2, count) the tile publishes."""
+    PH, PW, CIN = x.shape
+    nslices, nkg = CIN // 32, CIN // 8
+    lanes = np.arange(64)
+    m, h, n = lanes & 31, lanes >> 5, lanes & 31
+    wfl = wpk_bytes.view(np.float32)
+    acc = np.zeros((12, 3, 2, 16, 64), np.float64)              # [wave][jj][nt][r][lane]
+    for s in range(nslices):
+        Hs = np.full(UW_HB, np.nan, f)
+        for t in range(768):                                    # staging: thread t, pieces i = 0..2
+            c4 = t & 7
+            for i in range(3):
+                pix = (t >> 3) + 96 * i
+                hy = (pix * 1928) >> 16
+                assert hy == pix // 34
+                hx = pix - hy * UW_HW
+                sy, sx = sy0 - 1 + hy, sx0 - 1 + hx
+                v = pix < UW_HP and 0 <= sy < PH and 0 <= sx < PW
+                q = np.zeros(4, f)
+                if v:
+                    ch = s * 32 + c4 * 4
+                    q = x[sy, sx, ch:ch + 4].astype(f)
+                    if scale is not None:
+                        q = (q * scale[ch:ch + 4] + shift[ch:ch + 4]).astype(f)
+                        if relu:
+                            q = np.maximum(q, 0)
+                dst = ((t >> 3) + i * 96) * LDSS + c4 * 4
+                Hs[dst:dst + 4] = q
+        for wave in range(12):
+            kind, row = wave >> 2, wave & 3
+            kap = f(0.0 if kind == 1 else 1.0)
+            ra = ((row + (0 if kind == 0 else 1)) * UW_HW + m) * LDSS + 4 * h
+            rb = ((row + (1 if kind <= 1 else 2)) * UW_HW + m) * LDSS + 4 * h
+            wlo, wso = lanes * 16, kind * 3 * 2048
+            for kg in range(4):
+                kgg = s * 4 + kg
+                rd = lambda base, dx: Hs[(base + dx * LDSS + kg * 8)[:, None] + np.arange(4)[None, :]]      # [lane][4]
+                L = []
+                for dx in range(3):
+                    Ra, Rb = rd(ra, dx), rd(rb, dx)
+                    assert not np.isnan(Ra).any() and not np.isnan(Rb).any()
+                    L.append((Ra - kap * Rb).astype(f))
+                V = (L[0] - L[1], L[1], L[1] - L[2])
+                for jj in range(3):
+                    for nt in range(2):
+                        off = wlo + nt * 1024 + wso + kgg * 18432 + jj * 2048
+                        assert (off + 16 <= nkg * 18 * 1024).all()
+                        B = wfl[(off // 4)[:, None] + np.arange(4)[None, :]]                                  # [lane][4]
+                        for st in range(4):
+                            a2 = V[jj][:, st].reshape(2, 32).astype(np.float64)       # [k][i]: lane l holds A[l & 31][l >> 5]
+                            b2 = B[:, st].reshape(2, 32).astype(np.float64)           # [k][j]: lane l holds B[l >> 5][l & 31]
+                            D = a2.T @ b2                                             # [i][j]
+                            for r in range(16):
+                                i_ = (r & 3) + 8 * (r >> 2) + 4 * h                   # D layout: register r of lane l is D[i_][l & 31]
+                                acc[wave, jj, nt, r] += D[i_, n]
+    acc = acc.astype(f)
+    # output transform through the exchange area
+    Z = np.full(8 * 64 * 2 * LDSS, np.nan, f)
+    for wave in range(12):
+        kind, row = wave >> 2, wave & 3
+        if kind == 1:
+            continue
+        zw = (((4 if kind else 0) + row) * 64 + n) * 2 * LDSS + 4 * h
+        for nt in range(2):
+            for g in range(4):
+                for e in range(4):
+                    r = 4 * g + e
+                    Z[zw + nt * 32 * 2 * LDSS + 8 * g + e] = acc[wave, 0, nt, r] + acc[wave, 1, nt, r]
+                    Z[zw + nt * 32 * 2 * LDSS + LDSS + 8 * g + e] = acc[wave, 1, nt, r] - acc[wave, 2, nt, r]
+    Y = np.full((8, 64, 64), np.nan, f)
+    stt = np.zeros((4, 64, 2), f)
+    wn = np.zeros(4, np.int64)
+    for row in range(4):
+        wave = 4 + row
+        z0r = ((0 + row) * 64 + n) * 2 * LDSS + 4 * h
+        z3r = ((4 + row) * 64 + n) * 2 * LDSS + 4 * h
+        sy = sy0 + row
+        vals = [[[] for _ in range(64)] for _ in range(2)]
+        for nt in range(2):
+            co = nt * 32 + n
+            for g in range(4):
+                for e in range(4):
+                    r = 4 * g + e
+                    a0, a1 = Z[z0r + nt * 32 * 2 * LDSS + 8 * g + e], Z[z0r + nt * 32 * 2 * LDSS + LDSS + 8 * g + e]
+                    c0, c1 = Z[z3r + nt * 32 * 2 * LDSS + 8 * g + e], Z[z3r + nt * 32 * 2 * LDSS + LDSS + 8 * g + e]
+                    assert not (np.isnan(a0).any() or np.isnan(a1).any() or np.isnan(c0).any() or np.isnan(c1).any())
+                    b0, b1 = acc[wave, 0, nt, r] + acc[wave, 1, nt, r], acc[wave, 1, nt, r] - acc[wave, 2, nt, r]
+                    bv = bias[co]
+                    y = (a0 + b0 + bv, a1 + b1 + bv, b0 - c0 + bv, b1 - c1 + bv)
+                    sx = sx0 + (r & 3) + 8 * (r >> 2) + 4 * h
+                    for l in range(64):
+                        if sy < PH and sx[l] < PW:
+                            my, mx = row, sx[l] - sx0
+                            Y[2 * my, 2 * mx, co[l]], Y[2 * my, 2 * mx + 1, co[l]] = y[0][l], y[1][l]
+                            Y[2 * my + 1, 2 * mx, co[l]], Y[2 * my + 1, 2 * mx + 1, co[l]] = y[2][l], y[3][l]
+                            vals[nt][l] += [y[0][l], y[1][l], y[2][l], y[3][l]]
+        for nt in range(2):
+            for l in range(32):
+                v = np.array(vals[nt][l] + vals[nt][l + 32], np.float64)
+                mu = v.mean() if v.size else 0.0
+                stt[row, nt * 32 + l] = (mu, ((v - mu) ** 2).sum())
+        wn[row] = len(vals[0][0]) + len(vals[0][32])
+    cnt = int(wn.sum())
+    mean = (wn[:, None] * stt[:, :, 0]).sum(0) / max(cnt, 1)
+    m2 = (stt[:, :, 1] + wn[:, None] * (stt[:, :, 0] - mean) ** 2).sum(0)
+    return Y, mean, m2, cnt
+
+
+@pytest.mark.parametrize("cin,relu", [(32, True), (64, False)])
+def test_up2w_lane_level_restatement_matches_direct_convolution(up2w_packer, cin, relu):
+    """conv3_up2w_kernel (csrc/kernels_up2.hip) + conv_up2w_pack (csrc/up2_pack.h): nearest x2 upsampling followed by the zero-padded
+    3x3 convolution (models_video.lua:123-128), on the physical pixels with nine transform positions."""
+    rng = np.random.default_rng(11 + cin)
+    PH, PW, COUT = 6, 37, 64                                   # 2 x 2 tiles, ragged in both directions
+    x = rng.standard_normal((PH, PW, cin)).astype(np.float32)
+    w = (rng.standard_normal((COUT, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, COUT).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, cin).astype(np.float32)
+    xin = x * scale + shift
+    if relu:
+        xin = np.maximum(xin, 0)
+    up = np.repeat(np.repeat(xin, 2, axis=0), 2, axis=1)
+    ref = direct_conv(np.pad(up, ((1, 1), (1, 1), (0, 0))), w, b)          # [2 PH][2 PW][64]
+    wpk = up2w_packer(w)
+    assert wpk.size == (cin // 8) * 9 * 2 * 64 * 4
+    out = np.full((2 * PH, 2 * PW, COUT), np.nan, np.float32)
+    for ty in range((PH + 3) // 4):
+        for tx in range((PW + 31) // 32):
+            Y, mean, m2, cnt = emulate_up2w_tile(x, wpk.view(np.uint8), b, scale, shift, relu, ty * 4, tx * 32)
+            hh, ww = min(8, 2 * PH - ty * 8), min(64, 2 * PW - tx * 64)
+            assert np.isnan(Y[hh:]).all() and np.isnan(Y[:, ww:]).all()
+            out[ty * 8: ty * 8 + hh, tx * 64: tx * 64 + ww] = Y[:hh, :ww]
+            blk = ref[ty * 8: ty * 8 + hh, tx * 64: tx * 64 + ww].reshape(-1, COUT)
+            assert cnt == blk.shape[0]
+            assert np.abs(mean - blk.mean(0)).max() < 1e-5 and np.abs(m2 - ((blk - blk.mean(0)) ** 2).sum(0)).max() < 1e-3 * max(1.0, m2.max())
+    err = np.abs(out - ref).max()
+    assert err < 2e-5, err
+
+
+def test_up2w_fragment_reads_are_bank_conflict_free():
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    lanes = np.arange(64)
+    m, h = lanes & 31, lanes >> 5
+    for hrow in range(6):
+        for dx in range(3):
+            for kg in range(4):
+                addr = (((hrow * UW_HW + m) * LDSS + 4 * h) + dx * LDSS + kg * 8) * 4
+                assert (addr % 16 == 0).all()
+                for g in groups:
+                    assert len(set((addr[g] // 16) % 16)) == 16
