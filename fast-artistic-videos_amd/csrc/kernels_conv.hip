@@ -2451,7 +2451,9 @@ namespace {
 // One pass over the per-tile (mean, M2, count) partials in fp64:  mean = sum n_b mean_b / M,  var = (sum M2_b + sum n_b mean_b^2) / M
 // - mean^2 (biased).  The cancellation in the last step costs (mean^2 / var) ulps of fp64 -- far below the fp32 result's own
 // rounding -- and saves the second dependent sweep + block reduction of the textbook two-pass merge: this kernel is pure
-// latency (16 launches per frame), not bandwidth.
+// latency (16 launches per frame), not bandwidth.  (Measured and dropped, profiles/r02p_*: blocks of 16 channels x 64 rows with
+// line-coalesced reads and four loads in flight per thread -- 6.2 us against 5.2 us for this form: the launch plus ONE round trip
+// to memory for data another XCD's L2 has just written back is what the 5 us are made of, not the read pattern.)
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials, const int* counts, int mblocks, int M, int bp,
                                                           int Cpitch, const float* gamma, const float* beta,
                                                           float eps, float* scale, float* shift)
@@ -2490,7 +2492,10 @@ __device__ __forceinline__ float4 apply_affine_g(float4 v, const Affine& a, int 
     return v;
 }
 
-// statistics of t(x) over [M][C]: one block per 128 pixels, two passes (mean, then M2) over the tile
+// statistics of t(x) over [M][C]: one block per 128 pixels.  NPT > 0: the block's elements stay in registers between the mean
+// and the M2 sweep (NPT = 128 / (256 / (C / 4)) float4 per thread: 8 for C = 64, 16 for C = 128) -- one read of the tensor
+// instead of two; NPT = 0: any channel count, the tile is read twice.
+template <int NPT>
 __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C, const Affine a, float2* partials)
 {
     __shared__ float red[1024];
@@ -2503,7 +2508,18 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C
     const int cnt = min(128, M - m0);
     const bool active = pl < nl;
     float4 s = make_float4(0, 0, 0, 0);
-    if (active)
+    float4 keep[NPT > 0 ? NPT : 1];
+    if (NPT > 0) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int pix = pl + i * nl;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (pix < cnt) { v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g); v = apply_affine_g(v, a, 4 * g); }
+            keep[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) { s.x += keep[i].x; s.y += keep[i].y; s.z += keep[i].z; s.w += keep[i].w; }      // (elements past cnt are zeros)
+    } else if (active)
         for (int pix = pl; pix < cnt; pix += nl) {
             float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
             v = apply_affine_g(v, a, 4 * g);
@@ -2520,12 +2536,20 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C
     float4 q = make_float4(0, 0, 0, 0);
     if (active) {
         const float4 mu = *reinterpret_cast<const float4*>(mean_s + 4 * g);
-        for (int pix = pl; pix < cnt; pix += nl) {
-            float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
-            v = apply_affine_g(v, a, 4 * g);
-            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
-            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
-        }
+        if (NPT > 0) {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const float4 v = keep[i];
+                const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+                if (pl + i * nl < cnt) { q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w); }
+            }
+        } else
+            for (int pix = pl; pix < cnt; pix += nl) {
+                float4 v = *reinterpret_cast<const float4*>(x + (size_t)(m0 + pix) * C + 4 * g);
+                v = apply_affine_g(v, a, 4 * g);
+                const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+            }
         *reinterpret_cast<float4*>(red + pl * C + 4 * g) = q;
     }
     __syncthreads();
@@ -2559,6 +2583,7 @@ __global__ __launch_bounds__(256) void res_add_kernel(const float* y, const floa
     }
 }
 
+template <int NPT>      // > 0: the joined values of the segment stay in registers for the M2 sweep (128 / (256 / (C / 4)) float4 per thread)
 __global__ __launch_bounds__(256) void res_add_stats_kernel(const float* y, const float* scale, const float* shift,
                                                             const float* skip, int SW, int shave, const Affine sa,
                                                             int OW, int C, float* z, float2* partials, int* counts)
@@ -2576,7 +2601,25 @@ __global__ __launch_bounds__(256) void res_add_stats_kernel(const float* y, cons
     const float* kr = skip + ((size_t)(oy + shave) * SW + x0 + shave) * C + 4 * g;
     float* zr = z + ((size_t)oy * OW + x0) * C + 4 * g;
     float4 sm = make_float4(0, 0, 0, 0);
-    if (active)
+    float4 keep[NPT > 0 ? NPT : 1];
+    if (NPT > 0) {
+        float4 kk[NPT > 0 ? NPT : 1];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int px = pl + i * nl;
+            keep[i] = make_float4(0, 0, 0, 0); kk[i] = make_float4(0, 0, 0, 0);
+            if (px < cnt) { keep[i] = *reinterpret_cast<const float4*>(yr + (size_t)px * C); kk[i] = *reinterpret_cast<const float4*>(kr + (size_t)px * C); }
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int px = pl + i * nl;
+            float4 v = affine4(keep[i], scale + 4 * g, shift + 4 * g, 0);
+            const float4 k = apply_affine_g(kk[i], sa, 4 * g);
+            v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w;
+            if (px < cnt) { *reinterpret_cast<float4*>(zr + (size_t)px * C) = v; sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w; }
+            keep[i] = v;
+        }
+    } else if (active)
         for (int px = pl; px < cnt; px += nl) {
             float4 v = *reinterpret_cast<const float4*>(yr + (size_t)px * C);
             v = affine4(v, scale + 4 * g, shift + 4 * g, 0);
@@ -2597,6 +2640,14 @@ __global__ __launch_bounds__(256) void res_add_stats_kernel(const float* y, cons
     float4 q = make_float4(0, 0, 0, 0);
     if (active) {
         const float4 mu = *reinterpret_cast<const float4*>(mean_s + 4 * g);
+        if (NPT > 0) {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const float4 v = keep[i];
+                const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+                if (pl + i * nl < cnt) { q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w); }
+            }
+        } else
         for (int px = pl; px < cnt; px += nl) {
             const float4 v = *reinterpret_cast<const float4*>(zr + (size_t)px * C);      // this thread's own stores
             const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
@@ -2667,8 +2718,11 @@ int launch_in_finalize(const float* partials, const int* counts, int mblocks, in
 int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st)
 {
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "stats: unsupported channel count %d", C);
-    hipLaunchKernelGGL(stats_kernel, dim3((M + 127) / 128), dim3(256), 0, st, x, M, C, t,
-                       reinterpret_cast<float2*>(partials));
+    const dim3 grid((M + 127) / 128);
+    float2* pp = reinterpret_cast<float2*>(partials);
+    if (C == 64) hipLaunchKernelGGL(stats_kernel<8>, grid, dim3(256), 0, st, x, M, C, t, pp);
+    else if (C == 128) hipLaunchKernelGGL(stats_kernel<16>, grid, dim3(256), 0, st, x, M, C, t, pp);
+    else hipLaunchKernelGGL(stats_kernel<0>, grid, dim3(256), 0, st, x, M, C, t, pp);
     FAV_LAUNCH_CHECK("stats_kernel");
     return FAV_OK;
 }
@@ -2678,9 +2732,13 @@ int launch_res_add(const float* y, const float* scale, const float* shift, const
 {
     const int OH = SH - 2 * shave, OW = SW - 2 * shave;
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && OH > 0 && OW > 0, "res_add: bad shape (C=%d)", C);
-    if (partials)
-        hipLaunchKernelGGL(res_add_stats_kernel, dim3(res_add_stat_blocks(OH, OW)), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z,
-                           reinterpret_cast<float2*>(partials), counts);
+    if (partials) {
+        const dim3 grid(res_add_stat_blocks(OH, OW));
+        float2* pp = reinterpret_cast<float2*>(partials);
+        if (C == 128) hipLaunchKernelGGL(res_add_stats_kernel<16>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z, pp, counts);
+        else if (C == 64) hipLaunchKernelGGL(res_add_stats_kernel<8>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z, pp, counts);
+        else hipLaunchKernelGGL(res_add_stats_kernel<0>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z, pp, counts);
+    }
     else
         hipLaunchKernelGGL(res_add_kernel, dim3(grid_for((size_t)OH * OW * (C / 4))), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t,
                            OH, OW, C, z);
