@@ -297,7 +297,13 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
-    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(cs, c8_counts, st) : launch_conv(cs, st)))); };
+    // generic kernel while look-ahead masks are in flight: its stream-K hand-off assumes that all blocks are resident at once, and the
+    // side queues' kernels land on any CU -- owners then wait for blocks that have not started (d128: 186 us against 115 us alone,
+    // profiles/r02p_4arg_kernel_stats.csv).  Data-parallel grids do not wait for anybody.
+    ConvLaunch cg = cs;
+    static const int side_sk_mode = getenv("FAV_SIDE_SK") ? atoi(getenv("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
+    if (reserve_cus > 0 && side_sk_mode != 1) cg.no_sk = 1;
+    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
