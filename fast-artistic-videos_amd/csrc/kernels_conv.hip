@@ -2461,12 +2461,24 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials
     __shared__ double sh[8];
     const int c = blockIdx.x, t = threadIdx.x;
     double s1 = 0, s2 = 0;
-    for (int b = t; b < mblocks; b += 256) {
-        const double n = (double)(counts ? counts[b] : min(bp, M - b * bp));
-        const float2 pr = partials[(size_t)b * Cpitch + c];
-        const double mu = (double)pr.x;
-        s1 += n * mu;
-        s2 += (double)pr.y + n * mu * mu;
+    float gq = 1.f, bq = 0.f;
+    if (t == 0) { gq = gamma ? gamma[c] : 1.f; bq = beta ? beta[c] : 0.f; }      // requested before the sweep, used after it
+    // four independent rows per thread in flight (one batch covers 1024 partial rows: a single round trip to memory for every layer
+    // of the 1280x720 network; a rolled loop waits for each row before it asks for the next)
+    for (int b0 = t; b0 < mblocks; b0 += 1024) {
+        float2 pr[4]; int nb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + 256 * k, bc = min(b, mblocks - 1);
+            pr[k] = partials[(size_t)bc * Cpitch + c];
+            nb[k] = b < mblocks ? (counts ? counts[bc] : min(bp, M - bc * bp)) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double n = (double)nb[k], mu = (double)pr[k].x;
+            s1 += n * mu;
+            s2 += (nb[k] ? (double)pr[k].y : 0.0) + n * mu * mu;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((t & 63) == 0) { sh[2 * (t >> 6)] = s1; sh[2 * (t >> 6) + 1] = s2; }
@@ -2476,7 +2488,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float2* partials
         const double mean = a / (double)M;
         double var = q / (double)M - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+        const double g = (double)gq, bt = (double)bq;
         const double sc = g / sqrt(var + (double)eps);
         scale[c] = (float)sc;
         shift[c] = (float)(bt - mean * sc);
