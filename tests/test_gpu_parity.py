@@ -195,8 +195,9 @@ def test_canonical_network_vs_oracle(favlib, oracle, cuda, canonical):
 
 
 def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_ones(favlib, oracle, cuda, canonical, tmp_path):
-    """FAV_NO_WINO / FAV_NO_UP2 / FAV_NO_FOLD_UP2 / FAV_NO_FIRST select the direct-form kernels of the same layers (read once per process, so
-    a child process runs them): both builds of the canonical network agree with the oracle, and with each other far inside the tolerance."""
+    """FAV_NO_WINO / FAV_NO_UP2 / FAV_NO_FOLD_UP2 / FAV_NO_FIRST select the direct-form kernels of the same layers, FAV_UP2_PHASES the
+    phase-merged form of U2 + c3s1-64 (read once per process, so child processes run them): every build of the canonical network agrees
+    with the oracle, and with the default build far inside the tolerance."""
     import subprocess, sys
     rng = np.random.default_rng(6)
     x = (rng.standard_normal((7, 88, 120)) * 60).astype(np.float32)
@@ -212,6 +213,11 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     got = favlib.Net(canonical, 0).forward(T(x, cuda)).cpu().numpy()
     assert np.abs(direct - ref).max() <= 5e-2 and np.abs(got - ref).max() <= 5e-2
     assert np.abs(got - direct).max() <= 2e-2, np.abs(got - direct).max()
+    # FAV_UP2_PHASES: U2 + c3s1-64 as four phase-wise 2x2 convolutions (conv3_up2_kernel) instead of the nine-position form
+    env = dict(os.environ, FAV_UP2_PHASES="1")
+    subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
+    phases = np.load(tmp_path / "direct.npy")
+    assert np.abs(phases - ref).max() <= 5e-2 and np.abs(got - phases).max() <= 2e-2, (np.abs(phases - ref).max(), np.abs(got - phases).max())
 
 
 @pytest.mark.parametrize("inorm", [True, False])
