@@ -156,6 +156,12 @@ int launch_conv3_wino(const ConvLaunch& p, const float* wpk, int* counts, hipStr
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
 int conv3_up2_tiles(int OH, int OW);
 int launch_conv3_up2(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
+// the 3x3 stride-2 layers (d64 / d128) with fragment-order weights read global -> registers, halo chunks of 16 channels double-buffered
+// in LDS, whole tiles per block (kernels_s2.hip); wpk = conv_s2w_pack() (s2_pack.h); partials per TR x 32 output-pixel tile (TR = 4 for
+// 64 output channels, 2 for 128)
+bool conv3s2w_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
+int conv3s2w_tiles(int OH, int OW, int coutp);
+int launch_conv3s2w(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 layers: halo-resident implicit GEMM (stream-K, needs the ConvLaunch sk_* fields); partials per 8x32 tile
 bool conv3_halo_eligible(int cin_pitch, int coutp, int k, int stride);
 int conv3_halo_tiles(int OH, int OW, bool edge_b);      // edge_b: fp32 kernel (16 x 16 tiles on a narrow ragged right edge)

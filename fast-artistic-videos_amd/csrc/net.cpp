@@ -22,6 +22,7 @@
 #include "fav_internal.h"
 #include "wino_pack.h"
 #include "up2_pack.h"
+#include "s2_pack.h"
 #include "first_pack.h"
 
 using namespace fav;
@@ -29,7 +30,7 @@ using namespace fav;
 namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
-struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wup2 = nullptr; float* wfirst = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wup2 = nullptr; float* ws2w = nullptr; float* wfirst = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
 struct Act {
@@ -77,10 +78,10 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr, getenv("FAV_NO_S2W") != nullptr};
     return t;
 }
 
@@ -111,7 +112,7 @@ struct fav_net {
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
-    bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_up2 = false, use_first = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
+    bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_up2 = false, use_first = false, use_s2w = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -128,7 +129,7 @@ struct fav_net {
     {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
-        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wup2); (void)hipFree(c.wfirst); (void)hipFree(c.wgt16); }
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (auto& b : bufs) (void)hipFree(b.p);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
@@ -186,6 +187,11 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 conv_up2w_pack(L.w.data(), L.cin, wu9);                            // the nine-position form follows the phase-merged one
                 wu.insert(wu.end(), wu9.begin(), wu9.end());
                 rc = dev_upload(wu, 0, &d.wup2); if (rc) return rc;
+            }
+            if (!L.transposed && L.cin == d.cinp && conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 0)) {      // 3x3 stride 2: fragment order
+                std::vector<float> ws;
+                conv_s2w_pack(L.w.data(), L.cin, L.cout, ws);
+                rc = dev_upload(ws, 0, &d.ws2w); if (rc) return rc;
             }
             if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
                 // [ky][n = c*k + kx][ci] for the row-folded last-layer kernel
@@ -303,7 +309,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     ConvLaunch cg = cs;
     static const int side_sk_mode = getenv("FAV_SIDE_SK") ? atoi(getenv("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
     if (reserve_cus > 0 && side_sk_mode != 1) cg.no_sk = 1;
-    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
+    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
@@ -318,8 +324,8 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    // kernel id: 6 first layer with F(2,3) along x, 500+N 3x3 on a x2-upsampled input (merged taps), 400+N Winograd 3x3, 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
-    prof_tile[conv_index] = use_first ? 6 : use_up2 ? 500 + c.COUTp : use_wino ? 400 + c.COUTp : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
+    // kernel id: 6 first layer with F(2,3) along x, 500+N 3x3 on a x2-upsampled input (merged taps), 700+N stride-2 3x3 (fragment-order weights), 400+N Winograd 3x3, 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
+    prof_tile[conv_index] = use_first ? 6 : use_s2w ? 700 + c.COUTp : use_up2 ? 500 + c.COUTp : use_wino ? 400 + c.COUTp : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
     return rc;
 }
 
@@ -367,16 +373,18 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const bool first = c8 && d.wfirst != nullptr && !tuning().no_first && !tuning().no_c8d && conv_c8d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups);
             const bool up2 = !L.transposed && d.wup2 != nullptr && precision == 0 && !tuning().no_up2 &&
                              conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
-            const bool h3 = !wino && !up2 && !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
-            const bool s2 = !L.transposed && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
-            nxt.mblocks = first ? conv_first_tiles(c.OH, c.OW) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? conv3_wino_tiles(c.OH, c.OW) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
+            const bool s2w = !L.transposed && d.ws2w != nullptr && !tuning().no_s2w &&
+                             conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
+            const bool h3 = !wino && !up2 && !s2w && !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
+            const bool s2 = !L.transposed && !s2w && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
+            nxt.mblocks = first ? conv_first_tiles(c.OH, c.OW) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? conv3_wino_tiles(c.OH, c.OW) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
-            if (want_stats && (c8 || h3 || s2 || wino || up2)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
+            if (want_stats && (c8 || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
-            c8_counts = (c8 || h3 || s2 || wino || up2) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_up2 = up2; use_first = first;
+            c8_counts = (c8 || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_up2 = up2; use_first = first; use_s2w = s2w;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
-            use_c8 = false; use_h3 = false; use_s2 = false; use_wino = false; use_up2 = false; use_first = false;
+            use_c8 = false; use_h3 = false; use_s2 = false; use_wino = false; use_up2 = false; use_first = false; use_s2w = false;
             cur = nxt;
             break;
         }
