@@ -80,14 +80,15 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
     // staging piece i of this thread: halo pixel p0 + 128 i (plane-major), 16-byte chunk c4; its place inside the halo is fixed
     const int c4 = t & 3, p0 = t >> 2;
     float* const hst = Hs + p0 * SW_P + c4 * 4;
-    int hyx[NPC];
+    int hyx[NPC], hbase[NPC];                                           // position inside the halo; byte offset from the halo's origin pixel
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
         const int pe = p0 + 128 * i;
-        int hy = 0x7000, hx = 0;                                        // pixels past the halo: never inside the image -> zeros
+        int hy = 0x7000, hx = 0;                                        // pixels past the halo (scratch): never inside the image
         if (pe < EP) { hy = pe / SW_EW; hx = 2 * (pe - hy * SW_EW); }
         else if (pe < HP) { const int q = pe - EP; hy = q / SW_OW; hx = 2 * (q - hy * SW_OW) + 1; }
         hyx[i] = hy << 16 | hx;
+        hbase[i] = ((pe < HP ? (hy * p.IWp + hx) * p.CIN : 0) + c4 * 4) * 4;
     }
     for (int i = t; i < CIN; i += 512) { aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f; }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
@@ -104,24 +105,31 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 
     int ho[NPC]; float hm[NPC];
     v4f hq[NPC];
+    // interior tiles (the halo lies inside the image: all but the frame of border tiles): one add per piece, no masks
+    bool hmask = false;
 #define SW_TILE_SETUP(tile_)                                                                        \
     {   const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
-        _Pragma("unroll") for (int i = 0; i < NPC; ++i) {                                           \
-            const int iy = 2 * ty_ * TR - p.pad + (hyx[i] >> 16), ix = 2 * tx_ * 32 - p.pad + (hyx[i] & 0xffff); \
-            const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);       \
-            ho[i] = ((v ? (iy * p.IWp + ix) * CIN : 0) + c4 * 4) * 4;                               \
-            hm[i] = v ? 1.f : 0.f;                                                                  \
-        } }
+        const int iy0_ = 2 * ty_ * TR - p.pad, ix0_ = 2 * tx_ * 32 - p.pad;                         \
+        hmask = iy0_ < 0 || ix0_ < 0 || iy0_ + 2 * TR >= p.IH || ix0_ + 64 >= p.IW;                  \
+        if (!hmask) {                                                                               \
+            const int org_ = (iy0_ * p.IWp + ix0_) * CIN * 4;                                       \
+            _Pragma("unroll") for (int i = 0; i < NPC; ++i) ho[i] = hbase[i] + org_;                \
+        } else {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < NPC; ++i) {                                       \
+                const int iy = iy0_ + (hyx[i] >> 16), ix = ix0_ + (hyx[i] & 0xffff);                \
+                const bool v = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);   \
+                ho[i] = ((v ? (iy * p.IWp + ix) * CIN : 0) + c4 * 4) * 4;                           \
+                hm[i] = v ? 1.f : 0.f;                                                              \
+            } } }
 #define SW_LOAD_H(chunk_)                                                                           \
     { _Pragma("unroll") for (int i = 0; i < NPC; ++i) hq[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[i], (chunk_) * 64, 0)); }
 #define SW_COMMIT(chunk_, par_)                                                                     \
     {   const v4f sc_ = *reinterpret_cast<const v4f*>(affr + (chunk_) * 16), sh_ = *reinterpret_cast<const v4f*>(affr + CIN + (chunk_) * 16); \
         _Pragma("unroll") for (int i = 0; i < NPC; ++i) {                                           \
-            v4f v_ = hq[i];                                                                         \
-            v_.x = fmaxf(fmaf(v_.x, sc_.x, sh_.x), lo1) * hm[i]; v_.y = fmaxf(fmaf(v_.y, sc_.y, sh_.y), lo1) * hm[i]; \
-            v_.z = fmaxf(fmaf(v_.z, sc_.z, sh_.z), lo1) * hm[i]; v_.w = fmaxf(fmaf(v_.w, sc_.w, sh_.w), lo1) * hm[i]; \
-            *reinterpret_cast<v4f*>(hst + (par_) * HB + i * 128 * SW_P) = v_;                        \
-        } }
+            hq[i].x = fmaxf(fmaf(hq[i].x, sc_.x, sh_.x), lo1); hq[i].y = fmaxf(fmaf(hq[i].y, sc_.y, sh_.y), lo1); \
+            hq[i].z = fmaxf(fmaf(hq[i].z, sc_.z, sh_.z), lo1); hq[i].w = fmaxf(fmaf(hq[i].w, sc_.w, sh_.w), lo1); } \
+        if (hmask) { _Pragma("unroll") for (int i = 0; i < NPC; ++i) hq[i] *= hm[i]; }              /* zero padding applies after the transform */ \
+        _Pragma("unroll") for (int i = 0; i < NPC; ++i) *reinterpret_cast<v4f*>(hst + (par_) * HB + i * 128 * SW_P) = hq[i]; }
     v4f fb[2][9], fa[3];
 #define SW_LOAD_B(set_, chunk_, kg_)                                                                \
     {   const int so_ = (((chunk_) * 2 + (kg_)) * 9) * NTC * 1024 + wnt;                            \
@@ -130,16 +138,18 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 #define SW_READ_A(slot_, T_, kg_, par_) { fa[slot_] = *reinterpret_cast<const v4f*>(SW_ABASE(T_) + SW_AOFF(T_) + (kg_) * 8 + (par_) * HB); }
     // one channel group: nine taps x four MFMA steps; the fragments of taps 0 and 1 were read by the caller, tap T + 2 is read at tap T
     // (NXT_: after the ninth tap of group 0 the first two taps of group 1 follow)
-#define SW_GROUP(set_, kg_, par_, NXT_)                                                             \
-    {   _Pragma("unroll") for (int tp = 0; tp < 9; ++tp) {                                          \
+#define SW_MFMA4(a_, b_)                                                                            \
+    {   acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).x, (b_).x, acc, 0, 0, 0);                   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).y, (b_).y, acc, 0, 0, 0);                   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).z, (b_).z, acc, 0, 0, 0);                   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).w, (b_).w, acc, 0, 0, 0); }
+#define SW_TAPS(set_, kg_, par_, T0_, T1_, NXT_)                                                    \
+    {   _Pragma("unroll") for (int tp = (T0_); tp < (T1_); ++tp) {                                  \
             if (tp + 2 < 9) { SW_READ_A_DYN((tp + 2) % 3, tp + 2, kg_, par_); }                      \
             else if (NXT_) { SW_READ_A_DYN((tp + 2) % 3, tp + 2 - 9, 1, par_); }                    \
-            const v4f a_ = fa[tp % 3], b_ = fb[set_][tp];                                           \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, b_.x, acc, 0, 0, 0);                   \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, b_.y, acc, 0, 0, 0);                   \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, b_.z, acc, 0, 0, 0);                   \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, b_.w, acc, 0, 0, 0);                   \
+            SW_MFMA4(fa[tp % 3], fb[set_][tp]);                                                     \
         } }
+#define SW_GROUP(set_, kg_, par_, NXT_) SW_TAPS(set_, kg_, par_, 0, 9, NXT_)
     // (tap index is a compile-time constant after unrolling; the helper picks plane and offset from it)
 #define SW_READ_A_DYN(slot_, T_, kg_, par_)                                                         \
     { const int T__ = (T_); const float* b__ = (T__ % 3 == 1) ? aO : aE;                            \
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
+    SW_READ_A_DYN(0, 0, 0, 0); SW_READ_A_DYN(1, 1, 0, 0);
     int par = 0, pend = -1;
     int oy0 = (tile / p.tiles_x) * TR, ox0 = (tile - (tile / p.tiles_x) * p.tiles_x) * 32;
     const int n = lane & 31, co = nt * 32 + n;
@@ -172,7 +183,6 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
             // first channel group: weights of the second requested, the next chunk's halo requested
             SW_LOAD_B(1, chunk, 1);
             if (have_next) SW_LOAD_H(nchunk);
-            SW_READ_A_DYN(0, 0, 0, par); SW_READ_A_DYN(1, 1, 0, par);
             __builtin_amdgcn_sched_barrier(0);
             SW_GROUP(0, 0, par, true);
             __builtin_amdgcn_sched_barrier(0);
@@ -180,9 +190,17 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
             SW_LOAD_B(0, nchunk, 0);
             if (have_next) SW_COMMIT(nchunk, par ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            SW_GROUP(1, 1, par, false);
+            // taps 0..6 (the reads of taps 7 and 8 are issued by then), the chunk's barrier, then the first two fragments of the next
+            // chunk are requested from the other buffer while taps 7 and 8 multiply out of registers
+            SW_TAPS(1, 1, par, 0, 7, false);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const v4f a7_ = fa[7 % 3], a8_ = fa[8 % 3];
+                SW_READ_A_DYN(0, 0, 0, par ^ 1); SW_READ_A_DYN(1, 1, 0, par ^ 1);
+                SW_MFMA4(a7_, fb[1][7]); SW_MFMA4(a8_, fb[1][8]);
+            }
             if (pend >= 0) {
                 // InstanceNorm partial of the previous tile: exact merge (Chan et al.) of its TR row waves
                 if (t < COUT) {
@@ -203,23 +221,40 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
             const int oy = oy0 + row;
             float sm = 0.f; int nv = 0;
             float* const ob = p.out + ((size_t)oy * p.OW + ox0 + 4 * h) * COUT + co;
+            const bool full = oy0 + TR <= p.OH && ox0 + 32 <= p.OW;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mi = (r & 3) + 8 * (r >> 2);
-                const float v = acc[r] + bv;
-                acc[r] = v;
-                if (oy < p.OH && ox0 + 4 * h + mi < p.OW) { ob[(size_t)mi * COUT] = v; sm += v; ++nv; }
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[r] + bv;
+                    acc[r] = v;
+                    ob[(size_t)((r & 3) + 8 * (r >> 2)) * COUT] = v;
+                    sm += v;
+                }
+                nv = 16;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mi = (r & 3) + 8 * (r >> 2);
+                    const float v = acc[r] + bv;
+                    acc[r] = v;
+                    if (oy < p.OH && ox0 + 4 * h + mi < p.OW) { ob[(size_t)mi * COUT] = v; sm += v; ++nv; }
+                }
             }
             if (p.partials != nullptr) {
                 const int nw = nv + __shfl_xor(nv, 32);
                 const float ssum = sm + __shfl_xor(sm, 32);
                 const float mu = nw ? ssum / (float)nw : 0.f;
                 float q = 0.f;
+                if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mi = (r & 3) + 8 * (r >> 2);
-                    const float d = acc[r] - mu;
-                    if (oy < p.OH && ox0 + 4 * h + mi < p.OW) q = fmaf(d, d, q);
+                    for (int r = 0; r < 16; ++r) { const float d = acc[r] - mu; q = fmaf(d, d, q); }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mi = (r & 3) + 8 * (r >> 2);
+                        const float d = acc[r] - mu;
+                        if (oy < p.OH && ox0 + 4 * h + mi < p.OW) q = fmaf(d, d, q);
+                    }
                 }
                 q += __shfl_xor(q, 32);
                 if (lane < 32) stt[row * COUT + co] = make_float2(mu, q);
@@ -253,6 +288,8 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 #undef SW_LOAD_B
 #undef SW_READ_A
 #undef SW_GROUP
+#undef SW_TAPS
+#undef SW_MFMA4
 #undef SW_READ_A_DYN
 }
 
