@@ -41,21 +41,24 @@ struct S2wArgs {
     int IH, IW, IWp, CIN, OH, OW, pad, tiles_x, tiles_y, stages, relu1;
 };
 
-template <int TR> struct SwGeo {
+template <int NTC, int TR> struct SwGeo {
+    static constexpr int NW = NTC * TR;                     // waves per block: one per (tile of 32 output channels, output row)
+    static constexpr int NTH = 64 * NW;
     static constexpr int HR = 2 * TR + 1;                   // halo rows
     static constexpr int EP = HR * SW_EW;                   // pixels in the even plane
     static constexpr int HP = EP + HR * SW_OW;              // halo pixels
-    static constexpr int NPC = (HP * 4 + 511) / 512;        // 16-byte pieces per thread and chunk
-    static constexpr int HB = NPC * 128 * SW_P;             // floats per buffer (pixels HP .. NPC * 128 - 1 are scratch)
+    static constexpr int PS = NTH / 4;                      // pixels staged per pass of the block (four 16-byte pieces per pixel)
+    static constexpr int NPC = (HP + PS - 1) / PS;          // pieces per thread and chunk
+    static constexpr int HB = NPC * PS * SW_P;              // floats per buffer (pixels HP .. NPC * PS - 1 are scratch)
 };
 
 template <int NTC, int TR>
-__global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
+__global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(const S2wArgs p)
 {
-    static_assert(NTC * TR == 8, "eight waves");
+    using G = SwGeo<NTC, TR>;
+    static_assert(G::NW % 4 == 0 && G::NW >= 8 && G::NW <= 16, "whole waves per SIMD");
     constexpr int COUT = NTC * 32;
-    using G = SwGeo<TR>;
-    constexpr int EP = G::EP, HP = G::HP, NPC = G::NPC, HB = G::HB;
+    constexpr int EP = G::EP, HP = G::HP, NPC = G::NPC, HB = G::HB, PS = G::PS, NTH = G::NTH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Hs = smem;                                             // [2][HB]
     float* const aff = smem + 2 * HB;                                   // [2][CIN]
@@ -77,20 +80,20 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 #define SW_AOFF(T_) (((T_) % 3 == 1) ? ((T_) / 3) * SW_OW * SW_P : (((T_) / 3) * SW_EW + ((T_) % 3 == 2 ? 1 : 0)) * SW_P)
 #define SW_ABASE(T_) (((T_) % 3 == 1) ? aO : aE)
 
-    // staging piece i of this thread: halo pixel p0 + 128 i (plane-major), 16-byte chunk c4; its place inside the halo is fixed
+    // staging piece i of this thread: halo pixel p0 + PS i (plane-major), 16-byte chunk c4; its place inside the halo is fixed
     const int c4 = t & 3, p0 = t >> 2;
     float* const hst = Hs + p0 * SW_P + c4 * 4;
     int hyx[NPC], hbase[NPC];                                           // position inside the halo; byte offset from the halo's origin pixel
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
-        const int pe = p0 + 128 * i;
+        const int pe = p0 + PS * i;
         int hy = 0x7000, hx = 0;                                        // pixels past the halo (scratch): never inside the image
         if (pe < EP) { hy = pe / SW_EW; hx = 2 * (pe - hy * SW_EW); }
         else if (pe < HP) { const int q = pe - EP; hy = q / SW_OW; hx = 2 * (q - hy * SW_OW) + 1; }
         hyx[i] = hy << 16 | hx;
         hbase[i] = ((pe < HP ? (hy * p.IWp + hx) * p.CIN : 0) + c4 * 4) * 4;
     }
-    for (int i = t; i < CIN; i += 512) { aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f; }
+    for (int i = t; i < CIN; i += NTH) { aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f; }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float* const affr = aff + c4 * 4;
 
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
             hq[i].x = fmaxf(fmaf(hq[i].x, sc_.x, sh_.x), lo1); hq[i].y = fmaxf(fmaf(hq[i].y, sc_.y, sh_.y), lo1); \
             hq[i].z = fmaxf(fmaf(hq[i].z, sc_.z, sh_.z), lo1); hq[i].w = fmaxf(fmaf(hq[i].w, sc_.w, sh_.w), lo1); } \
         if (hmask) { _Pragma("unroll") for (int i = 0; i < NPC; ++i) hq[i] *= hm[i]; }              /* zero padding applies after the transform */ \
-        _Pragma("unroll") for (int i = 0; i < NPC; ++i) *reinterpret_cast<v4f*>(hst + (par_) * HB + i * 128 * SW_P) = hq[i]; }
+        _Pragma("unroll") for (int i = 0; i < NPC; ++i) *reinterpret_cast<v4f*>(hst + (par_) * HB + i * PS * SW_P) = hq[i]; }
     v4f fb[2][9], fa[3];
 #define SW_LOAD_B(set_, chunk_, kg_)                                                                \
     {   const int so_ = (((chunk_) * 2 + (kg_)) * 9) * NTC * 1024 + wnt;                            \
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 #define SW_READ_A(slot_, T_, kg_, par_) { fa[slot_] = *reinterpret_cast<const v4f*>(SW_ABASE(T_) + SW_AOFF(T_) + (kg_) * 8 + (par_) * HB); }
     // one channel group: nine taps x four MFMA steps; the fragments of taps 0 and 1 were read by the caller, tap T + 2 is read at tap T
     // (NXT_: after the ninth tap of group 0 the first two taps of group 1 follow)
+#define SW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define SW_MFMA4(a_, b_)                                                                            \
     {   acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).x, (b_).x, acc, 0, 0, 0);                   \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_).y, (b_).y, acc, 0, 0, 0);                   \
@@ -177,29 +181,39 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
         const int ntile = tile + (int)gridDim.x;
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bool last = chunk == nch - 1;
-            const bool have_next = !last || ntile < ntiles;
             const int nchunk = last ? 0 : chunk + 1;
-            if (last && have_next) SW_TILE_SETUP(ntile);                // (ho / hm now describe the tile being fetched)
-            // first channel group: weights of the second requested, the next chunk's halo requested
-            SW_LOAD_B(1, chunk, 1);
-            if (have_next) SW_LOAD_H(nchunk);
-            __builtin_amdgcn_sched_barrier(0);
-            SW_GROUP(0, 0, par, true);
-            __builtin_amdgcn_sched_barrier(0);
-            // second channel group: weights of the next chunk's first group requested, the halo committed
-            SW_LOAD_B(0, nchunk, 0);
-            if (have_next) SW_COMMIT(nchunk, par ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // taps 0..6 (the reads of taps 7 and 8 are issued by then), the chunk's barrier, then the first two fragments of the next
-            // chunk are requested from the other buffer while taps 7 and 8 multiply out of registers
-            SW_TAPS(1, 1, par, 0, 7, false);
+            if (last && ntile < ntiles) SW_TILE_SETUP(ntile);           // (ho / hm now describe the tile being fetched)
+            // Global requests are spread over the taps (one weight fragment per tap, the halo pieces with the first taps): eight waves
+            // asking for 14 KB each right behind the barrier would keep the matrix pipes waiting for the address unit.
+            // (after the block's last chunk the requests fetch a chunk nobody reads: no branches in the loop body)
+            const int so1 = ((chunk * 2 + 1) * 9) * NTC * 1024 + wnt, so0 = ((nchunk * 2) * 9) * NTC * 1024 + wnt;
+            // first channel group; requested: the weights of the second, the next chunk's halo
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                fb[1][tp] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so1 + tp * NTC * 1024, 0));
+                if (tp < NPC) hq[tp] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[tp], nchunk * 64, 0));
+                if (tp + 2 < 9) { SW_READ_A_DYN((tp + 2) % 3, tp + 2, 0, par); } else { SW_READ_A_DYN((tp + 2) % 3, tp + 2 - 9, 1, par); }
+                SW_FENCE(); SW_MFMA4(fa[tp % 3], fb[0][tp]); SW_FENCE();
+            }
+            // second channel group; requested: the weights of the next chunk's first group; the halo is committed behind tap 2
+#pragma unroll
+            for (int tp = 0; tp < 7; ++tp) {
+                fb[0][tp] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so0 + tp * NTC * 1024, 0));
+                if (tp + 2 < 9) { SW_READ_A_DYN((tp + 2) % 3, tp + 2, 1, par); }
+                SW_FENCE(); SW_MFMA4(fa[tp % 3], fb[1][tp]); SW_FENCE();
+                if (tp == 2) { __builtin_amdgcn_sched_barrier(0); SW_COMMIT(nchunk, par ^ 1); __builtin_amdgcn_sched_barrier(0); }
+            }
+            // the reads of taps 7 and 8 are issued: the chunk's barrier; the first two fragments of the next chunk are requested from
+            // the other buffer while taps 7 and 8 multiply out of registers
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             {
                 const v4f a7_ = fa[7 % 3], a8_ = fa[8 % 3];
+                fb[0][7] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so0 + 7 * NTC * 1024, 0));
+                fb[0][8] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so0 + 8 * NTC * 1024, 0));
                 SW_READ_A_DYN(0, 0, 0, par ^ 1); SW_READ_A_DYN(1, 1, 0, par ^ 1);
-                SW_MFMA4(a7_, fb[1][7]); SW_MFMA4(a8_, fb[1][8]);
+                SW_FENCE(); SW_MFMA4(a7_, fb[1][7]); SW_MFMA4(a8_, fb[1][8]); SW_FENCE();
             }
             if (pend >= 0) {
                 // InstanceNorm partial of the previous tile: exact merge (Chan et al.) of its TR row waves
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv3s2w_kernel(const S2wArgs p)
 #undef SW_GROUP
 #undef SW_TAPS
 #undef SW_MFMA4
+#undef SW_FENCE
 #undef SW_READ_A_DYN
 }
 
@@ -297,7 +312,7 @@ template <int NTC, int TR>
 int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
 {
     const auto kern = conv3s2w_kernel<NTC, TR>;
-    const size_t lds = (size_t)(2 * SwGeo<TR>::HB + 2 * a.CIN) * sizeof(float) + (size_t)TR * NTC * 32 * sizeof(float2) + 16 * sizeof(int);
+    const size_t lds = (size_t)(2 * SwGeo<NTC, TR>::HB + 2 * a.CIN) * sizeof(float) + (size_t)TR * NTC * 32 * sizeof(float2) + 16 * sizeof(int);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
@@ -308,7 +323,7 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::min(tiles, std::max(1, cus[dv] - reserve_cus));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SwGeo<NTC, TR>::NTH), lds, st, a);
     FAV_LAUNCH_CHECK("conv3s2w_kernel");
     return FAV_OK;
 }
@@ -320,7 +335,9 @@ bool conv3s2w_eligible(int cin_pitch, int cout, int coutp, int k, int stride, in
     return k == 3 && stride == 2 && pad <= 1 && ups == 0 && stages <= 1 && cin_pitch % 16 == 0 && cin_pitch >= 32 && cin_pitch <= 512 &&
            cout == coutp && (coutp == 64 || coutp == 128);
 }
-int conv3s2w_tiles(int OH, int OW, int coutp) { const int tr = coutp == 64 ? 4 : 2; return ((OH + tr - 1) / tr) * ((OW + 31) / 32); }
+// tile rows: d64 4 (8 waves); d128 3 (12 waves: 737 tiles = 3 rounds on 256 CUs at 1280x720; with 2 rows 1100 tiles = 5 rounds where 4.3 would do)
+static int s2w_rows(int coutp) { static const int r128 = getenv("FAV_S2W_ROWS128") ? atoi(getenv("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 ? 2 : 3); }      // (tuning: read once)
+int conv3s2w_tiles(int OH, int OW, int coutp) { const int tr = s2w_rows(coutp); return ((OH + tr - 1) / tr) * ((OW + 31) / 32); }
 
 int launch_conv3s2w(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
 {
@@ -331,9 +348,9 @@ int launch_conv3s2w(const ConvLaunch& c, const float* wpk, int* counts, hipStrea
     a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.stages = c.pre.stages; a.relu1 = c.pre.relu1;
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW; a.pad = c.pad;
-    const int tr = c.COUTp == 64 ? 4 : 2;
+    const int tr = s2w_rows(c.COUTp);
     a.tiles_x = (c.OW + 31) / 32; a.tiles_y = (c.OH + tr - 1) / tr;
-    return c.COUTp == 64 ? launch_s2w_t<2, 4>(a, c.reserve_cus, st) : launch_s2w_t<4, 2>(a, c.reserve_cus, st);
+    return c.COUTp == 64 ? launch_s2w_t<2, 4>(a, c.reserve_cus, st) : tr == 2 ? launch_s2w_t<4, 2>(a, c.reserve_cus, st) : launch_s2w_t<4, 3>(a, c.reserve_cus, st);
 }
 
 }  // namespace fav

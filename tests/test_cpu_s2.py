@@ -39,12 +39,16 @@ def packer(tmp_path_factory):
     return pack
 
 
-def geo(TR):
+def geo(TR, NTC=None):
+    """SwGeo<NTC, TR> of the kernel: one wave per (tile of 32 output channels, output row)"""
+    NTC = NTC if NTC is not None else 8 // TR
+    NTH = 64 * NTC * TR
     HR = 2 * TR + 1
     EP = HR * SW_EW
     HP = EP + HR * SW_OW
-    NPC = (HP * 4 + 511) // 512
-    return HR, EP, HP, NPC, NPC * 128 * SW_P
+    PS = NTH // 4
+    NPC = (HP + PS - 1) // PS
+    return HR, EP, HP, NPC, NPC * PS * SW_P, NTH, PS
 
 
 def a_off(tap, EP, row, m, h):
@@ -58,17 +62,18 @@ def a_off(tap, EP, row, m, h):
 def emulate_tile(x, wpk, bias, scale, shift, relu, pad, NTC, TR, ty, tx, OH, OW, f=np.float32):
     IH, IW, CIN = x.shape
     COUT = NTC * 32
-    HR, EP, HP, NPC, HB = geo(TR)
+    HR, EP, HP, NPC, HB, NTH, PS = geo(TR, NTC)
+    NW = NTC * TR
     nch = CIN // 16
     lanes = np.arange(64)
     m, h, n = lanes & 31, lanes >> 5, lanes & 31
-    acc = np.zeros((8, 16, 64), np.float64)
+    acc = np.zeros((NW, 16, 64), np.float64)
     for chunk in range(nch):
         Hs = np.full(HB, np.nan, f)
-        for t in range(512):
+        for t in range(NTH):
             c4, p0 = t & 3, t >> 2
             for i in range(NPC):
-                pe = p0 + 128 * i
+                pe = p0 + PS * i
                 if pe < EP:
                     hy = pe // SW_EW; hx = 2 * (pe - hy * SW_EW)
                 elif pe < HP:
@@ -84,10 +89,10 @@ def emulate_tile(x, wpk, bias, scale, shift, relu, pad, NTC, TR, ty, tx, OH, OW,
                         v = (v * scale[ch:ch + 4] + shift[ch:ch + 4]).astype(f)
                         if relu:
                             v = np.maximum(v, 0)
-                dst = (p0 + 128 * i) * SW_P + c4 * 4
+                dst = (p0 + PS * i) * SW_P + c4 * 4
                 assert dst + 4 <= HB
                 Hs[dst:dst + 4] = v
-        for wave in range(8):
+        for wave in range(NW):
             nt, row = wave % NTC, wave // NTC
             for kg in range(2):
                 for tap in range(9):
@@ -107,7 +112,7 @@ def emulate_tile(x, wpk, bias, scale, shift, relu, pad, NTC, TR, ty, tx, OH, OW,
     Y = np.full((TR, 32, COUT), np.nan, f)
     stt = np.zeros((TR, COUT, 2)); wn = np.zeros(TR, np.int64)
     oy0, ox0 = ty * TR, tx * 32
-    for wave in range(8):
+    for wave in range(NW):
         nt, row = wave % NTC, wave // NTC
         co = nt * 32 + n
         oy = oy0 + row
@@ -132,11 +137,12 @@ def emulate_tile(x, wpk, bias, scale, shift, relu, pad, NTC, TR, ty, tx, OH, OW,
     return Y, mean, m2, cnt
 
 
-@pytest.mark.parametrize("cin,cout,pad,ih,iw", [(32, 64, 1, 18, 70), (64, 128, 1, 11, 68), (32, 64, 0, 19, 67)], ids=["d64", "d128", "d64-pad0"])
-def test_s2w_lane_level_restatement_matches_direct_convolution(packer, cin, cout, pad, ih, iw):
+@pytest.mark.parametrize("cin,cout,tr,pad,ih,iw", [(32, 64, 4, 1, 18, 70), (64, 128, 3, 1, 15, 68), (64, 128, 2, 1, 11, 68), (32, 64, 4, 0, 19, 67)],
+                         ids=["d64", "d128-3rows", "d128-2rows", "d64-pad0"])
+def test_s2w_lane_level_restatement_matches_direct_convolution(packer, cin, cout, tr, pad, ih, iw):
     rng = np.random.default_rng(17 + cin)
     NTC = cout // 32
-    TR = 8 // NTC
+    TR = tr
     x = rng.standard_normal((ih, iw, cin)).astype(np.float32)
     w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
     b = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
@@ -171,8 +177,8 @@ def test_s2w_fragment_reads_are_bank_conflict_free():
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
     groups += [[l + 32 for l in g] for g in groups]
     lanes = np.arange(64)
-    for TR in (4, 2):
-        _, EP, _, _, _ = geo(TR)
+    for TR, NTC in ((4, 2), (2, 4), (3, 4)):
+        _, EP, _, _, _, _, _ = geo(TR, NTC)
         for row in range(TR):
             for tap in range(9):
                 for kg in range(2):
