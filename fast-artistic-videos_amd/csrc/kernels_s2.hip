@@ -336,6 +336,7 @@ bool conv3s2w_eligible(int cin_pitch, int cout, int coutp, int k, int stride, in
            cout == coutp && (coutp == 64 || coutp == 128);
 }
 // tile rows: d64 4 (8 waves); d128 3 (12 waves: 737 tiles = 3 rounds on 256 CUs at 1280x720; with 2 rows 1100 tiles = 5 rounds where 4.3 would do)
+// (measured and not kept: d64 with 6 rows on 12 waves -- 104 us against 98.8 us with 4 rows on 8: profiles/r02y_s2w_rows_ab.log)
 static int s2w_rows(int coutp) { static const int r128 = getenv("FAV_S2W_ROWS128") ? atoi(getenv("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 ? 2 : 3); }      // (tuning: read once)
 int conv3s2w_tiles(int OH, int OW, int coutp) { const int tr = s2w_rows(coutp); return ((OH + tr - 1) / tr) * ((OW + 31) / 32); }
 
