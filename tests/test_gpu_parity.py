@@ -195,7 +195,7 @@ def test_canonical_network_vs_oracle(favlib, oracle, cuda, canonical):
 
 
 def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_ones(favlib, oracle, cuda, canonical, tmp_path):
-    """FAV_NO_WINO / FAV_NO_UP2 / FAV_NO_FOLD_UP2 / FAV_NO_FIRST select the direct-form kernels of the same layers, FAV_UP2_PHASES the
+    """FAV_NO_WINO / FAV_NO_UP2 / FAV_NO_FOLD_UP2 / FAV_NO_FIRST / FAV_NO_S2W select the earlier kernels of the same layers, FAV_UP2_PHASES the
     phase-merged form of U2 + c3s1-64 (read once per process, so child processes run them): every build of the canonical network agrees
     with the oracle, and with the default build far inside the tolerance."""
     import subprocess, sys
@@ -206,7 +206,7 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
              "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
              "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "direct.npy")))
-    env = dict(os.environ, FAV_NO_WINO="1", FAV_NO_UP2="1", FAV_NO_FOLD_UP2="1", FAV_NO_FIRST="1")
+    env = dict(os.environ, FAV_NO_WINO="1", FAV_NO_UP2="1", FAV_NO_FOLD_UP2="1", FAV_NO_FIRST="1", FAV_NO_S2W="1")
     subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
     direct = np.load(tmp_path / "direct.npy")
     ref = oracle.net_forward(_layers(canonical), x)
