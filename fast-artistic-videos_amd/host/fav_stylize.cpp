@@ -265,16 +265,19 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     };
 
     Pool writers(nwriters);
-    hipStream_t st, st_copy;                 // compute queue; upload queue (the next frame's inputs travel while this frame computes)
-    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess) die("hipStreamCreate failed");
-    hipEvent_t ev_up[3], ev_done[2];
+    // compute queue; upload queue (the next frame's inputs travel while this frame computes); download queue (the 8-bit frame leaves
+    // while the next frame computes: on the compute queue the 2.8 MB copy held back the next frame's kernels for its whole duration)
+    hipStream_t st, st_copy, st_down;
+    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess) die("hipStreamCreate failed");
+    hipEvent_t ev_up[3], ev_done[2], ev_out[2];
+    for (auto& e : ev_out) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
     fav_stream* fs = nullptr;
     int W = 0, H = 0;
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
     Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
-    uint8_t* d_out8 = nullptr;
+    uint8_t* d_out8s[2] = {nullptr, nullptr};    // frames alternate: frame i + 2 is enqueued after the host has seen frame i's download complete
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
@@ -375,7 +378,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
             if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
             const size_t n = (size_t)W * H;
-            if (hipMalloc((void**)&d_out8, n * 3)) die("hipMalloc failed");
+            if (hipMalloc((void**)&d_out8s[0], n * 3) || hipMalloc((void**)&d_out8s[1], n * 3)) die("hipMalloc failed");
             for (auto& dv : dev)
                 if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
                     hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
@@ -408,6 +411,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             upload(nxt, (dset + 1) % 3);
             if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
+        uint8_t* const d_out8 = d_out8s[done & 1];
         const bool teval = !o.s("temporal_eval_file").empty();
         if (teval && !d_prev) { if (hipMalloc((void**)&d_prev, (size_t)W * H * 12) || hipMalloc((void**)&d_cur, (size_t)W * H * 12)) die("hipMalloc failed"); }
         if (teval && !cur.single) check(fav_stream_get_state(fs, d_prev, st), "fav_stream_get_state");
@@ -429,9 +433,11 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         const auto tw = std::chrono::steady_clock::now();
         uint8_t* hb = slots.take();                      // a pinned output slot nobody is reading (blocks while the PNG pool is behind)
         t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st);     // stream order protects d_out8 from frame i+1
         Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
-        hipEventRecord(ev_done[now.ev], st);
+        hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image is complete on the compute queue ...
+        hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
+        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st_down);
+        hipEventRecord(ev_done[now.ev], st_down);
         const auto tg = std::chrono::steady_clock::now();
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i is already queued
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
@@ -461,12 +467,13 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
     fav_stream_destroy(fs);
     hipFree(d_prev); hipFree(d_cur);
-    hipFree(d_out8); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
+    hipFree(d_out8s[0]); hipFree(d_out8s[1]); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
     for (auto p : h_out) hipHostFree(p);
     for (auto& p : pin) { hipHostFree(p.frame); hipHostFree(p.bw); hipHostFree(p.fw); hipHostFree(p.cert); }
     for (auto& e : ev_up) hipEventDestroy(e);
     for (auto& e : ev_done) hipEventDestroy(e);
-    hipStreamDestroy(st); hipStreamDestroy(st_copy);
+    for (auto& e : ev_out) hipEventDestroy(e);
+    hipStreamDestroy(st); hipStreamDestroy(st_copy); hipStreamDestroy(st_down);
 }
 
 }  // namespace
