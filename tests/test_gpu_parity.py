@@ -259,6 +259,12 @@ def test_unsupported_models_fail_with_status(favlib, cuda, tmp_path):
         favlib.Net(p, 0)
     with pytest.raises(favlib.FavError):
         favlib.Net(str(tmp_path / "missing.t7"), 0)
+    # 48 channels: the implicit-GEMM K order needs a power of two from 32 channels on -- a status, not a crash (this model used to
+    # overrun the repacked weight matrix)
+    p48 = str(tmp_path / "c48.t7")
+    t7.make_synthetic_checkpoint(p48, arch="c9s1-48,d64,c9s1-3", seed=3)
+    with pytest.raises(favlib.FavError, match="48 input channels"):
+        favlib.Net(p48, 0)
 
 
 # ---------------------------------------------------------------------------------------------- pipeline
@@ -650,6 +656,30 @@ def test_conv_on_upsampled_join_in_networks(favlib, oracle, cuda, tmp_path, arch
     x = (np.random.default_rng(14).standard_normal((7, h, w)) * 60).astype(np.float32)
     ref = oracle.net_forward(layers, x)
     got = net.forward(T(x, cuda)).cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 5e-2, err
+    assert np.abs(ref).std() > 5
+
+
+@pytest.mark.parametrize("arch,size", [
+    ("c9s1-32,d64,d128,c9s1-3", (92, 140)),        # canonical head: 46 x 70 -> 23 x 35 (ragged 4-row tiles) -> 12 x 18 (3-row tiles)
+    ("c3s1-64,d64,c9s1-3", (54, 66)),              # 64 input channels: four 16-channel chunks per tile; 27 x 33 outputs (one column past a tile)
+    ("c3s1-128,d128,c9s1-3", (34, 134)),           # 128 input channels, 128 outputs: eight chunks, 17 x 67 outputs = 6 x 3 tiles with ragged edges
+    ("c3s1-32,d128,c9s1-3", (22, 62)),             # 32 input channels into 128 outputs: two chunks per tile
+], ids=["canonical-head", "cin64-d64", "cin128-d128", "cin32-d128"])
+def test_stride2_layers_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
+    """d64 / d128 (3x3, stride 2, zero padding 1, models_video.lua:88-92) run on conv3s2w_kernel (csrc/kernels_s2.hip): border tiles,
+    ragged right / bottom tiles and chunk counts other than the canonical network's, against the oracle's direct form."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=81)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    h, w = size
+    x = (np.random.default_rng(15).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    net.check()
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
     assert err <= 5e-2, err
