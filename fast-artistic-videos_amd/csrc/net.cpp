@@ -153,10 +153,11 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             if (L.cin > chan_pitch || (chan_pitch != 8 && L.cin != chan_pitch)) {
                 set_error("network: conv expects %d input channels, producer has %d", L.cin, chan_pitch); return FAV_EFORMAT; }
             if (L.k < 1 || L.stride < 1 || L.pad < 0) { set_error("network: bad convolution geometry"); return FAV_EFORMAT; }
-            // the implicit-GEMM K order walks 32-channel slices of a pixel and locates a channel with shifts: from 32 channels on the
-            // count must be a power of two (32, 64, 128, 256: every architecture string of models_video.lua / train_video.lua:21-23)
-            if (d.cinp >= 32 && (d.cinp & (d.cinp - 1)) != 0) {
-                set_error("network: a convolution with %d input channels is unsupported (from 32 on the channel count must be a power of two)", d.cinp);
+            // channel pitches are powers of two (the generic kernel locates (tap, channel) with shifts, the elementwise kernels split 256
+            // threads over the channels): 4 ... 1024 -- every architecture string of models_video.lua / train_video.lua:21-23.  Refused
+            // here, at load time: a 48-channel model used to overrun the repacked weight matrix before any launch could refuse it
+            if ((d.cinp & (d.cinp - 1)) != 0) {
+                set_error("network: a convolution with %d input channels is unsupported (channel counts must be powers of two)", d.cinp);
                 return FAV_EUNSUPPORTED; }
             d.coutp = (L.cout + 31) / 32 * 32;
             d.kpad = (L.k * L.k * d.cinp + 31) / 32 * 32;

@@ -259,8 +259,8 @@ def test_unsupported_models_fail_with_status(favlib, cuda, tmp_path):
         favlib.Net(p, 0)
     with pytest.raises(favlib.FavError):
         favlib.Net(str(tmp_path / "missing.t7"), 0)
-    # 48 channels: the implicit-GEMM K order needs a power of two from 32 channels on -- a status, not a crash (this model used to
-    # overrun the repacked weight matrix)
+    # 48 channels: channel pitches are powers of two -- a status at load time, not a crash (this model used to overrun the repacked
+    # weight matrix)
     p48 = str(tmp_path / "c48.t7")
     t7.make_synthetic_checkpoint(p48, arch="c9s1-48,d64,c9s1-3", seed=3)
     with pytest.raises(favlib.FavError, match="48 input channels"):
