@@ -93,11 +93,32 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* img, const float
     for (int c = 0; c < C; ++c) ob[(size_t)c * on] = sample(ib + (size_t)c * H * W, t);
 }
 
+// certainty from the checker's PGM byte: image.load(...,1) = byte/255; -invert_occlusion and
+// -fix_occlusions of fast_artistic_video.lua:79-86,99-112
+__device__ __forceinline__ float cert_from_mask(const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ, int border, int y, int x, int H, int W)
+{
+    const size_t i = (size_t)y * W + x;
+    float c = (float)mask[i] / 255.f;
+    if (invert) c = (c + -1.f) * -1.f;
+    if (fix_occ) {
+        const float2 f = bw_flo[i];
+        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
+        float ones = t.w00 + t.w01 + t.w10 + t.w11;         // warp of an all-ones image
+        ones = ones + -0.5f;
+        const float sg = ones > 0.f ? 1.f : (ones < 0.f ? -1.f : 0.f);
+        c *= fmaxf(sg, 0.f);
+    }
+    return c;
+}
+
 // utils.min_filter (utils.lua:161-169): 1 - maxpool_{r x r, stride 1, pad r/2}(1 - cert); max-pooling pads with -inf, i.e. the
 // windows are truncated at the borders.  max is exact and order-free, so the r x r window is evaluated separably on an LDS
 // tile (rows, then columns): 2r instead of r*r taps, each input element read from memory once per tile.
 constexpr int MF_TX = 64, MF_TY = 16, MF_RMAX = 15;
-__global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, float* out, int H, int W, int r)
+// FROM_MASK: the tile is filled from the checker's mask byte with the certainty options applied on the way in (cert_from_mask; 1.5x of that cheap work is repeated in the tiles' halos) -- one launch and one 3.7 MB plane less per frame
+template <bool FROM_MASK>
+__global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ,
+                                                         int border, float* out, int H, int W, int r)
 {
     __shared__ float a[MF_TY + MF_RMAX - 1][MF_TX + MF_RMAX];        // 1 - cert, -inf outside the image
     __shared__ float b[MF_TY + MF_RMAX - 1][MF_TX + 1];              // row maxima
@@ -108,7 +129,10 @@ __global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, floa
         const int ly = e / TW, lx = e - ly * TW;
         const int yy = y0 + ly - p, xx = x0 + lx - p;
         float v = -INFINITY;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = cert[(size_t)yy * W + xx] * -1.f + 1.f;     // MulConstant(-1), AddConstant(1)
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const float c = FROM_MASK ? cert_from_mask(mask, bw_flo, invert, fix_occ, border, yy, xx, H, W) : cert[(size_t)yy * W + xx];
+            v = c * -1.f + 1.f;                                      // MulConstant(-1), AddConstant(1)
+        }
         a[ly][lx] = v;
     }
     __syncthreads();
@@ -146,27 +170,6 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* frame, const
         in7[(3 + c) * n + i] = pr;
     }
     in7[6 * n + i] = cv;                                                             // core:171 / :136
-}
-
-// certainty from the checker's PGM byte: image.load(...,1) = byte/255; -invert_occlusion and
-// -fix_occlusions of fast_artistic_video.lua:79-86,99-112
-__global__ __launch_bounds__(256) void cert_raw_kernel(const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ,
-                                                       int border, float* cert, int H, int W)
-{
-    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const size_t i = (size_t)y * W + x;
-    float c = (float)mask[i] / 255.f;
-    if (invert) c = (c + -1.f) * -1.f;
-    if (fix_occ) {
-        const float2 f = bw_flo[i];
-        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
-        float ones = t.w00 + t.w01 + t.w10 + t.w11;         // warp of an all-ones image
-        ones = ones + -0.5f;
-        const float sg = ones > 0.f ? 1.f : (ones < 0.f ? -1.f : 0.f);
-        c *= fmaxf(sg, 0.f);
-    }
-    cert[i] = c;
 }
 
 // Fused A2 + A6 + A7 + reflection pad -> padded NHWC8 network input [H+2p][W+2p][8]
@@ -266,7 +269,7 @@ int launch_warp(const float* img, const float* flow, float* out, int B, int C, i
 int launch_min_filter_f32(const float* cert, float* out, int H, int W, int r, hipStream_t st)
 {
     FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
-    hipLaunchKernelGGL(min_filter_kernel, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, cert, out, H, W, r);
+    hipLaunchKernelGGL(min_filter_kernel<false>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, cert, nullptr, nullptr, 0, 0, 0, out, H, W, r);
     FAV_LAUNCH_CHECK("min_filter_kernel");
     return FAV_OK;
 }
@@ -282,10 +285,12 @@ int launch_assemble(const float* frame, const float* warped, const float* cert, 
 int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int invert, int fix_occ, int border, int r,
                         float* cert_tmp, float* cert, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(cert_raw_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, mask,
-                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert_tmp, H, W);
-    FAV_LAUNCH_CHECK("cert_raw_kernel");
-    return launch_min_filter_f32(cert_tmp, cert, H, W, r, st);
+    FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
+    (void)cert_tmp;                           // (the un-eroded certainty is no longer materialised: the erosion reads the mask byte)
+    hipLaunchKernelGGL(min_filter_kernel<true>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, nullptr, mask,
+                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert, H, W, r);
+    FAV_LAUNCH_CHECK("min_filter_kernel");
+    return FAV_OK;
 }
 
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo, const float* cert,
