@@ -191,7 +191,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # RCCL over xGMI
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.lookahead < 0:
-        args.lookahead = 1 if args.structure else 0      # (3-argument mode: 544 with, 548 frames/s without the look-ahead -- scripts/ab_lookahead.sh)
+        args.lookahead = 1 if args.structure else 0      # (3-argument mode: 574 with, 582 frames/s without the look-ahead at r02ze; 544 / 548 at r02n -- scripts/ab_lookahead.sh)
 
     # ---- weights: rank 0 parses the (synthetic, canonical-architecture) .t7 and broadcasts the packed blob
     ckpt = os.path.join(tempfile.gettempdir(), f"fav_bench_canonical_{os.getpid()}.t7")
