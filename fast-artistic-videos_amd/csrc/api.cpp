@@ -119,6 +119,26 @@ extern "C" int fav_min_filter_f32(const float* cert, float* out, int H, int W, i
     return launch_min_filter_f32(cert, out, H, W, r, static_cast<hipStream_t>(stream));
 }
 
+// ---- A9 on the GPU: the bytes of the PNG file (kernels_png.hip)
+extern "C" size_t fav_png_capacity(int W, int H) { return (W > 0 && H > 0) ? png_capacity(W, H) : 0; }
+extern "C" size_t fav_png_workspace_bytes(int W, int H) { return (W > 0 && H > 0) ? png_workspace_bytes(W, H) : 0; }
+
+extern "C" int fav_png_encode_rgb8(const uint8_t* rgb_hwc, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
+                                   void* workspace, size_t workspace_bytes, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(rgb_hwc, "fav_png_encode_rgb8: null image");
+    int rc = ensure_device(); if (rc) return rc;
+    return launch_png_encode(rgb_hwc, nullptr, W, H, png_out, capacity, png_bytes_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fav_png_encode_f32(const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
+                                  void* workspace, size_t workspace_bytes, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(rgb_planar, "fav_png_encode_f32: null image");
+    int rc = ensure_device(); if (rc) return rc;
+    return launch_png_encode(nullptr, rgb_planar, W, H, png_out, capacity, png_bytes_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int fav_assemble_input_f32(const float* frame_rgb, const float* warped_rgb, const float* cert, float* in7, int H,
                                       int W, fav_hipstream_t stream)
 {

@@ -214,6 +214,11 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const flo
                       const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st,
                       int fill_random = 0, unsigned seed = 0, unsigned index = 0);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
+size_t png_capacity(int W, int H);
+size_t png_workspace_bytes(int W, int H);
+int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,
+                      void* workspace, size_t ws_bytes, hipStream_t st);
+int launch_unpad_input(const float* in8, int H, int W, int pad, float* in7, hipStream_t st);
 int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,
                          int H, int W, double* partial256, hipStream_t st);
 

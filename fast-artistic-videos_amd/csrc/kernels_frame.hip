@@ -24,24 +24,30 @@ __device__ __forceinline__ int reflect(int i, int n)
 // bilinear weights/taps shared by all channels of one output pixel
 struct Taps {
     int o00, o01, o10, o11;     // linear offsets y*W+x (clamped so they are always addressable)
-    float w00, w01, w10, w11;   // already zeroed for invalid taps
+    float w00, w01, w10, w11;   // the weights as the reference forms them (NOT zeroed for taps outside the image)
+    unsigned in;                // bit k set: tap k lies inside the image; otherwise its VALUE is 0 (BilinearSamplerBDHW.cu:86-101)
 };
 
 // FAV_BORDER_STN: BilinearSamplerBDHW.cu:13-23,72-73,92-106.  yf = dy + y, xf = dx + x.
+// Bit-exact with the reference kernel compiled for gfx950 (oracle/_ref/libwarp_ref_nofma.so, tests/golden/warp_*.npz): the
+// same float -> int conversion (saturating, NaN -> 0), the weights left as computed and the out-of-image VALUES zeroed, so
+// that a non-finite weight meets a zero exactly as in the reference (inf x 0 = NaN for infinite flows).
 __device__ __forceinline__ Taps taps_stn(float yf, float xf, int H, int W)
 {
     Taps t;
     const int x0 = (int)floorf(xf), y0 = (int)floorf(yf);
     const float wx = 1.f - (xf - (float)x0), wy = 1.f - (yf - (float)y0);
-    const bool xi0 = x0 >= 0 && x0 <= W - 1, xi1 = x0 + 1 >= 0 && x0 + 1 <= W - 1;
-    const bool yi0 = y0 >= 0 && y0 <= H - 1, yi1 = y0 + 1 >= 0 && y0 + 1 <= H - 1;
-    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
-    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    const int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);          // INT_MAX + 1 wraps like the hardware add
+    const bool xi0 = x0 >= 0 && x0 <= W - 1, xi1 = x1 >= 0 && x1 <= W - 1;
+    const bool yi0 = y0 >= 0 && y0 <= H - 1, yi1 = y1 >= 0 && y1 <= H - 1;
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
     t.o00 = yc0 * W + xc0; t.o01 = yc0 * W + xc1; t.o10 = yc1 * W + xc0; t.o11 = yc1 * W + xc1;
-    t.w00 = (xi0 && yi0) ? wx * wy : 0.f;
-    t.w01 = (xi1 && yi0) ? (1.f - wx) * wy : 0.f;
-    t.w10 = (xi0 && yi1) ? wx * (1.f - wy) : 0.f;
-    t.w11 = (xi1 && yi1) ? (1.f - wx) * (1.f - wy) : 0.f;
+    t.w00 = wx * wy;
+    t.w01 = (1.f - wx) * wy;
+    t.w10 = wx * (1.f - wy);
+    t.w11 = (1.f - wx) * (1.f - wy);
+    t.in = (unsigned)(xi0 && yi0) | ((unsigned)(xi1 && yi0) << 1) | ((unsigned)(xi0 && yi1) << 2) | ((unsigned)(xi1 && yi1) << 3);
     return t;
 }
 
@@ -52,6 +58,7 @@ __device__ __forceinline__ Taps taps_cpu(float iy, float ix, int H, int W)
     if (iy < 0.f || iy > (float)(H - 1) || ix < 0.f || ix > (float)(W - 1)) {
         t.o00 = t.o01 = t.o10 = t.o11 = 0;
         t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+        t.in = 0u;
         return t;
     }
     const int xw = (int)floorf(ix), yn = (int)floorf(iy);
@@ -62,6 +69,7 @@ __device__ __forceinline__ Taps taps_cpu(float iy, float ix, int H, int W)
     t.w11 = (ix - (float)xw) * (iy - (float)yn);
     const int xec = min(xe, W - 1), ysc = min(ys, H - 1);
     t.o00 = yn * W + xw; t.o01 = yn * W + xec; t.o10 = ysc * W + xw; t.o11 = ysc * W + xec;
+    t.in = 15u;
     return t;
 }
 
@@ -72,8 +80,10 @@ __device__ __forceinline__ Taps make_taps(int border, float yf, float xf, int H,
 
 __device__ __forceinline__ float sample(const float* plane, const Taps& t)
 {
-    // summation order of BilinearSamplerBDHW.cu:103-106
-    return t.w00 * plane[t.o00] + t.w01 * plane[t.o01] + t.w10 * plane[t.o10] + t.w11 * plane[t.o11];
+    // summation order of BilinearSamplerBDHW.cu:103-106; taps outside the image contribute weight x 0 (:86-101)
+    const float v00 = (t.in & 1u) ? plane[t.o00] : 0.f, v01 = (t.in & 2u) ? plane[t.o01] : 0.f;
+    const float v10 = (t.in & 4u) ? plane[t.o10] : 0.f, v11 = (t.in & 8u) ? plane[t.o11] : 0.f;
+    return t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
 }
 
 __global__ __launch_bounds__(256) void warp_kernel(const float* img, const float* flow, float* out, int C, int H, int W,
@@ -103,7 +113,9 @@ __device__ __forceinline__ float cert_from_mask(const uint8_t* mask, const float
     if (fix_occ) {
         const float2 f = bw_flo[i];
         const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
-        float ones = t.w00 + t.w01 + t.w10 + t.w11;         // warp of an all-ones image
+        // warp of an all-ones image (fast_artistic_video.lua:79-86): weight x (1 | 0), the reference's expression
+        float ones = t.w00 * ((t.in & 1u) ? 1.f : 0.f) + t.w01 * ((t.in & 2u) ? 1.f : 0.f) + t.w10 * ((t.in & 4u) ? 1.f : 0.f) +
+                     t.w11 * ((t.in & 8u) ? 1.f : 0.f);
         ones = ones + -0.5f;
         const float sg = ones > 0.f ? 1.f : (ones < 0.f ? -1.f : 0.f);
         c *= fmaxf(sg, 0.f);
@@ -214,6 +226,19 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
     o[0] = lo; o[1] = hi;
 }
 
+// test view of the fused input: interior of the padded NHWC8 buffer -> planar [7][H][W] (fav_stream_get_input_f32)
+__global__ __launch_bounds__(256) void unpad_input_kernel(const float* in8, int H, int W, int pad, float* in7)
+{
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    const float4* p = reinterpret_cast<const float4*>(in8 + ((size_t)(y + pad) * (W + 2 * pad) + (x + pad)) * 8);
+    const float4 lo = p[0], hi = p[1];
+    in7[i] = lo.x; in7[n + i] = lo.y; in7[2 * n + i] = lo.z; in7[3 * n + i] = lo.w;
+    in7[4 * n + i] = hi.x; in7[5 * n + i] = hi.y; in7[6 * n + i] = hi.z;
+}
+
 // image.save: clamp to [0,1], *255, truncate [Torch7 `image`, recalled]; planar float RGB -> HWC u8
 __global__ __launch_bounds__(256) void quantize_kernel(const float* rgb, uint8_t* out, int H, int W)
 {
@@ -299,6 +324,13 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const flo
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
                        prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
     FAV_LAUNCH_CHECK("prep_input_kernel");
+    return FAV_OK;
+}
+
+int launch_unpad_input(const float* in8, int H, int W, int pad, float* in7, hipStream_t st)
+{
+    hipLaunchKernelGGL(unpad_input_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st, in8, H, W, pad, in7);
+    FAV_LAUNCH_CHECK("unpad_input_kernel");
     return FAV_OK;
 }
 

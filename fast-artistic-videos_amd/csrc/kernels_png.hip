@@ -1,0 +1,371 @@
+// kernels_png.hip -- A9 on the GPU: image.save("<prefix>-%05d.png", img) (fast_artistic_video.lua:160-170) as two kernels that
+// turn the stylised frame into the bytes of an RGB8 PNG file, so that the host only write()s them.
+//
+// Why: zlib on the host costs 25 ms per 1280x720 frame and core (round 2: Sub filter + Z_RLE, level 1); one GPU at 500 frames/s
+// needs 12.5 cores for it and eight GPUs behind a 16-CPU quota cannot have them.  Everything else of the
+// per-frame path already runs on the device.
+//
+// Format (restated lane by lane in oracle/png_model.py, which the CPU suite checks against zlib / PIL and the GPU suite against these
+// kernels byte for byte):
+//   * one IDAT chunk = one zlib stream (78 01); every image row is PNG filter type 1 (Sub) and ONE fixed-Huffman deflate block whose
+//     tokens are literals and distance-3 matches (repeated pixels and constant gradients become runs after the Sub filter), followed
+//     by an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that re-aligns the stream to a byte boundary: rows are
+//     independent byte strings;
+//   * png_rows_kernel: one wave per row.  64 positions per step: the match predicate f[p] == f[p-3] becomes a 64-bit ballot, run starts
+//     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes, 15 bits), token
+//     bit offsets from a wave prefix sum, tokens are OR-ed into the row's LDS bit buffer; Adler-32 parts (sum f, sum (n-i) f[i]);
+//   * png_pack_kernel: one block per row.  Prefix sum of the row sizes, the row copied to its final byte offset (dword stores from an
+//     LDS copy through a funnel shift, bytes at the two ragged ends), its CRC-32 (32-byte pieces, bitwise) raised to its position
+//     (x^(8 * bytes after it) mod P, square and multiply) and XOR-ed into one device word -- CRC-32 is linear, so the order does not
+//     matter; the last block to finish adds the chunk prelude and trailer, combines the Adler-32 and writes header, length, CRC, IEND
+//     and the file size.
+//   The output pointer may be device memory or host-mapped pinned memory (fav_stylize passes the latter: the packed bytes cross PCIe
+//   once, the host never touches them before write()).
+// HBM-bound by construction: 2.8 MB (u8) or 11 MB (planar float, quantisation fused: clamp, x255, truncate as quantize_kernel) in,
+// <= 3.1 MB staged + packed out.
+#include <cstring>
+
+#include "fav_internal.h"
+
+namespace fav {
+namespace {
+
+constexpr uint32_t CRC_POLY = 0xEDB88320u;      // CRC-32 (ISO-HDLC, zlib / PNG), reflected
+
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0), as zlib's multmodp
+__device__ __host__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+
+struct CrcPow { uint32_t x2n[32]; };            // x^(2^k) mod P, k = 0..31 (host-computed, passed by value)
+
+// x^(8 * nbytes) mod P
+__device__ inline uint32_t crc_xpow8(const CrcPow& t, unsigned long long nbytes)
+{
+    uint32_t p = 1u << 31;                      // x^0
+    int k = 3;                                  // x^(n * 2^3)
+    while (nbytes) {
+        if (nbytes & 1ull) p = crc_mulmod(t.x2n[k & 31], p);
+        nbytes >>= 1; ++k;
+    }
+    return p;
+}
+
+// standard CRC-32 (init ~0, final ~) of a short byte string in LDS / registers, bitwise
+__device__ inline uint32_t crc_bytes(const uint8_t* s, int n)
+{
+    uint32_t c = 0xFFFFFFFFu;
+    for (int i = 0; i < n; ++i) {
+        c ^= s[i];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1u)));
+    }
+    return ~c;
+}
+
+__device__ __forceinline__ uint32_t brev_n(uint32_t x, int n) { return __brev(x) >> (32 - n); }
+
+// row geometry shared by both kernels and the host
+__host__ __device__ inline int png_row_stride(int W)
+{
+    const int n = 3 * W + 1;
+    return (((3 + 9 * n + 7 + 3 + 7) / 8 + 4 + 3) & ~3) + 8;      // worst case: every byte a 9-bit literal; + 8 for the 2-word OR
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kernel 1: one wave per image row -> stage[row * stride ...], sizes[row], adler[row] = (sum f mod 65521, sum (n - i) f[i] mod 65521)
+// LDS: raw row (3W bytes at a dword-aligned base + the source misalignment), filtered row f (n = 3W + 1 bytes), output bit buffer.
+template <bool FROM_F32>
+__global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, uint8_t* stage,
+                                                      int stride, uint32_t* sizes, uint2* adler)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x, row = blockIdx.x;
+    const int nraw = 3 * W, n = nraw + 1;
+    const int raw_words = (nraw + 3 + 3) / 4 + 1, f_words = (n + 3) / 4 + 1, out_words = stride / 4;
+    uint32_t* raww = lds;
+    uint8_t* f = reinterpret_cast<uint8_t*>(lds + raw_words);
+    uint32_t* out = lds + raw_words + f_words;
+    const uint8_t* raw;
+    if (FROM_F32) {
+        // image.save: clamp to [0,1], x255, truncate (quantize_kernel); planar float RGB [3][H][W] -> interleaved bytes
+        uint8_t* r8 = reinterpret_cast<uint8_t*>(raww);
+        const size_t plane = (size_t)H * W;
+        const float* src = rgb_planar + (size_t)row * W;
+        for (int x = lane; x < W; x += 64) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = src[c * plane + x];
+                v = fminf(fmaxf(v, 0.f), 1.f);
+                r8[3 * x + c] = (uint8_t)(v * 255.f);
+            }
+        }
+        raw = r8;
+    } else {
+        const size_t base = (size_t)row * nraw;
+        const size_t a0 = base & ~(size_t)3;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb_hwc + a0);
+        const int nw = (int)((base + nraw - a0 + 3) / 4);
+        for (int i = lane; i < nw; i += 64) raww[i] = src[i];      // (the frame buffer is readable to the next dword boundary: hipMalloc granularity)
+        raw = reinterpret_cast<const uint8_t*>(raww) + (base - a0);
+    }
+    for (int i = lane; i < out_words; i += 64) out[i] = 0u;
+    __syncthreads();
+    // Sub filter + Adler-32 parts
+    unsigned long long sa = 0, sb = 0;
+    if (lane == 0) { f[0] = 1; sa = 1; sb = (unsigned long long)n; }
+    for (int p = 1 + lane; p < n; p += 64) {
+        const int j = p - 1;
+        const uint32_t v = (uint32_t)(raw[j] - (j >= 3 ? raw[j - 3] : 0)) & 255u;
+        f[p] = (uint8_t)v;
+        sa += v; sb += (unsigned long long)(n - p) * v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    __syncthreads();
+    // tokens
+    if (lane == 0) out[0] = 2u;                                    // BFINAL = 0, BTYPE = 01 (fixed Huffman), LSB first
+    __syncthreads();
+    int bitpos = 3;
+    for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < n;
+        const uint32_t v = valid ? f[p] : 0u;
+        const bool m = valid && p >= 3 && v == f[p - 3];
+        const unsigned long long mask = __ballot(m);
+        uint32_t val = 0; int nb = 0;
+        if (valid) {
+            bool lit = true;
+            if (m) {
+                const unsigned long long below = ~mask & ((1ull << lane) - 1ull);
+                const int s = below ? 64 - __clzll((long long)below) : 0;
+                const unsigned long long above = (~mask >> lane) >> 1;
+                const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                const int L = e - s;
+                if (L >= 3) {
+                    lit = false;
+                    if (lane == s) {                               // the run's first lane emits the match, the others nothing
+                        int sym, eb, ev;
+                        if (L <= 10) { sym = 254 + L; eb = 0; ev = 0; }
+                        else if (L <= 18) { sym = 265 + ((L - 11) >> 1); eb = 1; ev = (L - 11) & 1; }
+                        else if (L <= 34) { sym = 269 + ((L - 19) >> 2); eb = 2; ev = (L - 19) & 3; }
+                        else { sym = 273 + ((L - 35) >> 3); eb = 3; ev = (L - 35) & 7; }
+                        val = brev_n((uint32_t)(sym - 256), 7); nb = 7;
+                        val |= (uint32_t)ev << nb; nb += eb;
+                        val |= 8u << nb; nb += 5;                   // distance 3 = code 2, 5 bits, reversed: 01000
+                    }
+                }
+            }
+            if (lit) {
+                if (v < 144u) { val = brev_n(0x30u + v, 8); nb = 8; }
+                else { val = brev_n(0x190u + v - 144u, 9); nb = 9; }
+            }
+        }
+        int incl = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        const int total = __shfl(incl, 63);
+        if (nb) {
+            const int o = bitpos + incl - nb;
+            const unsigned long long vv = (unsigned long long)val << (o & 31);
+            atomicOr(&out[o >> 5], (uint32_t)vv);
+            if (vv >> 32) atomicOr(&out[(o >> 5) + 1], (uint32_t)(vv >> 32));
+        }
+        bitpos += total;
+    }
+    // end of block (7 zero bits), empty stored block (3 zero bits, pad to a byte, 00 00 FF FF)
+    bitpos += 7 + 3;
+    const int bo = (bitpos + 7) >> 3;
+    const int size = bo + 4;
+    __syncthreads();
+    if (lane == 0) {
+        uint8_t* o8 = reinterpret_cast<uint8_t*>(out);
+        o8[bo + 2] = 0xFF; o8[bo + 3] = 0xFF;
+        sizes[row] = (uint32_t)size;
+        adler[row] = make_uint2((uint32_t)(sa % 65521ull), (uint32_t)(sb % 65521ull));
+    }
+    __syncthreads();
+    uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (size_t)row * stride);
+    const int nwo = (size + 3) >> 2;
+    for (int i = lane; i < nwo; i += 64) dst[i] = out[i];
+}
+
+struct PngHeader { uint8_t b[33]; };            // signature + IHDR chunk (host-built)
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kernel 2: one block per row: place the row, fold its CRC in; the last block finishes the file.
+// ctl[0] = CRC accumulator, ctl[1] = finished-block counter (both zeroed by the launcher before the call).
+__global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int stride, const uint32_t* sizes, const uint2* adler, int W, int H,
+                                                       uint8_t* png, uint32_t* png_bytes, uint32_t* ctl, PngHeader hdr, CrcPow pw)
+{
+    extern __shared__ uint32_t lds[];           // the row's bytes (stride) + reduction scratch
+    __shared__ unsigned long long red[256];
+    __shared__ uint32_t redx[256];
+    __shared__ int is_last;
+    const int t = threadIdx.x, row = blockIdx.x;
+    // offsets: sum of the sizes before this row, and of all rows
+    unsigned long long before = 0, all = 0;
+    for (int i = t; i < H; i += 256) { const uint32_t s = sizes[i]; all += s; if (i < row) before += s; }
+    red[t] = before; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    before = red[0]; __syncthreads();
+    red[t] = all; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    all = red[0]; __syncthreads();
+    const int size = (int)sizes[row];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + (size_t)row * stride);
+    const int nws = (size + 3) >> 2;
+    for (int i = t; i < nws + 1; i += 256) lds[i] = i < nws ? src[i] : 0u;
+    __syncthreads();
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(lds);
+    // copy to png[43 + before ...): whole destination dwords through a funnel shift, ragged ends byte-wise
+    const unsigned long long D = 43ull + before;
+    const unsigned long long d_first = (D + 3) >> 2, d_end = (D + (unsigned long long)size) >> 2;      // dwords [d_first, d_end) lie inside
+    uint32_t* png32 = reinterpret_cast<uint32_t*>(png);
+    if (d_end > d_first) {
+        for (unsigned long long d = d_first + t; d < d_end; d += 256) {
+            const int si = (int)(4ull * d - D);
+            const uint32_t lo = lds[si >> 2], hi = lds[(si >> 2) + 1];
+            png32[d] = __funnelshift_r(lo, hi, 8 * (si & 3));
+        }
+        const int head = (int)(4ull * d_first - D);                                                    // 0..3 bytes before the first whole dword
+        if (t < head) png[D + t] = s8[t];
+        const int tail0 = (int)(4ull * d_end - D);                                                     // bytes after the last whole dword
+        if (t < size - tail0) png[D + tail0 + t] = s8[tail0 + t];
+    } else {
+        for (int i = t; i < size; i += 256) png[D + i] = s8[i];
+    }
+    // CRC-32 of the row's bytes: 32-byte pieces counted from the END (a piece's power is then x^(8 * 32 * index)), XOR of the raised parts
+    uint32_t acc = 0;
+    const int npieces = (size + 31) >> 5;
+    for (int j = t; j < npieces; j += 256) {
+        const int hi = size - 32 * j, lo = hi - 32 > 0 ? hi - 32 : 0;
+        const uint32_t c = crc_bytes(s8 + lo, hi - lo);
+        acc ^= crc_mulmod(crc_xpow8(pw, 32ull * j), c);
+    }
+    redx[t] = acc; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) redx[t] ^= redx[t + s]; __syncthreads(); }
+    if (t == 0) {
+        const unsigned long long after = all - before - (unsigned long long)size + 6ull;               // + final block (2) + Adler-32 (4)
+        atomicXor(&ctl[0], crc_mulmod(crc_xpow8(pw, after), redx[0]));
+        __threadfence();
+        is_last = atomicAdd(&ctl[1], 1u) == (uint32_t)(H - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- the last block to finish: Adler-32, trailer, chunk CRC, header, IEND, file size
+    __threadfence();
+    const unsigned long long n = 3ull * W + 1ull;
+    unsigned long long s1 = 0, s2 = 0;
+    for (int k = t; k < H; k += 256) {
+        const uint2 ab = adler[k];
+        s1 += ab.x;
+        s2 += (ab.y + ((n * (unsigned long long)(H - 1 - k)) % 65521ull) * ab.x) % 65521ull;
+    }
+    red[t] = s1; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    s1 = red[0]; __syncthreads();
+    red[t] = s2; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    s2 = red[0];
+    if (t == 0) {
+        const uint32_t a1 = (uint32_t)((1ull + s1) % 65521ull);
+        const uint32_t a2 = (uint32_t)((((n % 65521ull) * ((unsigned long long)H % 65521ull)) % 65521ull + s2) % 65521ull);
+        const uint32_t ad = (a2 << 16) | a1;
+        const unsigned long long E = 43ull + all;                  // end of the row data
+        uint8_t tr[6] = {0x03, 0x00, (uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad};
+        for (int i = 0; i < 6; ++i) png[E + i] = tr[i];
+        const uint8_t pre[6] = {'I', 'D', 'A', 'T', 0x78, 0x01};
+        uint32_t crc = atomicXor(&ctl[0], 0u);
+        crc ^= crc_mulmod(crc_xpow8(pw, all + 6ull), crc_bytes(pre, 6));
+        crc ^= crc_bytes(tr, 6);
+        for (int i = 0; i < 33; ++i) png[i] = hdr.b[i];
+        const uint32_t len = (uint32_t)(all + 8ull);               // zlib header (2) + rows + final block (2) + Adler-32 (4)
+        png[33] = (uint8_t)(len >> 24); png[34] = (uint8_t)(len >> 16); png[35] = (uint8_t)(len >> 8); png[36] = (uint8_t)len;
+        for (int i = 0; i < 6; ++i) png[37 + i] = pre[i];
+        png[E + 6] = (uint8_t)(crc >> 24); png[E + 7] = (uint8_t)(crc >> 16); png[E + 8] = (uint8_t)(crc >> 8); png[E + 9] = (uint8_t)crc;
+        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+        for (int i = 0; i < 12; ++i) png[E + 10 + i] = iend[i];
+        *png_bytes = (uint32_t)(E + 22ull);
+        __threadfence_system();
+    }
+}
+
+uint32_t host_crc32(const uint8_t* s, size_t n)
+{
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) { c ^= s[i]; for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1u))); }
+    return ~c;
+}
+
+}  // namespace
+
+size_t png_capacity(int W, int H) { return 43 + (size_t)H * png_row_stride(W) + 6 + 4 + 12 + 8; }
+// workspace: [ctl: 4 words, 16 B][sizes: H words][adler: H uint2][stage: H * stride], each part 16-byte aligned
+size_t png_workspace_bytes(int W, int H)
+{
+    const size_t h4 = ((size_t)H * 4 + 15) & ~(size_t)15, h8 = ((size_t)H * 8 + 15) & ~(size_t)15;
+    return 16 + h4 + h8 + (size_t)H * png_row_stride(W) + 16;
+}
+
+int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,
+                      void* workspace, size_t ws_bytes, hipStream_t st)
+{
+    FAV_REQUIRE((rgb_hwc != nullptr) != (rgb_planar != nullptr), "png: exactly one of the u8 and the float source must be given");
+    FAV_REQUIRE(W >= 1 && H >= 1 && W <= 16000 && H <= 65535, "png: %dx%d is outside the encoder's range (width <= 16000, height <= 65535)", W, H);
+    FAV_REQUIRE(png_out && png_bytes && workspace, "png: null argument");
+    FAV_REQUIRE(capacity >= png_capacity(W, H), "png: output capacity %zu < fav_png_capacity = %zu", capacity, png_capacity(W, H));
+    FAV_REQUIRE(ws_bytes >= png_workspace_bytes(W, H), "png: workspace %zu < fav_png_workspace_bytes = %zu", ws_bytes, png_workspace_bytes(W, H));
+    FAV_REQUIRE((reinterpret_cast<uintptr_t>(png_out) & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "png: output must be 4-byte, workspace 16-byte aligned");
+    const int stride = png_row_stride(W);
+    const size_t h4 = ((size_t)H * 4 + 15) & ~(size_t)15, h8 = ((size_t)H * 8 + 15) & ~(size_t)15;
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    uint32_t* ctl = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* sizes = reinterpret_cast<uint32_t*>(ws + 16);
+    uint2* adler = reinterpret_cast<uint2*>(ws + 16 + h4);
+    uint8_t* stage = ws + 16 + h4 + h8;
+    FAV_HIP(hipMemsetAsync(ctl, 0, 16, st));
+    const int nraw = 3 * W, n = nraw + 1;
+    const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)stride / 4) * 4;
+    const size_t lds2 = (size_t)stride + 8;
+    static thread_local bool attr_set = false;
+    if (!attr_set && (lds1 > 48 * 1024 || lds2 > 48 * 1024)) {
+        // (rows wider than ~2600 pixels: raise the dynamic LDS limit once; 160 KB per CU on gfx950)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+        attr_set = true;
+    }
+    if (rgb_planar)
+        hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler);
+    else
+        hipLaunchKernelGGL(png_rows_kernel<false>, dim3(H), dim3(64), lds1, st, rgb_hwc, nullptr, W, H, stage, stride, sizes, adler);
+    FAV_LAUNCH_CHECK("png_rows_kernel");
+    PngHeader hdr;
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    memcpy(hdr.b, sig, 8);
+    uint8_t* q = hdr.b + 8;
+    q[0] = 0; q[1] = 0; q[2] = 0; q[3] = 13; memcpy(q + 4, "IHDR", 4);
+    q[8] = (uint8_t)(W >> 24); q[9] = (uint8_t)(W >> 16); q[10] = (uint8_t)(W >> 8); q[11] = (uint8_t)W;
+    q[12] = (uint8_t)(H >> 24); q[13] = (uint8_t)(H >> 16); q[14] = (uint8_t)(H >> 8); q[15] = (uint8_t)H;
+    q[16] = 8; q[17] = 2; q[18] = 0; q[19] = 0; q[20] = 0;          // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, not interlaced
+    const uint32_t c = host_crc32(q + 4, 17);
+    q[21] = (uint8_t)(c >> 24); q[22] = (uint8_t)(c >> 16); q[23] = (uint8_t)(c >> 8); q[24] = (uint8_t)c;
+    CrcPow pw;
+    uint32_t p = 1u << 30;                                          // x^1
+    pw.x2n[0] = p;
+    for (int k = 1; k < 32; ++k) pw.x2n[k] = p = crc_mulmod(p, p);
+    hipLaunchKernelGGL(png_pack_kernel, dim3(H), dim3(256), lds2, st, stage, stride, sizes, adler, W, H, static_cast<uint8_t*>(png_out), png_bytes, ctl,
+                       hdr, pw);
+    FAV_LAUNCH_CHECK("png_pack_kernel");
+    return FAV_OK;
+}
+
+}  // namespace fav

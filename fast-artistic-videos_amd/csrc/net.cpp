@@ -311,11 +311,12 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
     // generic kernel while look-ahead masks are in flight: its stream-K hand-off assumes that all blocks are resident at once, and the
     // side queues' kernels land on any CU -- owners then wait for blocks that have not started (d128: 186 us against 115 us alone,
-    // profiles/r02p_4arg_kernel_stats.csv).  Data-parallel grids do not wait for anybody.
+    // profiles/r02p_4arg_kernel_stats.csv).  Data-parallel grids do not wait for anybody.  The halo-resident 3x3 kernel (bf16 fast
+    // mode, FAV_NO_WINO) hands tiles over the same way and takes the same descriptor.
     ConvLaunch cg = cs;
     static const int side_sk_mode = getenv("FAV_SIDE_SK") ? atoi(getenv("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
     if (reserve_cus > 0 && side_sk_mode != 1) cg.no_sk = 1;
-    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cs, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
+    auto go = [&]() { return use_first ? launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cg, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
@@ -729,6 +730,7 @@ struct fav_stream {
     float* cert_tmp = nullptr; float* cert = nullptr;
     uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
     void* ws = nullptr; size_t ws_bytes = 0;
+    void* png_ws = nullptr; size_t png_ws_bytes = 0;      // workspace of fav_stream_encode_png (allocated on first use)
     // look-ahead mask (fav_stream_prefetch_mask)
     // two side queues with their own structure workspaces: the masks of frames i+1 and i+2 are computed concurrently
     // (each 4-argument mask contains a ~3 ms sequential fp32 chain, CMatrix::avg), three look-ahead slots
@@ -745,7 +747,7 @@ struct fav_stream {
         if (ev_in) (void)hipEventDestroy(ev_in);
         for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); (void)hipFree(pf.cert); }
         for (int i = 0; i < NSIDE; ++i) (void)hipFree(side_cert_tmp[i]);
-        (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws);
+        (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws); (void)hipFree(png_ws);
     }
 };
 
@@ -951,6 +953,24 @@ extern "C" int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, f
     FAV_HIP(hipMemcpyAsync(s->state, state_rgb_f32, (size_t)3 * s->H * s->W * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     s->has_state = true;
     return FAV_OK;
+}
+
+extern "C" int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && s->has_state, "fav_stream_encode_png: no stylised frame yet");
+    FAV_HIP(hipSetDevice(s->net->device));
+    if (!s->png_ws) {
+        s->png_ws_bytes = png_workspace_bytes(s->W, s->H);
+        FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
+    }
+    return launch_png_encode(nullptr, s->state, s->W, s->H, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fav_stream_get_input_f32(const fav_stream* s, float* in7, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && in7 && s->frame_counter > 0, "fav_stream_get_input_f32: no frame has been assembled yet");
+    FAV_HIP(hipSetDevice(s->net->device));
+    return launch_unpad_input(s->in8, s->H, s->W, s->net->pad, in7, static_cast<hipStream_t>(stream));
 }
 
 extern "C" const uint8_t* fav_stream_last_mask(const fav_stream* s) { return s ? s->mask : nullptr; }

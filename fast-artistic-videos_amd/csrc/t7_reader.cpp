@@ -128,10 +128,18 @@ struct Reader {
             v->body = obj(depth + 1);
             return v;
         }
-        case 6: case 7: case 8: {
-            // TYPE_FUNCTION / LEGACY_TYPE_RECUR_FUNCTION / TYPE_RECUR_FUNCTION [recalled, File.lua]: index, dumped
-            // bytecode (int32 length + bytes), then the upvalue table.  Closures stored in a checkpoint's `opt` or in a
-            // module field are irrelevant to the forward pass: parsed and ignored.
+        case 6: {
+            // TYPE_FUNCTION (the legacy record) [recalled, File.lua]: NO memo index -- dumped bytecode (int32 length + bytes),
+            // then the upvalue table.  Only the RECUR_FUNCTION records below carry an index.
+            v->kind = Val::FUNC;
+            (void)rawstr();
+            (void)obj(depth + 1);
+            return v;
+        }
+        case 7: case 8: {
+            // LEGACY_TYPE_RECUR_FUNCTION / TYPE_RECUR_FUNCTION [recalled, File.lua]: index, dumped bytecode (int32 length +
+            // bytes), then the upvalue table.  Closures stored in a checkpoint's `opt` or in a module field are irrelevant to the
+            // forward pass: parsed and ignored.
             const int idx = i32();
             auto it = memo.find(idx);
             if (it != memo.end()) return it->second;

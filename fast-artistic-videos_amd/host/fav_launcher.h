@@ -6,12 +6,22 @@
 //   * rank 0 parses the checkpoint(s); the packed blob (fav_net_pack_host) reaches the other ranks through ONE collective per
 //     model, ncclBroadcast (RCCL over xGMI; ncclCommInitRank + a unique-id file) -- there is no other exchange: a video's frame i
 //     needs only its own frame i-1;
-//   * host thread budget per worker = usable CPUs (cgroup quota respected) / workers.
+//   * host thread budget per worker = usable CPUs (cgroup quota respected) / workers; each worker is pinned to its contiguous share of
+//     the launcher's CPU affinity mask (-pin_workers 0 turns that off);
+//   * failure handling: the launcher parses the checkpoint(s) itself before forking, reaps with waitpid(-1) and stops every other
+//     worker when one fails (a rank blocked in an RCCL call never returns after a peer has gone); workers die with the launcher.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <chrono>
@@ -42,11 +52,9 @@ inline std::vector<std::string> split_list(const std::string& v)
     return out;
 }
 
-// CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (containers: the GPU box of this project
-// shows 256 hardware threads under a 16-CPU quota -- 32 deflate threads there only fight each other)
-inline int effective_cpus()
+// CPU quota of the cgroup in whole CPUs (rounded up), or a very large number when there is none
+inline int quota_cpus()
 {
-    int n = std::max(1, (int)std::thread::hardware_concurrency());
     long long quota = -1, period = 0;
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
         char q[64] = "";
@@ -57,16 +65,38 @@ inline int effective_cpus()
         fclose(g);
         if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
     }
-    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1ll, (quota + period - 1) / period));
-    return n;
+    if (quota > 0 && period > 0) return (int)std::max(1ll, (quota + period - 1) / period);
+    return 1 << 20;
 }
 
-// PNG writer threads of one worker when `world` workers share the host: deflate is the slowest host stage (~25 ms per 1280x720
-// frame and core at the default -png_level 1), so a worker gets its share of the usable CPUs (the loaders mostly wait on I/O)
-inline int writer_budget(int requested, int world)
+// CPUs the calling process may run on (its affinity mask), in ascending order
+inline std::vector<int> allowed_cpus()
+{
+    std::vector<int> out;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) out.push_back(c);
+    return out;
+}
+
+// CPUs this process may actually use: its affinity mask, capped by the cgroup CPU quota (containers: the GPU box of this project
+// shows 256 hardware threads under a 16-CPU quota -- 32 deflate threads there only fight each other)
+inline int effective_cpus()
+{
+    const int aff = (int)allowed_cpus().size();
+    return std::max(1, std::min(aff > 0 ? aff : (int)std::thread::hardware_concurrency(), quota_cpus()));
+}
+
+// PNG writer threads of one worker when `world` workers share the host: the worker's share of the affinity mask (already narrowed
+// when the launcher pinned it) and of the quota (which cannot be narrowed per process: divide)
+inline int writer_budget(int requested, int world, bool pinned = false)
 {
     if (requested > 0) return requested;
-    return std::max(4, std::min(32, effective_cpus() / std::max(1, world)));
+    world = std::max(1, world);
+    int aff = std::max(1, (int)allowed_cpus().size());
+    if (!pinned) aff = std::max(1, aff / world);
+    const int q = std::max(1, quota_cpus() / world);
+    return std::max(2, std::min(32, std::min(aff, q)));
 }
 
 inline void ncheck(ncclResult_t r, const char* what) { if (r != ncclSuccess) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(r)); }
@@ -103,20 +133,73 @@ inline std::vector<uint8_t> pack_model(const std::string& path)
 inline std::string json_str(const std::string& v) { std::string o = "\""; for (char c : v) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o + "\""; }
 
 
-// launcher: one worker process per GPU, each re-executing this binary with its rank; returns the worst exit code.
-// `idf` receives the path the workers exchange the RCCL unique id (and, with -timing, their results) through.
-inline int spawn_workers(int argc, char** argv, int world, std::string* idf_out)
+// ---- exchange directory -----------------------------------------------------------------------------------------------------
+// Everything the launcher and its workers exchange through the file system (the RCCL unique id, the per-rank results) lives in a
+// PRIVATE directory: mkdtemp (mode 0700) under $TMPDIR or /tmp, files created with O_CREAT|O_EXCL|O_NOFOLLOW, the directory removed
+// by the launcher on every exit path.  (Round 2 reused a predictable, unlinked mkstemp name in world-writable /tmp.)
+inline std::string make_exchange_dir()
 {
-    char idf[] = "/tmp/fav_rccl_id_XXXXXX";
-    const int fd = mkstemp(idf);
-    if (fd < 0) die("cannot create the RCCL id file");
-    close(fd); unlink(idf);                                   // the name is reused: rank 0 creates <name> atomically
+    const char* base = getenv("TMPDIR");
+    std::string t = std::string(base && *base ? base : "/tmp") + "/fav_launch_XXXXXX";
+    std::vector<char> buf(t.begin(), t.end()); buf.push_back(0);
+    if (!mkdtemp(buf.data())) die("cannot create the launcher's exchange directory under " + t);
+    return buf.data();
+}
+
+inline bool write_private_file(const std::string& path, const void* data, size_t n)
+{
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
+    const bool ok = write(fd, data, n) == (ssize_t)n;
+    return close(fd) == 0 && ok;
+}
+
+inline void remove_exchange_dir(const std::string& dir, int world)
+{
+    if (dir.empty()) return;
+    unlink((dir + "/id").c_str()); unlink((dir + "/id.tmp").c_str());
+    for (int r = 0; r < world; ++r) unlink((dir + "/id.rank" + std::to_string(r)).c_str());
+    rmdir(dir.c_str());
+}
+
+// worker r of `world` gets the r-th contiguous share of the launcher's CPUs, so that the loaders / PNG writers of different workers
+// do not migrate across each other's cores (a quota, unlike an affinity mask, cannot be split this way: writer_budget divides it)
+inline std::vector<int> worker_cpu_share(const std::vector<int>& cpus, int r, int world)
+{
+    if ((int)cpus.size() < world) return cpus;                 // fewer CPUs than workers: everybody shares all of them
+    const size_t lo = cpus.size() * (size_t)r / (size_t)world, hi = cpus.size() * (size_t)(r + 1) / (size_t)world;
+    return std::vector<int>(cpus.begin() + lo, cpus.begin() + hi);
+}
+
+// launcher: one worker process per GPU, each re-executing this binary with its rank; returns the worst exit code.
+// validate_models (called by the CLIs before anything else): the checkpoints every worker depends on are parsed by the launcher
+// first (host-only), so a typo or a damaged file ends the job with the reader's message before any process waits inside a
+// collective.  The first worker that fails takes its siblings down (SIGTERM,
+// SIGKILL after a grace period): a rank blocked in ncclCommInitRank / ncclBroadcast never returns once a peer is gone.
+// `dir_out` receives the exchange directory (remove_exchange_dir after reading the results).
+inline void validate_models(const std::vector<std::string>& models)
+{
+    for (const std::string& m : models) if (!m.empty()) (void)pack_model(m);      // dies with fav_last_error() (core.lua:39-43)
+}
+
+inline int spawn_workers(int argc, char** argv, int world, bool pin, std::string* dir_out)
+{
+    const std::string dir = make_exchange_dir();
+    const std::string idf = dir + "/id";
+    const std::vector<int> cpus = allowed_cpus();
     std::vector<pid_t> kids;
     fflush(stdout); fflush(stderr);
     for (int r = 0; r < world; ++r) {
         const pid_t pid = fork();                             // (exec follows at once: no HIP state is shared)
-        if (pid < 0) die("fork failed");
+        if (pid < 0) { for (pid_t k : kids) kill(k, SIGTERM); remove_exchange_dir(dir, world); die("fork failed"); }
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGTERM);                 // a worker does not outlive its launcher
+            if (pin && world > 1) {
+                const std::vector<int> mine = worker_cpu_share(cpus, r, world);
+                cpu_set_t set; CPU_ZERO(&set);
+                for (int c : mine) CPU_SET(c, &set);
+                if (!mine.empty()) (void)sched_setaffinity(0, sizeof set, &set);
+            }
             std::vector<std::string> args(argv, argv + argc);
             args.insert(args.end(), {"-worker_rank", std::to_string(r), "-worker_world", std::to_string(world), "-rccl_id_file", idf});
             std::vector<char*> av;
@@ -127,15 +210,48 @@ inline int spawn_workers(int argc, char** argv, int world, std::string* idf_out)
         }
         kids.push_back(pid);
     }
-    int worst = 0;
-    for (pid_t k : kids) { int stt = 0; waitpid(k, &stt, 0); const int rc = WIFEXITED(stt) ? WEXITSTATUS(stt) : 128; if (rc > worst) worst = rc; }
-    *idf_out = idf;
+    int worst = 0; size_t alive = kids.size(); bool killed = false;
+    auto t_kill = std::chrono::steady_clock::now();
+    while (alive > 0) {
+        int stt = 0;
+        const pid_t k = waitpid(-1, &stt, killed ? WNOHANG : 0);
+        if (k > 0) {
+            auto it = std::find(kids.begin(), kids.end(), k);
+            if (it == kids.end()) continue;
+            *it = -1; --alive;
+            const int rc = WIFEXITED(stt) ? WEXITSTATUS(stt) : 128 + (WIFSIGNALED(stt) ? WTERMSIG(stt) : 0);
+            if (rc != 0 && !killed) {
+                worst = rc;                                   // the first failure is the job's exit code
+                fprintf(stderr, "worker %d exited with status %d: stopping the other workers\n", (int)(it - kids.begin()), rc);
+                for (pid_t o : kids) if (o > 0) kill(o, SIGTERM);
+                killed = true; t_kill = std::chrono::steady_clock::now();
+            }
+        } else if (k < 0 && errno != EINTR) {
+            break;                                            // ECHILD: nothing left to wait for
+        } else if (killed) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_kill).count() > 5.0)
+                for (pid_t o : kids) if (o > 0) kill(o, SIGKILL);
+            usleep(20000);
+        }
+    }
+    *dir_out = dir;
     return worst;
 }
 
-// after the workers: total frames / slowest worker's stylisation time (each worker left "<frames> <seconds>" in <idf>.rank<r>)
-inline void print_aggregate(const std::string& idf, int world, size_t nstreams)
+// test hook of the reaper (CPU suite, -dry_run only): FAV_TEST_WORKER_FAIL=<rank> makes that worker exit with status 3 and the
+// others block like a rank inside a collective whose peer has gone
+inline void dry_run_failure_hook(int rank)
 {
+    const char* e = getenv("FAV_TEST_WORKER_FAIL");
+    if (!e || rank < 0) return;
+    if (atoi(e) == rank) { fprintf(stderr, "[rank %d] simulated failure\n", rank); exit(3); }
+    sleep(120);
+}
+
+// after the workers: total frames / slowest worker's stylisation time (each worker left "<frames> <seconds>" in <idf>.rank<r>)
+inline void print_aggregate(const std::string& dir, int world, size_t nstreams)
+{
+    const std::string idf = dir + "/id";
     int frames = 0; double secs = 0; std::string per = "";
     for (int r = 0; r < world; ++r) {
         const std::string f = idf + ".rank" + std::to_string(r);
@@ -153,7 +269,8 @@ inline void print_aggregate(const std::string& idf, int world, size_t nstreams)
 inline void write_worker_result(const std::string& idf, int rank, int frames, double seconds)
 {
     const std::string f = idf + ".rank" + std::to_string(rank);
-    if (FILE* fp = fopen(f.c_str(), "w")) { fprintf(fp, "%d %.6f\n", frames, seconds); fclose(fp); }
+    char line[64]; const int n = snprintf(line, sizeof line, "%d %.6f\n", frames, seconds);
+    if (!write_private_file(f, line, (size_t)n)) fprintf(stderr, "cannot write %s\n", f.c_str());
 }
 
 // worker side: rank 0 parses + packs, everybody receives the blob(s) over RCCL and builds its network(s) on `device`
@@ -161,12 +278,14 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
                              fav_net** net, fav_net** net_img, size_t nstreams, int nwriters)
 {
     ncclUniqueId id;
+    std::vector<uint8_t> blob, blob_img;
     if (rank == 0) {
+        // parse and pack BEFORE the id is published: if the checkpoint is unusable this rank dies here, the launcher stops the
+        // others (they are still polling for the id file, not inside a collective)
+        blob = pack_model(vid_path); if (!img_path.empty()) blob_img = pack_model(img_path);
         ncheck(ncclGetUniqueId(&id), "ncclGetUniqueId");
         const std::string tmp = idf + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof id, 1, f) != 1) die("cannot write " + tmp);
-        fclose(f);
+        if (!write_private_file(tmp, &id, sizeof id)) die("cannot write " + tmp);
         if (rename(tmp.c_str(), idf.c_str())) die("cannot publish " + idf);
     } else {
         const auto t0 = std::chrono::steady_clock::now();
@@ -181,8 +300,6 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
     ncclComm_t comm;
     ncheck(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
     hipStream_t bst; if (hipStreamCreate(&bst) != hipSuccess) die("hipStreamCreate failed");
-    std::vector<uint8_t> blob, blob_img;
-    if (rank == 0) { blob = pack_model(vid_path); if (!img_path.empty()) blob_img = pack_model(img_path); }
     const auto tb = std::chrono::steady_clock::now();
     broadcast_blob(comm, rank, blob, bst);
     broadcast_blob(comm, rank, blob_img, bst);
@@ -193,7 +310,6 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
            blob.size(), blob_img.empty() ? "" : " (+ image model)", bms, nstreams, nwriters);
     hipStreamDestroy(bst);
     ncclCommDestroy(comm);
-    if (rank == 0) unlink(idf.c_str());
 }
 
 }  // namespace favl

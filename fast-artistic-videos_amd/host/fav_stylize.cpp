@@ -10,7 +10,9 @@
 //
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
-// makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>,
+// makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>,
+// -png_encoder <gpu|host> (gpu, default: the PNG file's bytes are produced on the device, the host only write()s them -- fixed-Huffman
+// deflate, larger files; host: zlib on the writer threads at -png_level <0..9>, ~25 ms per 1280x720 frame and core),
 // -precision <fp32|bf16> (fp32 = parity mode, default; bf16 = optional fast mode, see include/fav.h),
 // -seed <n> (key of the documented RNG behind -fill_occlusions uniform-random, unseeded in the reference),
 // -writers <n>, -timing <0|1>, -temporal_eval_file <path> (the temporal-consistency number of -evaluate, fav.lua:128-151,
@@ -28,11 +30,14 @@
 //   -force_dist 1         take the worker / RCCL path even for -gpus 1;  -dry_run 1: workers print their assignment and exit
 //                         without touching a device (plumbing test).
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -174,7 +179,7 @@ bool read_png_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& W, i
 // tiny thread pool for PNG encode + write
 class Pool {
 public:
-    explicit Pool(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); }); }
+    explicit Pool(int n, int device = -1) { for (int i = 0; i < n; ++i) th_.emplace_back([this, device] { if (device >= 0) (void)hipSetDevice(device); run(); }); }
     ~Pool() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
     void submit(std::function<void()> f) { { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); ++pending_; } cv_.notify_one(); }
     void wait_below(size_t n) { std::unique_lock<std::mutex> l(m_); done_.wait(l, [&] { return pending_ <= n; }); }
@@ -213,7 +218,14 @@ struct FrameIn {           // everything frame i needs from disk
 };
 
 
-struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0; };
+struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0, cpu_s = 0; long long png_bytes = 0; };
+
+double process_cpu_seconds()
+{
+    struct rusage ru;
+    if (getrusage(RUSAGE_SELF, &ru)) return 0.0;
+    return ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+}
 
 // One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
 // `net` / `net_img` live on the current device; `nwriters` PNG threads.
@@ -264,7 +276,13 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         return in;
     };
 
-    Pool writers(nwriters);
+    // -png_encoder gpu (default): the PNG file's bytes are produced on the device (fav_stream_encode_png: Sub filter + fixed-Huffman /
+    // run-length deflate per row + Adler-32 / CRC-32 combine), leave as ONE exact-size DMA and the writer thread only write()s them;
+    // -png_encoder host: the 8-bit frame is downloaded and deflated by zlib on the writer threads (-png_level; ~25 ms per frame and core)
+    const bool gpu_png = o.s("png_encoder") == "gpu";
+    int cur_device = 0; (void)hipGetDevice(&cur_device);
+    const double cpu0 = process_cpu_seconds();
+    Pool writers(nwriters, cur_device);
     // compute queue; upload queue (the next frame's inputs travel while this frame computes); download queue (the 8-bit frame leaves
     // while the next frame computes: on the compute queue the 2.8 MB copy held back the next frame's kernels for its whole duration)
     hipStream_t st, st_copy, st_down;
@@ -278,6 +296,13 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
     Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
     uint8_t* d_out8s[2] = {nullptr, nullptr};    // frames alternate: frame i + 2 is enqueued after the host has seen frame i's download complete
+    // gpu_png: device PNG buffers (two, alternating like d_out8s), their sizes on the device and in pinned host memory, and per pinned
+    // output slot the event of the exact-size copy into it
+    uint8_t* d_png[2] = {nullptr, nullptr}; uint32_t* d_png_size[2] = {nullptr, nullptr}; uint32_t* h_png_size = nullptr;
+    hipEvent_t png_copy_ev[2] = {nullptr, nullptr};       // last copy OUT of d_png[k]: the next encode into it waits for this
+    size_t png_cap = 0;
+    std::map<uint8_t*, hipEvent_t> slot_ev;
+    std::atomic<long long> png_bytes_total{0};
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
@@ -350,10 +375,28 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         const int lvl = o.i("png_level");
         const std::string path = nm; uint8_t* hb = pd.hb; const int w_ = W, h_ = H;
         Slots* sl = &slots;
-        writers.submit([hb, path, w_, h_, lvl, sl] {
-            if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error());
-            sl->give(hb);                                     // only now may the slot receive another frame
-        });
+        if (gpu_png) {
+            // the size word has arrived (ev_done): ONE DMA of exactly the file's bytes, then the writer thread only write()s
+            const uint32_t nbytes = h_png_size[pd.ev];
+            if (nbytes < 57 || nbytes > png_cap) die("fav_stream_encode_png returned an impossible size");
+            hipEvent_t cev = slot_ev[hb];
+            if (hipMemcpyAsync(hb, d_png[pd.ev], nbytes, hipMemcpyDeviceToHost, st_down) != hipSuccess || hipEventRecord(cev, st_down) != hipSuccess) die("D2H of the PNG failed");
+            png_copy_ev[pd.ev] = cev;
+            png_bytes_total += nbytes;
+            writers.submit([hb, path, nbytes, cev, sl] {
+                if (hipEventSynchronize(cev) != hipSuccess) { fprintf(stderr, "GPU error while downloading %s\n", path.c_str()); exit(1); }
+                const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+                size_t off = 0;
+                while (fd >= 0 && off < nbytes) { const ssize_t k = write(fd, hb + off, nbytes - off); if (k <= 0) break; off += (size_t)k; }
+                if (fd < 0 || off != nbytes || close(fd)) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
+                sl->give(hb);
+            });
+        } else {
+            writers.submit([hb, path, w_, h_, lvl, sl] {
+                if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error());
+                sl->give(hb);                                     // only now may the slot receive another frame
+            });
+        }
         pd.valid = false;
     };
     auto pop_next = [&](FrameIn& out) {
@@ -378,11 +421,19 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
             if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
             const size_t n = (size_t)W * H;
-            if (hipMalloc((void**)&d_out8s[0], n * 3) || hipMalloc((void**)&d_out8s[1], n * 3)) die("hipMalloc failed");
+            if (gpu_png) {
+                png_cap = fav_png_capacity(W, H);
+                for (int k = 0; k < 2; ++k) if (hipMalloc((void**)&d_png[k], png_cap) || hipMalloc((void**)&d_png_size[k], 16)) die("hipMalloc failed");
+                if (hipHostMalloc((void**)&h_png_size, 64, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+            } else if (hipMalloc((void**)&d_out8s[0], n * 3) || hipMalloc((void**)&d_out8s[1], n * 3)) die("hipMalloc failed");
             for (auto& dv : dev)
                 if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
                     hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
-            for (auto& p : h_out) { if (hipHostMalloc((void**)&p, n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed"); slots.add(p); }
+            for (auto& p : h_out) {
+                if (hipHostMalloc((void**)&p, gpu_png ? png_cap : n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+                if (gpu_png) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed"); slot_ev[p] = e; }
+                slots.add(p);
+            }
             for (auto& p : pin)
                 if (hipHostMalloc((void**)&p.frame, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, n * 8, hipHostMallocDefault) ||
                     hipHostMalloc((void**)&p.fw, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&p.cert, n, hipHostMallocDefault)) die("hipHostMalloc failed");
@@ -411,7 +462,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             upload(nxt, (dset + 1) % 3);
             if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
-        uint8_t* const d_out8 = d_out8s[done & 1];
+        uint8_t* const d_out8 = gpu_png ? nullptr : d_out8s[done & 1];
         const bool teval = !o.s("temporal_eval_file").empty();
         if (teval && !d_prev) { if (hipMalloc((void**)&d_prev, (size_t)W * H * 12) || hipMalloc((void**)&d_cur, (size_t)W * H * 12)) die("hipMalloc failed"); }
         if (teval && !cur.single) check(fav_stream_get_state(fs, d_prev, st), "fav_stream_get_state");
@@ -434,9 +485,15 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         uint8_t* hb = slots.take();                      // a pinned output slot nobody is reading (blocks while the PNG pool is behind)
         t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
-        hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image is complete on the compute queue ...
+        if (gpu_png) {
+            // two frames ago this buffer's bytes left through the download queue: that copy must have finished (it has, long ago)
+            if (png_copy_ev[now.ev]) hipStreamWaitEvent(st, png_copy_ev[now.ev], 0);
+            check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, d_png_size[now.ev], st), "fav_stream_encode_png");
+        }
+        hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image / PNG is complete on the compute queue ...
         hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
-        hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st_down);
+        if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
+        else hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st_down);
         hipEventRecord(ev_done[now.ev], st_down);
         const auto tg = std::chrono::steady_clock::now();
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i is already queued
@@ -465,6 +522,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     res->tail = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count();
     res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
+    res->cpu_s = process_cpu_seconds() - cpu0; res->png_bytes = png_bytes_total.load();
+    for (int k = 0; k < 2; ++k) { hipFree(d_png[k]); hipFree(d_png_size[k]); }
+    if (h_png_size) hipHostFree(h_png_size);
+    for (auto& kv : slot_ev) hipEventDestroy(kv.second);
     fav_stream_destroy(fs);
     hipFree(d_prev); hipFree(d_cur);
     hipFree(d_out8s[0]); hipFree(d_out8s[1]); for (auto& dv : dev) { hipFree(dv.frame); hipFree(dv.cert); hipFree(dv.bw); hipFree(dv.fw); }
@@ -492,8 +553,8 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
-           {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"},
+           {"png_level", "1"}, {"png_encoder", "gpu"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
+           {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"}, {"pin_workers", "1"},
            // internal (set by the launcher for its workers)
            {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
@@ -514,6 +575,7 @@ int main(int argc, char** argv)
     if (o.f("evaluate")) die("-evaluate needs the VGG-16 perceptual-loss network: outside the hot-path scope (DESIGN.md)");
     if (o.d("scale_factor") != 1.0) die("-scale_factor != 1 is not supported");
     if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
+    if (o.s("png_encoder") != "gpu" && o.s("png_encoder") != "host") die("-png_encoder must be gpu (the file's bytes are produced on the device) or host (zlib, -png_level)");
     if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
     const bool dry = o.i("dry_run") != 0;
     std::vector<std::string> streams = favl::split_list(o.s("streams"));
@@ -528,13 +590,17 @@ int main(int argc, char** argv)
     // ------------------------------------------------------------------------------------------ launcher
     if (rank < 0 && (world > 1 || o.i("force_dist"))) {
         if (!dry) {
+            std::vector<std::string> models{o.s("model_vid")};
+            if (o.s("model_img") != "self") models.push_back(o.s("model_img"));
+            favl::validate_models(models);                        // before any worker exists: ERROR + nonzero exit, never a hang
             const int ndev = fav_device_count();
             if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
             if (o.i("gpu") + world > ndev) die("-gpus " + o.s("gpus") + " from -gpu " + o.s("gpu") + ": only " + std::to_string(ndev) + " devices");
         }
-        std::string idf;
-        const int worst = favl::spawn_workers(argc, argv, world, &idf);
-        if (o.i("timing") && !dry && worst == 0) favl::print_aggregate(idf, world, streams.size());
+        std::string xdir;
+        const int worst = favl::spawn_workers(argc, argv, world, o.i("pin_workers") != 0, &xdir);
+        if (o.i("timing") && !dry && worst == 0) favl::print_aggregate(xdir, world, streams.size());
+        favl::remove_exchange_dir(xdir, world);
         return worst;
     }
 
@@ -544,10 +610,11 @@ int main(int argc, char** argv)
     const int device = o.i("gpu") + (dist ? rank : 0);
     std::vector<std::string> mine;
     for (size_t s = 0; s < streams.size(); ++s) if (!dist || (int)(s % (size_t)world) == rank) mine.push_back(streams[s]);     // stream s -> GPU s mod N
-    const int nwriters = favl::writer_budget(o.i("writers"), dist ? world : 1);
+    const int nwriters = favl::writer_budget(o.i("writers"), dist ? world : 1, dist && world > 1 && o.i("pin_workers") != 0);
     if (dry) {
+        favl::dry_run_failure_hook(rank);
         std::string js = "{\"rank\": " + std::to_string(std::max(rank, 0)) + ", \"world\": " + std::to_string(dist ? world : 1) + ", \"device\": " + std::to_string(device) +
-                         ", \"writers\": " + std::to_string(nwriters) + ", \"streams\": [";
+                         ", \"cpus\": " + std::to_string(favl::allowed_cpus().size()) + ", \"writers\": " + std::to_string(nwriters) + ", \"streams\": [";
         for (size_t k = 0; k < mine.size(); ++k) {
             js += std::string(k ? ", " : "") + "{\"name\": " + favl::json_str(mine[k]);
             for (const char* po : path_opts) js += std::string(", \"") + po + "\": " + favl::json_str(named ? favl::subst_stream(o.s(po), mine[k]) : o.s(po));
@@ -582,11 +649,14 @@ int main(int argc, char** argv)
         run_stream(os, net, net_img, nwriters, &r);
         frames += r.frames; seconds += r.seconds;
         if (o.i("timing"))
-            printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"setup_s\": %.3f, \"png_tail_s\": %.3f, \"png_writers\": %d}\n",
+            printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"setup_s\": %.3f, \"png_tail_s\": %.3f, \"png_writers\": %d, "
+                   "\"png_encoder\": \"%s\", \"host_cpu_ms_per_frame\": %.3f, \"png_mb_per_frame\": %.3f, \"usable_cpus\": %d}\n",
                    named ? ("\"stream\": " + favl::json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
-                   r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, r.setup, r.tail, nwriters);
+                   r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, r.setup, r.tail, nwriters,
+                   o.s("png_encoder").c_str(), 1e3 * r.cpu_s / std::max(r.frames, 1), 1e-6 * (double)r.png_bytes / std::max(r.frames, 1), favl::effective_cpus());
     }
     check(fav_net_check(net), "at exit");
+    if (net_img) check(fav_net_check(net_img), "at exit (image model)");
     if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds);
     fflush(stdout);
     fav_net_destroy(net); fav_net_destroy(net_img);

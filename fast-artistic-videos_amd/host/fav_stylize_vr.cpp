@@ -126,6 +126,10 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
         const auto t0 = std::chrono::steady_clock::now();
         check(fav_vr_face(vr, i, d_frame, temporal ? d_flow : nullptr, temporal ? d_cert : nullptr, nullptr, st), "fav_vr_face");
         hipc(hipStreamSynchronize(st), "sync");
+        // a stream-K hand-off that timed out: fail at THIS face, before any output derived from it is written (fav.h: the check
+        // comes before a PNG is queued); the image model stylises the faces without a prior
+        check(fav_net_check(vid), "stylising a face");
+        if (img) check(fav_net_check(img), "stylising a face (image model)");
         if (timing) printf("Elapsed time for stylizing face %d of frame %d: %.4f\n", face, file_idx, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         fav_free_host(rgb); fav_free_host(flo); fav_free_host(cert);
         if (mode == 5) {                                                                                            // :527-557
@@ -134,6 +138,7 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
             if (d_equi) hipc(hipMemcpyAsync(h_equi.data(), d_equi, h_equi.size(), hipMemcpyDeviceToHost, st), "D2H");
             if (d_cube) hipc(hipMemcpyAsync(h_cube.data(), d_cube, h_cube.size(), hipMemcpyDeviceToHost, st), "D2H");
             hipc(hipStreamSynchronize(st), "sync");
+            check(fav_net_check(vid), "finishing a frame");
             const int out_idx = (i - 1) / 6 + 1;                                                                    // :517 (not offset by -start_frame)
             const std::string prefix = v["output_prefix"]; const int lvl = I("png_level");
             std::vector<uint8_t> e = h_equi, cb = h_cube;
@@ -158,6 +163,7 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
     }
     if (vr) fav_vr_destroy(vr);
     check(fav_net_check(vid), "stylising the video");
+    if (img) check(fav_net_check(img), "stylising the video (image model)");
     (void)hipFree(d_frame); (void)hipFree(d_cert); (void)hipFree(d_flow); (void)hipFree(d_equi); (void)hipFree(d_cube);
     hipStreamDestroy(st);
     *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
@@ -177,7 +183,7 @@ int main(int argc, char** argv)
         {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
         {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
         {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
-        {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
+        {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"pin_workers", "1"}, {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
     std::map<std::string, bool> b = {
         {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},
         {"create_inconsistent_border", false}, {"backward", false}, {"out_equi", false}, {"out_cubemap", false}, {"evaluate", false},
@@ -214,13 +220,17 @@ int main(int argc, char** argv)
         die("-streams: -output_prefix must contain %S (the videos would overwrite each other's frames)");
     if (rank < 0 && (world > 1 || I("force_dist"))) {                                   // launcher: one worker process per GPU
         if (!dry) {
+            std::vector<std::string> models{v["model_vid"]};
+            if (!v["model_img"].empty() && v["model_img"] != "self") models.push_back(v["model_img"]);
+            favl::validate_models(models);                        // before any worker exists
             const int ndev = fav_device_count();
             if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
             if (I("gpu") + world > ndev) die("-gpus " + v["gpus"] + " from -gpu " + v["gpu"] + ": only " + std::to_string(ndev) + " devices");
         }
-        std::string idf;
-        const int worst = favl::spawn_workers(argc, argv, world, &idf);
-        if (timing && !dry && worst == 0) favl::print_aggregate(idf, world, streams.size());
+        std::string xdir;
+        const int worst = favl::spawn_workers(argc, argv, world, I("pin_workers") != 0, &xdir);
+        if (timing && !dry && worst == 0) favl::print_aggregate(xdir, world, streams.size());
+        favl::remove_exchange_dir(xdir, world);
         return worst;
     }
     const bool dist = rank >= 0;
@@ -229,6 +239,7 @@ int main(int argc, char** argv)
     std::vector<std::string> mine;
     for (size_t s_ = 0; s_ < streams.size(); ++s_) if (!dist || (int)(s_ % (size_t)world) == rank) mine.push_back(streams[s_]);
     if (dry) {
+        favl::dry_run_failure_hook(rank);
         std::string js = "{\"rank\": " + std::to_string(std::max(rank, 0)) + ", \"world\": " + std::to_string(dist ? world : 1) + ", \"device\": " + std::to_string(device) + ", \"streams\": [";
         for (size_t k = 0; k < mine.size(); ++k) {
             js += std::string(k ? ", " : "") + "{\"name\": " + favl::json_str(mine[k]);

@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
     L.fav_net_destroy.argtypes = [C.c_void_p]; L.fav_net_destroy.restype = None
     L.fav_stream_destroy.argtypes = [C.c_void_p]; L.fav_stream_destroy.restype = None
     L.fav_free_host.argtypes = [C.c_void_p]; L.fav_free_host.restype = None
+    for f in (L.fav_png_capacity, L.fav_png_workspace_bytes):
+        f.restype = C.c_size_t; f.argtypes = [C.c_int, C.c_int]
     L.fav_vr_destroy.argtypes = [C.c_void_p]; L.fav_vr_destroy.restype = None
     _lib = L
     return L
@@ -61,7 +63,8 @@ EXPORTS = [
     "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
-    "fav_stream_set_state", "fav_stream_last_mask", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
+    "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32",
+    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
     "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device",
@@ -330,6 +333,24 @@ class Stream:
         _chk_f32(t, "state")
         _check(lib().fav_stream_set_state(self.h, _p(t), _stream()))
 
+    def png_buffers(self):
+        """(out, nbytes) device buffers for encode_png_into: capacity fav_png_capacity(W, H), one int32"""
+        torch = _torch()
+        cap = lib().fav_png_capacity(self.W, self.H)
+        dev = torch.device("cuda", self.net.device)
+        return torch.empty((cap + 3) // 4 * 4, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def encode_png_into(self, out, nbytes):
+        """fav_stream_encode_png: the current stylised frame as the bytes of a PNG file, enqueued on the current stream (no sync)"""
+        _check(lib().fav_stream_encode_png(self.h, _p(out), C.c_size_t(out.numel()), _p(nbytes), _stream()))
+
+    def last_input(self):
+        """[7][H][W] network input of the last frame (content | prior | certainty), un-padded copy of the fused kernel's output"""
+        torch = _torch()
+        out = torch.empty((7, self.H, self.W), dtype=torch.float32, device=f"cuda:{self.net.device}")
+        _check(lib().fav_stream_get_input_f32(self.h, _p(out), _stream()))
+        return out
+
     def last_mask(self):
         """copy of the u8 certainty mask used for the last frame (before the min filter)"""
         torch = _torch()
@@ -339,6 +360,32 @@ class Stream:
         src = _from_ptr_u8(ptr, self.H * self.W, self.net.device)
         out.view(-1).copy_(src)
         return out
+
+
+def png_encode(img, from_stream: "Stream" = None) -> bytes:
+    """A9 on the GPU: the bytes of the PNG file (fav_png_encode_rgb8 for a u8 [H][W][3] tensor, fav_png_encode_f32 for a float
+    [3][H][W] tensor, fav_stream_encode_png for a Stream's current frame)."""
+    torch = _torch()
+    if from_stream is not None:
+        h, w, dev = from_stream.H, from_stream.W, torch.device("cuda", from_stream.net.device)
+    elif img.dtype == torch.uint8:
+        h, w, dev = img.shape[0], img.shape[1], img.device
+    else:
+        h, w, dev = img.shape[1], img.shape[2], img.device
+    cap = lib().fav_png_capacity(w, h)
+    out = torch.empty((cap + 3) // 4 * 4, dtype=torch.uint8, device=dev)
+    nbytes = torch.zeros(1, dtype=torch.int32, device=dev)
+    if from_stream is not None:
+        _check(lib().fav_stream_encode_png(from_stream.h, _p(out), C.c_size_t(cap), _p(nbytes), _stream()))
+    else:
+        wsb = lib().fav_png_workspace_bytes(w, h)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        assert img.is_contiguous()
+        fn = lib().fav_png_encode_rgb8 if img.dtype == torch.uint8 else lib().fav_png_encode_f32
+        _check(fn(_p(img), w, h, _p(out), C.c_size_t(cap), _p(nbytes), _p(ws), C.c_size_t(wsb), _stream()))
+    torch.cuda.synchronize()
+    n = int(nbytes.item())
+    return bytes(out[:n].cpu().numpy().tobytes())
 
 
 def sequential_sum(x) -> float:

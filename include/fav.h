@@ -200,6 +200,9 @@ int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const 
 /* read / overwrite the recurrent state ([3][H][W] float RGB) -- for -continue_with */
 int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
 int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream);
+/* test view: the 7-channel network input of the LAST frame as run_next_image assembles it (fast_artistic_video_core.lua:161-171:
+ * content | masked warped prior + fill | certainty), [7][H][W] fp32, copied out of the fused kernel's padded buffer */
+int fav_stream_get_input_f32(const fav_stream* s, float* in7, fav_hipstream_t stream);
 /* device pointer of the last certainty mask used (u8 [H][W], before the min filter) -- tests */
 const uint8_t* fav_stream_last_mask(const fav_stream* s);
 
@@ -263,6 +266,29 @@ int fav_read_pnm_into_host(const char* path, uint8_t* buf, size_t capacity_bytes
 int fav_write_pgm_host(const char* path, const uint8_t* data, int W, int H);
 int fav_write_png_rgb8_host(const char* path, const uint8_t* rgb_hwc, int W, int H, int zlib_level);
 void fav_free_host(void* p);
+
+/* ---- A9 on the GPU: image.save("<prefix>-%05d.png", img) (fast_artistic_video.lua:160-170) -----------------------------------
+ * The BYTES OF THE PNG FILE are produced on the device (Sub filter, one fixed-Huffman / run-length deflate block per image row
+ * re-aligned by an empty stored block, Adler-32 and CRC-32 combined from per-row parts: csrc/kernels_png.hip), so the host only
+ * write()s them: the zlib path above costs ~25 ms per 1280x720 frame and core.  The files decode to exactly the bytes
+ * fav_stream_* writes to out_rgb8_hwc (clamp to [0,1], x255, truncate); they are larger than zlib's (no entropy coding beyond the
+ * fixed code).
+ *   png_out        device-ACCESSIBLE memory of fav_png_capacity(W, H) bytes, 4-byte aligned: device memory or host-mapped pinned
+ *                  memory (hipHostMalloc: the packed bytes then cross PCIe once and are complete when the stream reaches the point
+ *                  after the call -- use an event WITH the system-scope fence);
+ *   png_bytes_out  device-accessible uint32: the file size;
+ *   workspace      fav_png_workspace_bytes(W, H) bytes of device memory, 16-byte aligned, owned by the caller, private to the call
+ *                  until the stream has passed it.
+ * fav_png_encode_rgb8: rgb_hwc = u8 [H][W][3];  fav_png_encode_f32: planar float RGB [3][H][W] (what fav_stream_get_state returns),
+ * quantisation fused.  Width <= 16000. */
+size_t fav_png_capacity(int W, int H);
+size_t fav_png_workspace_bytes(int W, int H);
+int fav_png_encode_rgb8(const uint8_t* rgb_hwc, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
+                        void* workspace, size_t workspace_bytes, fav_hipstream_t stream);
+int fav_png_encode_f32(const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
+                       void* workspace, size_t workspace_bytes, fav_hipstream_t stream);
+/* the stream's current stylised frame (the recurrent state) as a PNG file, with the stream's own workspace */
+int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
 
 #ifdef __cplusplus
 }

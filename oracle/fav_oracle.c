@@ -41,34 +41,62 @@ void orc_set_threads(int n)
  *   flowFileLoader.lua:27-29), out [C][Ho][Wo].  Each of the 4 taps is zeroed individually when
  *   its integer coordinates fall outside the image (:92-101).
  * ------------------------------------------------------------------------------------------ */
-void orc_warp_stn(const float* img, const float* flow, float* out,
-                  int C, int H, int W, int Ho, int Wo)
+/* float -> int as the GPU the reference kernel runs on converts (v_cvt_i32_f32 on gfx950, cvt.rzi.s32.f32 on NVIDIA):
+ * saturating, NaN -> 0.  (x86's cvttss2si returns INT_MIN for all of these, C leaves them undefined.)  Pinned by
+ * tests/golden/warp_*.npz = outputs of the reference's own kernel (oracle/_ref/libwarp_ref*.so) on such flows. */
+static int gpu_f2i(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+/* exact_f32 = 0: the sum :103-106 evaluated in double and rounded once (the reference's nvcc / hipcc default build may
+ *                contract the fp32 expression into FMAs either way: this is the value both builds approximate);
+ * exact_f32 = 1: the fp32 expression exactly as written, no contraction (this file is compiled with -ffp-contract=off):
+ *                bit-identical to the reference kernel built with -ffp-contract=off (libwarp_ref_nofma.so). */
+static void warp_stn_impl(const float* img, const float* flow, float* out, int C, int H, int W, int Ho, int Wo, int exact_f32)
 {
 #pragma omp parallel for
     for (int y = 0; y < Ho; ++y)
         for (int x = 0; x < Wo; ++x) {
             float yf = flow[(size_t)0 * Ho * Wo + (size_t)y * Wo + x] + (float)y;   /* :72 */
             float xf = flow[(size_t)1 * Ho * Wo + (size_t)y * Wo + x] + (float)x;   /* :73 */
-            int x0 = (int)floorf(xf);            /* getTopLeft :13-23 */
-            int y0 = (int)floorf(yf);
+            int x0 = gpu_f2i(floorf(xf));            /* getTopLeft :13-23 */
+            int y0 = gpu_f2i(floorf(yf));
             float wx = 1.0f - (xf - (float)x0);
             float wy = 1.0f - (yf - (float)y0);
-            int xin0 = (x0 >= 0 && x0 <= W - 1), xin1 = (x0 + 1 >= 0 && x0 + 1 <= W - 1);
-            int yin0 = (y0 >= 0 && y0 <= H - 1), yin1 = (y0 + 1 >= 0 && y0 + 1 <= H - 1);
+            int x1 = (int)((unsigned)x0 + 1u), y1 = (int)((unsigned)y0 + 1u);       /* wraps like the hardware add */
+            int xin0 = (x0 >= 0 && x0 <= W - 1), xin1 = (x1 >= 0 && x1 <= W - 1);
+            int yin0 = (y0 >= 0 && y0 <= H - 1), yin1 = (y1 >= 0 && y1 <= H - 1);
             for (int c = 0; c < C; ++c) {
                 const float* p = img + (size_t)c * H * W;
-                float tl = (xin0 && yin0) ? p[(size_t)y0 * W + x0] : 0.0f;
-                float tr = (xin1 && yin0) ? p[(size_t)y0 * W + x0 + 1] : 0.0f;
-                float bl = (xin0 && yin1) ? p[(size_t)(y0 + 1) * W + x0] : 0.0f;
-                float br = (xin1 && yin1) ? p[(size_t)(y0 + 1) * W + x0 + 1] : 0.0f;
-                /* :103-106, evaluated in double here: the reference's nvcc build may contract the
-                 * fp32 expression into FMAs, so the oracle gives the exactly-rounded value and
-                 * the parity test uses a 1e-5 relative tolerance. */
-                double v = (double)wx * wy * tl + (double)(1.0f - wx) * wy * tr
-                         + (double)wx * (1.0f - wy) * bl + (double)(1.0f - wx) * (1.0f - wy) * br;
-                out[(size_t)c * Ho * Wo + (size_t)y * Wo + x] = (float)v;
+                float tl = (xin0 && yin0) ? p[(size_t)y0 * W + x0] : 0.0f;           /* :86-101 */
+                float tr = (xin1 && yin0) ? p[(size_t)y0 * W + x1] : 0.0f;
+                float bl = (xin0 && yin1) ? p[(size_t)y1 * W + x0] : 0.0f;
+                float br = (xin1 && yin1) ? p[(size_t)y1 * W + x1] : 0.0f;
+                float r;
+                if (exact_f32) {
+                    r = wx * wy * tl + (1.0f - wx) * wy * tr + wx * (1.0f - wy) * bl + (1.0f - wx) * (1.0f - wy) * br;
+                } else {
+                    double v = (double)wx * wy * tl + (double)(1.0f - wx) * wy * tr
+                             + (double)wx * (1.0f - wy) * bl + (double)(1.0f - wx) * (1.0f - wy) * br;
+                    r = (float)v;
+                }
+                out[(size_t)c * Ho * Wo + (size_t)y * Wo + x] = r;
             }
         }
+}
+
+void orc_warp_stn(const float* img, const float* flow, float* out, int C, int H, int W, int Ho, int Wo)
+{
+    warp_stn_impl(img, flow, out, C, H, W, Ho, Wo, 0);
+}
+
+void orc_warp_stn_f32(const float* img, const float* flow, float* out, int C, int H, int W, int Ho, int Wo)
+{
+    warp_stn_impl(img, flow, out, C, H, W, Ho, Wo, 1);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -3,9 +3,12 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 leg.  The product path never imports this module.
 
-Parity status: the consistency mask is pinned against the reference's own compiled
-consistencyChecker (oracle/_ref, tests/golden/mask_*); everything that restates un-vendored Torch7
-packages (nn, image) is "parity unpinned" -- the reference ships no golden vectors, weights or tests.
+Parity status: the consistency mask (A3/A4) is pinned against the reference's own compiled
+consistencyChecker (oracle/_ref, tests/golden/mask_*); the "stn" warp (A2, the reference's GPU path) is
+pinned against the reference's own kernel stnbdhw/BilinearSamplerBDHW.cu:1-109 compiled for gfx950
+(oracle/_ref/libwarp_ref*.so, tests/golden/warp_*.npz); everything that restates un-vendored Torch7
+packages (nn, image: A5-A9, the "cpu" warp) is "parity unpinned" -- the reference ships no golden
+vectors, weights or tests and Lua/Torch7 cannot run offline.
 """
 from __future__ import annotations
 
@@ -28,6 +31,8 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "libfav_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/consistencyChecker") and (force or not os.path.exists(REF_CHECKER)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/stnbdhw") and (force or not warp_ref_available()):
+        subprocess.check_call(["make", "-C", _HERE, "warp_ref"], stdout=subprocess.DEVNULL)
 
 
 def lib():
@@ -112,11 +117,38 @@ def read_pnm(path: str) -> np.ndarray:
 
 # ------------------------------------------------------------------------------------------ ops
 def warp(img: np.ndarray, flow_lua: np.ndarray, border: str = "stn") -> np.ndarray:
+    """border: "stn" (the reference's GPU kernel, sum rounded once from double), "stn_f32" (the same in fp32 exactly as
+    written: bit-identical to the reference kernel built without contraction), "cpu" (image.warp, recalled)."""
     img, pi = _f(img); flow_lua, pf = _f(flow_lua)
     c, h, w = img.shape; _, ho, wo = flow_lua.shape
     out = np.empty((c, ho, wo), np.float32)
-    fn = lib().orc_warp_stn if border == "stn" else lib().orc_warp_cpu
+    fn = {"stn": lib().orc_warp_stn, "stn_f32": lib().orc_warp_stn_f32, "cpu": lib().orc_warp_cpu}[border]
     fn(pi, pf, out.ctypes.data_as(C.POINTER(C.c_float)), c, h, w, ho, wo)
+    return out
+
+
+_WARP_REF = {}
+
+
+def warp_ref_available() -> bool:
+    return all(os.path.exists(os.path.join(_HERE, "_ref", n)) for n in ("libwarp_ref.so", "libwarp_ref_nofma.so"))
+
+
+def warp_ref_gpu(img_t, flow_t, contract: bool = True):
+    """The reference's OWN warp kernel (stnbdhw/BilinearSamplerBDHW.cu:48-109, compiled for gfx950 by oracle/Makefile into
+    oracle/_ref/) on torch device tensors: img [B][C][H][W], flow [B][2][Ho][Wo] -> [B][C][Ho][Wo].  contract=True is the
+    default-flags build (FMA contraction allowed, as nvcc's default), False the -ffp-contract=off build."""
+    import torch
+    name = "libwarp_ref.so" if contract else "libwarp_ref_nofma.so"
+    if name not in _WARP_REF:
+        _WARP_REF[name] = C.CDLL(os.path.join(_HERE, "_ref", name))
+    b, c, h, w = img_t.shape; ho, wo = flow_t.shape[2], flow_t.shape[3]
+    assert img_t.is_contiguous() and flow_t.is_contiguous() and img_t.dtype == torch.float32 and flow_t.dtype == torch.float32
+    out = torch.full((b, c, ho, wo), float("nan"), dtype=torch.float32, device=img_t.device)
+    rc = _WARP_REF[name].warp_ref_bdhw(C.c_void_p(img_t.data_ptr()), C.c_void_p(flow_t.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       b, c, h, w, ho, wo, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, f"reference warp kernel launch failed: hip error {rc}"
+    torch.cuda.synchronize()
     return out
 
 

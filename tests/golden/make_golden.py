@@ -5,6 +5,11 @@ restatement (the reference's Lua/Torch7 stack cannot run offline) -- it cross-ch
 is not a reference output.
 
     python tests/golden/make_golden.py
+    python tests/golden/make_golden.py --warp --out gpurun_out/golden      (ON THE GPU BOX: warp fixtures)
+
+The warp fixtures (warp_*.npz) are outputs of the reference's OWN warp kernel (stnbdhw/BilinearSamplerBDHW.cu:1-109 compiled for
+gfx950 by oracle/Makefile into oracle/_ref/libwarp_ref{,_nofma}.so); that kernel only runs on a GPU, so they are generated there
+(`gpurun -- python tests/golden/make_golden.py --warp --out gpurun_out/golden`) and copied into tests/golden/.
 """
 import os
 import subprocess
@@ -63,7 +68,51 @@ def net_fixture():
     print("tiny net", y.shape, float(np.abs(y).max()))
 
 
+def warp_cases():
+    """seeded inputs of the warp fixtures: name -> (img [B][C][H][W], flow [B][2][Ho][Wo])"""
+    rng = np.random.default_rng(4242)
+    cases = {}
+    img = rng.standard_normal((1, 3, 37, 53)).astype(np.float32)
+    flow = (rng.standard_normal((1, 2, 37, 53)) * 5).astype(np.float32)
+    flow[0, :, 0, :4] = [[-1.5] * 4, [-0.5, 0.0, 0.25, -2.0]]        # the 1-px fringe band where the taps leave the image one by one
+    flow[0, :, -1, -3:] = 0.75
+    flow[0, :, 5, 5] = [0.0, 0.0]; flow[0, :, 6, 6] = [1.0, -1.0]     # exact integer offsets (weight 1 / 0 taps)
+    flow[0, 1, 7, :] = (53 - 1) - np.arange(53)                       # lands exactly on the last column
+    flow[0, 1, 8, :] = -1 - np.arange(53)                             # exactly one column outside
+    cases["warp_fringe_37x53"] = (img, flow)
+    # wider than the 512 columns one block row of the reference's launch covers (BilinearSamplerBDHW.cu:58,119)
+    cases["warp_wide_8x600"] = (rng.standard_normal((1, 1, 8, 600)).astype(np.float32), (rng.standard_normal((1, 2, 8, 600)) * 3).astype(np.float32))
+    # batched, and the output takes the FLOW's size (BilinearSamplerBDHW.lua:54-82)
+    cases["warp_batch_resize"] = (rng.standard_normal((2, 3, 20, 31)).astype(np.float32), (rng.standard_normal((2, 2, 24, 40)) * 4).astype(np.float32))
+    img = (rng.random((1, 2, 16, 32)) + 0.5).astype(np.float32)
+    flow = (rng.standard_normal((1, 2, 16, 32)) * 2).astype(np.float32)
+    ext = np.array([np.nan, np.inf, -np.inf, 2.0 ** 31, -2.0 ** 31, 3e9, -3e9, 1e20, -1e20, -0.0, 1e-40, 2147483520.0, -2147483520.0,
+                    2.0 ** 31 - 200, 65536.5, -65536.5], np.float32)
+    flow[0, 0, 2, :16] = ext; flow[0, 1, 3, :16] = ext                # one axis extreme, the other ordinary
+    flow[0, 0, 4, :16] = ext; flow[0, 1, 4, :16] = ext[::-1]          # both
+    flow[0, 0, 5, :16] = ext; flow[0, 1, 5, :16] = 0.0                # extreme dy on an exact column
+    cases["warp_extreme_16x32"] = (img, flow)
+    return cases
+
+
+def warp_fixture(out_dir):
+    import torch
+    assert torch.cuda.is_available() and O.warp_ref_available(), "the warp fixtures need a GPU and oracle/_ref/libwarp_ref*.so"
+    os.makedirs(out_dir, exist_ok=True)
+    dev = torch.device("cuda:0")
+    for name, (img, flow) in warp_cases().items():
+        a = O.warp_ref_gpu(torch.from_numpy(img).to(dev), torch.from_numpy(flow).to(dev), contract=True).cpu().numpy()
+        b = O.warp_ref_gpu(torch.from_numpy(img).to(dev), torch.from_numpy(flow).to(dev), contract=False).cpu().numpy()
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), img=img, flow=flow, out=a, out_nofma=b)
+        fin = np.isfinite(a) & np.isfinite(b)
+        print(name, a.shape, "non-finite outputs", int((~np.isfinite(b)).sum()), "max |contracted - uncontracted|", float(np.abs(a - b)[fin].max()),
+              "differing elements", int((a[fin] != b[fin]).sum()))
+
+
 if __name__ == "__main__":
+    if "--warp" in sys.argv:
+        warp_fixture(sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE)
+        sys.exit(0)
     O.build()
     assert os.path.exists(O.REF_CHECKER), "oracle/_ref/consistencyChecker missing (needs /root/reference)"
     mask_fixture("mask_smooth_64x96.npz", 64, 96, "smooth", 100)

@@ -78,13 +78,15 @@ def test_launcher_shards_streams_across_workers(favlib, tmp_path):
         recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
         assert [d["rank"] for d in recs] == list(range(world)) and all(d["world"] == world for d in recs)
         assert [d["device"] for d in recs] == [1 + k for k in range(world)]            # devices -gpu .. -gpu + n - 1
-        hw = os.cpu_count()
-        try:        # the launcher caps the hardware threads by the cgroup CPU quota
+        aff = len(os.sched_getaffinity(0)); quota = 1 << 20
+        try:        # the writer budget: the worker's share of the affinity mask (workers are pinned) and of the cgroup CPU quota
             q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max": hw = min(hw, max(1, -(-int(q) // int(per))))
+            if q != "max": quota = max(1, -(-int(q) // int(per)))
         except OSError:
             pass
-        assert all(d["writers"] == max(4, min(32, hw // world)) for d in recs)
+        shares = [aff * (k + 1) // world - aff * k // world for k in range(world)] if aff >= world else [aff] * world
+        assert [d["cpus"] for d in recs] == shares                                     # each worker pinned to its contiguous share
+        assert [d["writers"] for d in recs] == [max(2, min(32, sh, max(1, quota // world))) for sh in shares]
         for d in recs:
             want = [n for k, n in enumerate(names) if k % world == d["rank"]]
             assert [s["name"] for s in d["streams"]] == want
@@ -100,6 +102,31 @@ def test_launcher_shards_streams_across_workers(favlib, tmp_path):
     bad = [a if a != "out/%S/out" else "out/out" for a in base]
     r = subprocess.run(bad + ["-gpus", "2"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "%S" in r.stderr
+
+
+def test_launcher_fails_fast_instead_of_hanging(favlib, golden_dir, tmp_path):
+    """`-gpus 2 -model_vid <typo>` used to hang (rank 0 died parsing AFTER the communicator was up, its peers
+    blocked in the broadcast).  Now (1) the launcher itself parses the checkpoint(s) before any worker exists, (2) a worker that
+    fails takes its siblings down (waitpid(-1) + SIGTERM), (3) the exchange files live in a private mkdtemp directory that the
+    launcher removes."""
+    import time
+    exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
+    base = [exe, "-input_pattern", "in/%S/f_%05d.ppm", "-flow_pattern", "in/%S/b_[%d]_{%d}.flo", "-forward_flow_pattern", "in/%S/f_{%d}_[%d].flo",
+            "-output_prefix", "out/%S/o", "-model_img", "self", "-streams", "a,b", "-gpus", "2"]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run(base + ["-model_vid", str(tmp_path / "typo.t7")], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "typo.t7" in r.stderr and time.time() - t0 < 20
+    damaged = tmp_path / "damaged.t7"
+    damaged.write_bytes(open(os.path.join(golden_dir, "tiny_model.t7"), "rb").read()[:5000])
+    r = subprocess.run(base + ["-model_vid", str(damaged)], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and r.stderr.strip()
+    # one worker fails while the other blocks: the launcher returns the failing status promptly and leaves nothing behind
+    t0 = time.time()
+    r = subprocess.run(base + ["-model_vid", "m.t7", "-dry_run", "1"], capture_output=True, text=True, timeout=60,
+                       env=dict(env, FAV_TEST_WORKER_FAIL="1"))
+    assert r.returncode == 3 and "stopping the other workers" in r.stderr and time.time() - t0 < 20, (r.returncode, r.stderr)
+    assert not [n for n in os.listdir(tmp_path) if n.startswith("fav_launch_")]
 
 
 def test_vr_launcher_shards_videos_across_workers(favlib):
@@ -145,6 +172,26 @@ def _warp_numpy(img, flow, mode):
                         continue
                     out[:, y, x] += wy * wx * img[:, yy, xx]
     return out
+
+
+@pytest.mark.parametrize("name", ["warp_fringe_37x53", "warp_wide_8x600", "warp_batch_resize", "warp_extreme_16x32"])
+def test_oracle_warp_matches_reference_kernel_golden(oracle, golden_dir, name):
+    """A2 pinned: the fixtures are outputs of the reference's OWN warp kernel (stnbdhw/BilinearSamplerBDHW.cu:1-109 compiled for
+    gfx950, run on an MI355X by tests/golden/make_golden.py --warp).  The fp32 restatement is bit-identical to the kernel built
+    without FMA contraction (NaN / +-inf / |flow| >= 2^31 included: the same saturating conversion), the double-rounded one stays
+    within 1e-6 relative of both builds."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    img, flow = g["img"], g["flow"]
+    scale = max(1.0, float(np.abs(img).max()))
+    for b in range(img.shape[0]):
+        o32 = oracle.warp(img[b], flow[b], "stn_f32")
+        assert np.array_equal(o32, g["out_nofma"][b], equal_nan=True)
+        if name == "warp_extreme_16x32":
+            continue        # (fp32 products of 1e20-sized weights overflow where the double-rounded form does not: fp32 form only)
+        o64 = oracle.warp(img[b], flow[b], "stn")
+        for ref in (g["out"][b], g["out_nofma"][b]):
+            assert np.isfinite(ref).all() and np.abs(o64 - ref).max() <= 1e-6 * scale
+    assert np.isnan(g["out_nofma"]).any() == (name == "warp_extreme_16x32")
 
 
 @pytest.mark.parametrize("mode", ["stn", "cpu"])

@@ -1,0 +1,50 @@
+"""CPU suite: the PNG format the GPU encoder writes (csrc/kernels_png.hip), through its lane-level restatement oracle/png_model.py:
+the files are valid PNGs for two independent decoders (PIL / libpng and a minimal zlib-based reader), for every shape class the
+kernels distinguish.  The GPU suite (tests/test_gpu_png.py) then compares the kernels' bytes with the model's."""
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+from fav_amd import synth
+
+
+def _cases():
+    rng = np.random.default_rng(5)
+    yield "smooth", synth.smooth_frame(40, 97, 1)
+    yield "noise", rng.integers(0, 256, (17, 70, 3), dtype=np.uint8)
+    yield "flat", np.full((9, 130, 3), 200, np.uint8)
+    yield "one-pixel", rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)
+    yield "gradient", np.tile((np.arange(300) % 256).astype(np.uint8)[None, :, None], (5, 1, 3))
+    yield "runs-across-steps", np.repeat(rng.integers(0, 256, (6, 9, 3), dtype=np.uint8), 37, axis=1)       # runs of 111 bytes: cut at 64
+    yield "high-bytes", rng.integers(144, 256, (4, 33, 3), dtype=np.uint8)                                   # 9-bit literals
+    yield "short-runs", np.repeat(rng.integers(0, 256, (3, 50, 3), dtype=np.uint8), 2, axis=1)             # runs of 3 (the shortest match)
+
+
+@pytest.mark.parametrize("name,img", list(_cases()), ids=[n for n, _ in _cases()])
+def test_png_model_files_decode_exactly(oracle, name, img):
+    import png_model as P
+    from PIL import Image
+    data = P.encode(img)
+    assert len(data) <= P.capacity(img.shape[1], img.shape[0])
+    pil = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
+    assert np.array_equal(pil, img)
+    assert np.array_equal(P.decode(data), img)          # checks every chunk CRC; zlib checks the Adler-32
+    # structure: one IDAT, rows byte-aligned by sync markers, final empty fixed block
+    idat = data[41:-16]
+    assert idat[:2] == b"\x78\x01" and idat[-6:-4] == b"\x03\x00"
+    assert idat.count(b"\x00\x00\xff\xff") >= img.shape[0]
+
+
+def test_png_model_token_codes_are_the_fixed_huffman_code():
+    """a literal-only and a match-only row against zlib's own inflater in raw mode"""
+    import png_model as P
+    for row in (np.arange(200, dtype=np.uint8), np.zeros(500, np.uint8), np.tile(np.array([7, 9, 250], np.uint8), 90)):
+        f = np.concatenate([np.array([1], np.uint8), row])
+        seg = P.encode_row(f)
+        out = zlib.decompressobj(-15).decompress(seg + b"\x03\x00")
+        assert out == f.tobytes()
+    for L in range(3, 65):
+        val, nb = P.match_code(L)
+        assert nb <= 15

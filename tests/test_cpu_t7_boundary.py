@@ -55,8 +55,12 @@ class Emitter:
             k(); v()
 
     def function(self):
+        # [recalled, File.lua] TYPE_FUNCTION (6, the legacy record) has NO memo index: size + dumped bytes + upvalues; only the
+        # RECUR_FUNCTION records (7 legacy, 8) carry one
         tag = int(self.rng.choice([6, 7, 8]))
-        self.i32(tag); self.i32(self.new_index()); self.string_body("\x1bLJ\x02 dumped bytecode")
+        self.i32(tag)
+        if tag != 6: self.i32(self.new_index())
+        self.string_body("\x1bLJ\x02 dumped bytecode")
         self.table([(lambda: self.number(1), lambda: self.string("upvalue"))])
 
     # tensors: every tensor is a view into ONE storage that is written with the first tensor and back-referenced afterwards

@@ -67,6 +67,68 @@ def test_warp_policies_differ_only_in_fringe(favlib, cuda):
     assert np.abs(a - b)[:, interior].max() < 1e-5
 
 
+WARP_GOLDEN = ["warp_fringe_37x53", "warp_wide_8x600", "warp_batch_resize", "warp_extreme_16x32"]
+
+
+@pytest.mark.parametrize("name", WARP_GOLDEN)
+def test_warp_bit_exact_vs_reference_kernel(favlib, oracle, cuda, golden_dir, name):
+    """A2 pinned: fav_warp_bdhw_f32(FAV_BORDER_STN) against the reference's OWN kernel (stnbdhw/BilinearSamplerBDHW.cu:1-109 compiled
+    for gfx950 into oracle/_ref/ by oracle/Makefile) -- live on this GPU and through the committed fixtures (its outputs on the
+    same inputs): fringe band, >512 columns, batched + resized output, NaN / +-inf / |flow| >= 2^31."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    img, flow = g["img"], g["flow"]
+    got = favlib.warp(T(img, cuda), T(flow, cuda), favlib.BORDER_STN).cpu().numpy()
+    scale = max(1.0, float(np.abs(img).max()))
+    refs = [("committed fixture", g["out_nofma"], g["out"])]
+    if oracle.warp_ref_available():          # oracle/_ref travels to the GPU box with the snapshot
+        refs.append(("live reference kernel", oracle.warp_ref_gpu(T(img, cuda), T(flow, cuda), contract=False).cpu().numpy(),
+                     oracle.warp_ref_gpu(T(img, cuda), T(flow, cuda), contract=True).cpu().numpy()))
+    for what, exact, contracted in refs:
+        # the expression as written (:103-106), no FMA contraction: every bit, NaNs in the same places
+        assert np.array_equal(got, exact, equal_nan=True), f"{name} vs {what}: {(~((got == exact) | (np.isnan(got) & np.isnan(exact)))).sum()} elements differ"
+        # the default-flags build may contract into FMAs: same NaN pattern, a few ulp apart
+        assert np.array_equal(np.isnan(got), np.isnan(contracted))
+        fin = np.isfinite(got) & np.isfinite(contracted)
+        assert np.array_equal(np.isfinite(got), np.isfinite(contracted)) and np.abs(got - contracted)[fin].max() <= 1e-6 * scale
+    # the C restatement against the same kernel: fp32 form bit-exact, double-rounded form within 1e-6 relative
+    for b in range(img.shape[0]):
+        o32 = oracle.warp(img[b], flow[b], "stn_f32")
+        assert np.array_equal(o32, g["out_nofma"][b], equal_nan=True)
+
+
+def test_fused_prior_bit_exact_vs_reference_kernel(favlib, oracle, cuda, golden_dir):
+    """the prior channels the fused per-frame kernel writes (prep_input_kernel: warp + preprocess + mask + concat) against the
+    reference's own warp kernel followed by the fp32 expressions of preprocess.lua:57-62 / core.lua:166-170"""
+    if not oracle.warp_ref_available():
+        pytest.skip("oracle/_ref/libwarp_ref*.so not built (needs /root/reference at build time)")
+    h, w = 48, 64
+    rng = np.random.default_rng(77)
+    state = (rng.standard_normal((3, h, w)) * 0.4 + 0.5).astype(np.float32)          # float, unclamped previous output
+    flo = (rng.standard_normal((h, w, 2)) * 4).astype(np.float32)
+    flo[0, :6] = [[0.0, -1.5], [-0.5, -1.5], [0.25, -0.5], [-2.0, 0.0], [np.inf, 0.0], [np.nan, 1.0]]
+    flo[-1, -3:] = 0.75
+    flo[5, :4] = [[2.0 ** 31, 0.0], [-3e9, 0.5], [0.0, 1e20], [0.0, -np.inf]]
+    frame = synth.smooth_frame(h, w, 5)
+    cert = np.full((h, w), 255, np.uint8)
+    net = favlib.Net(os.path.join(golden_dir, "tiny_model.t7"), 0)
+    st = favlib.Stream(net, h, w)
+    st.set_state(T(state, cuda))
+    st.next_frame_cert(T(frame, cuda), T(flo, cuda), T(cert, cuda))
+    in7 = st.last_input().cpu().numpy()
+    flow_lua = oracle.flo_to_lua(flo)
+    ref = oracle.warp_ref_gpu(T(state[None], cuda), T(flow_lua[None], cuda), contract=False).cpu().numpy()[0]
+    mean = np.array([103.939, 116.779, 123.68], np.float32)
+    one = np.float32(1.0)
+    for c in range(3):               # BGR
+        with np.errstate(invalid="ignore"):
+            want = (ref[2 - c] * np.float32(255.0) - mean[c]) * one
+        assert np.array_equal(in7[3 + c], want, equal_nan=True), f"prior channel {c}: {(~((in7[3 + c] == want) | (np.isnan(want) & np.isnan(in7[3 + c])))).sum()} differ"
+    assert np.array_equal(in7[6], np.ones((h, w), np.float32))
+    f01 = frame.astype(np.float32) / np.float32(255)
+    for c in range(3):
+        assert np.array_equal(in7[c], f01[..., 2 - c] * np.float32(255.0) - mean[c])
+
+
 # ---------------------------------------------------------------------------------------------- A3/A4 mask
 @pytest.mark.parametrize("name", ["mask_smooth_64x96.npz", "mask_rand_120x160.npz", "mask_smooth_180x320.npz"])
 def test_mask_bit_exact_vs_reference_golden(favlib, cuda, golden_dir, name):
@@ -429,6 +491,41 @@ def test_canonical_640x360_frame_vs_oracle(favlib, oracle, cuda, canonical):
     assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
     assert psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
     oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+
+
+def test_config2_640x360_32_frames_reference_masks(favlib, oracle, cuda, canonical):
+    """BASELINE config 2 AS WRITTEN: 640x360 x 32 frames, precomputed .flo + occlusion masks -- the masks are files written by the
+    REFERENCE's own consistencyChecker binary (oracle/_ref, 4-argument call of makeOptFlow_deepflow.sh:59-60), consumed through the
+    certainty path.  BASELINE.md section 4: teacher-forced per frame (gated on ALL 32 frames: <= 2e-4 de-processed, >= 50 dB) AND
+    free-running over the full clip (REPORTED: gpurun_out/parity_c2.json / profiles/r03_parity_c2.json).  The free-running distance
+    is not gateable over a whole clip with the synthetic random-init weights: the recurrent map frame -> frame amplifies ANY
+    perturbation ~3.1x per frame (measured GPU-vs-oracle AND oracle-vs-perturbed-oracle, profiles/r03_parity_sensitivity_control_c2.json),
+    so 6e-7 rms of rounding differences at frame 1 saturates around frame 13 on any two implementations, the oracle and itself
+    included.  Gated here: the first four free-running frames (<= 1e-3, as test_stream_vs_oracle_recurrent) and that the growth is
+    no faster than that sensitivity explains (<= 6x per frame)."""
+    if not os.path.exists(oracle.REF_CHECKER):
+        pytest.skip("oracle/_ref/consistencyChecker not built (needs /root/reference at build time)")
+    import json, sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import parity_clip
+    try:
+        res = parity_clip.run_clip(favlib, oracle, canonical, 360, 640, 32, mode="cert", seed=2000, pool=8,
+                                   threads=parity_clip.effective_cpus(), log=lambda s: None)
+    finally:
+        oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_c2.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    print({k: v for k, v in res.items() if k != "per_frame"})
+    assert res["frames_compared"] == 32
+    assert res["teacher_max_abs_worst"] <= 2e-4, res["teacher_max_abs_worst"]
+    assert res["teacher_psnr8_db_min"] >= 50.0
+    rows = res["per_frame"]
+    assert max(r["free_max_abs"] for r in rows[:4]) <= 1e-3, [r["free_max_abs"] for r in rows[:4]]
+    growth = [rows[k + 1]["free_rms"] / rows[k]["free_rms"] for k in range(8)]
+    assert max(growth) <= 6.0, growth
+    assert 5.0 < np.mean([r["reliable_pct"] for r in res["per_frame"][1:]]) < 99.0      # the masks gate a real share of the prior
 
 
 def test_canonical_1280x720_recurrent_step_vs_oracle(favlib, oracle, cuda, canonical, poison):

@@ -1,0 +1,82 @@
+"""GPU suite: the PNG encoder kernels (A9 on the device, csrc/kernels_png.hip) through the C ABI -- byte for byte against the
+lane-level model (oracle/png_model.py), decoded by PIL back to the exact 8-bit frame, from u8 and from float sources, and as the
+stream-level call fav_stylize uses."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from fav_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _decode(data):
+    from PIL import Image
+    return np.array(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+@pytest.mark.parametrize("shape,kind", [((40, 97), "smooth"), ((17, 70), "noise"), ((9, 130), "flat"), ((1, 1), "noise"), ((5, 300), "gradient"),
+                                        ((6, 333), "runs"), ((4, 33), "high"), ((3, 100), "short-runs"), ((2, 4001), "noise"), ((64, 64), "smooth")])
+def test_png_bytes_equal_the_model(favlib, oracle, cuda, shape, kind):
+    import png_model as P
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    if kind == "smooth": img = synth.smooth_frame(h, w, 3)
+    elif kind == "flat": img = np.full((h, w, 3), 200, np.uint8)
+    elif kind == "gradient": img = np.tile((np.arange(w) % 256).astype(np.uint8)[None, :, None], (h, 1, 3))
+    elif kind == "runs": img = np.repeat(rng.integers(0, 256, (h, (w + 36) // 37, 3), dtype=np.uint8), 37, axis=1)[:, :w]
+    elif kind == "high": img = rng.integers(144, 256, (h, w, 3), dtype=np.uint8)
+    elif kind == "short-runs": img = np.repeat(rng.integers(0, 256, (h, w // 2, 3), dtype=np.uint8), 2, axis=1)
+    else: img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img = np.ascontiguousarray(img)
+    got = favlib.png_encode(T(img, cuda))
+    want = P.encode(img)
+    assert got == want, f"{len(got)} vs {len(want)} bytes; first difference at {next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), -1)}"
+    assert np.array_equal(_decode(got), img)
+
+
+def test_png_from_float_state_and_stream(favlib, oracle, cuda, golden_dir):
+    """quantisation fused into the encoder (clamp, x255, truncate = quantize_kernel / image.save) and the stream-level entry point"""
+    import torch
+    rng = np.random.default_rng(9)
+    h, w = 37, 91
+    f = (rng.standard_normal((3, h, w)) * 0.5 + 0.5).astype(np.float32)
+    f[0, 0, :4] = [0.0, 1.0, 254.999 / 255, -3.0]
+    want8 = oracle.to_u8_hwc(f)
+    got = favlib.png_encode(T(f, cuda))
+    assert np.array_equal(_decode(got), want8)
+    # the stream's current frame: identical pixels to the u8 output of the same call
+    net = favlib.Net(os.path.join(golden_dir, "tiny_model.t7"), 0)
+    hh, ww = 48, 64
+    st = favlib.Stream(net, hh, ww)
+    _, u8 = st.first_frame(T(synth.smooth_frame(hh, ww, 1), cuda), want_u8=True)
+    png = favlib.png_encode(None, from_stream=st)
+    assert np.array_equal(_decode(png), u8.cpu().numpy())
+    assert png == favlib.png_encode(u8.contiguous())          # the u8 and the float source give the same file
+
+
+def test_png_full_size_1280x720_decodes_exactly(favlib, oracle, cuda):
+    """BASELINE config 3 size: decodes (PIL) to the exact bytes, every repeated call gives the same file, size within the capacity"""
+    import png_model as P
+    import torch
+    h, w = 720, 1280
+    rng = np.random.default_rng(1)
+    img = synth.smooth_frame(h, w, 8)
+    img[100:200, 300:900] = 17                       # a flat patch: long runs
+    img[300:400] = rng.integers(0, 256, (100, w, 3), dtype=np.uint8)
+    a = favlib.png_encode(T(img, cuda))
+    b = favlib.png_encode(T(img, cuda))
+    assert a == b and len(a) <= P.capacity(w, h)
+    assert np.array_equal(_decode(a), img)
+    # the model predicts the same bytes at full size for a band of rows (the whole frame takes the Python model too long)
+    rows = [0, 1, 150, 350, 719]
+    for y in rows:
+        seg = P.encode_row(P.filter_row(img[y]))
+        assert seg in a, f"row {y}"
