@@ -210,7 +210,7 @@ int launch_assemble(const float* frame, const float* warped, const float* cert, 
 int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int invert, int fix_occ, int border,
                         int r, float* cert_tmp, float* cert, int H, int W, hipStream_t st);
 // fused A2+A6+A7+reflection pad: writes the padded NHWC8 network input
-int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo,
+int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo,
                       const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st,
                       int fill_random = 0, unsigned seed = 0, unsigned index = 0);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* frame, const
 
 // Fused A2 + A6 + A7 + reflection pad -> padded NHWC8 network input [H+2p][W+2p][8]
 //   ch 0..2 content (BGR, mean-subtracted), ch 3..5 masked warped prior, ch 6 certainty, ch 7 zero
-__global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb,
+// prev_rgb: [3][Hs][Ws] -- the previous OUTPUT, which is larger than the frame when H or W is not a multiple of 4; the warp samples it
+// on the flow's H x W grid (BilinearSamplerBDHW.lua:71), bounds and pitch are the source's
+__global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws,
                                                          const float2* bw_flo, const float* cert, int border, int H,
                                                          int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
 {
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
     const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
     if (xp >= Wp) return;
     const int y = reflect(yp - pad, H), x = reflect(xp - pad, W);
-    const size_t i = (size_t)y * W + x, n = (size_t)H * W;
+    const size_t i = (size_t)y * W + x;
     const uint8_t* px = frame_hwc + i * 3;
     const float rgb[3] = {(float)px[0] / 255.f, (float)px[1] / 255.f, (float)px[2] / 255.f};   // image.load: byte/255
     float4 lo, hi;
@@ -212,8 +214,9 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
     }
     if (prev_rgb != nullptr) {
         const float2 f = bw_flo[i];                                     // .flo payload: (u, v) = (dx, dy)
-        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, H, W);
-        const float wr = sample(prev_rgb, t), wg = sample(prev_rgb + n, t), wb = sample(prev_rgb + 2 * n, t);
+        const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, Hs, Ws);
+        const size_t ns = (size_t)Hs * Ws;
+        const float wr = sample(prev_rgb, t), wg = sample(prev_rgb + ns, t), wb = sample(prev_rgb + 2 * ns, t);
         lo.w = fb + (wb * 255.f - 103.939f) * cv;                       // torch.add(fill, prev_warped_masked), core:169
         hi.x = fg + (wg * 255.f - 116.779f) * cv;
         hi.y = fr + (wr * 255.f - 123.68f) * cv;
@@ -318,11 +321,11 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
     return FAV_OK;
 }
 
-int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, const float* backward_flo, const float* cert,
+int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo, const float* cert,
                       int border, int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index)
 {
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
-                       prev_rgb, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
+                       prev_rgb, Hs, Ws, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
     FAV_LAUNCH_CHECK("prep_input_kernel");
     return FAV_OK;
 }

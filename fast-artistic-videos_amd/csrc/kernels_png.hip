@@ -11,19 +11,25 @@
 //     tokens are literals and distance-3 matches (repeated pixels and constant gradients become runs after the Sub filter), followed
 //     by an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that re-aligns the stream to a byte boundary: rows are
 //     independent byte strings;
-//   * png_rows_kernel: one wave per row.  64 positions per step: the match predicate f[p] == f[p-3] becomes a 64-bit ballot, run starts
-//     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes, 15 bits), token
-//     bit offsets from a wave prefix sum, tokens are OR-ed into the row's LDS bit buffer; Adler-32 parts (sum f, sum (n-i) f[i]);
+//   * png_rows_kernel: four waves per row.  A step = 64 positions: the match predicate f[p] == f[p-3] becomes a 64-bit ballot, run starts
+//     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes, 15 bits), so the
+//     steps are independent up to their bit offset: pass 1 takes every step's bit count (popcounts of four ballots of the token
+//     lengths), one scan over the steps gives the offsets, pass 2 forms the tokens and ORs them into the row's LDS bit buffer at
+//     offset + prefix (again from ballots: no cross-lane data movement); Adler-32 parts (sum f, sum (n-i) f[i]);
 //   * png_pack_kernel: one block per row.  Prefix sum of the row sizes, the row copied to its final byte offset (dword stores from an
-//     LDS copy through a funnel shift, bytes at the two ragged ends), its CRC-32 (32-byte pieces, bitwise) raised to its position
-//     (x^(8 * bytes after it) mod P, square and multiply) and XOR-ed into one device word -- CRC-32 is linear, so the order does not
-//     matter; the last block to finish adds the chunk prelude and trailer, combines the Adler-32 and writes header, length, CRC, IEND
-//     and the file size.
+//     LDS copy through a funnel shift, bytes at the two ragged ends), its CRC-32 (16-byte pieces, bitwise) raised to its position:
+//     CRC-32 is linear, crc(A || B) = crc(A) * x^(8 |B|) + crc(B) mod P, with x^(8 n) from three 256-entry tables;
+//   * png_finish_kernel (one block): XOR of the rows' parts + chunk prelude + trailer, Adler-32 from the rows' parts, header, length,
+//     IEND, file size.  (The first version finished in the last block of the pack kernel behind a device-scope fence per block: 88 us,
+//     the fences write back every XCD's L2; the kernel boundary costs 3 us.)
 //   The output pointer may be device memory or host-mapped pinned memory (fav_stylize passes the latter: the packed bytes cross PCIe
 //   once, the host never touches them before write()).
 // HBM-bound by construction: 2.8 MB (u8) or 11 MB (planar float, quantisation fused: clamp, x255, truncate as quantize_kernel) in,
 // <= 3.1 MB staged + packed out.
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "fav_internal.h"
 
@@ -32,29 +38,27 @@ namespace {
 
 constexpr uint32_t CRC_POLY = 0xEDB88320u;      // CRC-32 (ISO-HDLC, zlib / PNG), reflected
 
-// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0), as zlib's multmodp
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0): zlib's multmodp without its data-dependent exit, so that the
+// lanes of a wave do not diverge (32 x (select, xor, shift, select-xor))
 __device__ __host__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
 {
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
-        m >>= 1;
-        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    uint32_t p = 0;
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+        p ^= b & (0u - ((a >> i) & 1u));
+        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
     }
     return p;
 }
 
-struct CrcPow { uint32_t x2n[32]; };            // x^(2^k) mod P, k = 0..31 (host-computed, passed by value)
-
-// x^(8 * nbytes) mod P
-__device__ inline uint32_t crc_xpow8(const CrcPow& t, unsigned long long nbytes)
+// x^(8 n) mod P for n < 2^24 from three 256-entry tables indexed by the bytes of n (host-computed once per device, 3 KB):
+// x^(8 n) = T0[n & 255] * T1[(n >> 8) & 255] * T2[(n >> 16) & 255]
+struct CrcTables { const uint32_t* t; };        // t[0..255] = T0, t[256..511] = T1, t[512..767] = T2
+__device__ inline uint32_t crc_xpow8(const CrcTables& tb, unsigned n)
 {
-    uint32_t p = 1u << 31;                      // x^0
-    int k = 3;                                  // x^(n * 2^3)
-    while (nbytes) {
-        if (nbytes & 1ull) p = crc_mulmod(t.x2n[k & 31], p);
-        nbytes >>= 1; ++k;
-    }
+    uint32_t p = tb.t[n & 255u];
+    if (n >> 8) p = crc_mulmod(p, tb.t[256 + ((n >> 8) & 255u)]);
+    if (n >> 16) p = crc_mulmod(p, tb.t[512 + ((n >> 16) & 255u)]);
     return p;
 }
 
@@ -72,34 +76,43 @@ __device__ inline uint32_t crc_bytes(const uint8_t* s, int n)
 
 __device__ __forceinline__ uint32_t brev_n(uint32_t x, int n) { return __brev(x) >> (32 - n); }
 
-// row geometry shared by both kernels and the host
+// row geometry shared by the kernels and the host
 __host__ __device__ inline int png_row_stride(int W)
 {
     const int n = 3 * W + 1;
     return (((3 + 9 * n + 7 + 3 + 7) / 8 + 4 + 3) & ~3) + 8;      // worst case: every byte a 9-bit literal; + 8 for the 2-word OR
 }
 
+constexpr int PNG_ROW_WAVES = 4;                // waves per row block; wave w takes the 64-position steps w, w + 4, ...
+
 // ---------------------------------------------------------------------------------------------------------------------------------
-// kernel 1: one wave per image row -> stage[row * stride ...], sizes[row], adler[row] = (sum f mod 65521, sum (n - i) f[i] mod 65521)
-// LDS: raw row (3W bytes at a dword-aligned base + the source misalignment), filtered row f (n = 3W + 1 bytes), output bit buffer.
+// kernel 1: one block of four waves per image row -> stage[row * stride ...], sizes[row], adler[row] = (sum f, sum (n - i) f[i]) mod 65521
+// LDS: raw row (3W bytes at a dword-aligned base + the source misalignment), filtered row f (n = 3W + 1 bytes), per-step bit counts,
+// output bit buffer.  A step = 64 consecutive positions = one wave-wide ballot; runs never cross a step, so the steps are independent
+// up to their bit offset: pass 1 forms every step's tokens (kept in registers) and its bit count, a scan over the steps gives the
+// offsets, pass 2 ORs the tokens into the bit buffer.
 template <bool FROM_F32>
-__global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, uint8_t* stage,
-                                                      int stride, uint32_t* sizes, uint2* adler)
+__global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, uint8_t* stage,
+                                                                      int stride, uint32_t* sizes, uint2* adler)
 {
     extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x, row = blockIdx.x;
+    __shared__ unsigned long long red_a[PNG_ROW_WAVES], red_b[PNG_ROW_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
+    constexpr int NT = 64 * PNG_ROW_WAVES;
     const int nraw = 3 * W, n = nraw + 1;
-    const int raw_words = (nraw + 3 + 3) / 4 + 1, f_words = (n + 3) / 4 + 1, out_words = stride / 4;
+    const int nsteps = (n + 63) >> 6;
+    const int raw_words = (nraw + 3 + 3) / 4 + 1, f_words = (n + 3) / 4 + 1, step_words = nsteps + 1, out_words = stride / 4;
     uint32_t* raww = lds;
     uint8_t* f = reinterpret_cast<uint8_t*>(lds + raw_words);
-    uint32_t* out = lds + raw_words + f_words;
+    uint32_t* step_bits = lds + raw_words + f_words;               // [nsteps] bit count of a step, then its exclusive prefix
+    uint32_t* out = step_bits + step_words;
     const uint8_t* raw;
     if (FROM_F32) {
         // image.save: clamp to [0,1], x255, truncate (quantize_kernel); planar float RGB [3][H][W] -> interleaved bytes
         uint8_t* r8 = reinterpret_cast<uint8_t*>(raww);
         const size_t plane = (size_t)H * W;
         const float* src = rgb_planar + (size_t)row * W;
-        for (int x = lane; x < W; x += 64) {
+        for (int x = tid; x < W; x += NT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float v = src[c * plane + x];
@@ -113,15 +126,15 @@ __global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, co
         const size_t a0 = base & ~(size_t)3;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb_hwc + a0);
         const int nw = (int)((base + nraw - a0 + 3) / 4);
-        for (int i = lane; i < nw; i += 64) raww[i] = src[i];      // (the frame buffer is readable to the next dword boundary: hipMalloc granularity)
+        for (int i = tid; i < nw; i += NT) raww[i] = src[i];       // (the frame buffer is readable to the next dword boundary: hipMalloc granularity)
         raw = reinterpret_cast<const uint8_t*>(raww) + (base - a0);
     }
-    for (int i = lane; i < out_words; i += 64) out[i] = 0u;
+    for (int i = tid; i < out_words; i += NT) out[i] = 0u;
     __syncthreads();
     // Sub filter + Adler-32 parts
     unsigned long long sa = 0, sb = 0;
-    if (lane == 0) { f[0] = 1; sa = 1; sb = (unsigned long long)n; }
-    for (int p = 1 + lane; p < n; p += 64) {
+    if (tid == 0) { f[0] = 1; sa = 1; sb = (unsigned long long)n; }
+    for (int p = 1 + tid; p < n; p += NT) {
         const int j = p - 1;
         const uint32_t v = (uint32_t)(raw[j] - (j >= 3 ? raw[j - 3] : 0)) & 255u;
         f[p] = (uint8_t)v;
@@ -129,13 +142,50 @@ __global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, co
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    if (lane == 0) { red_a[wave] = sa; red_b[wave] = sb; }
     __syncthreads();
-    // tokens
-    if (lane == 0) out[0] = 2u;                                    // BFINAL = 0, BTYPE = 01 (fixed Huffman), LSB first
+    // pass 1: bit count of every step of this wave (token lengths only)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
+        const int p = (sidx << 6) + lane;
+        const bool valid = p < n;
+        const uint32_t v = valid ? f[p] : 0u;
+        const bool m = valid && p >= 3 && v == f[p - 3];
+        const unsigned long long mask = __ballot(m);
+        int nb = 0;
+        if (valid) {
+            nb = v < 144u ? 8 : 9;
+            if (m) {
+                const unsigned long long below = ~mask & lt;
+                const int s = below ? 64 - __clzll((long long)below) : 0;
+                const unsigned long long above = (~mask >> lane) >> 1;
+                const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                const int L = e - s;
+                if (L >= 3) nb = lane == s ? 12 + (L > 10) + (L > 18) + (L > 34) : 0;      // 7-bit length symbol + extra bits + 5-bit distance
+            }
+        }
+        const int total = __popcll(__ballot(nb & 1)) + 2 * __popcll(__ballot(nb & 2)) + 4 * __popcll(__ballot(nb & 4)) + 8 * __popcll(__ballot(nb & 8));
+        if (lane == 0) step_bits[sidx] = (uint32_t)total;
+    }
     __syncthreads();
-    int bitpos = 3;
-    for (int base = 0; base < n; base += 64) {
-        const int p = base + lane;
+    // exclusive scan of the step bit counts (wave 0; 64 steps per pass)
+    if (wave == 0) {
+        uint32_t carry = 3;                                        // block header: BFINAL = 0, BTYPE = 01 -> three bits
+        for (int s0 = 0; s0 < nsteps; s0 += 64) {
+            const int i = s0 + lane;
+            const uint32_t x = i < nsteps ? step_bits[i] : 0u;
+            uint32_t incl = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (i < nsteps) step_bits[i] = carry + incl - x;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) { step_bits[nsteps] = carry; out[0] = 2u; }
+    }
+    __syncthreads();
+    // pass 2: form the tokens and OR them in
+    for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
+        const int p = (sidx << 6) + lane;
         const bool valid = p < n;
         const uint32_t v = valid ? f[p] : 0u;
         const bool m = valid && p >= 3 && v == f[p - 3];
@@ -144,7 +194,7 @@ __global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, co
         if (valid) {
             bool lit = true;
             if (m) {
-                const unsigned long long below = ~mask & ((1ull << lane) - 1ull);
+                const unsigned long long below = ~mask & lt;
                 const int s = below ? 64 - __clzll((long long)below) : 0;
                 const unsigned long long above = (~mask >> lane) >> 1;
                 const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
@@ -168,47 +218,46 @@ __global__ __launch_bounds__(64) void png_rows_kernel(const uint8_t* rgb_hwc, co
                 else { val = brev_n(0x190u + v - 144u, 9); nb = 9; }
             }
         }
-        int incl = nb;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-        const int total = __shfl(incl, 63);
+        // exclusive prefix of nb (<= 15) over the wave from four ballots: no cross-lane data movement
+        const unsigned long long b0 = __ballot(nb & 1), b1 = __ballot(nb & 2), b2 = __ballot(nb & 4), b3 = __ballot(nb & 8);
+        const int excl = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt);
         if (nb) {
-            const int o = bitpos + incl - nb;
+            const int o = (int)step_bits[sidx] + excl;
             const unsigned long long vv = (unsigned long long)val << (o & 31);
             atomicOr(&out[o >> 5], (uint32_t)vv);
             if (vv >> 32) atomicOr(&out[(o >> 5) + 1], (uint32_t)(vv >> 32));
         }
-        bitpos += total;
     }
+    __syncthreads();
     // end of block (7 zero bits), empty stored block (3 zero bits, pad to a byte, 00 00 FF FF)
-    bitpos += 7 + 3;
+    const int bitpos = (int)step_bits[nsteps] + 7 + 3;
     const int bo = (bitpos + 7) >> 3;
     const int size = bo + 4;
-    __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         uint8_t* o8 = reinterpret_cast<uint8_t*>(out);
         o8[bo + 2] = 0xFF; o8[bo + 3] = 0xFF;
         sizes[row] = (uint32_t)size;
-        adler[row] = make_uint2((uint32_t)(sa % 65521ull), (uint32_t)(sb % 65521ull));
+        unsigned long long ta = 0, tb2 = 0;
+        for (int w = 0; w < PNG_ROW_WAVES; ++w) { ta += red_a[w]; tb2 += red_b[w]; }
+        adler[row] = make_uint2((uint32_t)(ta % 65521ull), (uint32_t)(tb2 % 65521ull));
     }
     __syncthreads();
     uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (size_t)row * stride);
     const int nwo = (size + 3) >> 2;
-    for (int i = lane; i < nwo; i += 64) dst[i] = out[i];
+    for (int i = tid; i < nwo; i += NT) dst[i] = out[i];
 }
 
 struct PngHeader { uint8_t b[33]; };            // signature + IHDR chunk (host-built)
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// kernel 2: one block per row: place the row, fold its CRC in; the last block finishes the file.
-// ctl[0] = CRC accumulator, ctl[1] = finished-block counter (both zeroed by the launcher before the call).
-__global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int stride, const uint32_t* sizes, const uint2* adler, int W, int H,
-                                                       uint8_t* png, uint32_t* png_bytes, uint32_t* ctl, PngHeader hdr, CrcPow pw)
+// kernel 2: one block per row: place the row at its byte offset and leave its CRC-32 contribution in crc_part[row].  No fences, no
+// atomics: the combination happens in kernel 3 behind the kernel boundary.
+__global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int stride, const uint32_t* sizes, int H, uint8_t* png,
+                                                       uint32_t* crc_part, unsigned long long* total_out, CrcTables tb)
 {
-    extern __shared__ uint32_t lds[];           // the row's bytes (stride) + reduction scratch
+    extern __shared__ uint32_t lds[];           // the row's bytes (stride)
     __shared__ unsigned long long red[256];
     __shared__ uint32_t redx[256];
-    __shared__ int is_last;
     const int t = threadIdx.x, row = blockIdx.x;
     // offsets: sum of the sizes before this row, and of all rows
     unsigned long long before = 0, all = 0;
@@ -242,59 +291,67 @@ __global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int
     } else {
         for (int i = t; i < size; i += 256) png[D + i] = s8[i];
     }
-    // CRC-32 of the row's bytes: 32-byte pieces counted from the END (a piece's power is then x^(8 * 32 * index)), XOR of the raised parts
+    // CRC-32 of the row's bytes: 16-byte pieces counted from the END (a piece's power is then x^(8 * 16 * index)), XOR of the raised parts
     uint32_t acc = 0;
-    const int npieces = (size + 31) >> 5;
+    const int npieces = (size + 15) >> 4;
     for (int j = t; j < npieces; j += 256) {
-        const int hi = size - 32 * j, lo = hi - 32 > 0 ? hi - 32 : 0;
+        const int hi = size - 16 * j, lo = hi - 16 > 0 ? hi - 16 : 0;
         const uint32_t c = crc_bytes(s8 + lo, hi - lo);
-        acc ^= crc_mulmod(crc_xpow8(pw, 32ull * j), c);
+        acc ^= crc_mulmod(crc_xpow8(tb, 16u * (unsigned)j), c);
     }
     redx[t] = acc; __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (t < s) redx[t] ^= redx[t + s]; __syncthreads(); }
     if (t == 0) {
         const unsigned long long after = all - before - (unsigned long long)size + 6ull;               // + final block (2) + Adler-32 (4)
-        atomicXor(&ctl[0], crc_mulmod(crc_xpow8(pw, after), redx[0]));
-        __threadfence();
-        is_last = atomicAdd(&ctl[1], 1u) == (uint32_t)(H - 1);
+        crc_part[row] = crc_mulmod(crc_xpow8(tb, (unsigned)after), redx[0]);
+        if (row == 0) *total_out = all;
     }
-    __syncthreads();
-    if (!is_last) return;
-    // ---- the last block to finish: Adler-32, trailer, chunk CRC, header, IEND, file size
-    __threadfence();
+}
+
+// kernel 3 (one block): XOR of the rows' CRC parts + chunk prelude + trailer, Adler-32 from the rows' parts, header, length, IEND, size
+__global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_part, const uint2* adler, const unsigned long long* total_in, int W, int H,
+                                                         uint8_t* png, uint32_t* png_bytes, PngHeader hdr, CrcTables tb)
+{
+    __shared__ unsigned long long red[256];
+    __shared__ uint32_t redx[256];
+    const int t = threadIdx.x;
+    const unsigned long long all = *total_in;
     const unsigned long long n = 3ull * W + 1ull;
-    unsigned long long s1 = 0, s2 = 0;
+    unsigned long long s1 = 0, s2 = 0; uint32_t x = 0;
     for (int k = t; k < H; k += 256) {
         const uint2 ab = adler[k];
         s1 += ab.x;
         s2 += (ab.y + ((n * (unsigned long long)(H - 1 - k)) % 65521ull) * ab.x) % 65521ull;
+        x ^= crc_part[k];
     }
+    redx[t] = x;
     red[t] = s1; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) { red[t] += red[t + s]; redx[t] ^= redx[t + s]; } __syncthreads(); }
     s1 = red[0]; __syncthreads();
     red[t] = s2; __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
     s2 = red[0];
-    if (t == 0) {
+    const unsigned long long E = 43ull + all;                      // end of the row data
+    if (t < 33) png[t] = hdr.b[t];
+    if (t == 64) {
         const uint32_t a1 = (uint32_t)((1ull + s1) % 65521ull);
         const uint32_t a2 = (uint32_t)((((n % 65521ull) * ((unsigned long long)H % 65521ull)) % 65521ull + s2) % 65521ull);
         const uint32_t ad = (a2 << 16) | a1;
-        const unsigned long long E = 43ull + all;                  // end of the row data
         uint8_t tr[6] = {0x03, 0x00, (uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad};
-        for (int i = 0; i < 6; ++i) png[E + i] = tr[i];
         const uint8_t pre[6] = {'I', 'D', 'A', 'T', 0x78, 0x01};
-        uint32_t crc = atomicXor(&ctl[0], 0u);
-        crc ^= crc_mulmod(crc_xpow8(pw, all + 6ull), crc_bytes(pre, 6));
+        uint32_t crc = redx[0];
+        crc ^= crc_mulmod(crc_xpow8(tb, (unsigned)(all + 6ull)), crc_bytes(pre, 6));
         crc ^= crc_bytes(tr, 6);
-        for (int i = 0; i < 33; ++i) png[i] = hdr.b[i];
         const uint32_t len = (uint32_t)(all + 8ull);               // zlib header (2) + rows + final block (2) + Adler-32 (4)
+        uint8_t tail[26];
+        for (int i = 0; i < 6; ++i) tail[i] = tr[i];
+        tail[6] = (uint8_t)(crc >> 24); tail[7] = (uint8_t)(crc >> 16); tail[8] = (uint8_t)(crc >> 8); tail[9] = (uint8_t)crc;
+        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+        for (int i = 0; i < 12; ++i) tail[10 + i] = iend[i];
+        for (int i = 0; i < 22; ++i) png[E + i] = tail[i];
         png[33] = (uint8_t)(len >> 24); png[34] = (uint8_t)(len >> 16); png[35] = (uint8_t)(len >> 8); png[36] = (uint8_t)len;
         for (int i = 0; i < 6; ++i) png[37 + i] = pre[i];
-        png[E + 6] = (uint8_t)(crc >> 24); png[E + 7] = (uint8_t)(crc >> 16); png[E + 8] = (uint8_t)(crc >> 8); png[E + 9] = (uint8_t)crc;
-        const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
-        for (int i = 0; i < 12; ++i) png[E + 10 + i] = iend[i];
         *png_bytes = (uint32_t)(E + 22ull);
-        __threadfence_system();
     }
 }
 
@@ -308,12 +365,37 @@ uint32_t host_crc32(const uint8_t* s, size_t n)
 }  // namespace
 
 size_t png_capacity(int W, int H) { return 43 + (size_t)H * png_row_stride(W) + 6 + 4 + 12 + 8; }
-// workspace: [ctl: 4 words, 16 B][sizes: H words][adler: H uint2][stage: H * stride], each part 16-byte aligned
+// workspace: [total: 16 B][sizes: H words][crc parts: H words][adler: H uint2][stage: H * stride], each part 16-byte aligned
 size_t png_workspace_bytes(int W, int H)
 {
     const size_t h4 = ((size_t)H * 4 + 15) & ~(size_t)15, h8 = ((size_t)H * 8 + 15) & ~(size_t)15;
-    return 16 + h4 + h8 + (size_t)H * png_row_stride(W) + 16;
+    return 16 + 2 * h4 + h8 + (size_t)H * png_row_stride(W) + 16;
 }
+
+namespace {
+// x^(8 n) tables (3 x 256 words), built once per device on the host with the same arithmetic the kernels use
+const uint32_t* crc_tables_for_device(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, uint32_t*>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& kv : cache) if (kv.first == device) return kv.second;
+    std::vector<uint32_t> t(768);
+    uint32_t x8 = 1u << 31;                                         // x^0
+    for (int k = 0; k < 8; ++k) x8 = crc_mulmod(x8, 1u << 30);      // x^8: one byte
+    uint32_t step = x8;
+    for (int tbl = 0; tbl < 3; ++tbl) {
+        uint32_t p = 1u << 31;
+        for (int i = 0; i < 256; ++i) { t[tbl * 256 + i] = p; p = crc_mulmod(p, step); }
+        step = p;                                                   // step^256: the next table's unit
+    }
+    uint32_t* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), t.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    cache.emplace_back(device, d);
+    return d;
+}
+}  // namespace
 
 int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,
                       void* workspace, size_t ws_bytes, hipStream_t st)
@@ -322,18 +404,22 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     FAV_REQUIRE(W >= 1 && H >= 1 && W <= 16000 && H <= 65535, "png: %dx%d is outside the encoder's range (width <= 16000, height <= 65535)", W, H);
     FAV_REQUIRE(png_out && png_bytes && workspace, "png: null argument");
     FAV_REQUIRE(capacity >= png_capacity(W, H), "png: output capacity %zu < fav_png_capacity = %zu", capacity, png_capacity(W, H));
+    FAV_REQUIRE(capacity < ((size_t)1 << 24) * 250, "png: image too large for the encoder's CRC tables");
     FAV_REQUIRE(ws_bytes >= png_workspace_bytes(W, H), "png: workspace %zu < fav_png_workspace_bytes = %zu", ws_bytes, png_workspace_bytes(W, H));
     FAV_REQUIRE((reinterpret_cast<uintptr_t>(png_out) & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "png: output must be 4-byte, workspace 16-byte aligned");
+    int device = 0; FAV_HIP(hipGetDevice(&device));
+    CrcTables tb{crc_tables_for_device(device)};
+    if (!tb.t) return hip_fail(hipErrorOutOfMemory, "png: CRC tables");
     const int stride = png_row_stride(W);
     const size_t h4 = ((size_t)H * 4 + 15) & ~(size_t)15, h8 = ((size_t)H * 8 + 15) & ~(size_t)15;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
-    uint32_t* ctl = reinterpret_cast<uint32_t*>(ws);
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(ws);
     uint32_t* sizes = reinterpret_cast<uint32_t*>(ws + 16);
-    uint2* adler = reinterpret_cast<uint2*>(ws + 16 + h4);
-    uint8_t* stage = ws + 16 + h4 + h8;
-    FAV_HIP(hipMemsetAsync(ctl, 0, 16, st));
+    uint32_t* crc_part = reinterpret_cast<uint32_t*>(ws + 16 + h4);
+    uint2* adler = reinterpret_cast<uint2*>(ws + 16 + 2 * h4);
+    uint8_t* stage = ws + 16 + 2 * h4 + h8;
     const int nraw = 3 * W, n = nraw + 1;
-    const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)stride / 4) * 4;
+    const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)((n + 63) / 64 + 1) + (size_t)stride / 4) * 4;
     const size_t lds2 = (size_t)stride + 8;
     static thread_local bool attr_set = false;
     if (!attr_set && (lds1 > 48 * 1024 || lds2 > 48 * 1024)) {
@@ -344,9 +430,9 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
         attr_set = true;
     }
     if (rgb_planar)
-        hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler);
+        hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler);
     else
-        hipLaunchKernelGGL(png_rows_kernel<false>, dim3(H), dim3(64), lds1, st, rgb_hwc, nullptr, W, H, stage, stride, sizes, adler);
+        hipLaunchKernelGGL(png_rows_kernel<false>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, rgb_hwc, nullptr, W, H, stage, stride, sizes, adler);
     FAV_LAUNCH_CHECK("png_rows_kernel");
     PngHeader hdr;
     const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
@@ -358,13 +444,10 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     q[16] = 8; q[17] = 2; q[18] = 0; q[19] = 0; q[20] = 0;          // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, not interlaced
     const uint32_t c = host_crc32(q + 4, 17);
     q[21] = (uint8_t)(c >> 24); q[22] = (uint8_t)(c >> 16); q[23] = (uint8_t)(c >> 8); q[24] = (uint8_t)c;
-    CrcPow pw;
-    uint32_t p = 1u << 30;                                          // x^1
-    pw.x2n[0] = p;
-    for (int k = 1; k < 32; ++k) pw.x2n[k] = p = crc_mulmod(p, p);
-    hipLaunchKernelGGL(png_pack_kernel, dim3(H), dim3(256), lds2, st, stage, stride, sizes, adler, W, H, static_cast<uint8_t*>(png_out), png_bytes, ctl,
-                       hdr, pw);
+    hipLaunchKernelGGL(png_pack_kernel, dim3(H), dim3(256), lds2, st, stage, stride, sizes, H, static_cast<uint8_t*>(png_out), crc_part, total, tb);
     FAV_LAUNCH_CHECK("png_pack_kernel");
+    hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(256), 0, st, crc_part, adler, total, W, H, static_cast<uint8_t*>(png_out), png_bytes, hdr, tb);
+    FAV_LAUNCH_CHECK("png_finish_kernel");
     return FAV_OK;
 }
 

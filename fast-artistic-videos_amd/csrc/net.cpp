@@ -85,6 +85,67 @@ const Tuning& tuning()
     return t;
 }
 
+bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul);
+int pow2_ceil(int c) { int p = 4; while (p < c) p <<= 1; return p; }
+
+// Channel pitches of the kernels are powers of two (the generic kernel locates (tap, channel) with shifts, the elementwise kernels
+// split 256 threads over the channels).  Architectures with other filter counts -- models_video.lua:55-140 builds any `c9s1-48,d96,...`,
+// the VR checkpoints have "more filters" (README.md:141) -- are EXECUTED as the next power of two with zero filters: a padded output
+// channel has zero weights and zero bias (identically 0), its InstanceNorm / BatchNorm gets scale 0 and shift 0 (stays 0 through ReLU,
+// residual joins and upsampling), and the next convolution has zero weights for it -- every real channel sees exactly the sums it saw
+// before (x + 0 * 0 = x).  `chan`: channels of the tensor flowing in (already padded).  The 3-channel last layer keeps its size.
+int pad_channel_counts(std::vector<Layer>& ls, int& chan, bool top)
+{
+    for (size_t li = 0; li < ls.size(); ++li) {
+        Layer& L = ls[li];
+        if (L.type == L_CONV) {
+            const bool first_input = chan == 8 && L.cin <= 8;            // the 7 (3) network inputs ride in an 8-channel pixel
+            const int cin_new = first_input ? L.cin : chan;
+            bool has_tanh = false; float mul = 1.f;
+            const bool is_final = top && L.cout == 3 && only_tail(ls, li + 1, has_tanh, mul) && has_tanh;
+            const int cout_new = is_final ? L.cout : pow2_ceil(L.cout);
+            if (!first_input && L.cin > chan) { set_error("network: conv expects %d input channels, producer has fewer", L.cin); return FAV_EFORMAT; }
+            if (cin_new != L.cin || cout_new != L.cout) {
+                std::vector<float> w((size_t)cout_new * cin_new * L.k * L.k, 0.f);
+                const size_t kk = (size_t)L.k * L.k;
+                for (int co = 0; co < L.cout; ++co)
+                    for (int ci = 0; ci < L.cin; ++ci) {
+                        const float* src = L.transposed ? &L.w[((size_t)ci * L.cout + co) * kk] : &L.w[((size_t)co * L.cin + ci) * kk];
+                        float* dst = L.transposed ? &w[((size_t)ci * cout_new + co) * kk] : &w[((size_t)co * cin_new + ci) * kk];
+                        std::copy(src, src + kk, dst);
+                    }
+                L.w.swap(w);
+                if (!L.b.empty()) L.b.resize((size_t)cout_new, 0.f);
+                L.cin = cin_new; L.cout = cout_new;
+            }
+            chan = L.cout;
+        } else if (L.type == L_IN) {
+            if ((int)L.gamma.size() > chan) { set_error("network: InstanceNormalization(%zu) after %d channels", L.gamma.size(), chan); return FAV_EFORMAT; }
+            L.gamma.resize((size_t)chan, 0.f); L.beta.resize((size_t)chan, 0.f);
+        } else if (L.type == L_BN) {
+            if ((int)L.mean.size() > chan) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan); return FAV_EFORMAT; }
+            L.gamma.resize((size_t)chan, 0.f); L.beta.resize((size_t)chan, 0.f); L.mean.resize((size_t)chan, 0.f); L.var.resize((size_t)chan, 1.f);
+        } else if (L.type == L_RES) {
+            int c = chan;
+            int rc = pad_channel_counts(L.block, c, false); if (rc) return rc;
+            if (c != chan) { set_error("network: residual branch changes the channel count"); return FAV_EUNSUPPORTED; }
+        }
+    }
+    return FAV_OK;
+}
+
+long long count_params(const std::vector<Layer>& ls)
+{
+    long long n = 0;
+    for (const Layer& L : ls) {
+        if (L.type == L_CONV) n += (long long)L.w.size() + (long long)L.b.size();
+        else if (L.type == L_IN) n += 2 * (long long)L.gamma.size();
+        else if (L.type == L_BN) n += 4 * (long long)L.mean.size();
+        else if (L.type == L_RES) n += count_params(L.block);
+    }
+    return n;
+}
+
 bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float& mul)
 {
     has_tanh = false; mul = 1.f;
@@ -100,7 +161,8 @@ bool only_tail(const std::vector<Layer>& ls, size_t from, bool& has_tanh, float&
 
 struct fav_net {
     int device = 0;
-    std::vector<Layer> layers;
+    std::vector<Layer> layers;    // as parsed from the checkpoint (describe / output size / parameter count)
+    std::vector<Layer> exec;      // what runs: the same network with channel counts padded to powers of two (pad_channel_counts)
     int pad = 0;                  // leading nn.SpatialReflectionPadding (train_video.lua:319-325)
     int in_channels = 0;
     long long params = 0;
@@ -219,7 +281,6 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                             }
                 rc = dev_upload(wf, 0, &d.wfold); if (rc) return rc;
             }
-            params += (long long)L.w.size() + (long long)L.b.size();
             chan_pitch = L.cout;
             maxc = std::max(maxc, std::max(d.coutp, d.cinp));
         } else if (L.type == L_IN) {
@@ -230,7 +291,6 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             rc = dev_upload(L.beta, 0, &d.beta); if (rc) return rc;
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.scale), L.gamma.size() * sizeof(float)));
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
-            params += 2 * (long long)L.gamma.size();
         } else if (L.type == L_BN) {
             if ((int)L.mean.size() != chan_pitch) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan_pitch); return FAV_EFORMAT; }
             // evaluate mode: a fixed per-channel affine, folded into the consumer's load like InstanceNorm's
@@ -243,7 +303,6 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             DevIN& d = ins.back();
             int rc = dev_upload(sc, 0, &d.scale); if (rc) return rc;
             rc = dev_upload(sh, 0, &d.shift); if (rc) return rc;
-            params += 4 * (long long)L.mean.size();
         } else if (L.type == L_RES) {
             int cp = chan_pitch;
             int rc = upload_layers(L.block, cp, maxc); if (rc) return rc;
@@ -270,8 +329,12 @@ int fav_net::upload()
     if (in_channels != 7 && in_channels != 3) {
         set_error("network: first convolution has %d input channels; video models take 7 (models_video.lua:57), image models 3", in_channels);
         return FAV_EUNSUPPORTED; }
+    exec = layers;
+    int chan0 = 8;
+    int rc = pad_channel_counts(exec, chan0, true); if (rc) return rc;
     int chan = 8, maxc = 8;
-    int rc = upload_layers(layers, chan, maxc); if (rc) return rc;
+    rc = upload_layers(exec, chan, maxc); if (rc) return rc;
+    params = count_params(layers);
     std::vector<float> o((size_t)maxc, 1.f), z((size_t)maxc, 0.f);
     rc = dev_upload(o, 0, &ones); if (rc) return rc;
     rc = dev_upload(z, 0, &zeros); if (rc) return rc;
@@ -513,7 +576,7 @@ int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, f
     st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0;
     Act cur;
     cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.C = 8;
-    return run(layers, cur, true, out_planar, out_raw);
+    return run(exec, cur, true, out_planar, out_raw);
 }
 
 // ================================================================================================
@@ -721,9 +784,12 @@ extern "C" int fav_conv2d_nchw_f32(const float* in, int Cin, int H, int W, const
 struct fav_stream {
     fav_net* net = nullptr;
     fav_net* img_net = nullptr;  // optional -model_img: stylises frames that have no prior (core.lua:59-66,146)
-    int H = 0, W = 0;
+    int H = 0, W = 0;            // frame (= flow, certainty, network input) size
+    int Ho = 0, Wo = 0;          // network output size: H x W when both are multiples of 4, up to 3 px more otherwise (two stride-2
+                                 // convolutions, two x2 upsamplings).  The reference keeps and saves the LARGER image and warps it
+                                 // with the flow's size (BilinearSamplerBDHW.lua:71: the output takes the grid's size), so does this
     fav_stream_opts opts{};
-    float* state = nullptr;      // last_frame_stylized: [3][H][W] float RGB, unclamped (fav.lua:169)
+    float* state = nullptr;      // last_frame_stylized: [3][Ho][Wo] float RGB, unclamped (fav.lua:169)
     bool has_state = false;
     unsigned frame_counter = 0;  // 1-based index of the frame being stylised (key of the uniform-random fill)
     float* in8 = nullptr;        // padded NHWC8 network input
@@ -783,15 +849,15 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
     FAV_REQUIRE(net && out && H > 0 && W > 0, "fav_stream_create: bad argument");
     FAV_REQUIRE(net->pad < H && net->pad < W, "fav_stream_create: %dx%d is smaller than the reflection padding %d", W, H, net->pad);
     int Ho, Wo; net->out_size(H, W, &Ho, &Wo);
-    FAV_REQUIRE(Ho == H && Wo == W, "frame size %dx%d gives a %dx%d output: the recurrent pipeline needs width and height to be multiples of 4 (two stride-2 convolutions)", W, H, Wo, Ho);
+    FAV_REQUIRE(Ho >= 1 && Wo >= 1, "frame size %dx%d is too small for the architecture", W, H);
     FAV_HIP(hipSetDevice(net->device));
     fav_stream* s = new fav_stream();
-    s->net = net; s->H = H; s->W = W;
+    s->net = net; s->H = H; s->W = W; s->Ho = Ho; s->Wo = Wo;
     if (o) s->opts = *o; else { s->opts.border_mode = FAV_BORDER_STN; s->opts.occlusions_min_filter = 7; s->opts.invert_occlusion = 0; s->opts.fix_occlusions = 0; s->opts.fill_random = 0; s->opts.seed = 0; }
     if (s->opts.occlusions_min_filter < 1) s->opts.occlusions_min_filter = 1;
     const size_t n = (size_t)H * W;
     s->ws_bytes = structure_workspace_bytes(W, H);
-    if (hipMalloc(reinterpret_cast<void**>(&s->state), 3 * n * 4) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&s->state), (size_t)3 * Ho * Wo * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->in8), (size_t)(H + 2 * net->pad) * (W + 2 * net->pad) * 32) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->cert_tmp), n * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->cert), n * 4) != hipSuccess ||
@@ -813,10 +879,10 @@ extern "C" void fav_stream_destroy(fav_stream* s) { delete s; }
 
 static int stream_finish(fav_stream* s, float* out_rgb_f32, uint8_t* out_rgb8_hwc, hipStream_t st)
 {
-    const size_t n = (size_t)s->H * s->W;
+    const size_t n = (size_t)s->Ho * s->Wo;
     s->has_state = true;
     if (out_rgb_f32) FAV_HIP(hipMemcpyAsync(out_rgb_f32, s->state, 3 * n * 4, hipMemcpyDeviceToDevice, st));
-    if (out_rgb8_hwc) return launch_quantize_rgb8(s->state, out_rgb8_hwc, s->H, s->W, st);
+    if (out_rgb8_hwc) return launch_quantize_rgb8(s->state, out_rgb8_hwc, s->Ho, s->Wo, st);
     return FAV_OK;
 }
 
@@ -828,7 +894,7 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     hipStream_t st = static_cast<hipStream_t>(stream);
     ++s->frame_counter;
     // the image model sees only the three content channels (core.lua:146): no fill there
-    int rc = launch_prep_input(frame_rgb_hwc, nullptr, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
+    int rc = launch_prep_input(frame_rgb_hwc, nullptr, 0, 0, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
                                s->img_net ? 0 : s->opts.fill_random, s->opts.seed, s->frame_counter);
     if (rc) return rc;
     fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
@@ -843,7 +909,7 @@ extern "C" int fav_stream_set_image_net(fav_stream* s, fav_net* image_net)
         FAV_REQUIRE(image_net->device == s->net->device, "fav_stream_set_image_net: the image model lives on another device");
         FAV_REQUIRE(image_net->pad == s->net->pad, "fav_stream_set_image_net: image model pads %d px, video model %d px (both read the same padded input)", image_net->pad, s->net->pad);
         int Ho, Wo; image_net->out_size(s->H, s->W, &Ho, &Wo);
-        FAV_REQUIRE(Ho == s->H && Wo == s->W, "fav_stream_set_image_net: the image model maps %dx%d to %dx%d", s->W, s->H, Wo, Ho);
+        FAV_REQUIRE(Ho == s->Ho && Wo == s->Wo, "fav_stream_set_image_net: the image model maps %dx%d to %dx%d, the video model to %dx%d", s->W, s->H, Wo, Ho, s->Wo, s->Ho);
     }
     s->img_net = image_net;
     return FAV_OK;
@@ -862,7 +928,7 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
                                      s->opts.occlusions_min_filter, s->cert_tmp, s->cert, s->H, s->W, st);
         if (rc) return rc;
         ++s->frame_counter;
-        rc = launch_prep_input(frame, s->state, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
+        rc = launch_prep_input(frame, s->state, s->Ho, s->Wo, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
                                s->opts.fill_random, s->opts.seed, s->frame_counter);
         if (rc) return rc;
     }
@@ -942,7 +1008,7 @@ extern "C" int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hip
 {
     FAV_REQUIRE(s && state_rgb_f32 && s->has_state, "fav_stream_get_state: no state");
     FAV_HIP(hipSetDevice(s->net->device));
-    FAV_HIP(hipMemcpyAsync(state_rgb_f32, s->state, (size_t)3 * s->H * s->W * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    FAV_HIP(hipMemcpyAsync(state_rgb_f32, s->state, (size_t)3 * s->Ho * s->Wo * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return FAV_OK;
 }
 
@@ -950,7 +1016,7 @@ extern "C" int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, f
 {
     FAV_REQUIRE(s && state_rgb_f32, "fav_stream_set_state: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
-    FAV_HIP(hipMemcpyAsync(s->state, state_rgb_f32, (size_t)3 * s->H * s->W * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    FAV_HIP(hipMemcpyAsync(s->state, state_rgb_f32, (size_t)3 * s->Ho * s->Wo * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     s->has_state = true;
     return FAV_OK;
 }
@@ -960,10 +1026,17 @@ extern "C" int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capaci
     FAV_REQUIRE(s && s->has_state, "fav_stream_encode_png: no stylised frame yet");
     FAV_HIP(hipSetDevice(s->net->device));
     if (!s->png_ws) {
-        s->png_ws_bytes = png_workspace_bytes(s->W, s->H);
+        s->png_ws_bytes = png_workspace_bytes(s->Wo, s->Ho);
         FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
     }
-    return launch_png_encode(nullptr, s->state, s->W, s->H, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, static_cast<hipStream_t>(stream));
+    return launch_png_encode(nullptr, s->state, s->Wo, s->Ho, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fav_stream_output_size(const fav_stream* s, int* Ho, int* Wo)
+{
+    FAV_REQUIRE(s && Ho && Wo, "fav_stream_output_size: null argument");
+    *Ho = s->Ho; *Wo = s->Wo;
+    return FAV_OK;
 }
 
 extern "C" int fav_stream_get_input_f32(const fav_stream* s, float* in7, fav_hipstream_t stream)

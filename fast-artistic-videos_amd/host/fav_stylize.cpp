@@ -290,9 +290,12 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipEvent_t ev_up[3], ev_done[2], ev_out[2];
     for (auto& e : ev_out) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
-    for (auto& e : ev_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed");
+    // events the HOST waits on: blocking (the waiting thread sleeps instead of spinning -- a spinning wait costs one core per waiter,
+    // 1.9 ms of CPU per frame for the main thread alone at 530 frames/s) and with the system-scope fence (the host reads what they cover)
+    for (auto& e : ev_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) die("hipEventCreate failed");
     fav_stream* fs = nullptr;
-    int W = 0, H = 0;
+    int W = 0, H = 0;                        // frame size
+    int Wo = 0, Ho = 0;                      // size of the stylised frames: the network's output (H x W when both are multiples of 4)
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
     Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
     uint8_t* d_out8s[2] = {nullptr, nullptr};    // frames alternate: frame i + 2 is enqueued after the host has seen frame i's download complete
@@ -373,7 +376,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         printf("Writing output image to %s\n", nm);
         mkdirs_for(nm);
         const int lvl = o.i("png_level");
-        const std::string path = nm; uint8_t* hb = pd.hb; const int w_ = W, h_ = H;
+        const std::string path = nm; uint8_t* hb = pd.hb; const int w_ = Wo, h_ = Ho;
         Slots* sl = &slots;
         if (gpu_png) {
             // the size word has arrived (ev_done): ONE DMA of exactly the file's bytes, then the writer thread only write()s
@@ -414,24 +417,28 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     next_to_issue = start + inc;
     for (int i = start; idx_ok(i) && cur.ok; i += inc) {                                                      // core:196-197
         if (first) {
-            if (have_resume && (-W != cur.W || -H != cur.H)) die("-continue_with: previous PNG size differs from the frames");
+            const int rW = -W, rH = -H;          // size of the reloaded PNG (-continue_with), if any
             W = cur.W; H = cur.H;
             fav_stream_opts so{border, o.i("occlusions_min_filter"), o.f("invert_occlusion") ? 1 : 0, o.f("fix_occlusions") ? 1 : 0,
                                o.s("fill_occlusions") == "uniform-random" ? 1 : 0, (unsigned)o.i("seed")};
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
+            check(fav_stream_output_size(fs, &Ho, &Wo), "fav_stream_output_size");
+            if (have_resume && (rW != Wo || rH != Ho)) die("-continue_with: the previous PNG's size differs from the stylised frames' (" + std::to_string(Wo) + "x" + std::to_string(Ho) + ")");
+            if (!o.s("temporal_eval_file").empty() && (Wo != W || Ho != H))
+                die("-temporal_eval_file: the stylised frames (" + std::to_string(Wo) + "x" + std::to_string(Ho) + ") are larger than the flow; the reference's func_eval fails on such sizes as well (fav.lua:128-151)");
             if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
-            const size_t n = (size_t)W * H;
+            const size_t n = (size_t)W * H, no = (size_t)Wo * Ho;
             if (gpu_png) {
-                png_cap = fav_png_capacity(W, H);
+                png_cap = fav_png_capacity(Wo, Ho);
                 for (int k = 0; k < 2; ++k) if (hipMalloc((void**)&d_png[k], png_cap) || hipMalloc((void**)&d_png_size[k], 16)) die("hipMalloc failed");
                 if (hipHostMalloc((void**)&h_png_size, 64, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
-            } else if (hipMalloc((void**)&d_out8s[0], n * 3) || hipMalloc((void**)&d_out8s[1], n * 3)) die("hipMalloc failed");
+            } else if (hipMalloc((void**)&d_out8s[0], no * 3) || hipMalloc((void**)&d_out8s[1], no * 3)) die("hipMalloc failed");
             for (auto& dv : dev)
                 if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
                     hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
             for (auto& p : h_out) {
-                if (hipHostMalloc((void**)&p, gpu_png ? png_cap : n * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
-                if (gpu_png) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed"); slot_ev[p] = e; }
+                if (hipHostMalloc((void**)&p, gpu_png ? png_cap : no * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+                if (gpu_png) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) die("hipEventCreate failed"); slot_ev[p] = e; }
                 slots.add(p);
             }
             for (auto& p : pin)
@@ -440,8 +447,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             pin_px = n; pinned_ready = true;
             if (have_resume) {
                 float* d_state = nullptr;
-                if (hipMalloc((void**)&d_state, n * 12) != hipSuccess) die("hipMalloc failed");
-                hipMemcpy(d_state, resume_state.data(), n * 12, hipMemcpyHostToDevice);
+                if (hipMalloc((void**)&d_state, no * 12) != hipSuccess) die("hipMalloc failed");
+                hipMemcpy(d_state, resume_state.data(), no * 12, hipMemcpyHostToDevice);
                 check(fav_stream_set_state(fs, d_state, st), "fav_stream_set_state");
                 hipStreamSynchronize(st); hipFree(d_state);
             }
@@ -493,7 +500,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image / PNG is complete on the compute queue ...
         hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
         if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
-        else hipMemcpyAsync(hb, d_out8, (size_t)W * H * 3, hipMemcpyDeviceToHost, st_down);
+        else hipMemcpyAsync(hb, d_out8, (size_t)Wo * Ho * 3, hipMemcpyDeviceToHost, st_down);
         hipEventRecord(ev_done[now.ev], st_down);
         const auto tg = std::chrono::steady_clock::now();
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i is already queued

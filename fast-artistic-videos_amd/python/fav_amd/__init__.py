@@ -63,7 +63,7 @@ EXPORTS = [
     "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
-    "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32",
+    "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size",
     "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
@@ -278,6 +278,9 @@ class Stream:
         hd = C.c_void_p()
         _check(lib().fav_stream_create(net.h, h, w, C.byref(o), C.byref(hd)))
         self.h = hd
+        ho, wo = C.c_int(), C.c_int()
+        _check(lib().fav_stream_output_size(hd, C.byref(ho), C.byref(wo)))
+        self.Ho, self.Wo = ho.value, wo.value          # size of the stylised frames (= H x W when both are multiples of 4)
 
     def close(self):
         if getattr(self, "h", None) and lib is not None:
@@ -295,8 +298,8 @@ class Stream:
 
     def _outs(self, dev, want_f32, want_u8):
         torch = _torch()
-        f = torch.empty((3, self.H, self.W), dtype=torch.float32, device=dev) if want_f32 else None
-        u = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+        f = torch.empty((3, self.Ho, self.Wo), dtype=torch.float32, device=dev) if want_f32 else None
+        u = torch.empty((self.Ho, self.Wo, 3), dtype=torch.uint8, device=dev) if want_u8 else None
         return f, u
 
     def first_frame(self, frame_u8_hwc, want_f32=True, want_u8=False, out_f32=None, out_u8=None):
@@ -325,7 +328,7 @@ class Stream:
 
     def state(self):
         torch = _torch()
-        out = torch.empty((3, self.H, self.W), dtype=torch.float32, device=f"cuda:{self.net.device}")
+        out = torch.empty((3, self.Ho, self.Wo), dtype=torch.float32, device=f"cuda:{self.net.device}")
         _check(lib().fav_stream_get_state(self.h, _p(out), _stream()))
         return out
 
@@ -336,7 +339,7 @@ class Stream:
     def png_buffers(self):
         """(out, nbytes) device buffers for encode_png_into: capacity fav_png_capacity(W, H), one int32"""
         torch = _torch()
-        cap = lib().fav_png_capacity(self.W, self.H)
+        cap = lib().fav_png_capacity(self.Wo, self.Ho)
         dev = torch.device("cuda", self.net.device)
         return torch.empty((cap + 3) // 4 * 4, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -367,7 +370,7 @@ def png_encode(img, from_stream: "Stream" = None) -> bytes:
     [3][H][W] tensor, fav_stream_encode_png for a Stream's current frame)."""
     torch = _torch()
     if from_stream is not None:
-        h, w, dev = from_stream.H, from_stream.W, torch.device("cuda", from_stream.net.device)
+        h, w, dev = from_stream.Ho, from_stream.Wo, torch.device("cuda", from_stream.net.device)
     elif img.dtype == torch.uint8:
         h, w, dev = img.shape[0], img.shape[1], img.device
     else:

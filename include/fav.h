@@ -170,7 +170,14 @@ typedef struct fav_stream_opts {
     unsigned seed;
 } fav_stream_opts;
 
+/* H x W: size of the frames (= flows = certainty maps).  The stylised frame has the NETWORK's output size Ho x Wo
+ * (fav_stream_output_size): equal to H x W when both are multiples of 4, up to 3 pixels larger otherwise (two stride-2
+ * convolutions, two x2 upsamplings).  As in the reference, that larger image is what is saved and kept as the recurrent state, and
+ * the next frame's warp samples it on the flow's H x W grid (stnbdhw/BilinearSamplerBDHW.lua:71: the output takes the grid's size;
+ * stylizeVideo_deepflow.sh:72-78 lets the user pick any w:h, e.g. 854x480).  Every out_rgb_f32 below is [3][Ho][Wo], every
+ * out_rgb8_hwc [Ho][Wo][3]. */
 int fav_stream_create(fav_net* net, int H, int W, const fav_stream_opts* opts_host, fav_stream** out);
+int fav_stream_output_size(const fav_stream* s, int* Ho, int* Wo);
 void fav_stream_destroy(fav_stream* s);
 /* -model_img <file>: a separate 3-channel image model (fast_artistic_video_core.lua:59-66,146) that stylises frames
  * without a prior (fav_stream_first_frame).  NULL restores 'self' (the video model with an all-occluded prior).  The
@@ -197,7 +204,7 @@ int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rgb_hwc, cons
  * fav_stream_next_frame_flow call with the same three pointers and mode consumes the prefetched mask. */
 int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
                              const float* forward_flo, int use_structure, fav_hipstream_t stream);
-/* read / overwrite the recurrent state ([3][H][W] float RGB) -- for -continue_with */
+/* read / overwrite the recurrent state ([3][Ho][Wo] float RGB) -- for -continue_with */
 int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
 int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream);
 /* test view: the 7-channel network input of the LAST frame as run_next_image assembles it (fast_artistic_video_core.lua:161-171:

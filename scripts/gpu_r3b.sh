@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-3 GPU call B: PNG encoder tests, CLI tests (default -png_encoder gpu), full bench line (e2e legs), rocprofv3 kernel stats.
+TAG=${1:-r03b}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+(timeout 600 python -m pytest tests/test_gpu_png.py -m gpu -q --timeout 300 2>&1 | tail -30) > $O/test_png_$TAG.log
+(timeout 900 python -m pytest tests/test_gpu_cli.py -m gpu -q --timeout 600 -x 2>&1 | tail -30) > $O/test_cli_$TAG.log
+timeout 1500 python bench.py --steps 40 --warmup 5 > $O/bench_$TAG.log 2> $O/bench_$TAG.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra --no-e2e > $O/prof_$TAG.log 2>&1
+cd $R
+for f in $(find $O/prof_$TAG -name "*kernel_stats.csv"); do cp $f $O/kernel_stats_$TAG.csv; done
+rm -rf $O/prof_$TAG
+echo "=== png tests"; cat $O/test_png_$TAG.log
+echo "=== cli tests"; cat $O/test_cli_$TAG.log
+echo "=== bench"; tail -5 $O/bench_$TAG.err; cat $O/bench_$TAG.log
+python - <<PY
+import csv
+try:
+    rows=list(csv.DictReader(open("$O/kernel_stats_$TAG.csv")))
+    for r in rows[:24]:
+        print(f"{r['Name'][:90]:90s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
+except Exception as e: print("no stats", e)
+PY

@@ -92,6 +92,32 @@ def test_fav_stylize_matches_oracle_loop(oracle, favlib, tmp_path, golden_dir, f
         assert abs(float(open(ev).read().split("\n")[1]) - sum(vals) / n) <= 1e-6 * max(sum(vals) / n, 1e-9)
 
 
+@pytest.mark.parametrize("encoder", ["gpu", "host"])
+def test_fav_stylize_frame_size_not_a_multiple_of_four(oracle, favlib, tmp_path, golden_dir, encoder):
+    """70x50 frames (stylizeVideo_deepflow.sh:72-78 lets the user pick any w:h): the PNGs have the network's output size 72x52, the
+    recurrent state is that larger image warped on the flow's grid (BilinearSamplerBDHW.lua:71), -continue_with reloads it"""
+    from PIL import Image
+    h, w, n = 50, 70, 3
+    frames, bws, fws = _write_clip(oracle, tmp_path, h, w, n, 60)
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    cmd = [os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
+           "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "0", "-output_prefix", str(tmp_path / "out" / "out"), "-gpu", "0",
+           "-model_vid", model, "-model_img", "self", "-png_encoder", encoder]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref = oracle.Stylizer(t7.extract_layers(t7.load(model)["model"]))
+    for i in range(1, n + 1):
+        f01 = np.transpose(frames[i - 1], (2, 0, 1)).astype(np.float32) / np.float32(255)
+        out = ref.first(f01) if i == 1 else ref.next(f01, bws[i - 1], oracle.consistency(bws[i - 1], fws[i - 1]).astype(np.float32) / np.float32(255))
+        png = np.asarray(Image.open(str(tmp_path / "out" / f"out-{i:05d}.png")))
+        assert png.shape == (52, 72, 3) == oracle.to_u8_hwc(out).shape
+        assert np.abs(png.astype(int) - oracle.to_u8_hwc(out).astype(int)).max() <= 1, f"frame {i}"
+    # resume from the (larger) PNG of frame 2
+    os.remove(tmp_path / "out" / "out-00003.png")
+    r = subprocess.run(cmd + ["-continue_with", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(tmp_path / "out" / "out-00003.png"), r.stderr
+
+
 def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
     exe = os.path.join(BIN, "fav_stylize")
     model = os.path.join(golden_dir, "tiny_model.t7")

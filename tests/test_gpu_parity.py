@@ -321,12 +321,64 @@ def test_unsupported_models_fail_with_status(favlib, cuda, tmp_path):
         favlib.Net(p, 0)
     with pytest.raises(favlib.FavError):
         favlib.Net(str(tmp_path / "missing.t7"), 0)
-    # 48 channels: channel pitches are powers of two -- a status at load time, not a crash (this model used to overrun the repacked
-    # weight matrix)
-    p48 = str(tmp_path / "c48.t7")
-    t7.make_synthetic_checkpoint(p48, arch="c9s1-48,d64,c9s1-3", seed=3)
-    with pytest.raises(favlib.FavError, match="48 input channels"):
-        favlib.Net(p48, 0)
+
+
+@pytest.mark.parametrize("arch", ["c9s1-48,d96,R96,R96,U2,c3s1-24,U2,c9s1-3", "c9s1-12,d20,d40,R40,U2,c3s1-20,U2,c9s1-3"])
+def test_filter_counts_that_are_not_powers_of_two(favlib, oracle, cuda, tmp_path, arch):
+    """models_video.lua:55-140 builds any `c9s1-48,d96,...` and the VR checkpoints have "more filters" (README.md:141): such networks
+    run with their channel counts padded to the next power of two by zero filters (exact: the padded channels are identically zero),
+    describe() and the parameter count still show the checkpoint's own sizes"""
+    p = str(tmp_path / "odd.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=13)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    assert net.describe() == favlib.describe_layers(layers)
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((7, 64, 88)) * 50).astype(np.float32)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    ref = oracle.net_forward(layers, x)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 5e-2, np.abs(got - ref).max()
+    assert np.abs(ref).std() > 10
+
+
+@pytest.mark.parametrize("size", [(438, 640), (480, 854), (50, 70), (53, 71)])
+def test_frame_sizes_that_are_not_multiples_of_four(favlib, oracle, cuda, golden_dir, size):
+    """stylizeVideo_deepflow.sh:72-78 lets the user pick any w:h (854x480 is not a multiple of 4): the network's output is then up to
+    3 pixels larger than the frame (two stride-2 convolutions, two x2 upsamplings); the reference keeps and saves that larger image
+    and warps it with the FLOW's size (BilinearSamplerBDHW.lua:71).  Three frames against the oracle, fused check and certainty path."""
+    h, w = size
+    path = os.path.join(golden_dir, "tiny_model.t7")
+    layers = _layers(path)
+    net = favlib.Net(path, 0)
+    ho, wo = net.output_size(h, w)
+    assert (ho, wo) != (h, w) and ho >= h and wo >= w and ho - h < 4 and wo - w < 4
+    frames, bws, fws = _clip(h, w, 3, 40)
+    st = favlib.Stream(net, h, w)
+    assert (st.Ho, st.Wo) == (ho, wo)
+    ref = oracle.Stylizer(layers)
+    o0, u0 = st.first_frame(T(frames[0], cuda), want_u8=True)
+    r0 = ref.first(_f01(frames[0]))
+    assert tuple(o0.shape) == (3, ho, wo) == r0.shape and tuple(u0.shape) == (ho, wo, 3)
+    assert np.abs(o0.cpu().numpy() - r0).max() <= 2e-4
+    m1 = oracle.consistency(bws[1], fws[1])
+    o1, _ = st.next_frame_flow(T(frames[1], cuda), T(bws[1], cuda), T(fws[1], cuda))
+    assert np.array_equal(st.last_mask().cpu().numpy(), m1)
+    tf = oracle.Stylizer(layers); tf.last = o0.cpu().numpy()
+    r1 = tf.next(_f01(frames[1]), bws[1], m1.astype(np.float32) / np.float32(255))           # teacher-forced: the larger state warped on the flow's grid
+    assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+    m2 = oracle.consistency(bws[2], fws[2], frames[2])
+    o2, u2 = st.next_frame_cert(T(frames[2], cuda), T(bws[2], cuda), T(m2, cuda), want_u8=True)
+    tf.last = o1.cpu().numpy()
+    r2 = tf.next(_f01(frames[2]), bws[2], m2.astype(np.float32) / np.float32(255))
+    assert np.abs(o2.cpu().numpy() - r2).max() <= 2e-4
+    assert np.abs(u2.cpu().numpy().astype(int) - oracle.to_u8_hwc(r2).astype(int)).max() <= 1
+    # the PNG of the larger frame, and the state round trip (-continue_with)
+    import io
+    from PIL import Image
+    png = favlib.png_encode(None, from_stream=st)
+    assert np.array_equal(np.array(Image.open(io.BytesIO(png)).convert("RGB")), u2.cpu().numpy())
+    assert tuple(st.state().shape) == (3, ho, wo)
 
 
 # ---------------------------------------------------------------------------------------------- pipeline
