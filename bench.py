@@ -175,7 +175,7 @@ def _cli_leg(base, d, name, extra_args, out_dir_glob, timeout=900, taskset=None)
         return {"error": (r.stderr or r.stdout)[-400:]}
     j = json.loads(lines[-1])
     res = {"fps": j["fps_end_to_end"], "seconds": j["seconds"], "frames": j["frames"]}
-    for k in ("png_writers", "wait_loader_s", "wait_png_pool_s", "setup_s", "png_tail_s", "png_encoder", "host_cpu_ms_per_frame", "png_mb_per_frame", "usable_cpus",
+    for k in ("png_writers", "wait_loader_s", "wait_png_pool_s", "setup_s", "png_tail_s", "png_encoder", "host_cpu_ms_per_frame", "cpu_ms_per_frame_loaders", "cpu_ms_per_frame_writers", "cpu_ms_per_frame_main", "png_mb_per_frame", "usable_cpus",
               "gpus", "streams", "fps_per_gpu"):
         if k in j:
             res[k] = j[k]

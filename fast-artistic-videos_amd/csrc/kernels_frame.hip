@@ -10,6 +10,7 @@
 // dense operand; the bilinear taps are gathers served by L2 (the flow is locally smooth).
 // Compiled with -ffp-contract=off so the fp32 expressions round like the CPU restatement.
 #include "fav_internal.h"
+#include "consistency_pixel.h"
 
 namespace fav {
 namespace {
@@ -105,10 +106,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* img, const float
 
 // certainty from the checker's PGM byte: image.load(...,1) = byte/255; -invert_occlusion and
 // -fix_occlusions of fast_artistic_video.lua:79-86,99-112
-__device__ __forceinline__ float cert_from_mask(const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ, int border, int y, int x, int H, int W)
+__device__ __forceinline__ float cert_from_byte(uint8_t mb, const float2* bw_flo, int invert, int fix_occ, int border, int y, int x, int H, int W)
 {
     const size_t i = (size_t)y * W + x;
-    float c = (float)mask[i] / 255.f;
+    float c = (float)mb / 255.f;
     if (invert) c = (c + -1.f) * -1.f;
     if (fix_occ) {
         const float2 f = bw_flo[i];
@@ -123,14 +124,25 @@ __device__ __forceinline__ float cert_from_mask(const uint8_t* mask, const float
     return c;
 }
 
+__device__ __forceinline__ float cert_from_mask(const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ, int border, int y, int x, int H, int W)
+{
+    return cert_from_byte(mask[(size_t)y * W + x], bw_flo, invert, fix_occ, border, y, x, H, W);
+}
+
 // utils.min_filter (utils.lua:161-169): 1 - maxpool_{r x r, stride 1, pad r/2}(1 - cert); max-pooling pads with -inf, i.e. the
 // windows are truncated at the borders.  max is exact and order-free, so the r x r window is evaluated separably on an LDS
 // tile (rows, then columns): 2r instead of r*r taps, each input element read from memory once per tile.
 constexpr int MF_TX = 64, MF_TY = 16, MF_RMAX = 15;
 // FROM_MASK: the tile is filled from the checker's mask byte with the certainty options applied on the way in (cert_from_mask; 1.5x of that cheap work is repeated in the tiles' halos) -- one launch and one 3.7 MB plane less per frame
-template <bool FROM_MASK>
+// FROM_MASK == 2: the tile is filled from the two FLOWS -- the forward-backward check itself (consistency_pixel, bit-exact) runs on
+// every tile position, the mask byte of the tile's own pixels is written out (tests, -temporal_eval_file, the VR path read it), the
+// certainty options and the erosion follow as above: the mask, the certainty and the eroded certainty of a frame in ONE launch
+// (the check is recomputed 1.5x in the tiles' halos; it replaces a 7.4 us kernel and a kernel boundary)
+template <int FROM_MASK>
 __global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, const uint8_t* mask, const float2* bw_flo, int invert, int fix_occ,
-                                                         int border, float* out, int H, int W, int r)
+                                                         int border, float* out, int H, int W, int r,
+                                                         const float2* fw_flo = nullptr, const float* structure = nullptr, const float* avg_ptr = nullptr,
+                                                         uint8_t* mask_out = nullptr)
 {
     __shared__ float a[MF_TY + MF_RMAX - 1][MF_TX + MF_RMAX];        // 1 - cert, -inf outside the image
     __shared__ float b[MF_TY + MF_RMAX - 1][MF_TX + 1];              // row maxima
@@ -142,7 +154,16 @@ __global__ __launch_bounds__(256) void min_filter_kernel(const float* cert, cons
         const int yy = y0 + ly - p, xx = x0 + lx - p;
         float v = -INFINITY;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const float c = FROM_MASK ? cert_from_mask(mask, bw_flo, invert, fix_occ, border, yy, xx, H, W) : cert[(size_t)yy * W + xx];
+            float c;
+            if (FROM_MASK == 2) {
+                const uint8_t mb = consistency_pixel(bw_flo, fw_flo, structure, avg_ptr, xx, yy, W, H);
+                if (ly >= p && ly < p + MF_TY && lx >= p && lx < p + MF_TX) mask_out[(size_t)yy * W + xx] = mb;      // the tile's own pixels
+                c = cert_from_byte(mb, bw_flo, invert, fix_occ, border, yy, xx, H, W);
+            } else if (FROM_MASK == 1) {
+                c = cert_from_mask(mask, bw_flo, invert, fix_occ, border, yy, xx, H, W);
+            } else {
+                c = cert[(size_t)yy * W + xx];
+            }
             v = c * -1.f + 1.f;                                      // MulConstant(-1), AddConstant(1)
         }
         a[ly][lx] = v;
@@ -297,7 +318,8 @@ int launch_warp(const float* img, const float* flow, float* out, int B, int C, i
 int launch_min_filter_f32(const float* cert, float* out, int H, int W, int r, hipStream_t st)
 {
     FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
-    hipLaunchKernelGGL(min_filter_kernel<false>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, cert, nullptr, nullptr, 0, 0, 0, out, H, W, r);
+    hipLaunchKernelGGL(min_filter_kernel<0>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, cert, nullptr, nullptr, 0, 0, 0, out, H, W, r,
+                       nullptr, nullptr, nullptr, nullptr);
     FAV_LAUNCH_CHECK("min_filter_kernel");
     return FAV_OK;
 }
@@ -315,9 +337,21 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
 {
     FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
     (void)cert_tmp;                           // (the un-eroded certainty is no longer materialised: the erosion reads the mask byte)
-    hipLaunchKernelGGL(min_filter_kernel<true>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, nullptr, mask,
-                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert, H, W, r);
+    hipLaunchKernelGGL(min_filter_kernel<1>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, nullptr, mask,
+                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert, H, W, r, nullptr, nullptr, nullptr, nullptr);
     FAV_LAUNCH_CHECK("min_filter_kernel");
+    return FAV_OK;
+}
+
+// forward-backward check + certainty options + erosion of one frame in one launch (A3/A4 + fav.lua:99-112 + A5)
+int launch_check_cert(const float* backward_flo, const float* forward_flo, const float* structure, const float* avg, uint8_t* mask_out,
+                      int invert, int fix_occ, int border, int r, float* cert, int H, int W, hipStream_t st)
+{
+    FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
+    hipLaunchKernelGGL(min_filter_kernel<2>, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, nullptr, nullptr,
+                       reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert, H, W, r,
+                       reinterpret_cast<const float2*>(forward_flo), structure, avg, mask_out);
+    FAV_LAUNCH_CHECK("min_filter_kernel<check>");
     return FAV_OK;
 }
 

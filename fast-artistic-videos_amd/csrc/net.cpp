@@ -971,8 +971,11 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->ws, s->ws_bytes, &structure, &avg, st); if (rc) return rc;
     }
-    int rc = launch_consistency(backward_flo, forward_flo, structure, avg, s->mask, s->W, s->H, st); if (rc) return rc;
-    return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st);
+    // check + certainty options + erosion in one tile kernel (the mask byte of every pixel is still written: fav_stream_last_mask)
+    int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, s->mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+                               s->opts.occlusions_min_filter, s->cert, s->H, s->W, st);
+    if (rc) return rc;
+    return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st, true);
 }
 
 extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
@@ -994,10 +997,9 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
     }
-    int rc = launch_consistency(backward_flo, forward_flo, structure, avg, pf.mask, s->W, s->H, sd); if (rc) return rc;
-    // certainty of the frame (mask options, fix_occlusions warp of ones, erosion): depends on the mask, the flow and the stream's options only
-    rc = launch_cert_prepare(pf.mask, backward_flo, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
-                             s->opts.occlusions_min_filter, s->side_cert_tmp[q], pf.cert, s->H, s->W, sd);
+    // mask + certainty of the frame (mask options, fix_occlusions warp of ones, erosion): depends on the flows and the stream's options only
+    int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, pf.mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
+                               s->opts.occlusions_min_filter, pf.cert, s->H, s->W, sd);
     if (rc) return rc;
     FAV_HIP(hipEventRecord(pf.done, sd));
     pf.valid = true; pf.frame = frame_rgb_hwc; pf.bw = backward_flo; pf.fw = forward_flo; pf.structure = use_structure != 0;

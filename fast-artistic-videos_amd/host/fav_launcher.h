@@ -248,28 +248,45 @@ inline void dry_run_failure_hook(int rank)
     sleep(120);
 }
 
-// after the workers: total frames / slowest worker's stylisation time (each worker left "<frames> <seconds>" in <idf>.rank<r>)
+// Host-side ceiling of a job: the CPUs this job may use / the CPU time one frame costs the host (file reads into pinned memory,
+// write() of the PNG, submission) -- what the end-to-end rate cannot exceed however many GPUs work.  Measured on the MI355X box
+// of this project at 1280x720 with the fused 3-argument check (profiles/r03*_bench.log, `host_cpu_ms_per_frame`): the defaults below.
+constexpr double HOST_CPU_MS_PER_FRAME_GPU_PNG = 7.0;       // -png_encoder gpu (17.5 MB read + 2.9 MB written per frame)
+constexpr double HOST_CPU_MS_PER_FRAME_HOST_PNG = 24.6;     // -png_encoder host -png_level 1 (zlib Sub + Z_RLE)
+inline std::string host_ceiling_json(double cpu_ms_per_frame, const char* source)
+{
+    const int cpus = effective_cpus();
+    char buf[512];
+    snprintf(buf, sizeof buf, "{\"usable_cpus\": %d, \"host_cpu_ms_per_frame\": %.3f, \"host_bound_ceiling_fps\": %.1f, \"source\": \"%s\"}",
+             cpus, cpu_ms_per_frame, cpu_ms_per_frame > 0 ? cpus * 1e3 / cpu_ms_per_frame : 0.0, source);
+    return buf;
+}
+
+// after the workers: total frames / slowest worker's stylisation time (each worker left "<frames> <seconds> <cpu seconds>" in
+// <idf>.rank<r>), and the host-bound ceiling those CPU seconds imply
 inline void print_aggregate(const std::string& dir, int world, size_t nstreams)
 {
     const std::string idf = dir + "/id";
-    int frames = 0; double secs = 0; std::string per = "";
+    int frames = 0; double secs = 0, cpu = 0; std::string per = "";
     for (int r = 0; r < world; ++r) {
         const std::string f = idf + ".rank" + std::to_string(r);
         FILE* fp = fopen(f.c_str(), "r");
-        int fr = 0; double sc = 0;
-        if (fp) { if (fscanf(fp, "%d %lf", &fr, &sc) != 2) { fr = 0; sc = 0; } fclose(fp); unlink(f.c_str()); }
-        frames += fr; secs = std::max(secs, sc);
+        int fr = 0; double sc = 0, cs = 0;
+        if (fp) { if (fscanf(fp, "%d %lf %lf", &fr, &sc, &cs) < 2) { fr = 0; sc = 0; cs = 0; } fclose(fp); unlink(f.c_str()); }
+        frames += fr; secs = std::max(secs, sc); cpu += cs;
         per += (r ? ", " : "") + std::to_string(fr ? fr / std::max(sc, 1e-9) : 0.0);
     }
+    const double ms = frames ? 1e3 * cpu / frames : 0.0;
     printf("{\"gpus\": %d, \"streams\": %zu, \"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"fps_per_gpu\": [%s], "
+           "\"host_cpu_ms_per_frame\": %.3f, \"host_ceiling\": %s, "
            "\"weights\": \"rank 0 parsed the .t7, ncclBroadcast of the packed blob\"}\n",
-           world, nstreams, frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str());
+           world, nstreams, frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str(), ms, host_ceiling_json(ms, "measured: CPU seconds of all workers / frames").c_str());
 }
 
-inline void write_worker_result(const std::string& idf, int rank, int frames, double seconds)
+inline void write_worker_result(const std::string& idf, int rank, int frames, double seconds, double cpu_seconds = 0.0)
 {
     const std::string f = idf + ".rank" + std::to_string(rank);
-    char line[64]; const int n = snprintf(line, sizeof line, "%d %.6f\n", frames, seconds);
+    char line[96]; const int n = snprintf(line, sizeof line, "%d %.6f %.6f\n", frames, seconds, cpu_seconds);
     if (!write_private_file(f, line, (size_t)n)) fprintf(stderr, "cannot write %s\n", f.c_str());
 }
 

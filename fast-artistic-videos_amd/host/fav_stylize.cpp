@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/resource.h>
+#include <time.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -218,7 +219,14 @@ struct FrameIn {           // everything frame i needs from disk
 };
 
 
-struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0, cpu_s = 0; long long png_bytes = 0; };
+struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0, cpu_s = 0, cpu_loaders = 0, cpu_writers = 0, cpu_main = 0; long long png_bytes = 0; };
+
+double thread_cpu_seconds()
+{
+    struct timespec ts;
+    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts)) return 0.0;
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
 
 double process_cpu_seconds()
 {
@@ -305,7 +313,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipEvent_t png_copy_ev[2] = {nullptr, nullptr};       // last copy OUT of d_png[k]: the next encode into it waits for this
     size_t png_cap = 0;
     std::map<uint8_t*, hipEvent_t> slot_ev;
-    std::atomic<long long> png_bytes_total{0};
+    std::atomic<long long> png_bytes_total{0}, cpu_loaders_us{0}, cpu_writers_us{0};
+    const double cpu_main0 = thread_cpu_seconds();
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
     std::vector<uint8_t*> h_out(nslots, nullptr);
@@ -342,7 +351,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         while ((int)inflight.size() < DEPTH && idx_ok(next_to_issue)) {
             const int i = next_to_issue, set = sets_used % (DEPTH + 1);
             const bool fo = (i == start) && !have_resume && start != 1;
-            inflight.emplace_back(set, std::thread([&, i, fo, set] { ready[set] = load_pinned(i, fo, set); }));
+            inflight.emplace_back(set, std::thread([&, i, fo, set] { ready[set] = load_pinned(i, fo, set); cpu_loaders_us += (long long)(1e6 * thread_cpu_seconds()); }));
             next_to_issue += inc; ++sets_used;
         }
     };
@@ -386,17 +395,23 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             if (hipMemcpyAsync(hb, d_png[pd.ev], nbytes, hipMemcpyDeviceToHost, st_down) != hipSuccess || hipEventRecord(cev, st_down) != hipSuccess) die("D2H of the PNG failed");
             png_copy_ev[pd.ev] = cev;
             png_bytes_total += nbytes;
-            writers.submit([hb, path, nbytes, cev, sl] {
+            std::atomic<long long>* cw = &cpu_writers_us;
+            writers.submit([hb, path, nbytes, cev, sl, cw] {
+                const double c0 = thread_cpu_seconds();
                 if (hipEventSynchronize(cev) != hipSuccess) { fprintf(stderr, "GPU error while downloading %s\n", path.c_str()); exit(1); }
                 const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
                 size_t off = 0;
                 while (fd >= 0 && off < nbytes) { const ssize_t k = write(fd, hb + off, nbytes - off); if (k <= 0) break; off += (size_t)k; }
                 if (fd < 0 || off != nbytes || close(fd)) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
+                *cw += (long long)(1e6 * (thread_cpu_seconds() - c0));
                 sl->give(hb);
             });
         } else {
-            writers.submit([hb, path, w_, h_, lvl, sl] {
+            std::atomic<long long>* cw = &cpu_writers_us;
+            writers.submit([hb, path, w_, h_, lvl, sl, cw] {
+                const double c0 = thread_cpu_seconds();
                 if (fav_write_png_rgb8_host(path.c_str(), hb, w_, h_, lvl)) fprintf(stderr, "%s\n", fav_last_error());
+                *cw += (long long)(1e6 * (thread_cpu_seconds() - c0));
                 sl->give(hb);                                     // only now may the slot receive another frame
             });
         }
@@ -530,6 +545,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     res->tail = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tail).count();
     res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
     res->cpu_s = process_cpu_seconds() - cpu0; res->png_bytes = png_bytes_total.load();
+    res->cpu_loaders = 1e-6 * cpu_loaders_us.load(); res->cpu_writers = 1e-6 * cpu_writers_us.load(); res->cpu_main = thread_cpu_seconds() - cpu_main0;
     for (int k = 0; k < 2; ++k) { hipFree(d_png[k]); hipFree(d_png_size[k]); }
     if (h_png_size) hipHostFree(h_png_size);
     for (auto& kv : slot_ev) hipEventDestroy(kv.second);
@@ -604,6 +620,9 @@ int main(int argc, char** argv)
             if (ndev <= 0) die(std::string("ERROR: ") + fav_last_error());
             if (o.i("gpu") + world > ndev) die("-gpus " + o.s("gpus") + " from -gpu " + o.s("gpu") + ": only " + std::to_string(ndev) + " devices");
         }
+        if (dry)      // what the host can sustain at most, whatever the GPUs do (the 8-GPU run explains itself)
+            printf("{\"host_ceiling\": %s}\n", favl::host_ceiling_json(o.s("png_encoder") == "gpu" ? favl::HOST_CPU_MS_PER_FRAME_GPU_PNG : favl::HOST_CPU_MS_PER_FRAME_HOST_PNG,
+                                                                       "default: measured on the project's MI355X box at 1280x720, fused 3-argument check").c_str());
         std::string xdir;
         const int worst = favl::spawn_workers(argc, argv, world, o.i("pin_workers") != 0, &xdir);
         if (o.i("timing") && !dry && worst == 0) favl::print_aggregate(xdir, world, streams.size());
@@ -648,23 +667,25 @@ int main(int argc, char** argv)
     printf("Model loaded.\n");
     if (net_img) printf("Model loaded.\n");
 
-    int frames = 0; double seconds = 0;
+    int frames = 0; double seconds = 0, cpu_seconds = 0;
     for (const std::string& name : mine) {
         Opt os = o;
         if (named) for (const char* po : path_opts) os.v[po] = favl::subst_stream(o.s(po), name);
         StreamResult r;
         run_stream(os, net, net_img, nwriters, &r);
-        frames += r.frames; seconds += r.seconds;
+        frames += r.frames; seconds += r.seconds; cpu_seconds += r.cpu_s;
         if (o.i("timing"))
             printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"setup_s\": %.3f, \"png_tail_s\": %.3f, \"png_writers\": %d, "
-                   "\"png_encoder\": \"%s\", \"host_cpu_ms_per_frame\": %.3f, \"png_mb_per_frame\": %.3f, \"usable_cpus\": %d}\n",
+                   "\"png_encoder\": \"%s\", \"host_cpu_ms_per_frame\": %.3f, \"cpu_ms_per_frame_loaders\": %.3f, \"cpu_ms_per_frame_writers\": %.3f, \"cpu_ms_per_frame_main\": %.3f, "
+                   "\"png_mb_per_frame\": %.3f, \"usable_cpus\": %d}\n",
                    named ? ("\"stream\": " + favl::json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
                    r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, r.setup, r.tail, nwriters,
-                   o.s("png_encoder").c_str(), 1e3 * r.cpu_s / std::max(r.frames, 1), 1e-6 * (double)r.png_bytes / std::max(r.frames, 1), favl::effective_cpus());
+                   o.s("png_encoder").c_str(), 1e3 * r.cpu_s / std::max(r.frames, 1), 1e3 * r.cpu_loaders / std::max(r.frames, 1), 1e3 * r.cpu_writers / std::max(r.frames, 1),
+                   1e3 * r.cpu_main / std::max(r.frames, 1), 1e-6 * (double)r.png_bytes / std::max(r.frames, 1), favl::effective_cpus());
     }
     check(fav_net_check(net), "at exit");
     if (net_img) check(fav_net_check(net_img), "at exit (image model)");
-    if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds);
+    if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds, cpu_seconds);
     fflush(stdout);
     fav_net_destroy(net); fav_net_destroy(net_img);
     return 0;

@@ -75,7 +75,10 @@ def test_launcher_shards_streams_across_workers(favlib, tmp_path):
     for world in (2, 3):
         r = subprocess.run(base + ["-gpus", str(world), "-gpu", "1"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stderr
-        recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        ceil = [d["host_ceiling"] for d in lines if "host_ceiling" in d]
+        assert len(ceil) == 1 and ceil[0]["host_bound_ceiling_fps"] == pytest.approx(ceil[0]["usable_cpus"] * 1e3 / ceil[0]["host_cpu_ms_per_frame"], rel=1e-3)
+        recs = sorted((d for d in lines if "rank" in d), key=lambda d: d["rank"])
         assert [d["rank"] for d in recs] == list(range(world)) and all(d["world"] == world for d in recs)
         assert [d["device"] for d in recs] == [1 + k for k in range(world)]            # devices -gpu .. -gpu + n - 1
         aff = len(os.sched_getaffinity(0)); quota = 1 << 20
