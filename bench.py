@@ -175,7 +175,7 @@ def _cli_leg(base, d, name, extra_args, out_dir_glob, timeout=900, taskset=None)
         return {"error": (r.stderr or r.stdout)[-400:]}
     j = json.loads(lines[-1])
     res = {"fps": j["fps_end_to_end"], "seconds": j["seconds"], "frames": j["frames"]}
-    for k in ("png_writers", "wait_loader_s", "wait_png_pool_s", "setup_s", "png_tail_s", "png_encoder", "host_cpu_ms_per_frame", "cpu_ms_per_frame_loaders", "cpu_ms_per_frame_writers", "cpu_ms_per_frame_main", "png_mb_per_frame", "usable_cpus",
+    for k in ("png_writers", "wait_loader_s", "wait_png_pool_s", "setup_s", "png_tail_s", "png_encoder", "host_cpu_ms_per_frame", "cpu_ms_per_frame_loaders", "cpu_ms_per_frame_writers", "cpu_ms_per_frame_writers_waiting_for_the_copy", "cpu_ms_per_frame_main", "png_mb_per_frame", "usable_cpus",
               "gpus", "streams", "fps_per_gpu"):
         if k in j:
             res[k] = j[k]
@@ -225,8 +225,7 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames
             # makeOptFlow_deepflow.sh:59; then the per-GPU share of a 16-CPU quota on an 8-GPU node: two cores
             out["host_zlib_png_level_1"] = _cli_leg(base, d, "zl", ["-structure", "0", "-png_encoder", "host", "-png_level", "1"] + outp("zl"), outd("zl"))
             out["gpu_png_4arg_check"] = _cli_leg(base, d, "g4", ["-structure", "1"] + outp("g4"), outd("g4"))
-            out["gpu_png_two_cores"] = _cli_leg(base, d, "g2", ["-structure", "0"] + outp("g2"), outd("g2"), taskset="0-1")
-            out["gpu_png_two_cores"]["note"] = "taskset -c 0-1: loaders, H2D/D2H submission and file writes of one GPU on two CPUs"
+            out["host_zlib_two_cores"] = _cli_leg(base, d, "z2", ["-structure", "0", "-png_encoder", "host", "-png_level", "1", "-num_frames", "100"] + outp("z2"), outd("z2"), taskset="0-1")
         # sustained leg: >= 3000 frames (same ring of inputs), shader clock sampled while it runs
         if sustained_frames and world == 1:
             _make_clip_dir(d, "long", frames_h, bw_h, fw_h, sustained_frames, O)
@@ -235,6 +234,11 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames
                 leg = _cli_leg(lb, d, "long", ["-structure", "0", "-output_prefix", f"{d}/long/o/out"], [f"{d}/long/o"], timeout=1200)
             leg["shader_clock"] = cs.summary()
             out["sustained"] = leg
+            # the per-GPU share of a 16-CPU quota on an 8-GPU node: the whole process (loaders, submission, file writes, the HIP
+            # runtime's own threads) confined to two CPUs
+            leg2 = _cli_leg(lb, d, "long2", ["-structure", "0", "-output_prefix", f"{d}/long/o2/out"], [f"{d}/long/o2"], timeout=1200, taskset="0-1")
+            leg2["note"] = "taskset -c 0-1 on the %d-frame clip" % sustained_frames
+            out["sustained_two_cores"] = leg2
         return out
     except Exception as e:          # the e2e leg must never take the bench line with it
         return {"error": repr(e)[:400]}

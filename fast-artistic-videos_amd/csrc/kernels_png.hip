@@ -9,8 +9,8 @@
 // kernels byte for byte):
 //   * one IDAT chunk = one zlib stream (78 01); every image row is PNG filter type 1 (Sub) and ONE fixed-Huffman deflate block whose
 //     tokens are literals and distance-3 matches (repeated pixels and constant gradients become runs after the Sub filter), followed
-//     by an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that re-aligns the stream to a byte boundary: rows are
-//     independent byte strings;
+//     by an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that re-aligns the stream to a byte boundary -- or, when
+//     that would be longer (noise-like rows), ONE stored block (5 + n bytes): rows are independent byte strings either way;
 //   * png_rows_kernel: four waves per row.  A step = 64 positions: the match predicate f[p] == f[p-3] becomes a 64-bit ballot, run starts
 //     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes, 15 bits), so the
 //     steps are independent up to their bit offset: pass 1 takes every step's bit count (popcounts of four ballots of the token
@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t brev_n(uint32_t x, int n) { return __brev(x)
 __host__ __device__ inline int png_row_stride(int W)
 {
     const int n = 3 * W + 1;
-    return (((3 + 9 * n + 7 + 3 + 7) / 8 + 4 + 3) & ~3) + 8;      // worst case: every byte a 9-bit literal; + 8 for the 2-word OR
+    return ((n + 5 + 3) & ~3) + 8;      // a row never takes more than its STORED form (5 + n bytes): see the kernel; + 8 for the 2-word OR
 }
 
 constexpr int PNG_ROW_WAVES = 4;                // waves per row block; wave w takes the 64-position steps w, w + 4, ...
@@ -152,6 +152,11 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         const uint32_t v = valid ? f[p] : 0u;
         const bool m = valid && p >= 3 && v == f[p - 3];
         const unsigned long long mask = __ballot(m);
+        if (mask == 0ull) {                                         // no repeats in this step (textures, noise): literals only
+            const int total = 8 * __popcll(__ballot(valid)) + __popcll(__ballot(valid && v >= 144u));
+            if (lane == 0) step_bits[sidx] = (uint32_t)total;
+            continue;
+        }
         int nb = 0;
         if (valid) {
             nb = v < 144u ? 8 : 9;
@@ -183,6 +188,29 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         if (lane == 0) { step_bits[nsteps] = carry; out[0] = 2u; }
     }
     __syncthreads();
+    // a row whose fixed-Huffman form would be longer than its STORED form (noise-like rows: half of the literals take 9 bits) becomes
+    // one stored block: 00 | LEN | ~LEN | the n filtered bytes (byte-aligned at both ends: no sync marker needed)
+    const int huff_size = (((int)step_bits[nsteps] + 7 + 3 + 7) >> 3) + 4;
+    if (huff_size > n + 5) {
+        uint8_t* o8 = reinterpret_cast<uint8_t*>(out);
+        if (tid == 0) {
+            out[0] = 0u;                                            // (wave 0 put the fixed-block header there)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            o8[1] = (uint8_t)n; o8[2] = (uint8_t)(n >> 8); o8[3] = (uint8_t)~n; o8[4] = (uint8_t)(~n >> 8);
+            sizes[row] = (uint32_t)(n + 5);
+            unsigned long long ta = 0, tb2 = 0;
+            for (int w = 0; w < PNG_ROW_WAVES; ++w) { ta += red_a[w]; tb2 += red_b[w]; }
+            adler[row] = make_uint2((uint32_t)(ta % 65521ull), (uint32_t)(tb2 % 65521ull));
+        }
+        for (int i = tid; i < n; i += NT) o8[5 + i] = f[i];
+        __syncthreads();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(stage + (size_t)row * stride);
+        const int nwo = (n + 5 + 3) >> 2;
+        for (int i = tid; i < nwo; i += NT) dst[i] = out[i];
+        return;
+    }
     // pass 2: form the tokens and OR them in
     for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
         const int p = (sidx << 6) + lane;
@@ -190,6 +218,18 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         const uint32_t v = valid ? f[p] : 0u;
         const bool m = valid && p >= 3 && v == f[p - 3];
         const unsigned long long mask = __ballot(m);
+        if (mask == 0ull) {                                         // literals only: 8 bits each, 9 for bytes >= 144
+            const bool hi9 = valid && v >= 144u;
+            const unsigned long long b9 = __ballot(hi9);
+            if (valid) {
+                const int o = (int)step_bits[sidx] + 8 * lane + __popcll(b9 & lt);
+                const uint32_t val = hi9 ? brev_n(0x190u + v - 144u, 9) : brev_n(0x30u + v, 8);
+                const unsigned long long vv = (unsigned long long)val << (o & 31);
+                atomicOr(&out[o >> 5], (uint32_t)vv);
+                if (vv >> 32) atomicOr(&out[(o >> 5) + 1], (uint32_t)(vv >> 32));
+            }
+            continue;
+        }
         uint32_t val = 0; int nb = 0;
         if (valid) {
             bool lit = true;

@@ -19,6 +19,8 @@
 #include <functional>
 #include <memory>
 
+#include <mutex>
+
 #include "fav_internal.h"
 #include "wino_pack.h"
 #include "up2_pack.h"
@@ -202,6 +204,7 @@ struct fav_net {
     int timed_conv(const ConvLaunch& c, int conv_index, const Layer& L);
     int run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw);
     int forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
+    int forward_padded_unordered(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     void out_size(int H, int W, int* Ho, int* Wo) const;
 };
 
@@ -555,9 +558,35 @@ void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
     *Ho = h; *Wo = w;
 }
 
+// The persistent / stream-K convolution grids assume that the forwards of ONE process on a device do not overlap (fav.h, concurrency
+// note).  Forwards enqueued on different HIP streams -- two networks, or one network driven from two streams -- used to be a
+// documented foot-gun; now the library orders them itself: every forward leaves an event behind, and a forward enqueued on a
+// different stream than the previous one on that device first waits for it (one hipStreamWaitEvent, nothing when the stream is the
+// same).  Other PROCESSES on the device remain the caller's business (fav_net_set_shared_device).
+namespace {
+struct DeviceOrder { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
+DeviceOrder& device_order(int device)
+{
+    static DeviceOrder order[64];
+    return order[(device >= 0 && device < 64) ? device : 0];
+}
+}  // namespace
+
 int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)
 {
     FAV_HIP(hipSetDevice(device));
+    DeviceOrder& ord = device_order(device);
+    std::lock_guard<std::mutex> order_lock(ord.mu);       // (handles are not thread-safe; this only keeps the bookkeeping consistent)
+    if (ord.valid && ord.last != stream) FAV_HIP(hipStreamWaitEvent(stream, ord.ev, 0));
+    const int rc_fwd = forward_padded_unordered(in8, H, W, out_planar, out_raw, stream);
+    if (!ord.ev) FAV_HIP(hipEventCreateWithFlags(&ord.ev, hipEventDisableTiming | hipEventDisableSystemFence));
+    FAV_HIP(hipEventRecord(ord.ev, stream));              // (device-scope, no timing: one marker per forward)
+    ord.valid = true; ord.last = stream;
+    return rc_fwd;
+}
+
+int fav_net::forward_padded_unordered(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)
+{
     if (sk_err_host && *reinterpret_cast<volatile unsigned*>(sk_err_host)) {      // reported by an earlier launch of this net
         *sk_err_host = 0;
         shared_device = true;

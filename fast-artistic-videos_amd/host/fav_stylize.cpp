@@ -30,6 +30,7 @@
 //   -force_dist 1         take the worker / RCCL path even for -gpus 1;  -dry_run 1: workers print their assignment and exit
 //                         without touching a device (plumbing test).
 #include <hip/hip_runtime.h>
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/resource.h>
 #include <time.h>
@@ -219,13 +220,54 @@ struct FrameIn {           // everything frame i needs from disk
 };
 
 
-struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0, cpu_s = 0, cpu_loaders = 0, cpu_writers = 0, cpu_main = 0; long long png_bytes = 0; };
+struct StreamResult { int frames = 0; double seconds = 0, wait_loader = 0, wait_gpu = 0, wait_png = 0, setup = 0, tail = 0, cpu_s = 0, cpu_loaders = 0, cpu_writers = 0, cpu_writer_sync = 0, cpu_main = 0; long long png_bytes = 0; };
+
+// Waiting for an event WITHOUT occupying a core: hipEventSynchronize spins on this runtime even for events created with
+// hipEventBlockingSync (measured: 1.8 ms of CPU per 1.8 ms frame in the thread that waits, profiles/r03g_e2e.log), so the host polls
+// with short sleeps instead.  The host runs a frame ahead of the GPU, so the added latency (<= the sleep) is never on the GPU's path.
+hipError_t wait_event_sleeping(hipEvent_t ev, unsigned sleep_us = 100)
+{
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        usleep(sleep_us);
+    }
+}
 
 double thread_cpu_seconds()
 {
     struct timespec ts;
     if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts)) return 0.0;
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// CPU time of every live thread of the process (name: seconds), for -timing: the HIP runtime's own threads show up here
+std::string thread_cpu_report()
+{
+    std::string out = "[";
+    DIR* d = opendir("/proc/self/task");
+    if (!d) return "[]";
+    const double tick = 1.0 / (double)sysconf(_SC_CLK_TCK);
+    bool first = true;
+    while (struct dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        const std::string p = std::string("/proc/self/task/") + e->d_name + "/stat";
+        FILE* f = fopen(p.c_str(), "r");
+        if (!f) continue;
+        char buf[1024]; const size_t n = fread(buf, 1, sizeof buf - 1, f); fclose(f); buf[n] = 0;
+        const char* lp = strchr(buf, '('); const char* rp = strrchr(buf, ')');
+        if (!lp || !rp) continue;
+        std::string comm(lp + 1, rp);
+        unsigned long ut = 0, stt = 0; char state;
+        // fields after ')': state ppid pgrp session tty tpgid flags minflt cminflt majflt cmajflt utime stime
+        if (sscanf(rp + 2, "%c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &state, &ut, &stt) != 3) continue;
+        const double sec = (ut + stt) * tick;
+        if (sec < 0.02) continue;
+        char item[128]; snprintf(item, sizeof item, "%s{\"thread\": \"%s\", \"cpu_s\": %.2f}", first ? "" : ", ", comm.c_str(), sec);
+        out += item; first = false;
+    }
+    closedir(d);
+    return out + "]";
 }
 
 double process_cpu_seconds()
@@ -293,8 +335,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     Pool writers(nwriters, cur_device);
     // compute queue; upload queue (the next frame's inputs travel while this frame computes); download queue (the 8-bit frame leaves
     // while the next frame computes: on the compute queue the 2.8 MB copy held back the next frame's kernels for its whole duration)
-    hipStream_t st, st_copy, st_down;
-    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess) die("hipStreamCreate failed");
+    // gpu_png: the file's bytes leave on a queue of their own (st_data): on st_down they would sit behind the NEXT frame's size word,
+    // which waits for that frame's kernels -- the writer thread then waited (spinning) a whole frame for a 0.1 ms DMA
+    hipStream_t st, st_copy, st_down, st_data;
+    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess || hipStreamCreate(&st_data) != hipSuccess) die("hipStreamCreate failed");
     hipEvent_t ev_up[3], ev_done[2], ev_out[2];
     for (auto& e : ev_out) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
@@ -313,7 +357,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipEvent_t png_copy_ev[2] = {nullptr, nullptr};       // last copy OUT of d_png[k]: the next encode into it waits for this
     size_t png_cap = 0;
     std::map<uint8_t*, hipEvent_t> slot_ev;
-    std::atomic<long long> png_bytes_total{0}, cpu_loaders_us{0}, cpu_writers_us{0};
+    std::atomic<long long> png_bytes_total{0}, cpu_loaders_us{0}, cpu_writers_us{0}, cpu_writer_sync_us{0};
     const double cpu_main0 = thread_cpu_seconds();
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
@@ -375,7 +419,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     Pending pend;
     auto finish = [&](Pending& pd) {
         if (!pd.valid) return;
-        if (hipEventSynchronize(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
+        if (wait_event_sleeping(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
         check(fav_net_check(net), "stylising a frame");      // a stream-K hand-off that timed out: fail at THIS frame, before its PNG exists
         if (net_img) check(fav_net_check(net_img), "stylising a frame");
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd.t0).count();
@@ -392,13 +436,15 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             const uint32_t nbytes = h_png_size[pd.ev];
             if (nbytes < 57 || nbytes > png_cap) die("fav_stream_encode_png returned an impossible size");
             hipEvent_t cev = slot_ev[hb];
-            if (hipMemcpyAsync(hb, d_png[pd.ev], nbytes, hipMemcpyDeviceToHost, st_down) != hipSuccess || hipEventRecord(cev, st_down) != hipSuccess) die("D2H of the PNG failed");
+            if (hipMemcpyAsync(hb, d_png[pd.ev], nbytes, hipMemcpyDeviceToHost, st_data) != hipSuccess || hipEventRecord(cev, st_data) != hipSuccess) die("D2H of the PNG failed");
             png_copy_ev[pd.ev] = cev;
             png_bytes_total += nbytes;
             std::atomic<long long>* cw = &cpu_writers_us;
-            writers.submit([hb, path, nbytes, cev, sl, cw] {
+            std::atomic<long long>* cs = &cpu_writer_sync_us;
+            writers.submit([hb, path, nbytes, cev, sl, cw, cs] {
                 const double c0 = thread_cpu_seconds();
-                if (hipEventSynchronize(cev) != hipSuccess) { fprintf(stderr, "GPU error while downloading %s\n", path.c_str()); exit(1); }
+                if (wait_event_sleeping(cev, 50) != hipSuccess) { fprintf(stderr, "GPU error while downloading %s\n", path.c_str()); exit(1); }
+                *cs += (long long)(1e6 * (thread_cpu_seconds() - c0));
                 const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
                 size_t off = 0;
                 while (fd >= 0 && off < nbytes) { const ssize_t k = write(fd, hb + off, nbytes - off); if (k <= 0) break; off += (size_t)k; }
@@ -513,13 +559,13 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, d_png_size[now.ev], st), "fav_stream_encode_png");
         }
         hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image / PNG is complete on the compute queue ...
+        const auto tg = std::chrono::steady_clock::now();
+        finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i's kernels are already queued
+        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
         hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
         if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
         else hipMemcpyAsync(hb, d_out8, (size_t)Wo * Ho * 3, hipMemcpyDeviceToHost, st_down);
         hipEventRecord(ev_done[now.ev], st_down);
-        const auto tg = std::chrono::steady_clock::now();
-        finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i is already queued
-        t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
         pend = now;
         if (cur.index >= 0) cur.release();               // malloc'ed (first frame); pinned sets are reused
         ++done;
@@ -546,6 +592,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     res->wait_loader = t_wait_load; res->wait_gpu = t_gpu; res->wait_png = t_wait_writer;
     res->cpu_s = process_cpu_seconds() - cpu0; res->png_bytes = png_bytes_total.load();
     res->cpu_loaders = 1e-6 * cpu_loaders_us.load(); res->cpu_writers = 1e-6 * cpu_writers_us.load(); res->cpu_main = thread_cpu_seconds() - cpu_main0;
+    res->cpu_writer_sync = 1e-6 * cpu_writer_sync_us.load();
     for (int k = 0; k < 2; ++k) { hipFree(d_png[k]); hipFree(d_png_size[k]); }
     if (h_png_size) hipHostFree(h_png_size);
     for (auto& kv : slot_ev) hipEventDestroy(kv.second);
@@ -557,7 +604,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     for (auto& e : ev_up) hipEventDestroy(e);
     for (auto& e : ev_done) hipEventDestroy(e);
     for (auto& e : ev_out) hipEventDestroy(e);
-    hipStreamDestroy(st); hipStreamDestroy(st_copy); hipStreamDestroy(st_down);
+    hipStreamDestroy(st); hipStreamDestroy(st_copy); hipStreamDestroy(st_down); hipStreamDestroy(st_data);
 }
 
 }  // namespace
@@ -676,15 +723,16 @@ int main(int argc, char** argv)
         frames += r.frames; seconds += r.seconds; cpu_seconds += r.cpu_s;
         if (o.i("timing"))
             printf("{%s\"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"wait_loader_s\": %.3f, \"h2d_gpu_d2h_s\": %.3f, \"wait_png_pool_s\": %.3f, \"setup_s\": %.3f, \"png_tail_s\": %.3f, \"png_writers\": %d, "
-                   "\"png_encoder\": \"%s\", \"host_cpu_ms_per_frame\": %.3f, \"cpu_ms_per_frame_loaders\": %.3f, \"cpu_ms_per_frame_writers\": %.3f, \"cpu_ms_per_frame_main\": %.3f, "
+                   "\"png_encoder\": \"%s\", \"host_cpu_ms_per_frame\": %.3f, \"cpu_ms_per_frame_loaders\": %.3f, \"cpu_ms_per_frame_writers\": %.3f, \"cpu_ms_per_frame_writers_waiting_for_the_copy\": %.3f, \"cpu_ms_per_frame_main\": %.3f, "
                    "\"png_mb_per_frame\": %.3f, \"usable_cpus\": %d}\n",
                    named ? ("\"stream\": " + favl::json_str(name) + ", \"gpu\": " + std::to_string(device) + ", ").c_str() : "",
                    r.frames, r.seconds, r.frames / std::max(r.seconds, 1e-9), r.wait_loader, r.wait_gpu, r.wait_png, r.setup, r.tail, nwriters,
-                   o.s("png_encoder").c_str(), 1e3 * r.cpu_s / std::max(r.frames, 1), 1e3 * r.cpu_loaders / std::max(r.frames, 1), 1e3 * r.cpu_writers / std::max(r.frames, 1),
+                   o.s("png_encoder").c_str(), 1e3 * r.cpu_s / std::max(r.frames, 1), 1e3 * r.cpu_loaders / std::max(r.frames, 1), 1e3 * r.cpu_writers / std::max(r.frames, 1), 1e3 * r.cpu_writer_sync / std::max(r.frames, 1),
                    1e3 * r.cpu_main / std::max(r.frames, 1), 1e-6 * (double)r.png_bytes / std::max(r.frames, 1), favl::effective_cpus());
     }
     check(fav_net_check(net), "at exit");
     if (net_img) check(fav_net_check(net_img), "at exit (image model)");
+    if (o.i("timing")) printf("thread CPU seconds (live threads, whole process): %s\n", thread_cpu_report().c_str());
     if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds, cpu_seconds);
     fflush(stdout);
     fav_net_destroy(net); fav_net_destroy(net_img);

@@ -81,6 +81,9 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
     int W = 0, H = 0, ew = 0, eh = 0, cw = 0, ch = 0;
     uint8_t *d_frame = nullptr, *d_cert = nullptr, *d_equi = nullptr, *d_cube = nullptr; float* d_flow = nullptr;
     std::vector<uint8_t> h_equi, h_cube;
+    // -png_encoder gpu (default): the two output images leave the device as finished PNG files (fav_png_encode_rgb8); host: zlib, -png_level
+    const bool gpu_png = v["png_encoder"] == "gpu";
+    uint8_t *d_png_e = nullptr, *d_png_c = nullptr; uint32_t* d_png_n = nullptr; void* d_png_ws = nullptr; size_t png_ws_bytes = 0, cap_e = 0, cap_c = 0;
     std::future<void> writer;
     const int start = I("start_frame"), total = I("num_frames") * 6;                                              // :571
     const auto t_all = std::chrono::steady_clock::now();
@@ -108,6 +111,12 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
             hipc(hipMalloc(reinterpret_cast<void**>(&d_flow), (size_t)W * H * 8), "hipMalloc");
             if (ew) { hipc(hipMalloc(reinterpret_cast<void**>(&d_equi), (size_t)ew * eh * 3), "hipMalloc"); h_equi.resize((size_t)ew * eh * 3); }
             if (b["out_cubemap"]) { hipc(hipMalloc(reinterpret_cast<void**>(&d_cube), (size_t)cw * ch * 3), "hipMalloc"); h_cube.resize((size_t)cw * ch * 3); }
+            if (gpu_png) {
+                if (ew) { cap_e = fav_png_capacity(ew, eh); hipc(hipMalloc(reinterpret_cast<void**>(&d_png_e), cap_e), "hipMalloc"); h_equi.resize(cap_e); png_ws_bytes = std::max(png_ws_bytes, fav_png_workspace_bytes(ew, eh)); }
+                if (b["out_cubemap"]) { cap_c = fav_png_capacity(cw, ch); hipc(hipMalloc(reinterpret_cast<void**>(&d_png_c), cap_c), "hipMalloc"); h_cube.resize(cap_c); png_ws_bytes = std::max(png_ws_bytes, fav_png_workspace_bytes(cw, ch)); }
+                hipc(hipMalloc(reinterpret_cast<void**>(&d_png_n), 16), "hipMalloc");
+                if (png_ws_bytes) hipc(hipMalloc(&d_png_ws, png_ws_bytes), "hipMalloc");
+            }
         } else if (w != W || h != H) die(img_path + ": face size changed");
         hipc(hipMemcpyAsync(d_frame, rgb, (size_t)W * H * 3, hipMemcpyHostToDevice, st), "H2D frame");
         const bool temporal = i >= 7 && !b["create_inconsistent"];
@@ -135,22 +144,40 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
         if (mode == 5) {                                                                                            // :527-557
             if (writer.valid()) writer.get();
             check(fav_vr_finish_frame(vr, d_equi, b["out_cubemap"] ? d_cube : nullptr, st), "fav_vr_finish_frame");
-            if (d_equi) hipc(hipMemcpyAsync(h_equi.data(), d_equi, h_equi.size(), hipMemcpyDeviceToHost, st), "D2H");
-            if (d_cube) hipc(hipMemcpyAsync(h_cube.data(), d_cube, h_cube.size(), hipMemcpyDeviceToHost, st), "D2H");
+            uint32_t png_n[2] = {0, 0};
+            if (gpu_png) {
+                if (d_equi) check(fav_png_encode_rgb8(d_equi, ew, eh, d_png_e, cap_e, d_png_n, d_png_ws, png_ws_bytes, st), "fav_png_encode_rgb8");
+                if (d_cube) check(fav_png_encode_rgb8(d_cube, cw, ch, d_png_c, cap_c, d_png_n + 1, d_png_ws, png_ws_bytes, st), "fav_png_encode_rgb8");   // (same stream: the workspace is free again)
+                hipc(hipMemcpyAsync(png_n, d_png_n, 8, hipMemcpyDeviceToHost, st), "D2H");
+                hipc(hipStreamSynchronize(st), "sync");
+                if (png_n[0] > cap_e || png_n[1] > cap_c) die("fav_png_encode_rgb8 returned an impossible size");
+                if (d_equi) hipc(hipMemcpyAsync(h_equi.data(), d_png_e, png_n[0], hipMemcpyDeviceToHost, st), "D2H");
+                if (d_cube) hipc(hipMemcpyAsync(h_cube.data(), d_png_c, png_n[1], hipMemcpyDeviceToHost, st), "D2H");
+            } else {
+                if (d_equi) hipc(hipMemcpyAsync(h_equi.data(), d_equi, h_equi.size(), hipMemcpyDeviceToHost, st), "D2H");
+                if (d_cube) hipc(hipMemcpyAsync(h_cube.data(), d_cube, h_cube.size(), hipMemcpyDeviceToHost, st), "D2H");
+            }
             hipc(hipStreamSynchronize(st), "sync");
             check(fav_net_check(vid), "finishing a frame");
             const int out_idx = (i - 1) / 6 + 1;                                                                    // :517 (not offset by -start_frame)
             const std::string prefix = v["output_prefix"]; const int lvl = I("png_level");
             std::vector<uint8_t> e = h_equi, cb = h_cube;
+            if (gpu_png) { e.resize(d_equi ? png_n[0] : 0); cb.resize(d_cube ? png_n[1] : 0); }
             writer = std::async(std::launch::async, [=]() {
                 char name[4096];
+                auto put = [&](const char* nm, const std::vector<uint8_t>& bytes) {          // the bytes ARE the file (GPU encoder)
+                    FILE* f = fopen(nm, "wb");
+                    if (!f || fwrite(bytes.data(), 1, bytes.size(), f) != bytes.size() || fclose(f)) die(std::string("writing ") + nm + " failed");
+                };
                 if (!e.empty()) {
                     snprintf(name, sizeof name, "%s-%05d_equi.png", prefix.c_str(), out_idx); mkdirs_for(name);
-                    if (fav_write_png_rgb8_host(name, e.data(), ew, eh, lvl)) die(std::string("writing ") + name + ": " + fav_last_error());
+                    if (gpu_png) put(name, e);
+                    else if (fav_write_png_rgb8_host(name, e.data(), ew, eh, lvl)) die(std::string("writing ") + name + ": " + fav_last_error());
                 }
                 if (!cb.empty()) {
                     snprintf(name, sizeof name, "%s-%05d_cubemap.png", prefix.c_str(), out_idx); mkdirs_for(name);
-                    if (fav_write_png_rgb8_host(name, cb.data(), cw, ch, lvl)) die(std::string("writing ") + name + ": " + fav_last_error());
+                    if (gpu_png) put(name, cb);
+                    else if (fav_write_png_rgb8_host(name, cb.data(), cw, ch, lvl)) die(std::string("writing ") + name + ": " + fav_last_error());
                 }
             });
             ++frames_done;
@@ -165,6 +192,7 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
     check(fav_net_check(vid), "stylising the video");
     if (img) check(fav_net_check(img), "stylising the video (image model)");
     (void)hipFree(d_frame); (void)hipFree(d_cert); (void)hipFree(d_flow); (void)hipFree(d_equi); (void)hipFree(d_cube);
+    (void)hipFree(d_png_e); (void)hipFree(d_png_c); (void)hipFree(d_png_n); (void)hipFree(d_png_ws);
     hipStreamDestroy(st);
     *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
     return frames_done;
@@ -182,7 +210,7 @@ int main(int argc, char** argv)
         {"cudnn_benchmark", "0"}, {"evaluation_file", "evaluation.txt"}, {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""},
         {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
         {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
-        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
+        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"png_encoder", "gpu"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
         {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"pin_workers", "1"}, {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
     std::map<std::string, bool> b = {
         {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},
@@ -209,6 +237,7 @@ int main(int argc, char** argv)
     if (v["model_vid"].empty()) die("Must give -model_vid");
     if (v["fill_occlusions"] != "vgg-mean" && v["fill_occlusions"] != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     if (v["precision"] != "fp32" && v["precision"] != "bf16") die("-precision must be fp32 or bf16");
+    if (v["png_encoder"] != "gpu" && v["png_encoder"] != "host") die("-png_encoder must be gpu or host");
     const bool timing = I("timing") != 0, dry = I("dry_run") != 0;
     std::vector<std::string> streams = favl::split_list(v["streams"]);
     const bool named = !streams.empty();

@@ -7,8 +7,9 @@ The format (A9, image.save of fast_artistic_video.lua:160-170 -> an RGB8 PNG):
   * one IDAT chunk holding one zlib stream (header 78 01);
   * every image row = PNG filter type 1 (Sub) = one fixed-Huffman deflate block (BFINAL 0, BTYPE 01) whose tokens are literals and
     distance-3 matches (run-length coding of repeated pixels / constant gradients), cut at 64-position boundaries (one wave step),
-    followed by an EMPTY STORED BLOCK (the Z_SYNC_FLUSH marker 00 00 FF FF) that re-aligns the stream to a byte boundary -- so rows
-    are encoded independently (one wave each) and concatenated at byte granularity;
+    followed by an EMPTY STORED BLOCK (the Z_SYNC_FLUSH marker 00 00 FF FF) that re-aligns the stream to a byte boundary -- or, when
+    that would be longer than the row itself, ONE stored block (00 | LEN | ~LEN | the filtered bytes) -- so rows are encoded
+    independently (one block of waves each) and concatenated at byte granularity;
   * a final empty fixed block (03 00), the Adler-32 of the filtered stream, the chunk CRC-32 -- both combined from per-row parts.
 """
 import struct
@@ -79,12 +80,14 @@ def encode_row(f):
     nbytes = bits // 8
     out = bytearray(acc.to_bytes(nbytes, "little"))
     out += b"\x00\x00\xff\xff"                                    # LEN = 0, NLEN = ~0
+    if len(out) > n + 5:                                          # the stored form is shorter (noise-like rows): 00 | LEN | ~LEN | bytes
+        return b"\x00" + struct.pack("<HH", n, n ^ 0xFFFF) + bytes(bytearray(int(x) for x in f))
     return bytes(out)
 
 
 def row_stride(width):
     n = 3 * width + 1
-    return (((3 + 9 * n + 7 + 3 + 7) // 8 + 4 + 3) & ~3) + 8
+    return ((n + 5 + 3) & ~3) + 8
 
 
 def capacity(width, height):

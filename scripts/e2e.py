@@ -21,13 +21,20 @@ for i in range(1, N + 1):
 exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
 base = [exe, "-input_pattern", d + "/frame_%05d.ppm", "-flow_pattern", d + "/flow/backward_[%d]_{%d}.flo", "-forward_flow_pattern", d + "/flow/forward_{%d}_[%d].flo",
         "-structure", "0", "-model_vid", model, "-model_img", "self", "-gpu", "0", "-timing", "1"]
-variants = os.environ.get("FAV_E2E_VARIANTS", "png1:-png_level 1;png0:-png_level 0;png1_w64:-png_level 1 -writers 64;png1_w16:-png_level 1 -writers 16")
+variants = os.environ.get("FAV_E2E_VARIANTS", "gpu_png:-png_encoder gpu;gpu_png_w2:-png_encoder gpu -writers 2;host_png1:-png_encoder host -png_level 1")
 for v in variants.split(";"):
     name, flags = v.split(":", 1)
+    env = dict(os.environ)
+    words = []
+    for wd in flags.split():            # NAME=VALUE words are environment settings of the run, the rest are flags
+        if "=" in wd and not wd.startswith("-"): k, val = wd.split("=", 1); env[k] = val
+        else: words.append(wd)
     t0 = time.time()
-    r = subprocess.run(base + ["-output_prefix", f"{d}/o_{name}/out"] + flags.split(), capture_output=True, text=True)
+    r = subprocess.run(base + ["-output_prefix", f"{d}/o_{name}/out"] + words, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     print(name, "wall %.2f s" % wall, line[-1] if line else ("FAILED " + r.stderr[-300:]), flush=True)
+    for l in r.stdout.splitlines():
+        if l.startswith("thread CPU seconds"): print("   ", l, flush=True)
     shutil.rmtree(f"{d}/o_{name}", ignore_errors=True)
 shutil.rmtree(d, ignore_errors=True)

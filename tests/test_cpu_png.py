@@ -31,10 +31,15 @@ def test_png_model_files_decode_exactly(oracle, name, img):
     pil = np.array(Image.open(io.BytesIO(data)).convert("RGB"))
     assert np.array_equal(pil, img)
     assert np.array_equal(P.decode(data), img)          # checks every chunk CRC; zlib checks the Adler-32
-    # structure: one IDAT, rows byte-aligned by sync markers, final empty fixed block
+    # structure: one IDAT, every row either a fixed block closed by a sync marker or one stored block, final empty fixed block
     idat = data[41:-16]
     assert idat[:2] == b"\x78\x01" and idat[-6:-4] == b"\x03\x00"
-    assert idat.count(b"\x00\x00\xff\xff") >= img.shape[0]
+    n = 3 * img.shape[1] + 1
+    segs = [P.encode_row(P.filter_row(img[y])) for y in range(img.shape[0])]
+    assert all(len(sg) <= n + 5 for sg in segs) and idat[2:-6] == b"".join(segs)
+    assert all(sg.endswith(b"\x00\x00\xff\xff") or (sg[0] == 0 and len(sg) == n + 5) for sg in segs)
+    if name in ("noise", "high-bytes"): assert all(len(sg) == n + 5 for sg in segs)          # incompressible rows are stored
+    if name in ("flat", "gradient"): assert all(len(sg) < n // 8 for sg in segs)
 
 
 def test_png_model_token_codes_are_the_fixed_huffman_code():
