@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_par
         for (int i = 0; i < 22; ++i) png[E + i] = tail[i];
         png[33] = (uint8_t)(len >> 24); png[34] = (uint8_t)(len >> 16); png[35] = (uint8_t)(len >> 8); png[36] = (uint8_t)len;
         for (int i = 0; i < 6; ++i) png[37 + i] = pre[i];
+        __threadfence_system();                                    // the bytes above before the size (png_bytes may be host-mapped: the host polls it)
         *png_bytes = (uint32_t)(E + 22ull);
+        __threadfence_system();
     }
 }
 

@@ -560,11 +560,13 @@ void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
 
 // The persistent / stream-K convolution grids assume that the forwards of ONE process on a device do not overlap (fav.h, concurrency
 // note).  Forwards enqueued on different HIP streams -- two networks, or one network driven from two streams -- used to be a
-// documented foot-gun; now the library orders them itself: every forward leaves an event behind, and a forward enqueued on a
-// different stream than the previous one on that device first waits for it (one hipStreamWaitEvent, nothing when the stream is the
-// same).  Other PROCESSES on the device remain the caller's business (fav_net_set_shared_device).
+// documented foot-gun; now the library orders them itself: when a forward arrives on another stream than the previous forward on
+// that device, the HOST first waits for the previous stream to drain (hipStreamSynchronize: rare, a misuse made safe).  No marker
+// is left in the compute queue in the common single-stream case: on this runtime an event record behind long-running kernels keeps
+// a runtime thread spinning until it fires (scripts/runtime_thread_bench.hip).  Other PROCESSES on the device remain the caller's
+// business (fav_net_set_shared_device).
 namespace {
-struct DeviceOrder { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
+struct DeviceOrder { std::mutex mu; hipStream_t last = nullptr; bool valid = false; };
 DeviceOrder& device_order(int device)
 {
     static DeviceOrder order[64];
@@ -577,12 +579,10 @@ int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, f
     FAV_HIP(hipSetDevice(device));
     DeviceOrder& ord = device_order(device);
     std::lock_guard<std::mutex> order_lock(ord.mu);       // (handles are not thread-safe; this only keeps the bookkeeping consistent)
-    if (ord.valid && ord.last != stream) FAV_HIP(hipStreamWaitEvent(stream, ord.ev, 0));
-    const int rc_fwd = forward_padded_unordered(in8, H, W, out_planar, out_raw, stream);
-    if (!ord.ev) FAV_HIP(hipEventCreateWithFlags(&ord.ev, hipEventDisableTiming | hipEventDisableSystemFence));
-    FAV_HIP(hipEventRecord(ord.ev, stream));              // (device-scope, no timing: one marker per forward)
+    if (ord.valid && ord.last != stream && hipStreamSynchronize(ord.last) != hipSuccess)
+        (void)hipGetLastError();       // the previous stream no longer exists (its owner synchronised and destroyed it): nothing to wait for
     ord.valid = true; ord.last = stream;
-    return rc_fwd;
+    return forward_padded_unordered(in8, H, W, out_planar, out_raw, stream);
 }
 
 int fav_net::forward_padded_unordered(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)

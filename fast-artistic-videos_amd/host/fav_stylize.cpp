@@ -330,15 +330,27 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     // run-length deflate per row + Adler-32 / CRC-32 combine), leave as ONE exact-size DMA and the writer thread only write()s them;
     // -png_encoder host: the 8-bit frame is downloaded and deflated by zlib on the writer threads (-png_level; ~25 ms per frame and core)
     const bool gpu_png = o.s("png_encoder") == "gpu";
+    // QUIET synchronisation (gpu_png, no 4-argument look-ahead): nothing but kernels ever enters the compute queue.  On this runtime
+    // a marker behind long-running kernels (hipEventRecord on the compute stream) or a device-side dependency between queues
+    // (hipStreamWaitEvent, a copy in front of kernels in one stream) is resolved by a runtime thread that SPINS until the marker
+    // fires -- one core per process, 1.6 ms of CPU per 1.8 ms frame (scripts/runtime_thread_bench.hip, profiles/r03k_runtime_thread.log:
+    // kernels only 0.03 cores in the background, + one event record per frame 0.70, + a cross-stream dependency 0.74).  So: uploads are
+    // DMA copies on their own queue and the HOST checks (sleeping poll on that queue's event) that frame i's inputs have arrived before
+    // it enqueues frame i's kernels -- they were requested a frame earlier; the frame's last kernel writes the PNG size into host-mapped
+    // memory, which the host polls; the PNG bytes then leave as one DMA on a third queue.
+    const bool quiet = gpu_png && !(fused_check && o.i("structure") != 0);
     int cur_device = 0; (void)hipGetDevice(&cur_device);
     const double cpu0 = process_cpu_seconds();
     Pool writers(nwriters, cur_device);
     // compute queue; upload queue (the next frame's inputs travel while this frame computes); download queue (the 8-bit frame leaves
     // while the next frame computes: on the compute queue the 2.8 MB copy held back the next frame's kernels for its whole duration)
-    // gpu_png: the file's bytes leave on a queue of their own (st_data): on st_down they would sit behind the NEXT frame's size word,
-    // which waits for that frame's kernels -- the writer thread then waited (spinning) a whole frame for a 0.1 ms DMA
-    hipStream_t st, st_copy, st_down, st_data;
-    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess || hipStreamCreate(&st_data) != hipSuccess) die("hipStreamCreate failed");
+    // gpu_png: the file's bytes must not sit behind the NEXT frame's size word on the download queue (that one waits for the next
+    // frame's kernels: the writer thread then waited a whole frame for a 0.1 ms DMA): finish() enqueues them first
+    // (three queues besides the library's two look-ahead queues: a process gets four hardware queues by default, and the 4-argument
+    //  mode lost 20 % when a sixth stream made its side queues share one with the compute queue)
+    hipStream_t st, st_copy, st_down;
+    if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess) die("hipStreamCreate failed");
+    hipStream_t const st_data = st_down;     // quiet mode: st_down carries nothing else; otherwise finish() enqueues frame i-1's bytes BEFORE frame i's size word
     hipEvent_t ev_up[3], ev_done[2], ev_out[2];
     for (auto& e : ev_out) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
@@ -411,7 +423,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         if (f.fw) hipMemcpyAsync(dv.fw, f.fw, n * 8, hipMemcpyHostToDevice, st_copy);
         if (f.cert) hipMemcpyAsync(dv.cert, f.cert, n, hipMemcpyHostToDevice, st_copy);
         hipEventRecord(ev_up[set], st_copy);
-        hipStreamWaitEvent(st, ev_up[set], 0);                     // everything enqueued on the compute queue from here on sees them
+        if (!quiet) hipStreamWaitEvent(st, ev_up[set], 0);         // everything enqueued on the compute queue from here on sees them
     };
     // the host runs one frame ahead of the GPU: frame i is enqueued before frame i-1's completion is awaited
     struct Pending { bool valid = false; int index = 0; bool single = false; uint8_t* hb = nullptr; int ev = 0;
@@ -419,7 +431,17 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     Pending pend;
     auto finish = [&](Pending& pd) {
         if (!pd.valid) return;
-        if (wait_event_sleeping(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
+        if (quiet) {
+            // the frame's last kernel (png_finish_kernel) stores the file size into host-mapped memory behind a system-scope fence
+            volatile uint32_t* sz = &h_png_size[pd.ev];
+            for (int spins = 0; *sz == 0u; ++spins) {
+                usleep(100);
+                if ((spins & 1023) == 1023) {                 // every ~0.1 s: has the GPU faulted? (a query, not a marker)
+                    const hipError_t e = hipStreamQuery(st);
+                    if (e != hipSuccess && e != hipErrorNotReady) die("GPU error while stylising a frame");
+                }
+            }
+        } else if (wait_event_sleeping(ev_done[pd.ev]) != hipSuccess) die("GPU error while stylising a frame");
         check(fav_net_check(net), "stylising a frame");      // a stream-K hand-off that timed out: fail at THIS frame, before its PNG exists
         if (net_img) check(fav_net_check(net_img), "stylising a frame");
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd.t0).count();
@@ -528,8 +550,9 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         if (have_next) {
             if (nxt.W != W || nxt.H != H) die("frame size changed inside the sequence");
             upload(nxt, (dset + 1) % 3);
-            if (fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
+            if (!quiet && fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
         }
+        if (quiet && wait_event_sleeping(ev_up[dset], 50) != hipSuccess) die("GPU error while uploading a frame");      // requested a frame ago: already there
         uint8_t* const d_out8 = gpu_png ? nullptr : d_out8s[done & 1];
         const bool teval = !o.s("temporal_eval_file").empty();
         if (teval && !d_prev) { if (hipMalloc((void**)&d_prev, (size_t)W * H * 12) || hipMalloc((void**)&d_cur, (size_t)W * H * 12)) die("hipMalloc failed"); }
@@ -555,17 +578,23 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
         if (gpu_png) {
             // two frames ago this buffer's bytes left through the download queue: that copy must have finished (it has, long ago)
-            if (png_copy_ev[now.ev]) hipStreamWaitEvent(st, png_copy_ev[now.ev], 0);
-            check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, d_png_size[now.ev], st), "fav_stream_encode_png");
+            if (png_copy_ev[now.ev]) {
+                if (quiet) { if (wait_event_sleeping(png_copy_ev[now.ev], 50) != hipSuccess) die("GPU error while downloading a frame"); }
+                else hipStreamWaitEvent(st, png_copy_ev[now.ev], 0);
+            }
+            if (quiet) h_png_size[now.ev] = 0u;          // the frame's last kernel overwrites it with the file size (host-mapped)
+            check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, quiet ? &h_png_size[now.ev] : d_png_size[now.ev], st), "fav_stream_encode_png");
         }
-        hipEventRecord(ev_out[now.ev], st);              // the frame's 8-bit image / PNG is complete on the compute queue ...
+        if (!quiet) hipEventRecord(ev_out[now.ev], st);  // the frame's 8-bit image / PNG is complete on the compute queue ...
         const auto tg = std::chrono::steady_clock::now();
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i's kernels are already queued
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
-        hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
-        if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
-        else hipMemcpyAsync(hb, d_out8, (size_t)Wo * Ho * 3, hipMemcpyDeviceToHost, st_down);
-        hipEventRecord(ev_done[now.ev], st_down);
+        if (!quiet) {
+            hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
+            if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
+            else hipMemcpyAsync(hb, d_out8, (size_t)Wo * Ho * 3, hipMemcpyDeviceToHost, st_down);
+            hipEventRecord(ev_done[now.ev], st_down);
+        }
         pend = now;
         if (cur.index >= 0) cur.release();               // malloc'ed (first frame); pinned sets are reused
         ++done;
@@ -604,7 +633,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     for (auto& e : ev_up) hipEventDestroy(e);
     for (auto& e : ev_done) hipEventDestroy(e);
     for (auto& e : ev_out) hipEventDestroy(e);
-    hipStreamDestroy(st); hipStreamDestroy(st_copy); hipStreamDestroy(st_down); hipStreamDestroy(st_data);
+    hipStreamDestroy(st); hipStreamDestroy(st_copy); hipStreamDestroy(st_down);
 }
 
 }  // namespace

@@ -18,9 +18,10 @@
  *     everything that shares a net (its fav_streams, a fav_vr) must be enqueued on the same HIP stream or be ordered by the
  *     caller.  The persistent / stream-K convolution kernels size their grids to the whole device (minus the CUs reserved for
  *     the library's own look-ahead queues) and hand partial tiles between co-resident blocks: two forwards must therefore not
- *     run CONCURRENTLY on one device.  Inside one process the library sees to that itself: a forward enqueued on another HIP
- *     stream than the previous forward on that device first waits for it (an event per forward, a hipStreamWaitEvent on a stream
- *     switch), so several nets / streams are SERIALISED, never wrong.  Across processes it cannot: one process per GPU (as
+ *     run CONCURRENTLY on one device.  Inside one process the library sees to that itself: when a forward is enqueued on another
+ *     HIP stream than the previous forward on that device, the host first waits for that previous stream to drain (the ONE case in
+ *     which an entry point synchronises), so several nets / streams are SERIALISED, never wrong.  A stream destroyed while it was
+ *     the last one used must have been synchronised by its owner.  Across processes it cannot: one process per GPU (as
  *     bench.py and the launcher do), or fav_net_set_shared_device.  Handles are not locked: do not call into the same handle
  *     from two host threads at once.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
