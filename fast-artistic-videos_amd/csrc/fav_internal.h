@@ -214,6 +214,16 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, i
                       const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st,
                       int fill_random = 0, unsigned seed = 0, unsigned index = 0);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
+// Huffman codes of the PNG encoder (png_tables.cpp): PNG_NTABLES model codes with their dynamic-block headers + the fixed code
+constexpr int PNG_NSYM = 277;            // literals 0..255, end of block 256, length symbols 257..276 (runs of 3..66)
+constexpr int PNG_NTABLES = 12;
+constexpr int PNG_HDR_WORDS = 40;
+struct PngTable {
+    uint32_t sym[PNG_NSYM];              // (code length << 16) | bit-reversed code
+    uint32_t hdr[PNG_HDR_WORDS];         // the block header behind BFINAL / BTYPE, LSB first
+    uint32_t hdr_bits, btype, dist_len, dist_code;
+};
+const std::vector<PngTable>& png_tables();
 size_t png_capacity(int W, int H);
 size_t png_workspace_bytes(int W, int H);
 int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,

@@ -7,15 +7,18 @@
 //
 // Format (restated lane by lane in oracle/png_model.py, which the CPU suite checks against zlib / PIL and the GPU suite against these
 // kernels byte for byte):
-//   * one IDAT chunk = one zlib stream (78 01); every image row is PNG filter type 1 (Sub) and ONE fixed-Huffman deflate block whose
-//     tokens are literals and distance-3 matches (repeated pixels and constant gradients become runs after the Sub filter), followed
-//     by an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that re-aligns the stream to a byte boundary -- or, when
-//     that would be longer (noise-like rows), ONE stored block (5 + n bytes): rows are independent byte strings either way;
+//   * one IDAT chunk = one zlib stream (78 01); every image row is PNG filter type 1 (Sub) and ONE deflate block whose tokens are
+//     literals and distance-3 matches (repeated pixels and constant gradients become runs after the Sub filter).  The block is the
+//     smallest, by exact bit count from the row's token histogram, of: a dynamic-Huffman block with one of twelve ready-made codes for
+//     Sub-filtered image rows (png_tables.cpp: the code AND its 35-60 byte header are built once on the host), a fixed-Huffman block,
+//     a stored block (5 + n bytes).  Huffman blocks end with an empty stored block (00 00 FF FF, zlib's Z_SYNC_FLUSH marker) that
+//     re-aligns the stream to a byte boundary: rows are independent byte strings either way;
 //   * png_rows_kernel: four waves per row.  A step = 64 positions: the match predicate f[p] == f[p-3] becomes a 64-bit ballot, run starts
-//     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes, 15 bits), so the
-//     steps are independent up to their bit offset: pass 1 takes every step's bit count (popcounts of four ballots of the token
-//     lengths), one scan over the steps gives the offsets, pass 2 forms the tokens and ORs them into the row's LDS bit buffer at
-//     offset + prefix (again from ballots: no cross-lane data movement); Adler-32 parts (sum f, sum (n-i) f[i]);
+//     and ends come from count-leading / trailing-zero on that word (runs are cut at the step boundary: <= 64 bytes), so the steps
+//     are independent up to their bit offset: pass 1 writes a 16-bit token descriptor per position and the token histogram, the
+//     block picks the code, pass 2 takes every step's bit count under that code (popcounts of five ballots of the token lengths),
+//     one scan over the steps gives the offsets, pass 3 forms the tokens and ORs them into the row's LDS bit buffer at offset +
+//     prefix (again from ballots: no cross-lane data movement); Adler-32 parts (sum f, sum (n-i) f[i]);
 //   * png_pack_kernel: one block per row.  Prefix sum of the row sizes, the row copied to its final byte offset (dword stores from an
 //     LDS copy through a funnel shift, bytes at the two ragged ends), its CRC-32 (16-byte pieces, bitwise) raised to its position:
 //     CRC-32 is linear, crc(A || B) = crc(A) * x^(8 |B|) + crc(B) mod P, with x^(8 n) from three 256-entry tables;
@@ -74,8 +77,6 @@ __device__ inline uint32_t crc_bytes(const uint8_t* s, int n)
     return ~c;
 }
 
-__device__ __forceinline__ uint32_t brev_n(uint32_t x, int n) { return __brev(x) >> (32 - n); }
-
 // row geometry shared by the kernels and the host
 __host__ __device__ inline int png_row_stride(int W)
 {
@@ -84,27 +85,33 @@ __host__ __device__ inline int png_row_stride(int W)
 }
 
 constexpr int PNG_ROW_WAVES = 4;                // waves per row block; wave w takes the 64-position steps w, w + 4, ...
+constexpr int PNG_HIST = 288;                   // histogram bins per wave: 277 symbols, [280] extra bits of the matches, [281] matches
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // kernel 1: one block of four waves per image row -> stage[row * stride ...], sizes[row], adler[row] = (sum f, sum (n - i) f[i]) mod 65521
-// LDS: raw row (3W bytes at a dword-aligned base + the source misalignment), filtered row f (n = 3W + 1 bytes), per-step bit counts,
-// output bit buffer.  A step = 64 consecutive positions = one wave-wide ballot; runs never cross a step, so the steps are independent
-// up to their bit offset: pass 1 forms every step's tokens (kept in registers) and its bit count, a scan over the steps gives the
-// offsets, pass 2 ORs the tokens into the bit buffer.
+// A step = 64 consecutive positions = one wave-wide ballot; runs never cross a step, so the steps are independent up to their bit
+// offset.  Pass 1 forms every position's token (symbol, run length) into a 16-bit descriptor and the row's token histogram; from the
+// histogram the block takes the EXACT size of the row under each of the ready-made codes (png_tables.cpp), the fixed code and the
+// stored form, and picks the smallest; pass 2 sums the token lengths of every step under the chosen code, a scan over the steps
+// gives the offsets, pass 3 ORs the tokens into the bit buffer.
 template <bool FROM_F32>
 __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, uint8_t* stage,
-                                                                      int stride, uint32_t* sizes, uint2* adler)
+                                                                      int stride, uint32_t* sizes, uint2* adler, const PngTable* tabs)
 {
     extern __shared__ uint32_t lds[];
     __shared__ unsigned long long red_a[PNG_ROW_WAVES], red_b[PNG_ROW_WAVES];
+    __shared__ uint32_t hist[PNG_ROW_WAVES][PNG_HIST];
+    __shared__ uint32_t tab[PNG_HIST];
+    __shared__ uint32_t pick[20];               // [0..12] row size under code k, [13] stored, [16] choice
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
     constexpr int NT = 64 * PNG_ROW_WAVES;
     const int nraw = 3 * W, n = nraw + 1;
     const int nsteps = (n + 63) >> 6;
-    const int raw_words = (nraw + 3 + 3) / 4 + 1, f_words = (n + 3) / 4 + 1, step_words = nsteps + 1, out_words = stride / 4;
+    const int raw_words = (nraw + 3 + 3) / 4 + 1, f_words = (n + 3) / 4 + 1, desc_words = (n + 1) / 2 + 1, step_words = nsteps + 1, out_words = stride / 4;
     uint32_t* raww = lds;
     uint8_t* f = reinterpret_cast<uint8_t*>(lds + raw_words);
-    uint32_t* step_bits = lds + raw_words + f_words;               // [nsteps] bit count of a step, then its exclusive prefix
+    uint16_t* desc = reinterpret_cast<uint16_t*>(lds + raw_words + f_words);      // per position: 0x8000 | (run - 3) << 9 | symbol, or 0 (no token)
+    uint32_t* step_bits = lds + raw_words + f_words + desc_words;                // [nsteps] bit count of a step, then its exclusive prefix
     uint32_t* out = step_bits + step_words;
     const uint8_t* raw;
     if (FROM_F32) {
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         raw = reinterpret_cast<const uint8_t*>(raww) + (base - a0);
     }
     for (int i = tid; i < out_words; i += NT) out[i] = 0u;
+    for (int i = tid; i < PNG_ROW_WAVES * PNG_HIST; i += NT) (&hist[0][0])[i] = 0u;
     __syncthreads();
     // Sub filter + Adler-32 parts
     unsigned long long sa = 0, sb = 0;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
     for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
     if (lane == 0) { red_a[wave] = sa; red_b[wave] = sb; }
     __syncthreads();
-    // pass 1: bit count of every step of this wave (token lengths only)
+    // pass 1: tokens -> descriptors + histogram
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
         const int p = (sidx << 6) + lane;
@@ -152,51 +160,53 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         const uint32_t v = valid ? f[p] : 0u;
         const bool m = valid && p >= 3 && v == f[p - 3];
         const unsigned long long mask = __ballot(m);
-        if (mask == 0ull) {                                         // no repeats in this step (textures, noise): literals only
-            const int total = 8 * __popcll(__ballot(valid)) + __popcll(__ballot(valid && v >= 144u));
-            if (lane == 0) step_bits[sidx] = (uint32_t)total;
-            continue;
-        }
-        int nb = 0;
-        if (valid) {
-            nb = v < 144u ? 8 : 9;
-            if (m) {
-                const unsigned long long below = ~mask & lt;
-                const int s = below ? 64 - __clzll((long long)below) : 0;
-                const unsigned long long above = (~mask >> lane) >> 1;
-                const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-                const int L = e - s;
-                if (L >= 3) nb = lane == s ? 12 + (L > 10) + (L > 18) + (L > 34) : 0;      // 7-bit length symbol + extra bits + 5-bit distance
+        if (!valid) continue;                                       // (after the ballot: every lane takes part in it)
+        uint32_t d = 0x8000u | v;                                   // a literal
+        if (m) {
+            const unsigned long long below = ~mask & lt;
+            const int s = below ? 64 - __clzll((long long)below) : 0;
+            const unsigned long long above = (~mask >> lane) >> 1;
+            const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            const int L = e - s;
+            if (L >= 3) {
+                if (lane == s) {                                   // the run's first position carries the match, the others nothing
+                    const int sym = L <= 10 ? 254 + L : L <= 18 ? 265 + ((L - 11) >> 1) : L <= 34 ? 269 + ((L - 19) >> 2) : 273 + ((L - 35) >> 3);
+                    d = 0x8000u | ((uint32_t)(L - 3) << 9) | (uint32_t)sym;
+                    atomicAdd(&hist[wave][280], (uint32_t)(sym < 265 ? 0 : (sym - 261) >> 2));
+                    atomicAdd(&hist[wave][281], 1u);
+                } else d = 0u;
             }
         }
-        const int total = __popcll(__ballot(nb & 1)) + 2 * __popcll(__ballot(nb & 2)) + 4 * __popcll(__ballot(nb & 4)) + 8 * __popcll(__ballot(nb & 8));
-        if (lane == 0) step_bits[sidx] = (uint32_t)total;
+        desc[p] = (uint16_t)d;
+        if (d) atomicAdd(&hist[wave][d & 511u], 1u);
     }
     __syncthreads();
-    // exclusive scan of the step bit counts (wave 0; 64 steps per pass)
-    if (wave == 0) {
-        uint32_t carry = 3;                                        // block header: BFINAL = 0, BTYPE = 01 -> three bits
-        for (int s0 = 0; s0 < nsteps; s0 += 64) {
-            const int i = s0 + lane;
-            const uint32_t x = i < nsteps ? step_bits[i] : 0u;
-            uint32_t incl = x;
+    for (int i = tid; i < PNG_HIST; i += NT) hist[0][i] = hist[0][i] + hist[1][i] + hist[2][i] + hist[3][i];
+    __syncthreads();
+    // the row's exact size under every code (wave w: codes w, w + 4, ...; the last one is the fixed code), and stored
+    for (int k = wave; k <= PNG_NTABLES; k += PNG_ROW_WAVES) {
+        const PngTable& T = tabs[k];
+        uint32_t c = 0;
+        for (int sidx = lane; sidx < PNG_NSYM; sidx += 64) c += hist[0][sidx] * (T.sym[sidx] >> 16);
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-            if (i < nsteps) step_bits[i] = carry + incl - x;
-            carry += __shfl(incl, 63);
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) {
+            const uint32_t bits = 3u + T.hdr_bits + c + hist[0][280] + hist[0][281] * T.dist_len + (T.sym[256] >> 16);
+            pick[k] = ((bits + 3u + 7u) >> 3) + 4u;                 // + the stored-block header of the sync marker, to a byte, + 00 00 FF FF
         }
-        if (lane == 0) { step_bits[nsteps] = carry; out[0] = 2u; }
     }
     __syncthreads();
-    // a row whose fixed-Huffman form would be longer than its STORED form (noise-like rows: half of the literals take 9 bits) becomes
-    // one stored block: 00 | LEN | ~LEN | the n filtered bytes (byte-aligned at both ends: no sync marker needed)
-    const int huff_size = (((int)step_bits[nsteps] + 7 + 3 + 7) >> 3) + 4;
-    if (huff_size > n + 5) {
+    if (tid == 0) {
+        pick[PNG_NTABLES + 1] = (uint32_t)(n + 5);                  // stored: 00 | LEN | ~LEN | n bytes
+        int best = 0;
+        for (int k = 1; k <= PNG_NTABLES + 1; ++k) if (pick[k] < pick[best]) best = k;      // the first minimum
+        pick[16] = (uint32_t)best;
+    }
+    __syncthreads();
+    const int choice = (int)pick[16];
+    if (choice == PNG_NTABLES + 1) {
+        // one stored block: byte-aligned at both ends, no sync marker needed
         uint8_t* o8 = reinterpret_cast<uint8_t*>(out);
-        if (tid == 0) {
-            out[0] = 0u;                                            // (wave 0 put the fixed-block header there)
-        }
-        __syncthreads();
         if (tid == 0) {
             o8[1] = (uint8_t)n; o8[2] = (uint8_t)(n >> 8); o8[3] = (uint8_t)~n; o8[4] = (uint8_t)(~n >> 8);
             sizes[row] = (uint32_t)(n + 5);
@@ -211,66 +221,83 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         for (int i = tid; i < nwo; i += NT) dst[i] = out[i];
         return;
     }
-    // pass 2: form the tokens and OR them in
+    // the chosen code into LDS, its block header into the bit buffer
+    const PngTable& T = tabs[choice];
+    const uint32_t hdr_bits = T.hdr_bits, dist_len = T.dist_len, dist_code = T.dist_code;
+    for (int i = tid; i < PNG_NSYM; i += NT) tab[i] = T.sym[i];
+    if (tid == 0) atomicOr(&out[0], T.btype << 1);                  // BFINAL = 0, BTYPE (LSB first)
+    for (int i = tid; i < (int)((hdr_bits + 31u) >> 5); i += NT) {
+        const uint32_t wd = T.hdr[i];
+        atomicOr(&out[i], wd << 3);
+        if (wd >> 29) atomicOr(&out[i + 1], wd >> 29);
+    }
+    __syncthreads();
+    // pass 2: bit count of every step under the chosen code
     for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
         const int p = (sidx << 6) + lane;
-        const bool valid = p < n;
-        const uint32_t v = valid ? f[p] : 0u;
-        const bool m = valid && p >= 3 && v == f[p - 3];
-        const unsigned long long mask = __ballot(m);
-        if (mask == 0ull) {                                         // literals only: 8 bits each, 9 for bytes >= 144
-            const bool hi9 = valid && v >= 144u;
-            const unsigned long long b9 = __ballot(hi9);
-            if (valid) {
-                const int o = (int)step_bits[sidx] + 8 * lane + __popcll(b9 & lt);
-                const uint32_t val = hi9 ? brev_n(0x190u + v - 144u, 9) : brev_n(0x30u + v, 8);
-                const unsigned long long vv = (unsigned long long)val << (o & 31);
-                atomicOr(&out[o >> 5], (uint32_t)vv);
-                if (vv >> 32) atomicOr(&out[(o >> 5) + 1], (uint32_t)(vv >> 32));
-            }
-            continue;
+        const uint32_t d = p < n ? desc[p] : 0u;
+        uint32_t nb = 0;
+        if (d) {
+            const uint32_t sym = d & 511u;
+            nb = tab[sym] >> 16;
+            if (sym >= 257u) nb += (sym < 265u ? 0u : (sym - 261u) >> 2) + dist_len;
         }
-        uint32_t val = 0; int nb = 0;
-        if (valid) {
-            bool lit = true;
-            if (m) {
-                const unsigned long long below = ~mask & lt;
-                const int s = below ? 64 - __clzll((long long)below) : 0;
-                const unsigned long long above = (~mask >> lane) >> 1;
-                const int e = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-                const int L = e - s;
-                if (L >= 3) {
-                    lit = false;
-                    if (lane == s) {                               // the run's first lane emits the match, the others nothing
-                        int sym, eb, ev;
-                        if (L <= 10) { sym = 254 + L; eb = 0; ev = 0; }
-                        else if (L <= 18) { sym = 265 + ((L - 11) >> 1); eb = 1; ev = (L - 11) & 1; }
-                        else if (L <= 34) { sym = 269 + ((L - 19) >> 2); eb = 2; ev = (L - 19) & 3; }
-                        else { sym = 273 + ((L - 35) >> 3); eb = 3; ev = (L - 35) & 7; }
-                        val = brev_n((uint32_t)(sym - 256), 7); nb = 7;
-                        val |= (uint32_t)ev << nb; nb += eb;
-                        val |= 8u << nb; nb += 5;                   // distance 3 = code 2, 5 bits, reversed: 01000
-                    }
-                }
-            }
-            if (lit) {
-                if (v < 144u) { val = brev_n(0x30u + v, 8); nb = 8; }
-                else { val = brev_n(0x190u + v - 144u, 9); nb = 9; }
+        const int total = __popcll(__ballot(nb & 1u)) + 2 * __popcll(__ballot(nb & 2u)) + 4 * __popcll(__ballot(nb & 4u)) + 8 * __popcll(__ballot(nb & 8u)) +
+                          16 * __popcll(__ballot(nb & 16u));
+        if (lane == 0) step_bits[sidx] = (uint32_t)total;
+    }
+    __syncthreads();
+    // exclusive scan of the step bit counts (wave 0; 64 steps per pass)
+    if (wave == 0) {
+        uint32_t carry = 3u + hdr_bits;
+        for (int s0 = 0; s0 < nsteps; s0 += 64) {
+            const int i = s0 + lane;
+            const uint32_t x = i < nsteps ? step_bits[i] : 0u;
+            uint32_t incl = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (i < nsteps) step_bits[i] = carry + incl - x;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) step_bits[nsteps] = carry;
+    }
+    __syncthreads();
+    // pass 3: form the tokens and OR them in
+    for (int sidx = wave; sidx < nsteps; sidx += PNG_ROW_WAVES) {
+        const int p = (sidx << 6) + lane;
+        const uint32_t d = p < n ? desc[p] : 0u;
+        uint32_t nb = 0, val = 0;
+        if (d) {
+            const uint32_t sym = d & 511u, e = tab[sym];
+            nb = e >> 16; val = e & 0xFFFFu;
+            if (sym >= 257u) {
+                const uint32_t L = ((d >> 9) & 63u) + 3u;
+                const uint32_t eb = sym < 265u ? 0u : (sym - 261u) >> 2;
+                const uint32_t ev = L <= 10u ? 0u : L <= 18u ? (L - 11u) & 1u : L <= 34u ? (L - 19u) & 3u : (L - 35u) & 7u;
+                val |= ev << nb; nb += eb;
+                val |= dist_code << nb; nb += dist_len;
             }
         }
-        // exclusive prefix of nb (<= 15) over the wave from four ballots: no cross-lane data movement
-        const unsigned long long b0 = __ballot(nb & 1), b1 = __ballot(nb & 2), b2 = __ballot(nb & 4), b3 = __ballot(nb & 8);
-        const int excl = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt);
+        // exclusive prefix of nb (< 32) over the wave from five ballots: no cross-lane data movement
+        const unsigned long long b0 = __ballot(nb & 1u), b1 = __ballot(nb & 2u), b2 = __ballot(nb & 4u), b3 = __ballot(nb & 8u), b4 = __ballot(nb & 16u);
         if (nb) {
+            const int excl = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt) + 16 * __popcll(b4 & lt);
             const int o = (int)step_bits[sidx] + excl;
             const unsigned long long vv = (unsigned long long)val << (o & 31);
             atomicOr(&out[o >> 5], (uint32_t)vv);
             if (vv >> 32) atomicOr(&out[(o >> 5) + 1], (uint32_t)(vv >> 32));
         }
     }
+    // end of block, then an empty stored block (3 zero bits, pad to a byte, 00 00 FF FF)
+    const int endbits = (int)step_bits[nsteps];
+    const uint32_t eob = tab[256];
+    if (tid == 0) {
+        const unsigned long long vv = (unsigned long long)(eob & 0xFFFFu) << (endbits & 31);
+        atomicOr(&out[endbits >> 5], (uint32_t)vv);
+        if (vv >> 32) atomicOr(&out[(endbits >> 5) + 1], (uint32_t)(vv >> 32));
+    }
     __syncthreads();
-    // end of block (7 zero bits), empty stored block (3 zero bits, pad to a byte, 00 00 FF FF)
-    const int bitpos = (int)step_bits[nsteps] + 7 + 3;
+    const int bitpos = endbits + (int)(eob >> 16) + 3;
     const int bo = (bitpos + 7) >> 3;
     const int size = bo + 4;
     if (tid == 0) {
@@ -415,6 +442,22 @@ size_t png_workspace_bytes(int W, int H)
 }
 
 namespace {
+// the encoder's Huffman codes (png_tables.cpp), uploaded once per device
+const PngTable* png_tables_for_device(int device)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, PngTable*>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& kv : cache) if (kv.first == device) return kv.second;
+    const std::vector<PngTable>& t = png_tables();
+    for (const PngTable& x : t) if (x.hdr_bits == 0xFFFFFFFFu) return nullptr;
+    PngTable* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), t.size() * sizeof(PngTable)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, t.data(), t.size() * sizeof(PngTable), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    cache.emplace_back(device, d);
+    return d;
+}
+
 // x^(8 n) tables (3 x 256 words), built once per device on the host with the same arithmetic the kernels use
 const uint32_t* crc_tables_for_device(int device)
 {
@@ -443,7 +486,7 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
                       void* workspace, size_t ws_bytes, hipStream_t st)
 {
     FAV_REQUIRE((rgb_hwc != nullptr) != (rgb_planar != nullptr), "png: exactly one of the u8 and the float source must be given");
-    FAV_REQUIRE(W >= 1 && H >= 1 && W <= 16000 && H <= 65535, "png: %dx%d is outside the encoder's range (width <= 16000, height <= 65535)", W, H);
+    FAV_REQUIRE(W >= 1 && H >= 1 && W <= 9000 && H <= 65535, "png: %dx%d is outside the encoder's range (width <= 9000, height <= 65535)", W, H);
     FAV_REQUIRE(png_out && png_bytes && workspace, "png: null argument");
     FAV_REQUIRE(capacity >= png_capacity(W, H), "png: output capacity %zu < fav_png_capacity = %zu", capacity, png_capacity(W, H));
     FAV_REQUIRE(capacity < ((size_t)1 << 24) * 250, "png: image too large for the encoder's CRC tables");
@@ -452,6 +495,8 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     int device = 0; FAV_HIP(hipGetDevice(&device));
     CrcTables tb{crc_tables_for_device(device)};
     if (!tb.t) return hip_fail(hipErrorOutOfMemory, "png: CRC tables");
+    const PngTable* tabs = png_tables_for_device(device);
+    if (!tabs) return hip_fail(hipErrorOutOfMemory, "png: Huffman tables");
     const int stride = png_row_stride(W);
     const size_t h4 = ((size_t)H * 4 + 15) & ~(size_t)15, h8 = ((size_t)H * 8 + 15) & ~(size_t)15;
     uint8_t* ws = static_cast<uint8_t*>(workspace);
@@ -461,20 +506,20 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     uint2* adler = reinterpret_cast<uint2*>(ws + 16 + 2 * h4);
     uint8_t* stage = ws + 16 + 2 * h4 + h8;
     const int nraw = 3 * W, n = nraw + 1;
-    const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)((n + 63) / 64 + 1) + (size_t)stride / 4) * 4;
+    const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)((n + 1) / 2 + 1) + (size_t)((n + 63) / 64 + 1) + (size_t)stride / 4) * 4;
     const size_t lds2 = (size_t)stride + 8;
     static thread_local bool attr_set = false;
     if (!attr_set && (lds1 > 48 * 1024 || lds2 > 48 * 1024)) {
         // (rows wider than ~2600 pixels: raise the dynamic LDS limit once; 160 KB per CU on gfx950)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
         attr_set = true;
     }
     if (rgb_planar)
-        hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler);
+        hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler, tabs);
     else
-        hipLaunchKernelGGL(png_rows_kernel<false>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, rgb_hwc, nullptr, W, H, stage, stride, sizes, adler);
+        hipLaunchKernelGGL(png_rows_kernel<false>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, rgb_hwc, nullptr, W, H, stage, stride, sizes, adler, tabs);
     FAV_LAUNCH_CHECK("png_rows_kernel");
     PngHeader hdr;
     const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};

@@ -64,7 +64,7 @@ EXPORTS = [
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size",
-    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
+    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_png_tables_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
     "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device",
@@ -389,6 +389,21 @@ def png_encode(img, from_stream: "Stream" = None) -> bytes:
     torch.cuda.synchronize()
     n = int(nbytes.item())
     return bytes(out[:n].cpu().numpy().tobytes())
+
+
+def png_tables():
+    """the encoder's Huffman codes (host-only): list of dicts {len[277], code[277], hdr (uint32 words), hdr_bits, btype, dist_len, dist_code}"""
+    cnt, tb = C.c_int(), C.c_int()
+    _check(lib().fav_png_tables_host(None, C.c_size_t(0), C.byref(cnt), C.byref(tb)))
+    buf = np.zeros(cnt.value * tb.value // 4, np.uint32)
+    _check(lib().fav_png_tables_host(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes), C.byref(cnt), C.byref(tb)))
+    out = []
+    w = tb.value // 4
+    for k in range(cnt.value):
+        t = buf[k * w:(k + 1) * w]
+        out.append({"len": (t[:277] >> 16).astype(int), "code": (t[:277] & 0xFFFF).astype(int), "hdr": t[277:277 + 40].copy(),
+                    "hdr_bits": int(t[317]), "btype": int(t[318]), "dist_len": int(t[319]), "dist_code": int(t[320])})
+    return out
 
 
 def sequential_sum(x) -> float:

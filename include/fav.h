@@ -279,11 +279,11 @@ int fav_write_png_rgb8_host(const char* path, const uint8_t* rgb_hwc, int W, int
 void fav_free_host(void* p);
 
 /* ---- A9 on the GPU: image.save("<prefix>-%05d.png", img) (fast_artistic_video.lua:160-170) -----------------------------------
- * The BYTES OF THE PNG FILE are produced on the device (Sub filter, one fixed-Huffman / run-length deflate block per image row
- * re-aligned by an empty stored block, Adler-32 and CRC-32 combined from per-row parts: csrc/kernels_png.hip), so the host only
- * write()s them: the zlib path above costs ~25 ms per 1280x720 frame and core.  The files decode to exactly the bytes
- * fav_stream_* writes to out_rgb8_hwc (clamp to [0,1], x255, truncate); they are larger than zlib's (no entropy coding beyond the
- * fixed code).
+ * The BYTES OF THE PNG FILE are produced on the device (Sub filter; one deflate block per image row -- run-length matches, the
+ * cheapest of twelve ready-made Huffman codes / the fixed code / stored, by exact bit count -- re-aligned by an empty stored block;
+ * Adler-32 and CRC-32 combined from per-row parts: csrc/kernels_png.hip, csrc/png_tables.cpp), so the host only write()s them: the
+ * zlib path above costs ~25 ms per 1280x720 frame and core.  The files decode to exactly the bytes fav_stream_* writes to
+ * out_rgb8_hwc (clamp to [0,1], x255, truncate); sizes are within a few per cent of zlib's level-1 run-length mode on image rows.
  *   png_out        device-ACCESSIBLE memory of fav_png_capacity(W, H) bytes, 4-byte aligned: device memory or host-mapped pinned
  *                  memory (hipHostMalloc: the packed bytes then cross PCIe once and are complete when the stream reaches the point
  *                  after the call -- use an event WITH the system-scope fence);
@@ -291,13 +291,18 @@ void fav_free_host(void* p);
  *   workspace      fav_png_workspace_bytes(W, H) bytes of device memory, 16-byte aligned, owned by the caller, private to the call
  *                  until the stream has passed it.
  * fav_png_encode_rgb8: rgb_hwc = u8 [H][W][3];  fav_png_encode_f32: planar float RGB [3][H][W] (what fav_stream_get_state returns),
- * quantisation fused.  Width <= 16000. */
+ * quantisation fused.  Width <= 9000. */
 size_t fav_png_capacity(int W, int H);
 size_t fav_png_workspace_bytes(int W, int H);
 int fav_png_encode_rgb8(const uint8_t* rgb_hwc, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
                         void* workspace, size_t workspace_bytes, fav_hipstream_t stream);
 int fav_png_encode_f32(const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
                        void* workspace, size_t workspace_bytes, fav_hipstream_t stream);
+/* host-only (no device needed): the encoder's Huffman codes, for tools that restate its bit layout (oracle/png_model.py).
+ * count tables of table_bytes bytes each: uint32 sym[277] = (code length << 16) | bit-reversed code; uint32 hdr[40] = the
+ * dynamic-block header behind BFINAL / BTYPE, LSB first; uint32 hdr_bits, btype, dist_len, dist_code.  The last table is the
+ * fixed code of RFC 1951 3.2.6.  out_host may be NULL to query count and table_bytes. */
+int fav_png_tables_host(void* out_host, size_t capacity, int* count, int* table_bytes);
 /* the stream's current stylised frame (the recurrent state) as a PNG file, with the stream's own workspace */
 int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
 

@@ -5,11 +5,13 @@ validated against zlib / PIL on the CPU (no GPU in the build container) and the 
 
 The format (A9, image.save of fast_artistic_video.lua:160-170 -> an RGB8 PNG):
   * one IDAT chunk holding one zlib stream (header 78 01);
-  * every image row = PNG filter type 1 (Sub) = one fixed-Huffman deflate block (BFINAL 0, BTYPE 01) whose tokens are literals and
-    distance-3 matches (run-length coding of repeated pixels / constant gradients), cut at 64-position boundaries (one wave step),
-    followed by an EMPTY STORED BLOCK (the Z_SYNC_FLUSH marker 00 00 FF FF) that re-aligns the stream to a byte boundary -- or, when
-    that would be longer than the row itself, ONE stored block (00 | LEN | ~LEN | the filtered bytes) -- so rows are encoded
-    independently (one block of waves each) and concatenated at byte granularity;
+  * every image row = PNG filter type 1 (Sub) = ONE deflate block whose tokens are literals and distance-3 matches (run-length coding
+    of repeated pixels / constant gradients), cut at 64-position boundaries (one wave step).  The block is the cheapest, by exact bit
+    count, of: a dynamic-Huffman block (BTYPE 10) with one of twelve ready-made codes for Sub-filtered image rows (csrc/png_tables.cpp:
+    length-limited Huffman codes of two-sided geometric literal distributions, header included), a fixed-Huffman block (BTYPE 01), a
+    stored block (00 | LEN | ~LEN | the filtered bytes).  Huffman blocks are followed by an EMPTY STORED BLOCK (the Z_SYNC_FLUSH
+    marker 00 00 FF FF) that re-aligns the stream to a byte boundary -- so rows are encoded independently (one block of waves each)
+    and concatenated at byte granularity;
   * a final empty fixed block (03 00), the Adler-32 of the filtered stream, the chunk CRC-32 -- both combined from per-row parts.
 """
 import struct
@@ -18,28 +20,26 @@ import zlib
 import numpy as np
 
 
-def _brev(x, n):
-    return int(format(x, "0%db" % n)[::-1], 2)
+_TABLES = None
 
 
-def literal_code(v):
-    """(value to OR in LSB-first, bit count) of a literal byte in the fixed Huffman code (RFC 1951 3.2.6)"""
-    if v < 144:
-        return _brev(0x30 + v, 8), 8
-    return _brev(0x190 + v - 144, 9), 9
+def tables():
+    """the encoder's Huffman codes, read from libfav (host-only call: no device needed) -- the model restates the kernels' BIT
+    LAYOUT and table choice; that the codes and headers are valid deflate is what zlib / PIL check on its output"""
+    global _TABLES
+    if _TABLES is None:
+        import fav_amd
+        _TABLES = fav_amd.png_tables()
+    return _TABLES
 
 
-def match_code(length):
-    """distance-3 match of 3..66 bytes: 7-bit length symbol (257..276) + extra bits + 5-bit distance code 2"""
+def length_symbol(length):
+    """run of 3..66 -> (symbol 257..276, extra bit count, extra value) (RFC 1951 3.2.5)"""
     assert 3 <= length <= 66
-    if length <= 10: sym, eb, ev = 254 + length, 0, 0
-    elif length <= 18: sym, eb, ev = 265 + (length - 11) // 2, 1, (length - 11) % 2
-    elif length <= 34: sym, eb, ev = 269 + (length - 19) // 4, 2, (length - 19) % 4
-    else: sym, eb, ev = 273 + (length - 35) // 8, 3, (length - 35) % 8
-    val, nb = _brev(sym - 256, 7), 7
-    val |= ev << nb; nb += eb
-    val |= _brev(2, 5) << nb; nb += 5
-    return val, nb
+    if length <= 10: return 254 + length, 0, 0
+    if length <= 18: return 265 + (length - 11) // 2, 1, (length - 11) % 2
+    if length <= 34: return 269 + (length - 19) // 4, 2, (length - 19) % 4
+    return 273 + (length - 35) // 8, 3, (length - 35) % 8
 
 
 def filter_row(raw):
@@ -51,11 +51,11 @@ def filter_row(raw):
     return np.concatenate([np.array([1], np.uint8), (raw.astype(np.int32) - prev.astype(np.int32)).astype(np.uint8)])
 
 
-def encode_row(f):
-    """one row's deflate segment (bytes) as the row wave writes it: 64 positions per step, runs of f[p] == f[p-3] inside a step"""
+def tokens(f):
+    """the row's tokens as the row kernel forms them: 64 positions per step, runs of f[p] == f[p-3] inside a step; a run of >= 3
+    becomes one match (distance 3), everything else literals.  -> list of (symbol, extra bits, extra value, is_match)"""
     n = len(f)
-    bits = 0; acc = 0
-    acc |= 2; bits = 3                                            # BFINAL = 0, BTYPE = 01 (LSB first: 0, 1, 0)
+    out = []
     for base in range(0, n, 64):
         m = [(base + l) < n and (base + l) >= 3 and f[base + l] == f[base + l - 3] for l in range(64)]
         l = 0
@@ -63,26 +63,53 @@ def encode_row(f):
             if m[l]:
                 e = l
                 while e < 64 and m[e]: e += 1
-                run = e - l
-                if run >= 3:
-                    val, nb = match_code(run)
-                    acc |= val << bits; bits += nb
+                if e - l >= 3:
+                    sym, eb, ev = length_symbol(e - l)
+                    out.append((sym, eb, ev, True))
                 else:
-                    for q in range(l, e):
-                        val, nb = literal_code(int(f[base + q])); acc |= val << bits; bits += nb
+                    for q in range(l, e): out.append((int(f[base + q]), 0, 0, False))
                 l = e
             else:
-                val, nb = literal_code(int(f[base + l])); acc |= val << bits; bits += nb
-                l += 1
-    bits += 7                                                     # end of block (symbol 256 = 0000000)
+                out.append((int(f[base + l]), 0, 0, False)); l += 1
+    return out
+
+
+def encode_row(f, want_choice=False):
+    """one row's deflate segment (bytes): the cheapest -- by exact bit count, first minimum in the order model codes 0.., fixed code,
+    stored -- of a dynamic-Huffman block with one of the encoder's model codes, a fixed-Huffman block, a stored block.  Huffman
+    blocks end with the end-of-block symbol and an empty stored block (00 00 FF FF) that re-aligns the stream to a byte boundary."""
+    n = len(f)
+    T = tables()
+    toks = tokens(f)
+    hist = np.zeros(277, np.int64)
+    xbits = nmatch = 0
+    for sym, eb, ev, is_m in toks:
+        hist[sym] += 1; xbits += eb; nmatch += int(is_m)
+    costs = []
+    for t in T:                                                    # the last table is the fixed code (no header)
+        costs.append(3 + t["hdr_bits"] + int((hist * t["len"]).sum()) + xbits + nmatch * t["dist_len"] + int(t["len"][256]))
+    sizes = [((c + 3 + 7) >> 3) + 4 for c in costs] + [n + 5]      # + stored-block header bits, padded to a byte, + LEN / NLEN
+    choice = int(np.argmin(sizes))                                 # first minimum
+    if choice == len(T):
+        seg = b"\x00" + struct.pack("<HH", n, n ^ 0xFFFF) + bytes(bytearray(int(x) for x in f))
+        return (seg, choice) if want_choice else seg
+    t = T[choice]
+    acc = (t["btype"] << 1); bits = 3                              # BFINAL = 0, BTYPE LSB first
+    hdr = 0
+    for i, wd in enumerate(t["hdr"]): hdr |= int(wd) << (32 * i)
+    acc |= (hdr & ((1 << t["hdr_bits"]) - 1)) << bits; bits += t["hdr_bits"]
+    for sym, eb, ev, is_m in toks:
+        acc |= int(t["code"][sym]) << bits; bits += int(t["len"][sym])
+        if is_m:
+            acc |= ev << bits; bits += eb
+            acc |= t["dist_code"] << bits; bits += t["dist_len"]
+    acc |= int(t["code"][256]) << bits; bits += int(t["len"][256])
+    assert bits == costs[choice]
     bits += 3                                                     # stored block header: BFINAL 0, BTYPE 00
     bits = (bits + 7) & ~7
-    nbytes = bits // 8
-    out = bytearray(acc.to_bytes(nbytes, "little"))
-    out += b"\x00\x00\xff\xff"                                    # LEN = 0, NLEN = ~0
-    if len(out) > n + 5:                                          # the stored form is shorter (noise-like rows): 00 | LEN | ~LEN | bytes
-        return b"\x00" + struct.pack("<HH", n, n ^ 0xFFFF) + bytes(bytearray(int(x) for x in f))
-    return bytes(out)
+    seg = acc.to_bytes(bits // 8, "little") + b"\x00\x00\xff\xff"
+    assert len(seg) == sizes[choice]
+    return (seg, choice) if want_choice else seg
 
 
 def row_stride(width):

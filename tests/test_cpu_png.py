@@ -38,18 +38,30 @@ def test_png_model_files_decode_exactly(oracle, name, img):
     segs = [P.encode_row(P.filter_row(img[y])) for y in range(img.shape[0])]
     assert all(len(sg) <= n + 5 for sg in segs) and idat[2:-6] == b"".join(segs)
     assert all(sg.endswith(b"\x00\x00\xff\xff") or (sg[0] == 0 and len(sg) == n + 5) for sg in segs)
-    if name in ("noise", "high-bytes"): assert all(len(sg) == n + 5 for sg in segs)          # incompressible rows are stored
+    if name == "noise": assert all(len(sg) == n + 5 for sg in segs)                          # incompressible rows are stored
     if name in ("flat", "gradient"): assert all(len(sg) < n // 8 for sg in segs)
+    if name == "smooth":                                                                      # an image-like row takes one of the model codes
+        choices = [P.encode_row(P.filter_row(img[y]), want_choice=True)[1] for y in range(img.shape[0])]
+        assert all(c < len(P.tables()) - 1 for c in choices) and len(data) < 0.8 * img.size      # (97-pixel rows: the 40-byte code header is 14 % of a row)
 
 
-def test_png_model_token_codes_are_the_fixed_huffman_code():
-    """a literal-only and a match-only row against zlib's own inflater in raw mode"""
+def test_png_rows_inflate_with_every_code(oracle, favlib):
+    """rows that select different codes (sharp to broad residuals, run-heavy, incompressible) against zlib's own inflater in raw mode;
+    every ready-made code and its header is a valid, complete deflate code"""
     import png_model as P
-    for row in (np.arange(200, dtype=np.uint8), np.zeros(500, np.uint8), np.tile(np.array([7, 9, 250], np.uint8), 90)):
+    rng = np.random.default_rng(3)
+    seen = set()
+    rows = [np.arange(200, dtype=np.uint8), np.zeros(500, np.uint8), np.tile(np.array([7, 9, 250], np.uint8), 90), rng.integers(0, 256, 900).astype(np.uint8)]
+    for scale in (0.4, 1, 2, 4, 8, 16, 30, 50):
+        rows.append((np.clip(np.rint(rng.laplace(0, scale, 1500)), -128, 127).astype(np.int64) % 256).astype(np.uint8))
+    run = np.repeat(rng.integers(0, 256, 40).astype(np.uint8), 3 * 20); rows.append(run)
+    for row in rows:
         f = np.concatenate([np.array([1], np.uint8), row])
-        seg = P.encode_row(f)
-        out = zlib.decompressobj(-15).decompress(seg + b"\x03\x00")
-        assert out == f.tobytes()
-    for L in range(3, 65):
-        val, nb = P.match_code(L)
-        assert nb <= 15
+        seg, choice = P.encode_row(f, want_choice=True)
+        seen.add(choice)
+        assert zlib.decompressobj(-15).decompress(seg + b"\x03\x00") == f.tobytes()
+        assert len(seg) <= len(f) + 5
+    T = P.tables()
+    assert len(seen) >= 6 and len(T) - 1 in seen and len(T) in seen, seen          # several model codes, the fixed code, a stored row
+    for t in T[:-1]:
+        assert abs(sum(2.0 ** -int(l) for l in t["len"]) - 1.0) < 1e-12 and t["len"].max() <= 15 and t["hdr_bits"] <= 40 * 32
