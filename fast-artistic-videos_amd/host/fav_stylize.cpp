@@ -207,6 +207,7 @@ class Slots {
 public:
     void add(uint8_t* p) { std::lock_guard<std::mutex> l(m_); free_.push_back(p); }
     uint8_t* take() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !free_.empty(); }); uint8_t* p = free_.back(); free_.pop_back(); return p; }
+    uint8_t* try_take() { std::lock_guard<std::mutex> l(m_); if (free_.empty()) return nullptr; uint8_t* p = free_.back(); free_.pop_back(); return p; }
     void give(uint8_t* p) { { std::lock_guard<std::mutex> l(m_); free_.push_back(p); } cv_.notify_one(); }
 private:
     std::mutex m_; std::condition_variable cv_; std::vector<uint8_t*> free_;
@@ -279,7 +280,7 @@ double process_cpu_seconds()
 
 // One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
 // `net` / `net_img` live on the current device; `nwriters` PNG threads.
-void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, StreamResult* res)
+void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, StreamResult* res)   // nwriters: the budget; adjusted below
 {
     const bool fused_check = !o.s("forward_flow_pattern").empty();
     const int border = o.s("warp_border") == "cpu" ? FAV_BORDER_CPU : FAV_BORDER_STN;
@@ -341,6 +342,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     const bool quiet = gpu_png && !(fused_check && o.i("structure") != 0);
     int cur_device = 0; (void)hipGetDevice(&cur_device);
     const double cpu0 = process_cpu_seconds();
+    if (gpu_png && o.i("writers") <= 0) nwriters = std::min(nwriters, 4);      // they only write() finished files: 0.5 ms per frame
     Pool writers(nwriters, cur_device);
     // compute queue; upload queue (the next frame's inputs travel while this frame computes); download queue (the 8-bit frame leaves
     // while the next frame computes: on the compute queue the 2.8 MB copy held back the next frame's kernels for its whole duration)
@@ -373,8 +375,17 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     const double cpu_main0 = thread_cpu_seconds();
     float *d_prev = nullptr, *d_cur = nullptr; std::vector<double> temporal;      // -temporal_eval_file
     const int nslots = nwriters + 2;   // pinned output slots in flight to the PNG pool (deflate ~55 ms/frame/thread)
-    std::vector<uint8_t*> h_out(nslots, nullptr);
+    std::vector<uint8_t*> h_out;       // allocated on demand, at most nslots
+    size_t slot_bytes = 0;
     Slots slots;
+    auto new_slot = [&]() {
+        uint8_t* p = nullptr;
+        if (hipHostMalloc((void**)&p, slot_bytes, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
+        if (gpu_png) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) die("hipEventCreate failed"); slot_ev[p] = e; }
+        h_out.push_back(p);
+        return p;
+    };
+
 
     // continue_with > 1: reload the previous stylised PNG as the recurrent state (8-bit; the reference's
     // video CLI does not reload anything and fails, fast_artistic_video.lua:89,153-156)
@@ -398,16 +409,31 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     constexpr int DEPTH = 6;
     Pinned pin[DEPTH + 1];
     bool pinned_ready = false;
-    auto load_pinned = [&](int i, bool first_of_run, int set) { return load(i, first_of_run, pinned_ready ? &pin[set] : nullptr); };
+    auto load_pinned = [&](int i, bool first_of_run, int set) {
+        if (pinned_ready && !pin[set].frame) {           // first use of this staging set: pinned here, by the loader thread that owns it
+            Pinned& p = pin[set];
+            if (hipHostMalloc((void**)&p.frame, pin_px * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, pin_px * 8, hipHostMallocDefault) ||
+                (fused_check ? hipHostMalloc((void**)&p.fw, pin_px * 8, hipHostMallocDefault) : hipHostMalloc((void**)&p.cert, pin_px, hipHostMallocDefault))) die("hipHostMalloc failed");
+        }
+        return load(i, first_of_run, pinned_ready ? &pin[set] : nullptr);
+    };
     auto idx_ok = [&](int i) { return backward ? i >= end : i <= end; };
-    std::deque<std::pair<int, std::thread>> inflight;      // (slot set, thread)
+    Pool loaders(DEPTH, cur_device);                       // persistent loader threads (a std::thread per frame cost ~0.1 ms of CPU each)
+    std::deque<std::pair<int, std::future<void>>> inflight;      // (slot set, completion of its load)
     std::vector<FrameIn> ready(DEPTH + 1);
     int next_to_issue = start, sets_used = 0;
     auto issue = [&]() {
         while ((int)inflight.size() < DEPTH && idx_ok(next_to_issue)) {
             const int i = next_to_issue, set = sets_used % (DEPTH + 1);
             const bool fo = (i == start) && !have_resume && start != 1;
-            inflight.emplace_back(set, std::thread([&, i, fo, set] { ready[set] = load_pinned(i, fo, set); cpu_loaders_us += (long long)(1e6 * thread_cpu_seconds()); }));
+            auto done_p = std::make_shared<std::promise<void>>();
+            inflight.emplace_back(set, done_p->get_future());
+            loaders.submit([&, i, fo, set, done_p] {
+                const double c0 = thread_cpu_seconds();
+                ready[set] = load_pinned(i, fo, set);
+                cpu_loaders_us += (long long)(1e6 * (thread_cpu_seconds() - c0));
+                done_p->set_value();
+            });
             next_to_issue += inc; ++sets_used;
         }
     };
@@ -489,7 +515,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         if (inflight.empty()) return false;
         const auto tl = std::chrono::steady_clock::now();
         const int set = inflight.front().first;
-        inflight.front().second.join(); inflight.pop_front();
+        inflight.front().second.get(); inflight.pop_front();
         out = ready[set];
         t_wait_load += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl).count();
         return out.ok;
@@ -511,6 +537,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
                 die("-temporal_eval_file: the stylised frames (" + std::to_string(Wo) + "x" + std::to_string(Ho) + ") are larger than the flow; the reference's func_eval fails on such sizes as well (fav.lua:128-151)");
             if (net_img) check(fav_stream_set_image_net(fs, net_img), "fav_stream_set_image_net");
             const size_t n = (size_t)W * H, no = (size_t)Wo * Ho;
+            if (gpu_png && Wo > 9000) die("-png_encoder gpu encodes rows of up to 9000 pixels (one image row lives in a CU's LDS); pass -png_encoder host for " + std::to_string(Wo) + "-wide frames");
             if (gpu_png) {
                 png_cap = fav_png_capacity(Wo, Ho);
                 for (int k = 0; k < 2; ++k) if (hipMalloc((void**)&d_png[k], png_cap) || hipMalloc((void**)&d_png_size[k], 16)) die("hipMalloc failed");
@@ -519,14 +546,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             for (auto& dv : dev)
                 if (hipMalloc((void**)&dv.frame, n * 3) || hipMalloc((void**)&dv.cert, n) || hipMalloc((void**)&dv.bw, n * 8) ||
                     hipMalloc((void**)&dv.fw, n * 8)) die("hipMalloc failed");
-            for (auto& p : h_out) {
-                if (hipHostMalloc((void**)&p, gpu_png ? png_cap : no * 3, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc failed");
-                if (gpu_png) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) die("hipEventCreate failed"); slot_ev[p] = e; }
-                slots.add(p);
-            }
-            for (auto& p : pin)
-                if (hipHostMalloc((void**)&p.frame, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&p.bw, n * 8, hipHostMallocDefault) ||
-                    hipHostMalloc((void**)&p.fw, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&p.cert, n, hipHostMallocDefault)) die("hipHostMalloc failed");
+            // pinned memory is paid for by the page (~0.2 ms per MB): two output slots now, the others when the pool first falls behind;
+            // every loader thread pins its own staging set on first use, in parallel with this thread's set-up
+            slot_bytes = gpu_png ? png_cap : no * 3;
+            for (int k = 0; k < std::min(2, nslots); ++k) slots.add(new_slot());
             pin_px = n; pinned_ready = true;
             if (have_resume) {
                 float* d_state = nullptr;
@@ -573,7 +596,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             temporal.push_back(tl);
         }
         const auto tw = std::chrono::steady_clock::now();
-        uint8_t* hb = slots.take();                      // a pinned output slot nobody is reading (blocks while the PNG pool is behind)
+        uint8_t* hb = slots.try_take();                  // a pinned output slot nobody is reading ...
+        if (!hb) hb = (int)h_out.size() < nslots ? new_slot() : slots.take();      // ... a new one while allowed, else wait for the PNG pool
         t_wait_writer += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
         Pending now; now.valid = true; now.index = i; now.single = cur.single; now.hb = hb; now.ev = done & 1; now.t0 = t0;
         if (gpu_png) {
@@ -603,7 +627,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     }
     finish(pend);
     const auto t_tail = std::chrono::steady_clock::now();       // the GPU is done: what follows is the PNG pool draining
-    for (auto& pr : inflight) pr.second.join();
+    for (auto& pr : inflight) pr.second.get();
     for (auto& r : ready) if (r.index >= 0) r.release();
     fflush(stdout);
     writers.wait_below(0);

@@ -111,6 +111,7 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
             hipc(hipMalloc(reinterpret_cast<void**>(&d_flow), (size_t)W * H * 8), "hipMalloc");
             if (ew) { hipc(hipMalloc(reinterpret_cast<void**>(&d_equi), (size_t)ew * eh * 3), "hipMalloc"); h_equi.resize((size_t)ew * eh * 3); }
             if (b["out_cubemap"]) { hipc(hipMalloc(reinterpret_cast<void**>(&d_cube), (size_t)cw * ch * 3), "hipMalloc"); h_cube.resize((size_t)cw * ch * 3); }
+            if (gpu_png && (ew > 9000 || (b["out_cubemap"] && cw > 9000))) die("-png_encoder gpu encodes rows of up to 9000 pixels; pass -png_encoder host for these output sizes");
             if (gpu_png) {
                 if (ew) { cap_e = fav_png_capacity(ew, eh); hipc(hipMalloc(reinterpret_cast<void**>(&d_png_e), cap_e), "hipMalloc"); h_equi.resize(cap_e); png_ws_bytes = std::max(png_ws_bytes, fav_png_workspace_bytes(ew, eh)); }
                 if (b["out_cubemap"]) { cap_c = fav_png_capacity(cw, ch); hipc(hipMalloc(reinterpret_cast<void**>(&d_png_c), cap_c), "hipMalloc"); h_cube.resize(cap_c); png_ws_bytes = std::max(png_ws_bytes, fav_png_workspace_bytes(cw, ch)); }
