@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize",
          "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include")]
-FILES = ["kernels_s2.hip", "kernels_up2.hip", "kernels_wino.hip"]
+FILES = ["kernels_s2.hip", "kernels_up2.hip", "kernels_wino.hip", "kernels_png.hip"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
@@ -65,3 +65,11 @@ def test_winograd_kernel_keeps_its_accumulators_in_registers(usage):
         u = _one(usage, "conv3_wino_kernel", inst)
         assert u["Occupancy"] == 2 and u["VGPRs"] <= 256, (inst, u)
         assert u["ScratchSize"] <= 96, (inst, u)   # epilogue only (scripts/isa_loops.py: no scratch access inside the K loops)
+
+
+def test_png_encoder_kernels_keep_everything_in_registers_and_lds(usage):
+    """the PNG encoder's three kernels index small per-thread arrays (the chunk header, the trailer) and per-lane token state: none of
+    it may end up in scratch memory"""
+    for name in ("png_rows_kernelILb1E", "png_rows_kernelILb0E", "png_pack_kernel", "png_finish_kernel"):
+        u = _one(usage, name)
+        assert u["ScratchSize"] == 0 and u["VGPRs"] <= 96, (name, u)
