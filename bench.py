@@ -217,7 +217,8 @@ def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames
                "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net + PNG encode (GPU) -> D2H (exact size) -> write() to /dev/shm",
                "h2d_bytes_per_frame": H * W * (3 + 8 + 8)}
         # the headline leg: the defaults of the CLI (-png_encoder gpu), 3-argument check = the workload of `value`
-        out["gpu_png"] = _cli_leg(base, d, "gpu", ["-structure", "0"] + outp("gpu"), outd("gpu"))
+        # (at --gpus N a launcher that cannot bring its RCCL communicator up must not hold the bench line back: 4 minutes)
+        out["gpu_png"] = _cli_leg(base, d, "gpu", ["-structure", "0"] + outp("gpu"), outd("gpu"), timeout=900 if world == 1 else 240)
         if quick:
             return out
         if world == 1:
@@ -564,7 +565,7 @@ def main():
             open(flag, "w").close()
         else:
             t_wait = time.time()
-            while not os.path.exists(flag) and time.time() - t_wait < 1800:
+            while not os.path.exists(flag) and time.time() - t_wait < 900:
                 time.sleep(0.05)
         dist.barrier()
         if rank == 0:
