@@ -422,6 +422,16 @@ def main():
     # not part of `value`: the same loop with the checker's 4-argument (image-structure) mode, which is what
     # makeOptFlow_deepflow.sh:59 runs in production; its masks are computed two frames ahead on the side queues
     extra = {}
+    if world == 1 and not args.no_extra:
+        # continuity with rounds 1-2, whose step ended at the de-processed frame (A9 was a host job then): the same loop without the PNG encode
+        for i in range(4):
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        n0 = max(8, args.steps // 2)
+        for i in range(4, 4 + n0):
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+        torch.cuda.synchronize()
+        extra["frames_per_s_without_png_encode"] = round(n0 / (time.perf_counter() - t1), 3)
     if world == 1 and not args.structure and not args.no_extra:
         def step4(i):
             k2 = (i + 2) % ring

@@ -230,6 +230,7 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
                       void* workspace, size_t ws_bytes, hipStream_t st);
 int launch_check_cert(const float* backward_flo, const float* forward_flo, const float* structure, const float* avg, uint8_t* mask_out,
                       int invert, int fix_occ, int border, int r, float* cert, int H, int W, hipStream_t st);
+int launch_store_flag(uint32_t* flag_host, uint32_t value, hipStream_t st);
 int launch_unpad_input(const float* in8, int H, int W, int pad, float* in7, hipStream_t st);
 int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,
                          int H, int W, double* partial256, hipStream_t st);

@@ -263,6 +263,14 @@ __global__ __launch_bounds__(256) void unpad_input_kernel(const float* in8, int 
     in7[4 * n + i] = hi.x; in7[5 * n + i] = hi.y; in7[6 * n + i] = hi.z;
 }
 
+// the tail of a host-ordered look-ahead: everything before it on its queue is complete when the host reads the value
+__global__ void store_flag_kernel(uint32_t* flag_host, uint32_t value)
+{
+    __threadfence_system();
+    *reinterpret_cast<volatile uint32_t*>(flag_host) = value;
+    __threadfence_system();
+}
+
 // image.save: clamp to [0,1], *255, truncate [Torch7 `image`, recalled]; planar float RGB -> HWC u8
 __global__ __launch_bounds__(256) void quantize_kernel(const float* rgb, uint8_t* out, int H, int W)
 {
@@ -361,6 +369,13 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, i
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
                        prev_rgb, Hs, Ws, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
     FAV_LAUNCH_CHECK("prep_input_kernel");
+    return FAV_OK;
+}
+
+int launch_store_flag(uint32_t* flag_host, uint32_t value, hipStream_t st)
+{
+    hipLaunchKernelGGL(store_flag_kernel, dim3(1), dim3(1), 0, st, flag_host, value);
+    FAV_LAUNCH_CHECK("store_flag_kernel");
     return FAV_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <memory>
 
 #include <mutex>
+#include <unistd.h>
 
 #include "fav_internal.h"
 #include "wino_pack.h"
@@ -835,11 +836,17 @@ struct fav_stream {
     struct Pref { uint8_t* mask = nullptr; float* cert = nullptr; hipEvent_t done = nullptr; bool valid = false;
                   const void *frame = nullptr, *bw = nullptr, *fw = nullptr; int structure = 0; };
     Pref pref[NPREF]; int pref_next = 0, side_next = 0;
+    // host-ordered look-ahead (fav_stream_set_host_ordered): no event ever enters the caller's queue or the side queues; a one-thread
+    // kernel behind the mask pipeline stores a sequence number into host-mapped memory, which fav_stream_next_frame_flow polls
+    bool host_ordered = false;
+    uint32_t* done_host = nullptr;      // [NPREF], hipHostMalloc
+    uint32_t pref_seq[NPREF] = {0, 0, 0}; uint32_t seq_counter = 0;
     ~fav_stream()
     {
         if (net) (void)hipSetDevice(net->device);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); } (void)hipFree(side_ws[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
+        if (done_host) (void)hipHostFree(done_host);
         for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); (void)hipFree(pf.cert); }
         for (int i = 0; i < NSIDE; ++i) (void)hipFree(side_cert_tmp[i]);
         (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws); (void)hipFree(png_ws);
@@ -989,7 +996,16 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
         if (pf.valid && pf.frame == frame_rgb_hwc && pf.bw == backward_flo && pf.fw == forward_flo && pf.structure == (use_structure != 0)) {
             // the mask was computed ahead of time on the side stream
             pf.valid = false;
-            FAV_HIP(hipStreamWaitEvent(st, pf.done, 0));
+            if (s->host_ordered) {
+                // the mask pipeline of this slot ends in a store of its sequence number to host-mapped memory: wait for it HERE, on the
+                // host (it was started a frame ago: normally no wait at all), then enqueue -- no dependency between the queues
+                const int slot = (int)(&pf - s->pref);
+                volatile uint32_t* flag = &s->done_host[slot];
+                for (int spins = 0; *flag != s->pref_seq[slot]; ++spins) {
+                    usleep(50);
+                    if ((spins & 2047) == 2047) { const hipError_t e = hipStreamQuery(s->side[0]); if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "look-ahead queue"); }
+                }
+            } else FAV_HIP(hipStreamWaitEvent(st, pf.done, 0));
             std::swap(s->mask, pf.mask);
             std::swap(s->cert, pf.cert);          // mask -> certainty (options, erosion) was done on the side queue as well
             return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st, true);
@@ -1020,8 +1036,10 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
     const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;
     hipStream_t sd = s->side[q];
-    FAV_HIP(hipEventRecord(s->ev_in, st));                 // inputs are complete at this point of the caller's stream
-    FAV_HIP(hipStreamWaitEvent(sd, s->ev_in, 0));          // (work enqueued on `stream` AFTER this call is not waited for)
+    if (!s->host_ordered) {
+        FAV_HIP(hipEventRecord(s->ev_in, st));                 // inputs are complete at this point of the caller's stream
+        FAV_HIP(hipStreamWaitEvent(sd, s->ev_in, 0));          // (work enqueued on `stream` AFTER this call is not waited for)
+    }                                                          // host-ordered: the caller has SEEN the inputs complete (fav.h)
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
@@ -1030,7 +1048,11 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, pf.mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
                                s->opts.occlusions_min_filter, pf.cert, s->H, s->W, sd);
     if (rc) return rc;
-    FAV_HIP(hipEventRecord(pf.done, sd));
+    if (s->host_ordered) {
+        const int slot = (int)(&pf - s->pref);
+        s->pref_seq[slot] = ++s->seq_counter;
+        rc = launch_store_flag(&s->done_host[slot], s->pref_seq[slot], sd); if (rc) return rc;
+    } else FAV_HIP(hipEventRecord(pf.done, sd));
     pf.valid = true; pf.frame = frame_rgb_hwc; pf.bw = backward_flo; pf.fw = forward_flo; pf.structure = use_structure != 0;
     return FAV_OK;
 }
@@ -1061,6 +1083,19 @@ extern "C" int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capaci
         FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
     }
     return launch_png_encode(nullptr, s->state, s->Wo, s->Ho, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fav_stream_set_host_ordered(fav_stream* s, int on)
+{
+    FAV_REQUIRE(s, "fav_stream_set_host_ordered: null stream");
+    FAV_HIP(hipSetDevice(s->net->device));
+    if (on && !s->done_host) {
+        FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->done_host), 64, hipHostMallocDefault));
+        for (int i = 0; i < fav_stream::NPREF; ++i) s->done_host[i] = 0u;
+    }
+    for (auto& pf : s->pref) pf.valid = false;          // look-aheads in flight in the other mode are dropped (their queues drain on their own)
+    s->host_ordered = on != 0;
+    return FAV_OK;
 }
 
 extern "C" int fav_stream_output_size(const fav_stream* s, int* Ho, int* Wo)

@@ -338,8 +338,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     // kernels only 0.03 cores in the background, + one event record per frame 0.70, + a cross-stream dependency 0.74).  So: uploads are
     // DMA copies on their own queue and the HOST checks (sleeping poll on that queue's event) that frame i's inputs have arrived before
     // it enqueues frame i's kernels -- they were requested a frame earlier; the frame's last kernel writes the PNG size into host-mapped
-    // memory, which the host polls; the PNG bytes then leave as one DMA on a third queue.
-    const bool quiet = gpu_png && !(fused_check && o.i("structure") != 0);
+    // memory, which the host polls; the PNG bytes then leave as one DMA on a third queue.  The 4-argument look-ahead (its mask pipeline
+    // runs a frame ahead on the library's side queues) is started after the host has seen that frame's upload finish and is waited
+    // for on the host as well (fav_stream_set_host_ordered): no event there either.
+    const bool quiet = gpu_png;       // (the 4-argument look-ahead runs host-ordered in this mode: fav_stream_set_host_ordered)
     int cur_device = 0; (void)hipGetDevice(&cur_device);
     const double cpu0 = process_cpu_seconds();
     if (gpu_png && o.i("writers") <= 0) nwriters = std::min(nwriters, 4);      // they only write() finished files: 0.5 ms per frame
@@ -532,6 +534,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
                                o.s("fill_occlusions") == "uniform-random" ? 1 : 0, (unsigned)o.i("seed")};
             check(fav_stream_create(net, H, W, &so, &fs), "fav_stream_create");
             check(fav_stream_output_size(fs, &Ho, &Wo), "fav_stream_output_size");
+            if (quiet) check(fav_stream_set_host_ordered(fs, 1), "fav_stream_set_host_ordered");
             if (have_resume && (rW != Wo || rH != Ho)) die("-continue_with: the previous PNG's size differs from the stylised frames' (" + std::to_string(Wo) + "x" + std::to_string(Ho) + ")");
             if (!o.s("temporal_eval_file").empty() && (Wo != W || Ho != H))
                 die("-temporal_eval_file: the stylised frames (" + std::to_string(Wo) + "x" + std::to_string(Ho) + ") are larger than the flow; the reference's func_eval fails on such sizes as well (fav.lua:128-151)");
@@ -573,7 +576,11 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         if (have_next) {
             if (nxt.W != W || nxt.H != H) die("frame size changed inside the sequence");
             upload(nxt, (dset + 1) % 3);
-            if (!quiet && fused_check && !nxt.single) check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
+            if (fused_check && !nxt.single && (!quiet || o.i("structure") != 0)) {
+                // quiet: the look-ahead may only start on inputs the host has seen arrive (0.35 ms of DMA; the GPU is busy with frame i-1)
+                if (quiet && wait_event_sleeping(ev_up[(dset + 1) % 3], 50) != hipSuccess) die("GPU error while uploading a frame");
+                check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
+            }
         }
         if (quiet && wait_event_sleeping(ev_up[dset], 50) != hipSuccess) die("GPU error while uploading a frame");      // requested a frame ago: already there
         uint8_t* const d_out8 = gpu_png ? nullptr : d_out8s[done & 1];

@@ -63,7 +63,7 @@ EXPORTS = [
     "fav_conv2d_nchw_f32", "fav_stream_create", "fav_stream_destroy",
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
-    "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size",
+    "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size", "fav_stream_set_host_ordered",
     "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_png_tables_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
@@ -335,6 +335,10 @@ class Stream:
     def set_state(self, t):
         _chk_f32(t, "state")
         _check(lib().fav_stream_set_state(self.h, _p(t), _stream()))
+
+    def set_host_ordered(self, on: bool):
+        """look-ahead without events: the caller synchronises the inputs itself before prefetch_mask (see include/fav.h)"""
+        _check(lib().fav_stream_set_host_ordered(self.h, 1 if on else 0))
 
     def png_buffers(self):
         """(out, nbytes) device buffers for encode_png_into: capacity fav_png_capacity(W, H), one int32"""

@@ -208,6 +208,14 @@ int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rgb_hwc, cons
  * fav_stream_next_frame_flow call with the same three pointers and mode consumes the prefetched mask. */
 int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const float* backward_flo,
                              const float* forward_flo, int use_structure, fav_hipstream_t stream);
+/* Host-ordered look-ahead (on != 0): fav_stream_prefetch_mask then records nothing on `stream` and nothing waits on it -- the CALLER
+ * guarantees that the three input buffers are complete when it calls (it has seen their upload finish) -- and the matching
+ * fav_stream_next_frame_flow waits for the look-ahead on the HOST (a sequence number the mask pipeline's last kernel stores into
+ * host-mapped memory; polled with short sleeps, normally already there) instead of making the compute queue wait on an event.
+ * Why: on this runtime every event record behind long-running kernels and every dependency between queues keeps a runtime thread
+ * spinning until it resolves -- one core per process ("quiet synchronisation").  Default: off (event-ordered, fully
+ * asynchronous). */
+int fav_stream_set_host_ordered(fav_stream* s, int on);
 /* read / overwrite the recurrent state ([3][Ho][Wo] float RGB) -- for -continue_with */
 int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
 int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, fav_hipstream_t stream);

@@ -428,16 +428,21 @@ def test_stream_vs_oracle_recurrent(favlib, oracle, cuda, golden_dir, mode):
     assert np.array_equal(st.state().cpu().numpy(), outs[-1])
 
 
-def test_stream_mask_lookahead(favlib, oracle, cuda, golden_dir):
-    """fav_stream_prefetch_mask: the next frame's mask computed on the side stream gives identical frames"""
+@pytest.mark.parametrize("host_ordered", [False, True])
+def test_stream_mask_lookahead(favlib, oracle, cuda, golden_dir, host_ordered):
+    """fav_stream_prefetch_mask: the next frame's mask computed on the side stream gives identical frames -- event-ordered (default)
+    and host-ordered (fav_stream_set_host_ordered: no event in any queue, the caller has seen the inputs complete, the consumer waits on
+    the host for a sequence number in host-mapped memory)"""
     import torch
     path = os.path.join(golden_dir, "tiny_model.t7")
     h, w, n = 48, 72, 4
     frames, bws, fws = _clip(h, w, n, 60)
     net = favlib.Net(path, 0)
     fr = [T(f, cuda) for f in frames]; bw = [None] + [T(b, cuda) for b in bws[1:]]; fw = [None] + [T(f, cuda) for f in fws[1:]]
+    torch.cuda.synchronize()                 # (host-ordered mode: the inputs are complete before any look-ahead starts)
     for structure in (False, True):
         a = favlib.Stream(net, h, w); b = favlib.Stream(net, h, w)
+        b.set_host_ordered(host_ordered)
         oa, _ = a.first_frame(fr[0]); ob, _ = b.first_frame(fr[0])
         b.prefetch_mask(fr[1], bw[1], fw[1], structure)
         for i in range(1, n):

@@ -80,3 +80,17 @@ def test_png_full_size_1280x720_decodes_exactly(favlib, oracle, cuda):
     for y in rows:
         seg = P.encode_row(P.filter_row(img[y]))
         assert seg in a, f"row {y}"
+
+
+def test_png_widest_supported_row_and_the_limit(favlib, oracle, cuda):
+    """a row lives in one CU's LDS (raw + filtered + token descriptors + bit buffer): 9000 pixels is the limit the entry points state;
+    the widest case runs with the raised dynamic-LDS attribute and decodes exactly, one pixel more is refused with a status"""
+    import png_model as P
+    rng = np.random.default_rng(4)
+    img = np.ascontiguousarray(np.repeat(rng.integers(0, 256, (2, 1800, 3), dtype=np.uint8), 5, axis=1))      # 9000 wide, runs of 5 pixels
+    img[1, 4000:4600] = rng.integers(0, 256, (600, 3), dtype=np.uint8)
+    data = favlib.png_encode(T(img, cuda))
+    assert np.array_equal(_decode(data), img) and len(data) <= P.capacity(9000, 2)
+    assert data == P.encode(img)
+    with pytest.raises(favlib.FavError, match="9000"):
+        favlib.png_encode(T(np.zeros((1, 9001, 3), np.uint8), cuda))
