@@ -375,7 +375,11 @@ __global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int
     }
 }
 
-// kernel 3 (one block): XOR of the rows' CRC parts + chunk prelude + trailer, Adler-32 from the rows' parts, header, length, IEND, size
+// kernel 3 (one block): XOR of the rows' CRC parts + chunk prelude + trailer, Adler-32 from the rows' parts, header, length, IEND, size.
+// It stays a kernel of its own on purpose: the file size it stores last may sit in host-mapped memory that the host polls before it
+// starts a DMA out of `png` -- the rows' bytes must have left the XCDs' L2 caches by then, which the boundary behind the pack
+// kernel guarantees and a "last block finishes" scheme inside it would not (short of a system-scope fence in every block: the
+// first version's 88 us).
 __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_part, const uint2* adler, const unsigned long long* total_in, int W, int H,
                                                          uint8_t* png, uint32_t* png_bytes, PngHeader hdr, CrcTables tb)
 {
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_par
     s2 = red[0];
     const unsigned long long E = 43ull + all;                      // end of the row data
     if (t < 33) png[t] = hdr.b[t];
+    __syncthreads();                                               // the header bytes happen-before thread 64's system-scope release below
     if (t == 64) {
         const uint32_t a1 = (uint32_t)((1ull + s1) % 65521ull);
         const uint32_t a2 = (uint32_t)((((n % 65521ull) * ((unsigned long long)H % 65521ull)) % 65521ull + s2) % 65521ull);
