@@ -251,7 +251,7 @@ inline void dry_run_failure_hook(int rank)
 // Host-side ceiling of a job: the CPUs this job may use / the CPU time one frame costs the host (file reads into pinned memory,
 // write() of the PNG, submission) -- what the end-to-end rate cannot exceed however many GPUs work.  Measured on the MI355X box
 // of this project at 1280x720 with the fused 3-argument check (profiles/r03*_bench.log, `host_cpu_ms_per_frame`): the defaults below.
-constexpr double HOST_CPU_MS_PER_FRAME_GPU_PNG = 3.3;       // -png_encoder gpu: 2.4 file reads (17.5 MB) + 0.5 write (2.8 MB) + 0.3 submission (profiles/e2e_r03l.log)
+constexpr double HOST_CPU_MS_PER_FRAME_GPU_PNG = 3.0;       // -png_encoder gpu: 2.2 file reads (17.5 MB) + 0.5 write (2.7 MB) + 0.2 submission (profiles/e2e_r03r.log)
 constexpr double HOST_CPU_MS_PER_FRAME_HOST_PNG = 24.6;     // -png_encoder host -png_level 1 (zlib Sub + Z_RLE)
 inline std::string host_ceiling_json(double cpu_ms_per_frame, const char* source)
 {

@@ -116,6 +116,10 @@ void wait_for_file(const std::string& path, double timeout_s)
         struct stat st;
         if (stat(path.c_str(), &st) == 0 && st.st_size > 0) {
             if ((long long)st.st_size == last) return;
+            // a file nobody has touched for a second is not being written any more: no second look (the two looks 2 ms apart are
+            // for files that appear while we wait; on finished inputs they were 4 ms of sleep per frame in every loader)
+            struct timespec now; clock_gettime(CLOCK_REALTIME, &now);
+            if ((now.tv_sec - st.st_mtim.tv_sec) + 1e-9 * (now.tv_nsec - st.st_mtim.tv_nsec) > 1.0) return;
             last = (long long)st.st_size;
         } else if (!announced) {
             printf("Waiting for file \"%s\"\n", path.c_str()); fflush(stdout); announced = true;
@@ -420,7 +424,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         return load(i, first_of_run, pinned_ready ? &pin[set] : nullptr);
     };
     auto idx_ok = [&](int i) { return backward ? i >= end : i <= end; };
-    Pool loaders(DEPTH, cur_device);                       // persistent loader threads (a std::thread per frame cost ~0.1 ms of CPU each)
+    // persistent loader threads (a std::thread per frame cost ~0.1 ms of CPU each); no more of them than CPUs to run them on
+    Pool loaders(std::min(DEPTH, std::max(2, favl::effective_cpus())), cur_device);
     std::deque<std::pair<int, std::future<void>>> inflight;      // (slot set, completion of its load)
     std::vector<FrameIn> ready(DEPTH + 1);
     int next_to_issue = start, sets_used = 0;
