@@ -183,16 +183,32 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
     __syncthreads();
     for (int i = tid; i < PNG_HIST; i += NT) hist[0][i] = hist[0][i] + hist[1][i] + hist[2][i] + hist[3][i];
     __syncthreads();
-    // the row's exact size under every code (wave w: codes w, w + 4, ...; the last one is the fixed code), and stored
-    for (int k = wave; k <= PNG_NTABLES; k += PNG_ROW_WAVES) {
-        const PngTable& T = tabs[k];
-        uint32_t c = 0;
-        for (int sidx = lane; sidx < PNG_NSYM; sidx += 64) c += hist[0][sidx] * (T.sym[sidx] >> 16);
+    // the row's exact size under every code (wave w: codes w, w + 4, w + 8, w + 12; the last one is the fixed code), and stored.
+    // All code lengths a lane needs (5 symbols x up to 4 codes) are requested in one batch: one memory latency, not one per code.
+    {
+        constexpr int KPW = (PNG_NTABLES + PNG_ROW_WAVES) / PNG_ROW_WAVES;      // codes per wave: 4
+        uint32_t len[KPW][5], hs[5];
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-        if (lane == 0) {
-            const uint32_t bits = 3u + T.hdr_bits + c + hist[0][280] + hist[0][281] * T.dist_len + (T.sym[256] >> 16);
-            pick[k] = ((bits + 3u + 7u) >> 3) + 4u;                 // + the stored-block header of the sync marker, to a byte, + 00 00 FF FF
+        for (int i = 0; i < 5; ++i) { const int sy = lane + 64 * i; hs[i] = sy < PNG_NSYM ? hist[0][sy] : 0u; }
+#pragma unroll
+        for (int q = 0; q < KPW; ++q) {
+            const int k = min(wave + PNG_ROW_WAVES * q, PNG_NTABLES);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { const int sy = min(lane + 64 * i, PNG_NSYM - 1); len[q][i] = tabs[k].sym[sy] >> 16; }
+        }
+#pragma unroll
+        for (int q = 0; q < KPW; ++q) {
+            const int k = wave + PNG_ROW_WAVES * q;
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) c += hs[i] * len[q][i];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+            if (lane == 0 && k <= PNG_NTABLES) {
+                const PngTable& T = tabs[k];
+                const uint32_t bits = 3u + T.hdr_bits + c + hist[0][280] + hist[0][281] * T.dist_len + (T.sym[256] >> 16);
+                pick[k] = ((bits + 3u + 7u) >> 3) + 4u;             // + the stored-block header of the sync marker, to a byte, + 00 00 FF FF
+            }
         }
     }
     __syncthreads();
@@ -323,18 +339,17 @@ __global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int
                                                        uint32_t* crc_part, unsigned long long* total_out, CrcTables tb)
 {
     extern __shared__ uint32_t lds[];           // the row's bytes (stride)
-    __shared__ unsigned long long red[256];
-    __shared__ uint32_t redx[256];
+    __shared__ uint32_t redx[8];
     const int t = threadIdx.x, row = blockIdx.x;
-    // offsets: sum of the sizes before this row, and of all rows
-    unsigned long long before = 0, all = 0;
+    // offsets: sum of the sizes before this row, and of all rows (both < 2^32: H <= 65535 rows of <= 27 KB); wave shuffles + one LDS hop
+    uint32_t before = 0, all = 0;
     for (int i = t; i < H; i += 256) { const uint32_t s = sizes[i]; all += s; if (i < row) before += s; }
-    red[t] = before; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
-    before = red[0]; __syncthreads();
-    red[t] = all; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
-    all = red[0]; __syncthreads();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+    if ((t & 63) == 0) { redx[t >> 6] = before; redx[4 + (t >> 6)] = all; }
+    __syncthreads();
+    before = redx[0] + redx[1] + redx[2] + redx[3]; all = redx[4] + redx[5] + redx[6] + redx[7];
+    __syncthreads();
     const int size = (int)sizes[row];
     const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + (size_t)row * stride);
     const int nws = (size + 3) >> 2;
@@ -366,11 +381,13 @@ __global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int
         const uint32_t c = crc_bytes(s8 + lo, hi - lo);
         acc ^= crc_mulmod(crc_xpow8(tb, 16u * (unsigned)j), c);
     }
-    redx[t] = acc; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) redx[t] ^= redx[t + s]; __syncthreads(); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d);
+    if ((t & 63) == 0) redx[t >> 6] = acc;
+    __syncthreads();
     if (t == 0) {
-        const unsigned long long after = all - before - (unsigned long long)size + 6ull;               // + final block (2) + Adler-32 (4)
-        crc_part[row] = crc_mulmod(crc_xpow8(tb, (unsigned)after), redx[0]);
+        const unsigned long long after = (unsigned long long)all - before - (unsigned long long)size + 6ull;      // + final block (2) + Adler-32 (4)
+        crc_part[row] = crc_mulmod(crc_xpow8(tb, (unsigned)after), redx[0] ^ redx[1] ^ redx[2] ^ redx[3]);
         if (row == 0) *total_out = all;
     }
 }
@@ -383,8 +400,8 @@ __global__ __launch_bounds__(256) void png_pack_kernel(const uint8_t* stage, int
 __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_part, const uint2* adler, const unsigned long long* total_in, int W, int H,
                                                          uint8_t* png, uint32_t* png_bytes, PngHeader hdr, CrcTables tb)
 {
-    __shared__ unsigned long long red[256];
-    __shared__ uint32_t redx[256];
+    __shared__ unsigned long long red[8];
+    __shared__ uint32_t redx[4];
     const int t = threadIdx.x;
     const unsigned long long all = *total_in;
     const unsigned long long n = 3ull * W + 1ull;
@@ -395,13 +412,12 @@ __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_par
         s2 += (ab.y + ((n * (unsigned long long)(H - 1 - k)) % 65521ull) * ab.x) % 65521ull;
         x ^= crc_part[k];
     }
-    redx[t] = x;
-    red[t] = s1; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) { red[t] += red[t + s]; redx[t] ^= redx[t + s]; } __syncthreads(); }
-    s1 = red[0]; __syncthreads();
-    red[t] = s2; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
-    s2 = red[0];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); x ^= __shfl_xor(x, d); }
+    if ((t & 63) == 0) { red[t >> 6] = s1; red[4 + (t >> 6)] = s2; redx[t >> 6] = x; }
+    __syncthreads();
+    s1 = red[0] + red[1] + red[2] + red[3]; s2 = red[4] + red[5] + red[6] + red[7];
+    x = redx[0] ^ redx[1] ^ redx[2] ^ redx[3];
     const unsigned long long E = 43ull + all;                      // end of the row data
     if (t < 33) png[t] = hdr.b[t];
     __syncthreads();                                               // the header bytes happen-before thread 64's system-scope release below
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256) void png_finish_kernel(const uint32_t* crc_par
         const uint32_t ad = (a2 << 16) | a1;
         uint8_t tr[6] = {0x03, 0x00, (uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad};
         const uint8_t pre[6] = {'I', 'D', 'A', 'T', 0x78, 0x01};
-        uint32_t crc = redx[0];
+        uint32_t crc = x;
         crc ^= crc_mulmod(crc_xpow8(tb, (unsigned)(all + 6ull)), crc_bytes(pre, 6));
         crc ^= crc_bytes(tr, 6);
         const uint32_t len = (uint32_t)(all + 8ull);               // zlib header (2) + rows + final block (2) + Adler-32 (4)
