@@ -359,7 +359,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     hipStream_t st, st_copy, st_down;
     if (hipStreamCreate(&st) != hipSuccess || hipStreamCreate(&st_copy) != hipSuccess || hipStreamCreate(&st_down) != hipSuccess) die("hipStreamCreate failed");
     hipStream_t const st_data = st_down;     // quiet mode: st_down carries nothing else; otherwise finish() enqueues frame i-1's bytes BEFORE frame i's size word
-    hipEvent_t ev_up[3], ev_done[2], ev_out[2];
+    constexpr int NDEV = 4;                  // device input sets: frame i (in use) + up to two frames of look-ahead + one being refilled
+    hipEvent_t ev_up[NDEV], ev_done[2], ev_out[2];
     for (auto& e : ev_out) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     for (auto& e : ev_up) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) die("hipEventCreate failed");
     // events the HOST waits on: blocking (the waiting thread sleeps instead of spinning -- a spinning wait costs one core per waiter,
@@ -369,7 +370,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     int W = 0, H = 0;                        // frame size
     int Wo = 0, Ho = 0;                      // size of the stylised frames: the network's output (H x W when both are multiples of 4)
     struct Dev { uint8_t* frame = nullptr; uint8_t* cert = nullptr; float* bw = nullptr; float* fw = nullptr; };
-    Dev dev[3];                              // device input sets: frame i (in use), frame i+1 (uploaded + mask look-ahead), spare
+    Dev dev[NDEV];
     uint8_t* d_out8s[2] = {nullptr, nullptr};    // frames alternate: frame i + 2 is enqueued after the host has seen frame i's download complete
     // gpu_png: device PNG buffers (two, alternating like d_out8s), their sizes on the device and in pinned host memory, and per pinned
     // output slot the event of the exact-size copy into it
@@ -528,10 +529,17 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         return out.ok;
     };
     // the first frame is loaded synchronously (its size sizes every buffer)
-    FrameIn cur = load(start, !have_resume && start != 1, nullptr), nxt;
-    bool have_next = false;
+    FrameIn cur = load(start, !have_resume && start != 1, nullptr);
+    // Look-ahead: frames i+1 .. i+LA are uploaded (device set of ahead[k] = dset + 1 + k) and, with the checker's 4-argument mode, their
+    // masks are under way on the side queues while frame i is enqueued.  That mode needs TWO frames: a mask takes 1.5 ms behind a
+    // 0.45 ms upload, a frame 1.9 ms -- one frame ahead, every frame waited 0.1 ms for its mask (period 2.05 ms: 460 frames/s;
+    // profiles/r03z_cli_4arg_trace.txt)
+    const int LA = (fused_check && o.i("structure") != 0) ? 2 : 1;
+    std::deque<FrameIn> ahead;
+    bool drained = false;
     next_to_issue = start + inc;
     for (int i = start; idx_ok(i) && cur.ok; i += inc) {                                                      // core:196-197
+        const bool first_iteration_of_run = first;
         if (first) {
             const int rW = -W, rH = -H;          // size of the reloaded PNG (-continue_with), if any
             W = cur.W; H = cur.H;
@@ -573,20 +581,30 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
         issue();                                         // keep DEPTH loads in flight
         const auto t0 = std::chrono::steady_clock::now();
-        // frame i+1: wait for its loader, upload it, and start its consistency mask on the side queues so the
-        // (sequential, ~3 ms) 4-argument structure pass overlaps frame i's network
-        have_next = idx_ok(i + inc) && pop_next(nxt);
+        static const bool loop_trace = getenv("FAV_LOOP_TRACE") != nullptr;      // where a loop iteration's host time goes (frames 100-111)
+        double tr_ms[6] = {0, 0, 0, 0, 0, 0};
+        auto tr_mark = [&](int k) { if (loop_trace) tr_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        // frames i+1 (i+2): wait for the loader, upload, and start the consistency mask on the side queues so the (sequential, 1.5 ms)
+        // 4-argument structure pass overlaps the network of the frames before it
         const Dev& dc = dev[dset];
-        const Dev& dn = dev[(dset + 1) % 3];
-        if (have_next) {
+        auto top_up = [&]() {
+        while ((int)ahead.size() < LA && !drained) {
+            FrameIn nxt;
+            if (!idx_ok(i + inc * ((int)ahead.size() + 1)) || !pop_next(nxt)) { drained = true; break; }
             if (nxt.W != W || nxt.H != H) die("frame size changed inside the sequence");
-            upload(nxt, (dset + 1) % 3);
+            const int nset = (dset + 1 + (int)ahead.size()) % NDEV;
+            const Dev& dn = dev[nset];
+            upload(nxt, nset);
             if (fused_check && !nxt.single && (!quiet || o.i("structure") != 0)) {
                 // quiet: the look-ahead may only start on inputs the host has seen arrive (0.35 ms of DMA; the GPU is busy with frame i-1)
-                if (quiet && wait_event_sleeping(ev_up[(dset + 1) % 3], 50) != hipSuccess) die("GPU error while uploading a frame");
+                if (quiet && wait_event_sleeping(ev_up[nset], 50) != hipSuccess) die("GPU error while uploading a frame");
                 check(fav_stream_prefetch_mask(fs, dn.frame, dn.bw, dn.fw, o.i("structure"), st), "fav_stream_prefetch_mask");
             }
+            ahead.push_back(nxt);
         }
+        };
+        if (first_iteration_of_run) top_up();            // (frame `start` is a single image: its successors' uploads start at once)
+        tr_mark(0);
         if (quiet && wait_event_sleeping(ev_up[dset], 50) != hipSuccess) die("GPU error while uploading a frame");      // requested a frame ago: already there
         uint8_t* const d_out8 = gpu_png ? nullptr : d_out8s[done & 1];
         const bool teval = !o.s("temporal_eval_file").empty();
@@ -607,6 +625,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             }
             temporal.push_back(tl);
         }
+        tr_mark(1);                                      // frame i enqueued
         const auto tw = std::chrono::steady_clock::now();
         uint8_t* hb = slots.try_take();                  // a pinned output slot nobody is reading ...
         if (!hb) hb = (int)h_out.size() < nslots ? new_slot() : slots.take();      // ... a new one while allowed, else wait for the PNG pool
@@ -622,9 +641,14 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, quiet ? &h_png_size[now.ev] : d_png_size[now.ev], st), "fav_stream_encode_png");
         }
         if (!quiet) hipEventRecord(ev_out[now.ev], st);  // the frame's 8-bit image / PNG is complete on the compute queue ...
+        tr_mark(2);                                      // PNG encode enqueued
+        top_up();                                        // behind frame i's kernels: the 0.45 ms this waits for the upload are not in front of them
         const auto tg = std::chrono::steady_clock::now();
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i's kernels are already queued
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        tr_mark(3);
+        if (loop_trace && done >= 100 && done < 112)
+            fprintf(stderr, "loop trace frame %d: look-ahead %.3f  frame enqueued %.3f  encode enqueued %.3f  previous frame finished %.3f ms\n", i, tr_ms[0], tr_ms[1], tr_ms[2], tr_ms[3]);
         if (!quiet) {
             hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
             if (gpu_png) hipMemcpyAsync(&h_png_size[now.ev], d_png_size[now.ev], 4, hipMemcpyDeviceToHost, st_down);      // (the bytes follow in finish(), exactly `size` of them)
@@ -634,8 +658,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         pend = now;
         if (cur.index >= 0) cur.release();               // malloc'ed (first frame); pinned sets are reused
         ++done;
-        if (!have_next) break;
-        cur = nxt; dset = (dset + 1) % 3;
+        if (ahead.empty()) break;
+        cur = ahead.front(); ahead.pop_front(); dset = (dset + 1) % NDEV;
     }
     finish(pend);
     const auto t_tail = std::chrono::steady_clock::now();       // the GPU is done: what follows is the PNG pool draining

@@ -30,11 +30,14 @@ for v in variants.split(";"):
         if "=" in wd and not wd.startswith("-"): k, val = wd.split("=", 1); env[k] = val
         else: words.append(wd)
     t0 = time.time()
-    r = subprocess.run(base + ["-output_prefix", f"{d}/o_{name}/out"] + words, capture_output=True, text=True, env=env)
+    wrap = [w.replace("{name}", name) for w in env.pop("FAV_E2E_WRAP", "").split()]      # e.g. "rocprofv3 --kernel-trace --stats -d gpurun_out/p_{name} -o t --"
+    r = subprocess.run(wrap + base + ["-output_prefix", f"{d}/o_{name}/out"] + words, capture_output=True, text=True, env=env)
     wall = time.time() - t0
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     print(name, "wall %.2f s" % wall, line[-1] if line else ("FAILED " + r.stderr[-300:]), flush=True)
     for l in r.stdout.splitlines():
         if l.startswith("thread CPU seconds"): print("   ", l, flush=True)
+    for l in r.stderr.splitlines():
+        if l.startswith("loop trace"): print("   ", l, flush=True)
     shutil.rmtree(f"{d}/o_{name}", ignore_errors=True)
 shutil.rmtree(d, ignore_errors=True)

@@ -118,6 +118,35 @@ def test_fav_stylize_frame_size_not_a_multiple_of_four(oracle, favlib, tmp_path,
     assert r.returncode == 0 and os.path.exists(tmp_path / "out" / "out-00003.png"), r.stderr
 
 
+@pytest.mark.parametrize("encoder", ["gpu", "host"])
+def test_fav_stylize_four_argument_checker_mode_with_two_frames_of_look_ahead(oracle, favlib, tmp_path, golden_dir, encoder):
+    """-structure 1 = consistencyChecker's 4-argument form (makeOptFlow_deepflow.sh:59-60: the video driver always passes the frame):
+    the CLI computes those masks two frames ahead on the side queues.  Seven frames -- more than the look-ahead, the mask slots and the
+    device input ring hold -- against the oracle with the 4-argument masks."""
+    from PIL import Image
+    h, w, n = 48, 64, 7
+    frames, bws, fws = _write_clip(oracle, tmp_path, h, w, n, 90)
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    cmd = [os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
+           "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "1", "-output_prefix", str(tmp_path / "out" / "out"), "-gpu", "0",
+           "-model_vid", model, "-model_img", "self", "-png_encoder", encoder]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.count("Writing output image to") == n, r.stderr
+    ref = oracle.Stylizer(t7.extract_layers(t7.load(model)["model"]))
+    differs = 0
+    for i in range(1, n + 1):
+        f01 = np.transpose(frames[i - 1], (2, 0, 1)).astype(np.float32) / np.float32(255)
+        if i == 1:
+            out = ref.first(f01)
+        else:
+            m4 = oracle.consistency(bws[i - 1], fws[i - 1], frames[i - 1])
+            differs += int((m4 != oracle.consistency(bws[i - 1], fws[i - 1])).sum())
+            out = ref.next(f01, bws[i - 1], m4.astype(np.float32) / np.float32(255))
+        png = np.asarray(Image.open(str(tmp_path / "out" / f"out-{i:05d}.png")))
+        assert np.abs(png.astype(int) - oracle.to_u8_hwc(out).astype(int)).max() <= 1, f"frame {i}"
+    assert differs > 0          # the structure term changes some mask pixels of this clip: the test can tell the two modes apart
+
+
 def test_fav_stylize_flag_contract(favlib, tmp_path, golden_dir):
     exe = os.path.join(BIN, "fav_stylize")
     model = os.path.join(golden_dir, "tiny_model.t7")
