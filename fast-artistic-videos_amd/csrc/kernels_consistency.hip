@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, fl
 
 // one lane per line; `n` samples with element stride `es`, line stride `ls`; scratch holds v1.
 // Arithmetic order exactly as CFilter.h:1426-1437 / 1451-1462.
-__global__ __launch_bounds__(64) void iir_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n,
+__global__ __launch_bounds__(256) void iir_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n,
                                                  int es, int ls, IIR c)
 {
-    const int line = blockIdx.x * 64 + threadIdx.x;
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nlines || n < 2) return;
     float* m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * ls;
     float* v1 = scratch0 + (size_t)blockIdx.y * plane_stride + (size_t)line * ls;
@@ -476,9 +476,13 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane
     // recursiveSmoothX: transpose -> one lane per (former) row walking coalesced memory -> transpose back
     hipLaunchKernelGGL(transpose_kernel, dim3((W + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, st, planes, tmp3, ps, H, W);
-    hipLaunchKernelGGL(iir_kernel, dim3((H + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, H, W, H, 1, c);
+    // One lane per line, so a pass is 34 / 60 waves of a 130-240 us dependent chain.  As blocks of ONE wave they spread over as many
+    // CUs as are free at that moment, and each of them then keeps a whole-CU block of the network's persistent grids waiting; as
+    // blocks of four waves (one per SIMD: the look-ahead register sets of the chain need more than 256 registers) they sit on 9 / 15 CUs
+    static const int ib = getenv("FAV_IIR_BLOCK") ? std::max(64, std::min(256, atoi(getenv("FAV_IIR_BLOCK")) / 64 * 64)) : 256;      // (tuning: read once)
+    hipLaunchKernelGGL(iir_kernel, dim3((H + ib - 1) / ib, 3), dim3(ib), 0, st, tmp3, ps, scratch, H, W, H, 1, c);
     hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (W + 31) / 32, 3), dim3(256), 0, st, tmp3, planes, ps, W, H);
-    hipLaunchKernelGGL(iir_kernel, dim3((W + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, W, H, W, 1, c);
+    hipLaunchKernelGGL(iir_kernel, dim3((W + ib - 1) / ib, 3), dim3(ib), 0, st, planes, ps, scratch, W, H, W, 1, c);
     hipLaunchKernelGGL(eigen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planes, planes + ps, planes + 2 * ps,
                        corners, n);
     hipLaunchKernelGGL(blockmax_kernel, dim3(nb), dim3(256), 0, st, corners, n, bmax);
