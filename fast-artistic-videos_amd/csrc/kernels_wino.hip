@@ -58,8 +58,6 @@ struct WinoArgs {
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
     int nfull;               // units 0 .. nfull-1 are computed whole, the rest in four quarters (32 output channels each)
     long long* dbg;          // optional in-kernel timeline (FAV_WINO_DBG), 24 slots per block
-    unsigned* cu_tickets;    // second form: one counter per CU (4096 entries), never reset -- co-resident blocks draw consecutive tickets
-    int phase_delay;         // second form: head start of a CU's first block in 10 ns ticks
 };
 
 // exact merge of NW groups' (mean, M2) with per-group counts (Chan et al.); same as kernels_conv.hip
@@ -357,308 +355,6 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Second form (round 3): TWO blocks of four waves per CU, each working on HALF a unit's output channels.
-//
-// In the form above a CU holds one block, and a unit is 1.5 us of prologue + 33 us of K loop + 4.9 us of output transform: for 16 %
-// of a unit's time the matrix pipes wait for LDS round trips, barriers and stores.  Hiding that behind the next unit's K loop needs a
-// second set of accumulators -- which is what a second resident block is.  The register file and the LDS are split instead of shared:
-//   * block = 4 waves; wave i owns transform LINE i: all four positions (i, j = 0..3) x NTW = 2 tiles of 32 output channels =
-//     128 accumulator registers (as before), a work item = (unit, 64 output channels); two items make a unit, both read the same
-//     packed weights (same order: position 4 i + j, channel tile 2 half + nt) -- per CU and unit the weights still cross once
-//   * input in slices of 16 channels at a pixel pitch of 20 floats (5 sixteen-byte slots: odd, conflict-free like the 36 above):
-//     two halo buffers of 23 KB; the input is staged once per item = twice per unit (it is 1/11 of the weights' bytes)
-//   * the column fold (A^T along j) is now entirely in registers; the row fold crosses the four waves through LDS ONCE (both output
-//     column parities together: 73.7 KB), so a block needs 74.7 KB and two fit the CU's 160 KB
-//   * per K step (8 channels) a wave issues 4 ds_read_b128 + 16 VALU for 32 MFMAs (0.5 VALU per MFMA; the pair of waves above: 0.25)
-//   * the two blocks of a CU must not run in lock-step (both in their output transform at the same time hides nothing): blocks take a
-//     ticket from a per-CU counter (hardware CU id) and the odd one starts `phase_delay` later -- once out of phase they stay there
-//     (while one is in its transform the other has the pipes to itself and gains exactly what it loses a unit later)
-// Same arithmetic in the same order as the first form: the results are bit-identical (tests/test_gpu_parity.py).
-constexpr int W2_LDSS = 20;                            // pixel pitch in floats (16 channels + 4)
-constexpr int W2_TROW = 18 * W2_LDSS;                  // 360
-constexpr int W2_TTYP = 4 * W2_TROW;                   // 1440: 360 sixteen-byte slots = 8 (mod 16)
-constexpr int W2_TBUF = 4 * W2_TTYP;                   // 5760 floats per halo buffer
-constexpr int W2_PS = 2 * 4 * 64 * LDSS;               // exchange [column parity b][line i][cout 64][36] = 73 728 B
-static_assert(2 * W2_TBUF <= W2_PS, "halo buffers overlay the exchange area");
-
-template <bool AFF>
-__global__ __launch_bounds__(256, 2) void conv3_wino2_kernel(const WinoArgs p)
-{
-    constexpr int NT = 256;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const Ts = smem;                       // [2][W2_TBUF] in the K loop, [2][4][NC][LDSS] in the epilogue
-    float* const aff = smem + W2_PS;              // [2][CIN]
-    __shared__ unsigned ticket;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);           // = transform line i
-    const int CIN = p.CIN, nslices = CIN >> 4, nkg = CIN >> 3;
-
-    int dbi = 0;
-#define DBG_T() { if (p.dbg && t == 0 && dbi < 21) p.dbg[blockIdx.x * 24 + dbi++] = wall_clock64(); }
-    DBG_T();
-    if (t == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        ticket = p.cu_tickets ? atomicAdd(p.cu_tickets + (((xcc & 15u) << 8) | ((hw >> 8) & 255u)), 1u) : 0u;      // XCC | SE, SH, CU
-    }
-    int lb;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
-    const float lo1 = (AFF && p.relu1) ? 0.f : -INFINITY;
-
-    // staging items: (tile row ty, raw column x, 16-byte channel chunk c4) -> raw rows 2 ty .. 2 ty + 3 of column x, four transformed
-    // lines out.  4 x 18 x 4 = 288 items: item A = t (pixel t >> 2 = 0..63), item B for wave 0 (pixels 64..71: ty 3, x 10..17; its upper
-    // half-wave repeats the lower one's items: same addresses, same values)
-    const int c4 = t & 3;
-    const int pixA = t >> 2, tyA = (pixA * 3641) >> 16, xA = pixA - tyA * 18;        // pixA / 18
-    const int xB = 10 + ((lane & 31) >> 2);
-    float* const tstA = Ts + tyA * W2_TTYP + ((xA & 1) * 9 + (xA >> 1)) * W2_LDSS + c4 * 4;
-    float* const tstB = Ts + 3 * W2_TTYP + ((xB & 1) * 9 + (xB >> 1)) * W2_LDSS + c4 * 4;
-    const float* const affr = aff + c4 * 4;
-
-    // fragments: lane = (tile m = lane & 31 -> ty = m >> 3, tx = m & 7; channel half h).  Raw columns 2 tx + d of line i sit at pixel
-    // ((d & 1) * 9 + tx + (d >> 1)): d = 0 -> +0, 1 -> +9, 2 -> +1, 3 -> +10
-    const int m = lane & 31, h = lane >> 5;
-    const float* const ab = Ts + (m >> 3) * W2_TTYP + wave * W2_TROW + (m & 7) * W2_LDSS + 4 * h;
-    const int wlo = lane * 16, wso = wave * 16384;       // weights: lane * 16 + [(4 wave + j) * 4096 + kg * 65536] + (2 half + nt) * 1024
-
-    __syncthreads();
-    if ((ticket & 1u) && p.phase_delay > 0) {           // the CU's second block: start out of phase with the first
-        const long long w0 = wall_clock64();
-        while (wall_clock64() - w0 < p.phase_delay) __builtin_amdgcn_s_sleep(64);
-    }
-    auto work = [&](auto ntw_c, const int u, const int nq) {
-        constexpr int NTW = decltype(ntw_c)::value;
-        constexpr int NC = 32 * NTW;               // output channels of the item
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 3) * 65536, 0x00020000);
-        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
-        const int uy = u / p.units_x, ux = u - uy * p.units_x;
-        const int oy0 = uy * 8, ox0 = ux * 16;
-        DBG_T();   /* item start */
-        int hoA[4], hoB[4];
-        {
-            const int ixa = min(ox0 + xA, p.IW - 1), ixb = min(ox0 + xB, p.IW - 1);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                hoA[a] = ((min(oy0 + 2 * tyA + a, p.IH - 1) * p.IWp + ixa) * CIN + c4 * 4) * 4;
-                hoB[a] = ((min(oy0 + 6 + a, p.IH - 1) * p.IWp + ixb) * CIN + c4 * 4) * 4;
-            }
-        }
-
-        v4f qr[4];
-        v4f sc, sh;
-#define W2_LOAD_RAW(qr, slice_, ho_)                                                                \
-        { _Pragma("unroll") for (int a = 0; a < 4; ++a) qr[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_[a], (slice_) * 64, 0)); }
-#define W2_AFF(slice_)                                                                              \
-        { if (AFF) { sc = *reinterpret_cast<const v4f*>(affr + (slice_) * 16); sh = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 16); } }
-#define W2_XF(v_)                                                                                   \
-        { if (AFF) { v_.x = fmaxf(fmaf(v_.x, sc.x, sh.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc.y, sh.y), lo1); \
-                     v_.z = fmaxf(fmaf(v_.z, sc.z, sh.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc.w, sh.w), lo1); } }
-#define W2_COMMIT(qr, dst_)                                                                         \
-        { W2_XF(qr[0]); W2_XF(qr[1]); W2_XF(qr[2]); W2_XF(qr[3]);                                    \
-          *reinterpret_cast<v4f*>(dst_) = qr[0] - qr[2];                                             \
-          *reinterpret_cast<v4f*>((dst_) + W2_TROW) = qr[1] + qr[2];                                 \
-          *reinterpret_cast<v4f*>((dst_) + 2 * W2_TROW) = qr[2] - qr[1];                             \
-          *reinterpret_cast<v4f*>((dst_) + 3 * W2_TROW) = qr[1] - qr[3]; }
-
-        v4f R0, R1, R2, R3, V0, V1, V2, V3, fb[4][NTW];
-        const int wlq = wlo + nq * 1024;
-#define W2_READ_T(par_, kg_)                                                                        \
-        { R0 = *reinterpret_cast<const v4f*>(ab + (par_) * W2_TBUF + (kg_) * 8);                    \
-          R1 = *reinterpret_cast<const v4f*>(ab + 9 * W2_LDSS + (par_) * W2_TBUF + (kg_) * 8);      \
-          R2 = *reinterpret_cast<const v4f*>(ab + W2_LDSS + (par_) * W2_TBUF + (kg_) * 8);          \
-          R3 = *reinterpret_cast<const v4f*>(ab + 10 * W2_LDSS + (par_) * W2_TBUF + (kg_) * 8); }
-        // B^T d B along the columns: V0 = c0 - c2, V1 = c1 + c2, V2 = c2 - c1, -V3 = c3 - c1 (the packed weights of j = 3 are negated)
-#define W2_MAKE_V() { V0 = R0 - R2; V1 = R1 + R2; V2 = R2 - R1; V3 = R3 - R1; }
-#define W2_LOAD_B(j_, kgg_)                                                                         \
-        { const int so_ = wso + (kgg_) * 65536 + (j_) * 4096;                                      \
-          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt)                                        \
-              fb[j_][nt] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlq + nt * 1024, so_, 0)); }
-#define W2_MFMA(j_, a_)                                                                             \
-        { _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[j_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.x, fb[j_][nt].x, acc[j_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[j_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.y, fb[j_][nt].y, acc[j_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[j_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.z, fb[j_][nt].z, acc[j_][nt], 0, 0, 0); \
-          _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) acc[j_][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_.w, fb[j_][nt].w, acc[j_][nt], 0, 0, 0); }
-
-        // ---- prologue: slice 0 -> halo buffer 0, the weights of the first K step
-        {
-            v4f qb[4];
-            W2_LOAD_RAW(qr, 0, hoA);
-            if (wave == 0) { W2_LOAD_RAW(qb, 0, hoB); }
-            W2_LOAD_B(0, 0); W2_LOAD_B(1, 0); W2_LOAD_B(2, 0); W2_LOAD_B(3, 0);
-            W2_AFF(0);
-            W2_COMMIT(qr, tstA);
-            if (wave == 0) { W2_COMMIT(qb, tstB); }
-        }
-        f32x16 acc[4][NTW];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
-        __syncthreads();
-        W2_READ_T(0, 0);
-        DBG_T();   /* loop start */
-        const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
-
-        // ---- K loop: per 16-channel slice two steps of 8 channels, per step the four positions j (4 NTW MFMAs each); the weights of
-        // position j for the NEXT step are requested right behind position j's MFMAs (three positions = 24 MFMAs ahead of their use).
-        //   step 0: next slice's item A requested at the start, committed before position 3; wave 0 then requests item B
-        //   step 1: item B committed before position 2; the slice's barrier sits before position 3: behind it the next slice's buffer
-        //           is complete and this slice's is no longer read
-        // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
-#define W2_FENCE() __builtin_amdgcn_sched_barrier(0)
-        for (int s = 0; s < nslices; ++s) {
-            const int par = s & 1;
-            const int sn = min(s + 1, nslices - 1);
-            float* const tA = tstA + (par ^ 1) * W2_TBUF;
-            float* const tB = tstB + (par ^ 1) * W2_TBUF;
-            const int kgg = s * 2;
-            // step 0
-            W2_MAKE_V(); W2_LOAD_RAW(qr, sn, hoA); W2_READ_T(par, 1);
-            W2_FENCE(); W2_MFMA(0, V0); W2_FENCE();
-            W2_LOAD_B(0, kgg + 1);
-            W2_FENCE(); W2_MFMA(1, V1); W2_FENCE();
-            W2_LOAD_B(1, kgg + 1);
-            W2_FENCE(); W2_MFMA(2, V2); W2_FENCE();
-            W2_LOAD_B(2, kgg + 1);
-            W2_AFF(sn); W2_COMMIT(qr, tA); if (wave == 0) { W2_LOAD_RAW(qr, sn, hoB); }
-            W2_FENCE(); W2_MFMA(3, V3); W2_FENCE();
-            W2_LOAD_B(3, kgg + 1);
-            // step 1
-            W2_MAKE_V();
-            W2_FENCE(); W2_MFMA(0, V0); W2_FENCE();
-            W2_LOAD_B(0, min(kgg + 2, nkg - 1));
-            W2_FENCE(); W2_MFMA(1, V1); W2_FENCE();
-            W2_LOAD_B(1, min(kgg + 2, nkg - 1));
-            if (wave == 0) { W2_COMMIT(qr, tB); }
-            W2_FENCE(); W2_MFMA(2, V2); W2_FENCE();
-            W2_LOAD_B(2, min(kgg + 2, nkg - 1));
-            __syncthreads();
-            W2_READ_T(par ^ 1, 0);
-            W2_FENCE(); W2_MFMA(3, V3); W2_FENCE();
-            W2_LOAD_B(3, min(kgg + 2, nkg - 1));
-        }
-#undef W2_FENCE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                    // every wave is done with the halo buffers: the exchange area takes their place
-        DBG_T();   /* loop end */
-        if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
-        DBG_T();   /* (no fix-up) */
-#undef W2_LOAD_RAW
-#undef W2_AFF
-#undef W2_XF
-#undef W2_COMMIT
-#undef W2_READ_T
-#undef W2_MAKE_V
-#undef W2_LOAD_B
-#undef W2_MFMA
-
-        // ---- output transform.  acc[j][nt][r] = M[i][j] of tile mi = (r & 3) + 8 (r >> 2) + 4 h, output channel nt * 32 + n.
-        // Column fold in registers (A^T = |1 1 1 0; 0 1 -1 -1| along j), in the first form's order of additions:
-        //   P[b = 0] = (M0 + M1) + M2,   P[b = 1] = M1 - (M2 + M3)
-        // Row fold across the four waves through LDS, both column parities in one pass:
-        //   Y[0][b] = (P0 + P1) + P2,   Y[1][b] = (P1 - P2) - P3      (P_i = line i's fold)
-        // Reduction thread (4 NC of them): output channel c = t % NC, tile row qq = t / NC (tiles 8 qq .. 8 qq + 7 = tx 0..7).
-        const int n = lane & 31;
-        const int c = t & (NC - 1), qq = (t / NC) & 3;
-        const bool red = t < 4 * NC;
-        const int co = nq * 32 + c;
-        const float bv = p.bias[co];
-        float yk[2][2][8];                 // [b][a][tx]
-        float* const pw = Ts + (wave * NC + n) * LDSS + 4 * h;
-        const float* const pr = Ts + c * LDSS + 8 * qq;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4f v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float m0 = acc[0][nt][4 * g + e], m1 = acc[1][nt][4 * g + e], m2 = acc[2][nt][4 * g + e], m3 = acc[3][nt][4 * g + e];
-                        v[e] = b == 0 ? (m0 + m1) + m2 : m1 - (m2 + m3);
-                    }
-                    *reinterpret_cast<v4f*>(pw + b * 4 * NC * LDSS + nt * 32 * LDSS + 8 * g) = v;
-                }
-        __syncthreads();
-        if (red) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    v4f z[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) z[i] = *reinterpret_cast<const v4f*>(pr + (b * 4 + i) * NC * LDSS + 4 * hf);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        yk[b][0][4 * hf + e] = (z[0][e] + z[1][e]) + z[2][e] + bv;
-                        yk[b][1][4 * hf + e] = (z[1][e] - z[2][e]) - z[3][e] + bv;
-                    }
-                }
-        }
-        __syncthreads();
-        // store + per-thread statistics of the 32 outputs (2 rows x 16 columns) of channel c
-        int nv = 0; float sm = 0.f;
-        if (red) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int oy = oy0 + 2 * qq + a;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int ox = ox0 + 2 * k + b;
-                    if (oy < p.OH && ox < p.OW) { p.out[((size_t)oy * p.OW + ox) * 128 + co] = yk[b][a][k]; sm += yk[b][a][k]; ++nv; }
-                }
-        }
-        }
-        if (p.partials != nullptr) {
-            const float mu = nv ? sm / (float)nv : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int oy = oy0 + 2 * qq + a;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int ox = ox0 + 2 * k + b;
-                        const float d = yk[b][a][k] - mu;
-                        if (oy < p.OH && ox < p.OW) m2 = fmaf(d, d, m2);
-                    }
-            }
-            float2* st = reinterpret_cast<float2*>(Ts);           // [4][NC]
-            int* wn = reinterpret_cast<int*>(Ts + 2 * 4 * 128);     // [4]
-            if (red) { st[qq * NC + c] = make_float2(mu, m2); if (c == 0) wn[qq] = nv; }
-            __syncthreads();
-            if (t < NC) {
-                int nn;
-                p.partials[(size_t)u * 128 + nq * 32 + t] = merge_group_stats(st, wn, 4, NC, t, &nn);
-                if (t == 0) p.counts[u] = nn;          // (the parts of a unit write the same count)
-            }
-            __syncthreads();
-        }
-        DBG_T();   /* epilogue end */
-    };
-    // items: units 0 .. nfull-1 as two halves (64 output channels), the rest -- a thin last round -- as four quarters
-    const int nitems = 2 * p.nfull + 4 * (p.units_x * p.units_y - p.nfull);
-    for (int it = lb; it < nitems; it += gridDim.x) {
-        if (it < 2 * p.nfull) work(std::integral_constant<int, 2>{}, it >> 1, (it & 1) * 2);
-        else work(std::integral_constant<int, 1>{}, p.nfull + ((it - 2 * p.nfull) >> 2), (it - 2 * p.nfull) & 3);
-    }
-    if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
-#undef DBG_T
-}
-
 // FAV_WINO_DBG=n: print the in-kernel timeline of the n-th launch
 void wino_debug_report(const long long* hbuf, int grid)
 {
@@ -717,52 +413,6 @@ int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
 }
 
 
-// second form: two blocks of four waves per CU (see conv3_wino2_kernel)
-template <bool AFF>
-int launch_wino2_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
-{
-    const auto kern = conv3_wino2_kernel<AFF>;
-    const size_t lds = (size_t)(W2_PS + 2 * a0.CIN) * sizeof(float);
-    const int dv = cur_dev();
-    static int cus[MAX_DEVICES] = {};
-    static unsigned* tickets[MAX_DEVICES] = {};
-    if (!cus[dv]) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        int occ = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
-        if (occ < 2) { set_error("winograd conv: two blocks do not fit on a CU (occupancy %d)", occ); return FAV_EHIP; }
-        if (!tickets[dv]) {
-            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&tickets[dv]), 4096 * sizeof(unsigned)));
-            FAV_HIP(hipMemset(tickets[dv], 0, 4096 * sizeof(unsigned)));
-        }
-        cus[dv] = prop.multiProcessorCount;
-    }
-    const int units = a0.units_x * a0.units_y;
-    const int grid = std::min(2 * units, 2 * std::max(1, cus[dv] - reserve_cus));      // two blocks per CU, always even
-    WinoArgs a = a0; a.dbg = nullptr; a.cu_tickets = tickets[dv];
-    // head start of a CU's first block: a third of the 33 us two co-resident items spend in their K loops (any value between one
-    // output transform + prologue and a K loop minus that keeps the two out of each other's transforms)
-    static const int delay = getenv("FAV_WINO_PHASE_NS") ? atoi(getenv("FAV_WINO_PHASE_NS")) / 10 : 1000;
-    a.phase_delay = delay;
-    // thin last round (see launch_wino_t): when the last round's half-units, cut once more, still fit the grid, they run as quarters
-    static const bool no_quarters = getenv("FAV_WINO_NO_QUARTERS") != nullptr;
-    const int halves = 2 * units, rounds = (halves + grid - 1) / grid, rem = halves - (rounds - 1) * grid;
-    a.nfull = (rounds >= 2 && rem * 2 <= grid && !no_quarters) ? (rounds - 1) * grid / 2 : units;
-    static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
-    static long long* dbuf = nullptr;
-    const bool dbg = dbg_n > 0 && --dbg_n == 0;
-    if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 24 * 8, st)); a.dbg = dbuf; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    FAV_LAUNCH_CHECK("conv3_wino2_kernel");
-    if (dbg) {
-        std::vector<long long> hb((size_t)512 * 24);
-        FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
-        wino_debug_report(hb.data(), grid);
-    }
-    return FAV_OK;
-}
-
 }  // namespace
 
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
@@ -783,10 +433,8 @@ int launch_conv3_wino(const ConvLaunch& c, const float* wpk, int* counts, hipStr
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW;
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 7) / 8;
-    a.dbg = nullptr; a.cu_tickets = nullptr; a.phase_delay = 0;
-    static const bool one_block = getenv("FAV_WINO_TWO_BLOCKS") == nullptr;     // the second form measured slower (profiles/r03w_wino_two_blocks_ab.log): opt-in, for A/B runs
-    if (one_block) return c.pre.stages >= 1 ? launch_wino_t<true>(a, c.reserve_cus, st) : launch_wino_t<false>(a, c.reserve_cus, st);
-    return c.pre.stages >= 1 ? launch_wino2_t<true>(a, c.reserve_cus, st) : launch_wino2_t<false>(a, c.reserve_cus, st);
+    a.dbg = nullptr;
+    return c.pre.stages >= 1 ? launch_wino_t<true>(a, c.reserve_cus, st) : launch_wino_t<false>(a, c.reserve_cus, st);
 }
 
 }  // namespace fav

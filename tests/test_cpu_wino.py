@@ -172,140 +172,6 @@ def test_fragment_reads_are_bank_conflict_free():
         assert len(set((addr[g0:g0 + 8] // 16) % 8)) == 8
 
 
-# ---------------------------------------------------------------------------------------------- second form: two blocks of four waves
-W2_LDSS, W2_TROW, W2_TTYP, W2_TBUF = 20, 18 * 20, 4 * 18 * 20, 16 * 18 * 20
-
-
-def emulate_item2(x, wpk, bias, scale, shift, relu, oy0, ox0, nq, ntw, f=np.float32):
-    """One work item of conv3_wino2_kernel: 8 x 16 output pixels x (32 ntw) output channels from channel 32 nq on; four waves, wave i =
-    transform line i with all four positions j, slices of 16 input channels at a pixel pitch of 20 floats.  Returns Y[8][16][32 ntw]."""
-    IH, IW, CIN = x.shape
-    nslices, nkg = CIN // 16, CIN // 8
-    NC = 32 * ntw
-    wpk = wpk.reshape(-1)
-    lanes = np.arange(64)
-    m, h = lanes & 31, lanes >> 5
-    acc = np.zeros((4, 4, ntw, 32, 32), f)                    # [wave = i][j][nt][tile mi][n]
-    for s in range(nslices):
-        T = np.full(W2_TBUF, np.nan, f)
-        items = [(t & 3, t >> 2) for t in range(256)] + [(l & 3, 64 + ((l & 31) >> 2)) for l in range(64)]     # item A of every thread, item B of wave 0
-        for c4, pix in items:
-            ty = (pix * 3641) >> 16
-            xx = pix - ty * 18
-            assert ty == pix // 18 and ty < 4
-            r = []
-            for a in range(4):
-                iy, ix = min(oy0 + 2 * ty + a, IH - 1), min(ox0 + xx, IW - 1)
-                ch = slice(s * 16 + c4 * 4, s * 16 + c4 * 4 + 4)
-                v = x[iy, ix, ch].astype(f)
-                if scale is not None:
-                    v = v * scale[ch] + shift[ch]
-                    if relu:
-                        v = np.maximum(v, 0)
-                r.append(v.astype(f))
-            dst = ty * W2_TTYP + ((xx & 1) * 9 + (xx >> 1)) * W2_LDSS + c4 * 4
-            for i, l in enumerate((r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3])):
-                T[dst + i * W2_TROW: dst + i * W2_TROW + 4] = l
-        for w in range(4):
-            ab = (m >> 3) * W2_TTYP + w * W2_TROW + (m & 7) * W2_LDSS + 4 * h
-            for kg in range(2):
-                idx = lambda base: T[(base + kg * 8)[:, None] + np.arange(4)[None, :]]     # [lane][4]
-                R0, R1, R2, R3 = idx(ab), idx(ab + 9 * W2_LDSS), idx(ab + W2_LDSS), idx(ab + 10 * W2_LDSS)
-                for R in (R0, R1, R2, R3):
-                    assert not np.isnan(R).any()
-                V = (R0 - R2, R1 + R2, R2 - R1, R3 - R1)
-                for j in range(4):
-                    for nt in range(ntw):
-                        # byte offset lane * 16 + nq * 1024 + nt * 1024 + wave * 16384 + kg * 65536 + j * 4096
-                        base = ((s * 2 + kg) * 65536 + w * 16384 + j * 4096 + (nq + nt) * 1024) // 4
-                        B = wpk[base: base + 256].reshape(64, 4)                             # [lane][4]
-                        for st in range(4):
-                            a2 = V[j][:, st].reshape(2, 32)
-                            b2 = B[:, st].reshape(2, 32)
-                            acc[w, j, nt] += (a2.T.astype(np.float64) @ b2.astype(np.float64)).astype(f)
-    Ps = np.zeros((2, 4, NC, LDSS), f)
-    for w in range(4):
-        m0, m1, m2, m3 = acc[w, 0], acc[w, 1], acc[w, 2], acc[w, 3]
-        for b in range(2):
-            P = (m0 + m1) + m2 if b == 0 else m1 - (m2 + m3)
-            for nt in range(ntw):
-                for lane in range(64):
-                    n, hh = lane & 31, lane >> 5
-                    for g in range(4):
-                        for e in range(4):
-                            rr = 4 * g + e
-                            mi = (rr & 3) + 8 * (rr >> 2) + 4 * hh
-                            Ps[b, w, nt * 32 + n, 8 * g + 4 * hh + e] = P[nt, mi, n]
-    Y = np.zeros((8, 16, NC), f)
-    for t in range(4 * NC):
-        c, qq = t & (NC - 1), (t // NC) & 3
-        for b in range(2):
-            z = [Ps[b, i, c, 8 * qq: 8 * qq + 8] for i in range(4)]
-            y0 = (z[0] + z[1]) + z[2] + bias[nq * 32 + c]
-            y1 = (z[1] - z[2]) - z[3] + bias[nq * 32 + c]
-            for k in range(8):
-                Y[2 * qq + 0, 2 * k + b, c] = y0[k]
-                Y[2 * qq + 1, 2 * k + b, c] = y1[k]
-    return Y
-
-
-@pytest.mark.parametrize("cin,aff", [(32, False), (48, True)])
-def test_second_form_is_bit_identical_to_the_first(packer, cin, aff):
-    """conv3_wino2_kernel (two blocks of four waves per CU, half / quarter units) performs the first form's arithmetic in the first form's
-    order: same products, same order of accumulation over the input channels, same order of additions in both folds"""
-    rng = np.random.default_rng(11 + cin)
-    IH, IW, COUT = 10, 18, 128
-    if cin % 32:                        # the first form needs whole 32-channel slices: compare on a zero-padded copy
-        cin1 = (cin + 31) // 32 * 32
-    else:
-        cin1 = cin
-    x = rng.standard_normal((IH, IW, cin)).astype(np.float32)
-    w = (rng.standard_normal((COUT, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
-    b = rng.uniform(-0.1, 0.1, COUT).astype(np.float32)
-    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32) if aff else None
-    shift = rng.uniform(-0.5, 0.5, cin).astype(np.float32) if aff else None
-    wpk = packer(w)
-    x1 = np.zeros((IH, IW, cin1), np.float32); x1[..., :cin] = x
-    w1 = np.zeros((COUT, cin1, 3, 3), np.float32); w1[:, :cin] = w
-    sc1 = sh1 = None
-    if aff:
-        sc1 = np.ones(cin1, np.float32); sc1[:cin] = scale
-        sh1 = np.zeros(cin1, np.float32); sh1[:cin] = shift
-    Y1 = emulate_unit(x1, packer(w1), b, sc1, sh1, aff, 0, 0)
-    halves = [emulate_item2(x, wpk, b, scale, shift, aff, 0, 0, nq, 2) for nq in (0, 2)]
-    Y2 = np.concatenate(halves, axis=2)
-    assert np.array_equal(Y1, Y2)
-    quarters = [emulate_item2(x, wpk, b, scale, shift, aff, 0, 0, nq, 1) for nq in range(4)]
-    assert np.array_equal(Y1, np.concatenate(quarters, axis=2))
-    xin = np.maximum(x * scale + shift, 0) if aff else x
-    ref = direct_conv(xin, w, b)
-    assert np.abs(Y2[:8, :16] - ref[:8, :16]).max() < 2e-5
-
-
-def test_second_form_fragment_reads_are_bank_conflict_free():
-    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
-    groups += [[l + 32 for l in g] for g in groups]
-    lanes = np.arange(64)
-    m, h = lanes & 31, lanes >> 5
-    for w in range(4):
-        ab = (m >> 3) * W2_TTYP + w * W2_TROW + (m & 7) * W2_LDSS + 4 * h
-        for off in (0, 1, 9, 10):
-            for kg in range(2):
-                for par in range(2):
-                    addr = (ab + off * W2_LDSS + kg * 8 + par * W2_TBUF) * 4
-                    assert (addr % 16 == 0).all()
-                    for g in groups:
-                        assert len(set((addr[g] // 16) % 16)) == 16
-    # epilogue exchange [b][i][NC][36]: reads by c = t & (NC - 1) at pitch 36 floats, tile row qq = t / NC
-    for NC in (64, 32):
-        for t0 in range(0, 4 * NC, 64):
-            t = t0 + lanes
-            addr = ((t & (NC - 1)) * LDSS + 8 * ((t // NC) & 3)) * 4
-            for g in groups:
-                assert len(set((addr[g] // 16) % 16)) == 16 or NC == 32
-    assert 2 * W2_TBUF <= 2 * 4 * 64 * LDSS and (2 * 4 * 64 * LDSS + 2 * 256) * 4 * 2 <= 160 * 1024      # two blocks per CU
-
-
 # ---------------------------------------------------------------------------------------------- first layer: F(2,3) along x
 @pytest.fixture(scope="module")
 def first_packer(tmp_path_factory):

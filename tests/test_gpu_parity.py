@@ -282,29 +282,6 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     assert np.abs(phases - ref).max() <= 5e-2 and np.abs(got - phases).max() <= 2e-2, (np.abs(phases - ref).max(), np.abs(got - phases).max())
 
 
-@pytest.mark.parametrize("size", [(88, 120), (360, 640), (720, 1280)])
-def test_two_block_winograd_form_is_bit_identical_to_the_one_block_form(favlib, cuda, canonical, tmp_path, size):
-    """conv3_wino2_kernel (two blocks of four waves per CU, items of 64 / 32 output channels, 16-channel slices) does the arithmetic of
-    conv3_wino_kernel (the default; FAV_WINO_TWO_BLOCKS is read once per process, so a child process runs the second form) in the same order: same bits out of the whole
-    network -- at 1280x720 the launches have two full rounds of half units and (first three layers) a thin last round of quarters"""
-    import subprocess, sys
-    H, W = size
-    rng = np.random.default_rng(H)
-    x = (rng.standard_normal((7, H, W)) * 60).astype(np.float32)
-    np.save(tmp_path / "x.npy", x)
-    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
-             "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
-             "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
-             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "one.npy")))
-    subprocess.check_call([sys.executable, "-c", child], env=dict(os.environ, FAV_WINO_TWO_BLOCKS="1"), timeout=300)
-    one = np.load(tmp_path / "one.npy")
-    net = favlib.Net(canonical, 0)
-    got = net.forward(T(x, cuda)).cpu().numpy()
-    assert np.array_equal(got, one), np.abs(got - one).max()
-    again = net.forward(T(x, cuda)).cpu().numpy()          # (the phase tickets advance from launch to launch: no effect on the result)
-    assert np.array_equal(got, again)
-
-
 @pytest.mark.parametrize("inorm", [True, False])
 def test_image_model_vs_oracle(favlib, oracle, cuda, tmp_path, golden_dir, inorm):
     """-model_img <file> -- 3-channel image model with nn.SpatialFullConvolution ('u' layers,
