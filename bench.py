@@ -466,7 +466,11 @@ def main():
         # Winograd F(2x2,3x3) on the fp32 matrix cores (kernels_wino.hip, kernel id 528).  `achieved` = ALGORITHMIC FLOPs (the direct
         # convolution's 2 * MACs) / HIP-event time of those launches; the kernel EXECUTES 16/36 of them, so
         # `achieved` may exceed the fp32 MFMA peak -- `executed_tflops` / `executed_frac` give the matrix-pipe view.
-        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 528 and n > 0]
+        # (kernel id 529 = the same kernel forming a pending residual join while it stages its input: three of the ten launches since
+        #  round 3 -- they do the work of the three res_add launches they replace and are slower for it)
+        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid in (528, 529) and n > 0]
+        dom_plain = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 528 and n > 0]
+        dom_join = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 529 and n > 0]
         dom_name = "conv3_wino_kernel (ten 3x3 128->128 residual convolutions, Winograd F(2x2,3x3), fp32 MFMA 32x32x2)"
         exec_ratio = 16.0 / 36.0
         if not dom:     # FAV_NO_WINO: the halo-resident direct form
@@ -521,6 +525,13 @@ def main():
                          "note": "frac = executed MFMA FLOPs / time / peak (utilisation of the matrix pipe); algorithmic_frac = direct-convolution FLOPs / time / peak "
                                  "(> 1: faster than any direct fp32 convolution could run)",
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
+                         "launches_with_residual_join": sum(n for ms, n, macs in dom_join) if dom_name.startswith("conv3_wino") else 0,
+                         "avg_launch_us_with_join": round(sum(ms for ms, n, macs in dom_join) / max(1, sum(n for ms, n, macs in dom_join)) * 1e3, 2) if dom_name.startswith("conv3_wino") and dom_join else None,
+                         "avg_launch_us_without_join": round(sum(ms for ms, n, macs in dom_plain) / max(1, sum(n for ms, n, macs in dom_plain)) * 1e3, 2) if dom_name.startswith("conv3_wino") and dom_plain else None,
+                         "frac_of_launches_without_join": (round(sum(2.0 * macs * n for ms, n, macs in dom_plain) / (sum(ms for ms, n, macs in dom_plain) / 1e3) / 1e12 * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4)
+                                                           if dom_name.startswith("conv3_wino") and dom_plain else None),
+                         "join_note": "three of the ten launches form the residual join z = skip + IN(branch) of the previous block while staging their input and write it out "
+                                      "(the work of the res_add launches they replace: 33 MB more to read, 33 MB to write, one more operand transform); `frac` is over all ten",
                          "timed_with": "HIP events (no system fence) around every convolution launch of every %d-th step of the timed region (%d of %d steps)" % (max(1, pe), n_prof_steps, args.steps),
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
                          "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None,

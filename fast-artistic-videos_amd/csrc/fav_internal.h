@@ -121,6 +121,10 @@ struct ConvLaunch {
     unsigned* sk_err = nullptr;     // host-mapped error word (device pointer): set by a hand-off wait that timed out
     int reserve_cus = 0;            // CUs left to concurrent side-queue work: persistent / stream-K grids shrink by this many
     int no_sk = 0;                  // shared device: data-parallel grids only (no hand-off between blocks, no co-residency assumption)
+    // Winograd kernel only.  A pending residual join as the input: in = the branch's raw output y (one pending InstanceNorm, no ReLU),
+    // join_skip = the skip tensor's pixel under y's pixel (0, 0) at the SAME row pitch IWp, join_out = where the joined tensor is
+    // written (pitch IWp as well).  OWp > 0: row pitch of `out` in pixels (the output is laid out under a later join's skip tensor).
+    const float* join_skip = nullptr; float* join_out = nullptr; int OWp = 0;
 };
 size_t conv_streamk_workspace_bytes();
 int conv_streamk_grid();
@@ -180,7 +184,7 @@ int launch_stats(const float* x, int M, int C, const Affine& t, float* partials,
 // (mean, M2, count) statistics of z ([res_add_stat_blocks(OH, OW)][C] float2 + counts) for an InstanceNorm that follows the join
 int launch_res_add(const float* y, const float* scale, const float* shift,
                    const float* skip, int SH, int SW, int shave, const Affine& skip_t,
-                   int C, float* z, float* partials, int* counts, hipStream_t st);
+                   int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch = 0);
 inline int res_add_stat_blocks(int OH, int OW) { return OH * ((OW + 127) / 128); }
 // NCHW [C][H][W] -> NHWC [H+2p][W+2p][Cp] with reflection padding p and zero channels >= C
 int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int Cp, float* out, hipStream_t st);

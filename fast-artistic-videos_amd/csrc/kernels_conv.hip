@@ -2740,9 +2740,10 @@ int launch_stats(const float* x, int M, int C, const Affine& t, float* partials,
 }
 
 int launch_res_add(const float* y, const float* scale, const float* shift, const float* skip, int SH, int SW,
-                   int shave, const Affine& skip_t, int C, float* z, float* partials, int* counts, hipStream_t st)
+                   int shave, const Affine& skip_t, int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch)
 {
     const int OH = SH - 2 * shave, OW = SW - 2 * shave;
+    if (skip_pitch > 0) SW = skip_pitch;              // the kernels use SW as the skip's row pitch only
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && OH > 0 && OW > 0, "res_add: bad shape (C=%d)", C);
     if (partials) {
         const dim3 grid(res_add_stat_blocks(OH, OW));

@@ -55,6 +55,8 @@ static_assert(2 * WG_TBUF <= WG_PS, "halo buffers overlay the exchange area");
 struct WinoArgs {
     const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
     float* out; float2* partials; int* counts;
+    const float* skip; float* zout;      // MODE 2 (pending residual join): the skip tensor's pixel under input pixel (0, 0) -- same pitch IWp --, the joined tensor
+    int OWp;                             // row pitch of `out` in pixels (OW, or the pitch of the tensor a later join adds it to)
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
     int nfull;               // units 0 .. nfull-1 are computed whole, the rest in four quarters (32 output channels each)
     long long* dbg;          // optional in-kernel timeline (FAV_WINO_DBG), 24 slots per block
@@ -72,10 +74,17 @@ __device__ __forceinline__ float2 merge_group_stats(const float2* st, const int*
     return make_float2(mean, m2);
 }
 
-// AFF: the input carries a pending per-channel scale/shift (+ReLU) -- the InstanceNorm of the producing convolution
-template <bool AFF>
+// MODE 1: the input carries a pending per-channel scale/shift (+ReLU) -- the InstanceNorm of the producing convolution.
+// MODE 2: the input is a pending RESIDUAL JOIN (models_video.lua:41-53): z = skip + scale * y + shift, formed while the halo is staged
+//   (same operations in the same order as res_add_kernel, kernels_conv.hip) and written out once -- every input pixel by the unit whose
+//   8 x 16 outputs start at it -- as the next block's skip.  y and skip share pitch and offsets (net.cpp lays y out under the skip),
+//   the skip rows bypass the register file: buffer_load ... lds into the part of the exchange area the halo buffers leave free, read
+//   back by the thread that requested them when it commits the item (requested BEFORE y's rows: loads return in order, so y's arrival
+//   implies theirs).
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 {
+    constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
     constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ts = smem;                       // [2][WG_TBUF] in the K loop, [8][128][LDSS] in the epilogue
@@ -95,7 +104,11 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
-    const float lo1 = (AFF && p.relu1) ? 0.f : -INFINITY;
+    const float lo1 = (MODE == 1 && p.relu1) ? 0.f : -INFINITY;
+    // landing area of the skip rows (MODE 2): [row a][thread] sixteen bytes each behind the two halo buffers, then wave 0's item B
+    float* const land = Ts + 2 * WG_TBUF;
+    static_assert(2 * WG_TBUF + 4 * 512 * 4 + 4 * 64 * 4 <= WG_PS, "skip landing area fits behind the halo buffers");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     // staging items: (tile row ty, raw column x, 16-byte channel chunk c4) -> raw rows 2 ty .. 2 ty + 3 of column x, four transformed
     // lines out.  4 x 18 x 8 = 576 items: item A = t (pixel t >> 3 = 0..63), item B = 512 + t for wave 0 (pixels 64..71: ty 3, x 10..17)
@@ -132,6 +145,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         //  alive between items cost 6 % in the K loop, against 0.4 us of prologue it hides)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 3) * 65536, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(JOIN ? p.zout : const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const int uy = u / p.units_x, ux = u - uy * p.units_x;
         const int oy0 = uy * 8, ox0 = ux * 16;
         DBG_T();   /* unit start */
@@ -146,16 +161,50 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
                 hoB[a] = ((min(oy0 + 6 + a, p.IH - 1) * p.IWp + ixb) * CIN + c4 * 4) * 4;
             }
         }
+        // MODE 2: which of an item's four rows this thread writes to the joined tensor (bits 0-3 item A, 4-7 item B): rows 2 ty, 2 ty + 1
+        // of columns 0..15 -- the unit's own 8 x 16 pixels -- plus the halo fringe (rows 8, 9 / columns 16, 17) where no other unit follows
+        int zm = 0;
+        if (JOIN && nq == 0) {
+            const bool lastx = ux == p.units_x - 1, lasty = uy == p.units_y - 1;
+            const bool ca = ox0 + xA < p.IW && (xA < 16 || lastx), cb = ox0 + xB < p.IW && (xB < 16 || lastx);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool ra = oy0 + 2 * tyA + a < p.IH && (a < 2 || (tyA == 3 && lasty));
+                const bool rb = oy0 + 6 + a < p.IH && (a < 2 || lasty);
+                zm |= (ca && ra ? 1 : 0) << a | (cb && rb ? 16 : 0) << a;
+            }
+        }
 
         v4f qr[4];
         v4f sc, sh;
+        const bool lasty_ = uy == p.units_y - 1;
+        float* const landA = land + wave * 256;            // (wave-uniform: M0 of the LDS loads)
+        float* const landB = land + 8192;
+        const float* const readA = land + t * 4;
+        const float* const readB = land + 8192 + lane * 4;
 #define WG_LOAD_RAW(qr, slice_, ho_)                                                                \
         { _Pragma("unroll") for (int a = 0; a < 4; ++a) qr[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_[a], (slice_) * 128, 0)); }
 #define WG_AFF(slice_)                                                                              \
         { if (AFF) { sc = *reinterpret_cast<const v4f*>(affr + (slice_) * 32); sh = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 32); } }
 #define WG_XF(v_)                                                                                   \
-        { if (AFF) { v_.x = fmaxf(fmaf(v_.x, sc.x, sh.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc.y, sh.y), lo1); \
-                     v_.z = fmaxf(fmaf(v_.z, sc.z, sh.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc.w, sh.w), lo1); } }
+        { if (MODE == 1) { v_.x = fmaxf(fmaf(v_.x, sc.x, sh.x), lo1); v_.y = fmaxf(fmaf(v_.y, sc.y, sh.y), lo1); \
+                           v_.z = fmaxf(fmaf(v_.z, sc.z, sh.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc.w, sh.w), lo1); } }
+        // MODE 2: skip rows straight into LDS (one instruction = one row of all 64 lanes, 1 KiB at the wave's place in the landing area)
+#define WG_LOAD_SKIP(slice_, ho_, lbase_, lrow_)                                                    \
+        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 4; ++a)                                 \
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)((lbase_) + a * (lrow_)), 16, ho_[a], (slice_) * 128, 0, 0); } }
+        // MODE 2: z = fma(y, scale, shift) + skip (res_add_kernel's order), written where the mask says so (elsewhere the offset is out of
+        // the buffer's range and the hardware drops the store), then transformed like any other input
+        // (the compiler does not see that the LDS reads depend on the LDS loads: an explicit wait -- at most `vm_` vector-memory
+        //  operations younger than the skip rows may still be in flight: y's four rows are needed here anyway, the eight weight
+        //  fragments requested since are not -- and a compiler barrier keep the reads behind the data)
+#define WG_JOIN(qr, slice_, ho_, lread_, lrow_, zbit_, vm_)                                         \
+        { if (JOIN) { asm volatile("s_waitcnt vmcnt(" #vm_ ")" ::: "memory");                       \
+              _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                       \
+              const v4f xs_ = *reinterpret_cast<const v4f*>((lread_) + a * (lrow_));                \
+              qr[a].x = fmaf(qr[a].x, sc.x, sh.x) + xs_.x; qr[a].y = fmaf(qr[a].y, sc.y, sh.y) + xs_.y; \
+              qr[a].z = fmaf(qr[a].z, sc.z, sh.z) + xs_.z; qr[a].w = fmaf(qr[a].w, sc.w, sh.w) + xs_.w; \
+              if (a < 2 || lasty_) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, qr[a]), zrs, (zm & ((zbit_) << a)) ? ho_[a] : (int)0xFFFFFFF0, (slice_) * 128, 0); } } }
         // B^T along the rows: l0 = r0 - r2, l1 = r1 + r2, l2 = r2 - r1, l3 = r1 - r3
 #define WG_COMMIT(qr, dst_)                                                                         \
         { WG_XF(qr[0]); WG_XF(qr[1]); WG_XF(qr[2]); WG_XF(qr[3]);                                    \
@@ -185,12 +234,33 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
         // ---- prologue: slice 0 -> halo buffer 0
         {
             v4f qb[4];
+            // (MODE 2: the first slice's skip rows through registers -- there are plenty before the accumulators exist.  The skip rows
+            //  arrive 2.4 us behind y's either way (in-kernel timeline, profiles/r04_lazy_join_ab.log) and that is exposed here, once per
+            //  unit; warming the L2 for the next unit's rows from inside the output transform did not move it)
+            v4f xa[4], xb[4];
+            if (JOIN) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    xa[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, hoA[a], 0, 0));
+                    if (wave == 0) xb[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, hoB[a], 0, 0));
+                }
+            }
             WG_LOAD_RAW(qr, 0, hoA);
             if (wave == 0) { WG_LOAD_RAW(qb, 0, hoB); }
             WG_LOAD_B(0, 0, 0);
             WG_AFF(0);
-            WG_COMMIT(qr, tstA);
-            if (wave == 0) { WG_COMMIT(qb, tstB); }
+#define WG_JOIN_REG(qr, xs, ho_, zbit_)                                                             \
+            { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 4; ++a) {                           \
+                  qr[a].x = fmaf(qr[a].x, sc.x, sh.x) + xs[a].x; qr[a].y = fmaf(qr[a].y, sc.y, sh.y) + xs[a].y; \
+                  qr[a].z = fmaf(qr[a].z, sc.z, sh.z) + xs[a].z; qr[a].w = fmaf(qr[a].w, sc.w, sh.w) + xs[a].w; \
+                  if (a < 2 || lasty_) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, qr[a]), zrs, (zm & ((zbit_) << a)) ? ho_[a] : (int)0xFFFFFFF0, 0, 0); } } }
+            WG_JOIN_REG(qr, xa, hoA, 1); WG_COMMIT(qr, tstA);
+            if (wave == 0) { WG_JOIN_REG(qb, xb, hoB, 16); WG_COMMIT(qb, tstB); }
+#undef WG_JOIN_REG
+            // the skip rows come from further away than y's (the tensor was written two launches ago): they are requested a whole
+            // slice before their use -- landing in LDS they cost no registers -- i.e. right behind the reads of the slice before
+            WG_LOAD_SKIP(min(1, nslices - 1), hoA, landA, 2048);
+            if (wave == 0) { WG_LOAD_SKIP(min(1, nslices - 1), hoB, landB, 256); }
         }
         f32x16 acc[2][NTW];
 #pragma unroll
@@ -213,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 #define WG_FENCE() __builtin_amdgcn_sched_barrier(0)
         for (int s = 0; s < nslices; ++s) {
             const int par = s & 1;
-            const int sn = min(s + 1, nslices - 1);
+            const int sn = min(s + 1, nslices - 1), sn2 = min(s + 2, nslices - 1);
             float* const tA = tstA + (par ^ 1) * WG_TBUF;
             float* const tB = tstB + (par ^ 1) * WG_TBUF;
             const int kgg = s * 4;
@@ -224,13 +294,13 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
             WG_FENCE(); WG_MFMA(1, A1, 1); WG_FENCE();
             // group 1
             WG_MAKE_A(); WG_LOAD_B(1, kgg + 1, 1);
-            WG_AFF(sn); WG_COMMIT(qr, tA); if (wave == 0) { WG_LOAD_RAW(qr, sn, hoB); }
+            WG_AFF(sn); WG_JOIN(qr, sn, hoA, readA, 2048, 1, 8); WG_COMMIT(qr, tA); WG_LOAD_SKIP(sn2, hoA, landA, 2048); if (wave == 0) { WG_LOAD_RAW(qr, sn, hoB); }
             WG_FENCE(); WG_MFMA(0, A0, 0); WG_FENCE();
             WG_READ_T(par, 2); WG_LOAD_B(0, kgg + 2, 0);
             WG_FENCE(); WG_MFMA(1, A1, 1); WG_FENCE();
             // group 2
             WG_MAKE_A(); WG_LOAD_B(1, kgg + 2, 1);
-            if (wave == 0) { WG_COMMIT(qr, tB); }
+            if (wave == 0) { WG_JOIN(qr, sn, hoB, readB, 256, 16, 8); WG_COMMIT(qr, tB); WG_LOAD_SKIP(sn2, hoB, landB, 256); }
             WG_FENCE(); WG_MFMA(0, A0, 0); WG_FENCE();
             WG_READ_T(par, 3); WG_LOAD_B(0, kgg + 3, 0);
             WG_FENCE(); WG_MFMA(1, A1, 1); WG_FENCE();
@@ -252,6 +322,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 #undef WG_AFF
 #undef WG_XF
 #undef WG_COMMIT
+#undef WG_LOAD_SKIP
+#undef WG_JOIN
 #undef WG_READ_T
 #undef WG_MAKE_A
 #undef WG_LOAD_B
@@ -313,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int ox = ox0 + 2 * k + b;
-                    if (oy < p.OH && ox < p.OW) { p.out[((size_t)oy * p.OW + ox) * 128 + co] = yk[b][a][k]; sm += yk[b][a][k]; ++nv; }
+                    if (oy < p.OH && ox < p.OW) { p.out[((size_t)oy * p.OWp + ox) * 128 + co] = yk[b][a][k]; sm += yk[b][a][k]; ++nv; }
                 }
         }
         }
@@ -373,10 +445,10 @@ void wino_debug_report(const long long* hbuf, int grid)
             grid, items, wk ? ck / (wk * 10.0) : 0.0, items ? sum[0] / items : 0.0, items ? sum[1] / items : 0.0, items ? sum[3] / items : 0.0, tend);
 }
 
-template <bool AFF>
+template <int MODE>
 int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
 {
-    const auto kern = conv3_wino_kernel<AFF>;
+    const auto kern = conv3_wino_kernel<MODE>;
     const size_t lds = (size_t)(WG_PS + 2 * a0.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
@@ -434,7 +506,12 @@ int launch_conv3_wino(const ConvLaunch& c, const float* wpk, int* counts, hipStr
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW;
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 7) / 8;
     a.dbg = nullptr;
-    return c.pre.stages >= 1 ? launch_wino_t<true>(a, c.reserve_cus, st) : launch_wino_t<false>(a, c.reserve_cus, st);
+    a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
+    if (c.join_skip != nullptr) {
+        FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd conv: a pending residual join needs its output tensor and exactly one pending normalisation");
+        return launch_wino_t<2>(a, c.reserve_cus, st);
+    }
+    return c.pre.stages >= 1 ? launch_wino_t<1>(a, c.reserve_cus, st) : launch_wino_t<0>(a, c.reserve_cus, st);
 }
 
 }  // namespace fav

@@ -45,8 +45,13 @@ struct Act {
     float* partials = nullptr;   // (mean, M2) tiles of the raw tensor from the producing conv, or null
     int mblocks = 0, ppitch = 0;
     int* counts = nullptr;       // per-partial pixel counts (first-layer kernel) or null
+    int pitch = 0;               // row pitch in pixels when the tensor sits inside a wider allocation (0: Wp)
+    // pending residual join (conv3_wino_kernel MODE 2): data = the branch's raw output, pre = its InstanceNorm, join_skip = the skip
+    // tensor's pixel under data's pixel (0, 0) at the same pitch; join_out = where the consuming convolution writes the joined tensor
+    const float* join_skip = nullptr; float* join_out = nullptr;
     int H() const { return Hp << ups; }
     int W() const { return Wp << ups; }
+    int P() const { return pitch ? pitch : Wp; }
 };
 
 int dev_upload(const std::vector<float>& h, size_t pad_to, float** out)
@@ -173,6 +178,8 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    // a residual block whose join stays pending (run(), L_RES): its last convolution lays its output out under the skip tensor
+    struct LazyOut { bool active = false; int pitch = 0, rows = 0, shave = 0, conv_index = -1; } lazy;
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
@@ -204,6 +211,7 @@ struct fav_net {
     int alloc(size_t bytes, float** out);
     int timed_conv(const ConvLaunch& c, int conv_index, const Layer& L);
     int run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw);
+    bool res_block_is_winograd(const Layer& R, size_t first_conv) const;
     int forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     int forward_padded_unordered(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     void out_size(int H, int W, int* Ho, int* Wo) const;
@@ -398,9 +406,29 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     prof_pending.push_back(r);
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
-    // kernel id: 6 first layer with F(2,3) along x, 500+N 3x3 on a x2-upsampled input (merged taps), 700+N stride-2 3x3 (fragment-order weights), 400+N Winograd 3x3, 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
-    prof_tile[conv_index] = use_first ? 6 : use_s2w ? 700 + c.COUTp : use_up2 ? 500 + c.COUTp : use_wino ? 400 + c.COUTp : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
+    // kernel id: 6 first layer with F(2,3) along x, 500+N 3x3 on a x2-upsampled input (merged taps), 700+N stride-2 3x3 (fragment-order weights), 400+N Winograd 3x3 (+1: with a pending residual join as its input), 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
+    prof_tile[conv_index] = use_first ? 6 : use_s2w ? 700 + c.COUTp : use_up2 ? 500 + c.COUTp : use_wino ? 400 + c.COUTp + (c.join_skip ? 1 : 0) : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
     return rc;
+}
+
+static int count_convs(const std::vector<Layer>& ls)
+{
+    int n = 0;
+    for (const Layer& l : ls) { if (l.type == L_CONV) ++n; else if (l.type == L_RES) n += count_convs(l.block); }
+    return n;
+}
+
+// conv - InstanceNorm - ReLU - conv - InstanceNorm (models_video.lua:10-39) with both convolutions on the Winograd kernel
+bool fav_net::res_block_is_winograd(const Layer& R, size_t first_conv) const
+{
+    const std::vector<Layer>& b = R.block;
+    if (tuning().no_wino || b.size() != 5 || b[0].type != L_CONV || b[1].type != L_IN || b[2].type != L_RELU || b[3].type != L_CONV || b[4].type != L_IN) return false;
+    if (first_conv + 1 >= convs.size()) return false;
+    for (int k = 0; k < 2; ++k) {
+        const Layer& c = b[k ? 3 : 0]; const DevConvW& d = convs[first_conv + (size_t)k];
+        if (c.transposed || d.wwino == nullptr || !conv3_wino_eligible(d.cinp, c.cout, d.coutp, c.k, c.stride, c.pad, 1, 0)) return false;
+    }
+    return true;
 }
 
 int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw)
@@ -413,7 +441,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const DevConvW& d = convs[conv_cursor++];
             if (cur.C != d.cinp) { set_error("internal: channel pitch mismatch (%d vs %d)", cur.C, d.cinp); return FAV_EINVAL; }
             ConvLaunch c;
-            c.in = cur.data; c.IH = cur.H(); c.IW = cur.W(); c.IWp = cur.Wp; c.ups = cur.ups; c.CIN = d.cinp;
+            c.in = cur.data; c.IH = cur.H(); c.IW = cur.W(); c.IWp = cur.P(); c.ups = cur.ups; c.CIN = d.cinp;
             c.pre = cur.pre;
             c.wgt = d.wgt; c.bias = d.bias; c.COUT = L.cout; c.COUTp = d.coutp; c.KH = c.KW = L.k; c.stride = L.stride;
             c.pad = L.pad; c.Kpad = d.kpad;
@@ -439,7 +467,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 return FAV_OK;        // Tanh / MulConstant / TotalVariation are folded into the epilogue
             }
             if (L.cout % 4 != 0) { set_error("network: %d output channels (must be a multiple of 4 except for the last layer)", L.cout); return FAV_EUNSUPPORTED; }
-            int rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc;
+            const bool pitched_out = lazy.active && (int)conv_cursor - 1 == lazy.conv_index;
+            int rc;
+            if (pitched_out) {
+                // the output of a block whose join stays pending: pixel (i, j) at the linear index of the skip's pixel (i + shave, j + shave)
+                if (c.OH != lazy.rows - 2 * lazy.shave || c.OW > lazy.pitch - 2 * lazy.shave) { set_error("internal: pending residual join of mismatching shapes"); return FAV_EINVAL; }
+                float* base = nullptr;
+                rc = alloc((size_t)lazy.rows * lazy.pitch * L.cout * sizeof(float), &base); if (rc) return rc;
+                nxt.data = base + ((size_t)lazy.shave * lazy.pitch + lazy.shave) * L.cout; nxt.pitch = lazy.pitch; c.OWp = lazy.pitch;
+            } else { rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc; }
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
             const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
             const bool wino = !L.transposed && d.wwino != nullptr && precision == 0 && !tuning().no_wino &&
@@ -455,6 +491,10 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
+            if (cur.join_skip != nullptr || pitched_out) {
+                if (!wino) { set_error("internal: a pending residual join next to a convolution that is not the Winograd kernel's"); return FAV_EINVAL; }
+                c.join_skip = cur.join_skip; c.join_out = cur.join_out;
+            }
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
             c8_counts = (c8 || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_up2 = up2; use_first = first; use_s2w = s2w;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
@@ -511,12 +551,39 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             Act skip = cur;
             Act br = cur;
             br.partials = nullptr;
-            int rc = run(L.block, br, false, nullptr, nullptr); if (rc) return rc;
+            int rc;
+            if (cur.join_skip != nullptr) {
+                // the previous block's join is pending: this block's first convolution forms it while staging its input and writes it
+                // out -- that tensor is this block's skip
+                float* zb = nullptr;
+                rc = alloc((size_t)cur.Hp * cur.P() * cur.C * sizeof(float), &zb); if (rc) return rc;
+                br.join_out = zb;
+                skip = Act(); skip.data = zb; skip.Hp = cur.Hp; skip.Wp = cur.Wp; skip.C = cur.C; skip.pitch = cur.P();
+            }
+            // Leave THIS block's join pending when the next layer is another residual block that starts with a Winograd convolution
+            // (models_video.lua:41-53, R128 x 5): the 15 us res_add launch (88 MB at the HBM roofline) becomes 33 MB of extra reads and
+            // 33 MB of writes inside a kernel that is bound by its matrix instructions.  The skip must be a plain tensor (the first
+            // block's skip still carries d128's InstanceNorm + ReLU: its join stays a launch).
+            static const bool no_lazy = getenv("FAV_NO_LAZY_JOIN") != nullptr;      // (tuning: read once)
+            const int nconv = count_convs(L.block);
+            const bool lazy_out = !no_lazy && precision == 0 && li + 1 < ls.size() && ls[li + 1].type == L_RES && skip.pre.stages == 0 && skip.ups == 0 &&
+                                  res_block_is_winograd(L, conv_cursor) && res_block_is_winograd(ls[li + 1], conv_cursor + (size_t)nconv);
+            if (lazy_out) { lazy.active = true; lazy.pitch = skip.P(); lazy.rows = skip.Hp; lazy.shave = L.shave; lazy.conv_index = (int)conv_cursor + nconv - 1; }
+            rc = run(L.block, br, false, nullptr, nullptr);
+            lazy.active = false;
+            if (rc) return rc;
             if (br.pre.stages != 1 || br.pre.relu1 || br.ups != 0) { set_error("network: residual branch must end in conv + InstanceNormalization"); return FAV_EUNSUPPORTED; }
             if (br.Hp != skip.Hp - 2 * L.shave || br.Wp != skip.Wp - 2 * L.shave || br.C != skip.C) {
                 set_error("network: residual branch output %dx%d does not match the shaved skip %dx%d", br.Wp, br.Hp,
                           skip.Wp - 2 * L.shave, skip.Hp - 2 * L.shave);
                 return FAV_EUNSUPPORTED; }
+            if (lazy_out) {
+                // nothing is launched: data = the branch's output (laid out under the skip), pre = its InstanceNorm, plus the skip
+                cur = br;
+                cur.partials = nullptr; cur.counts = nullptr;
+                cur.join_skip = skip.data + ((size_t)L.shave * skip.P() + L.shave) * skip.C; cur.join_out = nullptr;
+                break;
+            }
             Act z; z.Hp = br.Hp; z.Wp = br.Wp; z.C = br.C;
             rc = alloc((size_t)z.Hp * z.Wp * z.C * sizeof(float), &z.data); if (rc) return rc;
             // the join feeds an InstanceNorm (directly, or through the x2 nearest upsample of models_video.lua:94-98, which leaves
@@ -529,7 +596,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 float* cp = nullptr; rc = alloc((size_t)z.mblocks * sizeof(int), &cp); if (rc) return rc; z.counts = reinterpret_cast<int*>(cp);
             }
             rc = launch_res_add(br.data, br.pre.scale1, br.pre.shift1, skip.data, skip.Hp, skip.Wp, L.shave, skip.pre, z.C,
-                                z.data, z.partials, z.counts, st);
+                                z.data, z.partials, z.counts, st, skip.P());
             if (rc) return rc;
             cur = z;
             break;

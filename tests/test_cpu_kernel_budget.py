@@ -61,7 +61,7 @@ def test_nine_position_kernel_fits_three_waves_per_simd(usage):
 
 
 def test_winograd_kernel_keeps_its_accumulators_in_registers(usage):
-    for inst in ("ILb1E", "ILb0E"):
+    for inst in ("ILi0E", "ILi1E", "ILi2E"):       # plain input, pending InstanceNorm, pending residual join
         u = _one(usage, "conv3_wino_kernel", inst)
         assert u["Occupancy"] == 2 and u["VGPRs"] <= 256, (inst, u)
         assert u["ScratchSize"] <= 96, (inst, u)   # epilogue only (scripts/isa_loops.py: no scratch access inside the K loops)

@@ -146,6 +146,29 @@ def test_lane_level_restatement_matches_direct_convolution(packer, cin, aff):
     assert err < 2e-5, err
 
 
+def test_pending_join_is_written_exactly_once_per_input_pixel():
+    """conv3_wino_kernel MODE 2 (the residual join formed while the halo is staged): every input pixel of the convolution is written to the
+    joined tensor by exactly one staging item -- rows 2 ty, 2 ty + 1 of columns 0..15 of each unit plus the halo fringe of the last units"""
+    for OH, OW in ((11, 19), (16, 32), (8, 16), (23, 50), (180, 320)):
+        IH, IW = OH + 2, OW + 2
+        units_y, units_x = (OH + 7) // 8, (OW + 15) // 16
+        hits = np.zeros((IH, IW), np.int32)
+        for uy in range(units_y):
+            for ux in range(units_x):
+                oy0, ox0 = uy * 8, ux * 16
+                lastx, lasty = ux == units_x - 1, uy == units_y - 1
+                items = [(t >> 3) for t in range(512) if (t & 7) == 0] + [64 + (l >> 3) for l in range(64) if (l & 7) == 0]      # one channel chunk per pixel
+                for pix in items:
+                    ty, x = pix // 18, pix % 18
+                    assert (ty, x) == ((3, 10 + pix - 64) if pix >= 64 else (pix // 18, pix % 18))
+                    col_ok = ox0 + x < IW and (x < 16 or lastx)
+                    for a in range(4):
+                        row_ok = oy0 + 2 * ty + a < IH and (a < 2 or (ty == 3 and lasty))
+                        if col_ok and row_ok:
+                            hits[oy0 + 2 * ty + a, ox0 + x] += 1
+        assert (hits == 1).all(), (OH, OW, np.argwhere(hits != 1)[:5])
+
+
 def test_fragment_reads_are_bank_conflict_free():
     """ds_read_b128 is served in groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32 for the upper half-wave); within a
     group the 16-byte slots (address / 16 mod 16) must all differ (MI355X LDS: 64 banks x 4 B)."""

@@ -282,6 +282,30 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     assert np.abs(phases - ref).max() <= 5e-2 and np.abs(got - phases).max() <= 2e-2, (np.abs(phases - ref).max(), np.abs(got - phases).max())
 
 
+@pytest.mark.parametrize("size", [(88, 120), (90, 122), (360, 640), (720, 1280)])
+def test_pending_residual_joins_give_the_bits_of_the_launched_ones(favlib, cuda, canonical, tmp_path, size):
+    """The joins of residual blocks 2-4 (models_video.lua:41-53) are not launched: the next block's first Winograd convolution forms
+    z = skip + IN(branch) while it stages its halo (same operations in res_add_kernel's order) and writes it out as that block's skip;
+    the branch's output is laid out under the skip tensor for that.  FAV_NO_LAZY_JOIN (read once per process: a child process runs it)
+    launches every join -- same bits out of the whole network, at sizes with ragged last units in both directions."""
+    import subprocess, sys
+    H, W = size
+    rng = np.random.default_rng(H + W)
+    x = (rng.standard_normal((7, H, W)) * 60).astype(np.float32)
+    np.save(tmp_path / "x.npy", x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
+             "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "eager.npy")))
+    subprocess.check_call([sys.executable, "-c", child], env=dict(os.environ, FAV_NO_LAZY_JOIN="1"), timeout=300)
+    eager = np.load(tmp_path / "eager.npy")
+    net = favlib.Net(canonical, 0)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, eager), np.abs(got - eager).max()
+    assert np.array_equal(got, net.forward(T(x, cuda)).cpu().numpy())
+
+
 @pytest.mark.parametrize("inorm", [True, False])
 def test_image_model_vs_oracle(favlib, oracle, cuda, tmp_path, golden_dir, inorm):
     """-model_img <file> -- 3-channel image model with nn.SpatialFullConvolution ('u' layers,
