@@ -2024,6 +2024,7 @@ struct FoldArgs {
     int stages, relu1, relu2;
     float tanh_mul;
     int tiles_x, tiles_y;
+    long long* dbg;      // optional in-kernel timeline (FAV_FOLD_DBG): per block tile count and the time spent in staging+MFMA loop / epilogue
 };
 
 // 16 output rows per tile (8 accumulators per wave): every staged input row feeds up to 9 output rows, so a taller tile stages
@@ -2255,10 +2256,12 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
 
+        const long long w0 = p.dbg ? wall_clock64() : 0;
         FOLD_LOAD(pr_lo);
         __syncthreads();               // affine tables + weights visible; the previous tile's epilogue is done with the staging memory
         FOLD_STORE(0);
         __syncthreads();
+        const long long w1 = p.dbg ? wall_clock64() : 0;
 
         int cur = 0;
         for (int pr = pr_lo; pr <= pr_hi; ++pr) {
@@ -2291,6 +2294,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
 #undef FOLD_LOAD
 #undef FOLD_STORE
 
+        const long long w2 = p.dbg ? wall_clock64() : 0;
         // ---- epilogue in four passes (pass hh: output rows oy0 + g + 4 hh of the four row groups): D tiles -> LDS [4][64][33],
         // then the diagonal sum over kx with the logical -> physical column map
         float* D = As;
@@ -2322,6 +2326,10 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
             }
             __syncthreads();
         }
+        if (p.dbg && t == 0) {
+            long long* d = p.dbg + blockIdx.x * 8;
+            d[0] += 1; d[1] += w1 - w0; d[2] += w2 - w1; d[3] += wall_clock64() - w2; d[4] += pr_hi - pr_lo + 1;
+        }
     }
 }
 
@@ -2348,8 +2356,20 @@ int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
     a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
     const int tiles = a.tiles_x * a.tiles_y;
     const int nres = std::max(1, cus[dv] - reserve_cus);
+    static int dbg_n = getenv("FAV_FOLD_DBG") ? atoi(getenv("FAV_FOLD_DBG")) : 0;      // print the in-kernel timeline of the n-th launch
+    const bool dbg = dbg_n > 0 && --dbg_n == 0;
+    static long long* dbuf = nullptr;
+    a.dbg = nullptr;
+    if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 8 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 8 * 8, st)); a.dbg = dbuf; }
     hipLaunchKernelGGL((conv_rowfold_up2_kernel<CIN>), dim3(tiles < nres ? tiles : nres), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_rowfold_up2_kernel");
+    if (dbg) {
+        std::vector<long long> hb((size_t)512 * 8);
+        FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
+        double n = 0, a0 = 0, a1 = 0, a2 = 0, rows = 0;
+        for (int b = 0; b < 512; ++b) { n += hb[b * 8]; a0 += hb[b * 8 + 1]; a1 += hb[b * 8 + 2]; a2 += hb[b * 8 + 3]; rows += hb[b * 8 + 4]; }
+        if (n > 0) fprintf(stderr, "FOLDDBG tiles=%.0f  per tile: first row %.2f  loop %.2f (%.1f staged rows)  epilogue %.2f us\n", n, a0 / n * 0.01, a1 / n * 0.01, rows / n, a2 / n * 0.01);
+    }
     return FAV_OK;
 }
 
@@ -2392,6 +2412,7 @@ int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
 {
     FAV_REQUIRE(conv_fold_eligible(c.CIN, c.COUT, c.KW, c.stride) && c.KH == c.KW && c.final_mode, "row-folded conv: not eligible");
     FoldArgs a;
+    a.dbg = nullptr;
     a.in = c.in; a.wfold = wfold; a.bias = c.bias;
     a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.scale2 = c.pre.scale2; a.shift2 = c.pre.shift2;
     a.stages = c.pre.stages; a.relu1 = c.pre.relu1; a.relu2 = c.pre.relu2;
