@@ -150,6 +150,10 @@ int launch_conv_c8d(const ConvLaunch& p, int cin_real, const float* wc8d, int* c
 // eligibility as conv_c8d_eligible; partials per 8x64 tile with explicit counts
 int conv_first_tiles(int OH, int OW);
 int launch_conv_first(const ConvLaunch& p, int cin_real, const float* wpk, int* counts, hipStream_t st);
+// ... and with 2-D minimal filtering F(2x2,3x3) over its nine 3x3 blocks (conv_first2d_kernel); wpk = conv_first2d_pack() (first2d_pack.h);
+// partials per 16x32-pixel tile
+int conv_first2d_tiles(int OH, int OW);
+int launch_conv_first2d(const ConvLaunch& p, int cin_real, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 UNPADDED 128-channel layers (the residual blocks): Winograd F(2x2,3x3), kernels_wino.hip; wpk = conv_wino_pack()
 // of the [cout][cin][3][3] weights (wino_pack.h); partials per 8x16-pixel unit with explicit counts
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);

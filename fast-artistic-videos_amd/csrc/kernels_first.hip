@@ -18,6 +18,7 @@
 
 #include "fav_internal.h"
 #include "first_pack.h"
+#include "first2d_pack.h"
 
 namespace fav {
 
@@ -250,6 +251,229 @@ int launch_first_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
     return FAV_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same layer with 2-D minimal filtering (round 3): the 9x9 correlation as nine 3x3 correlations (filter rows 3 a + r, columns
+// 3 b + s), each computed with Winograd F(2x2, 3x3) and ACCUMULATED IN THE TRANSFORMED DOMAIN -- 16 multiplies per (channel, a, b) and
+// 2x2 outputs against 24 for the 1-D form above (first2d_pack.h).  The 1-D kernel is bound by its matrix instructions (84 % of a
+// tile's time); this form issues two thirds of them for twice the vector-ALU work per instruction (2 instead of 1).
+//
+// v_mfma_f32_16x16x4_f32: one wave = 16 tiles of 2x2 outputs x 32 channels, ALL sixteen positions in its own accumulators (16
+// positions x 2 channel halves x 4 registers = 128): the output transform never leaves the lane.  An instruction multiplies four k =
+// (channel, a, b) at once, one per group of 16 lanes; every lane group reads its own 4x4 patch -- rows 2 ty + 3 a + r, columns
+// 2 tx + 3 b + d of its channel's halo plane -- at a per-lane offset computed once per kernel and quad (first2d_pack.h fixes which k
+// share an instruction).  Block = 8 waves = 8 tile rows: 16 output rows x 32 columns, halo 24 x 40 pixels per channel as plain rows
+// (lanes of a group read every second word: no conflicts inside a group), 131 KB of transformed weights resident in LDS, each
+// B-operand read = 64 consecutive words.
+constexpr int G_TH = 16, G_TW = 32;
+constexpr int G_HR = G_TH + 8, G_HC = G_TW + 8;     // halo 24 x 40
+constexpr int G_CPL = G_HR * G_HC + 16;             // words per channel plane (+16: consecutive channels start in different bank quarters)
+constexpr int G_HP = G_HR * G_HC;                   // 960 halo pixels
+constexpr int G_NH = (G_HP + 511) / 512;            // 2 halo pixels per thread
+
+template <int CR>
+__global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
+{
+    constexpr int NQ = (9 * CR + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ws = smem;                        // [16][NQ][2][4][16]
+    float* const Hs = Ws + 16 * NQ * 128;          // [CR][24][40] (+16 per plane)
+    float* const red = Hs + CR * G_CPL;            // [8][32] float2 + [8] int
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int e = t; e < 16 * NQ * 32; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wpk + e * 4);
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    float4 hlo[G_NH], hhi[G_NH];
+#define G_LOAD_HALO(tile_)                                                                          \
+    {                                                                                               \
+        const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
+        _Pragma("unroll") for (int i = 0; i < G_NH; ++i) {                                          \
+            const int pix_ = t + 512 * i, hy_ = pix_ / G_HC, hx_ = pix_ - hy_ * G_HC;               \
+            const int iy_ = ty_ * G_TH - p.pad + hy_, ix_ = tx_ * G_TW - p.pad + hx_;               \
+            const bool v_ = (pix_ < G_HP) & ((unsigned)iy_ < (unsigned)p.IH) & ((unsigned)ix_ < (unsigned)p.IW); \
+            const int off_ = v_ ? (iy_ * p.IWp + ix_) * 8 : 0;                                      \
+            const float4 a_ = *reinterpret_cast<const float4*>(p.in + off_);                        \
+            const float4 b_ = CR > 4 ? *reinterpret_cast<const float4*>(p.in + off_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            hlo[i] = v_ ? a_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+            hhi[i] = v_ ? b_ : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+        }                                                                                           \
+    }
+#define G_STORE_HALO()                                                                              \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < G_NH; ++i) {                                          \
+            const int pix_ = t + 512 * i;                                                           \
+            if (pix_ < G_HP) {                                                                      \
+                float* d_ = Hs + pix_;                                                              \
+                const float c_[8] = {hlo[i].x, hlo[i].y, hlo[i].z, hlo[i].w, hhi[i].x, hhi[i].y, hhi[i].z, hhi[i].w}; \
+                _Pragma("unroll") for (int c = 0; c < CR; ++c) d_[c * G_CPL] = c_[c];               \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) G_LOAD_HALO(tile);
+    G_STORE_HALO();
+
+    // lane = (tile column tx, lane group g): the group's k of quad q is (c, a, b) = conv_first2d_combo(CR, q, g)
+    const int txl = lane & 15, g = lane >> 4;
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = 4 * q + g;
+        const int c = idx / 9, a = (idx - 9 * c) / 3, b = idx - 9 * c - 3 * a;
+        qoff[q] = idx < 9 * CR ? c * G_CPL + 3 * a * G_HC + 3 * b : 0;        // (no tap: zero weights, any address)
+    }
+    const float* const a_lane = Hs + 2 * wave * G_HC + 2 * txl;              // patch (0, 0) of tile (wave, txl)
+    const float* const b_lo = Ws + lane;                                     // positions 0..7
+    int hi_words = 8 * NQ * 128;
+    asm volatile("" : "+v"(hi_words));                                       // (an opaque OFFSET: see conv_first_kernel)
+    const float* const b_hi = b_lo + hi_words;                               // positions 8..15 (their offsets would not fit a DS immediate)
+    __syncthreads();
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) G_LOAD_HALO(nxt);
+        v4f acc[16][2];
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[ps][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        // per quad: the 4x4 patch (sixteen words, one quad ahead), then per transform line i: the row combination of the patch rows, the
+        // four column operands, and eight MFMAs (4 positions x 2 channel halves) whose weights were read one line ahead
+        float R[2][16], B[2][8];
+#define G_READ_R(set_, q_)                                                                          \
+        { const float* rb_ = a_lane + qoff[q_];                                                     \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) _Pragma("unroll") for (int d = 0; d < 4; ++d) R[set_][4 * r + d] = rb_[r * G_HC + d]; }
+#define G_READ_B(set_, q_, i_)                                                                      \
+        { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
+              B[set_][2 * j + nt] = ((i_) < 2 ? b_lo : b_hi)[(((4 * ((i_) & 1) + j) * NQ + (q_)) * 2 + nt) * 64]; }
+#define G_FENCE() __builtin_amdgcn_sched_barrier(0)
+        G_READ_R(0, 0);
+        G_READ_B(0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) { G_READ_R((q + 1) & 1, q + 1); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // B^T d along the rows: l0 = r0 - r2, l1 = r1 + r2, l2 = r2 - r1, l3 = r1 - r3; then the same along the columns
+                float L[4], V[4];
+                const float* Rq = R[q & 1];
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    L[d] = i == 0 ? Rq[d] - Rq[8 + d] : i == 1 ? Rq[4 + d] + Rq[8 + d] : i == 2 ? Rq[8 + d] - Rq[4 + d] : Rq[4 + d] - Rq[12 + d];
+                V[0] = L[0] - L[2]; V[1] = L[1] + L[2]; V[2] = L[2] - L[1]; V[3] = L[1] - L[3];
+                const int nset = (4 * q + i + 1) & 1;
+                if (i < 3) { G_READ_B(nset, q, i + 1); } else if (q + 1 < NQ) { G_READ_B(nset, q + 1, 0); }
+                G_FENCE();
+                const float* Bq = B[(4 * q + i) & 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[4 * i + j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[j], Bq[2 * j + nt], acc[4 * i + j][nt], 0, 0, 0);
+                G_FENCE();
+            }
+        }
+#undef G_READ_R
+#undef G_READ_B
+#undef G_FENCE
+        __syncthreads();                    // every wave is done with the halo
+        if (nxt < ntiles) G_STORE_HALO();
+
+        // ---- output transform (A^T M A, in registers) + epilogue.  Register r of an accumulator = tile column 4 g + r, lane & 15 =
+        // output channel inside the half nt
+        const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const int oy0 = ty * G_TH + 2 * wave, ox0 = tx * G_TW;
+        float y[2][4][2][2];               // [nt][r][row a][column b]
+        float sm[2] = {0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ch = nt * 16 + txl;
+            const float bv = p.bias[ch];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float Q[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = acc[4 * i][nt][r], m1 = acc[4 * i + 1][nt][r], m2 = acc[4 * i + 2][nt][r], m3 = acc[4 * i + 3][nt][r];
+                    Q[i][0] = (m0 + m1) + m2; Q[i][1] = (m1 - m2) - m3;
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    y[nt][r][0][b] = (Q[0][b] + Q[1][b]) + Q[2][b] + bv;
+                    y[nt][r][1][b] = (Q[1][b] - Q[2][b]) - Q[3][b] + bv;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
+                        if (oy < p.OH && ox < p.OW) {
+                            if (ch < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + ch] = y[nt][r][a][b];
+                            sm[nt] += y[nt][r][a][b];
+                        }
+                    }
+            }
+        }
+        if (p.partials != nullptr) {
+            float2* st = reinterpret_cast<float2*>(red);          // [8 waves][32]
+            int* wn = reinterpret_cast<int*>(red + 8 * 64);         // [8]
+            const int nrows = max(0, min(2, p.OH - oy0)), ncols = max(0, min(G_TW, p.OW - ox0));
+            const int nw = nrows * ncols;                           // valid pixels of this wave's two rows
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float s = sm[nt];
+                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                const float mu = nw ? s / (float)nw : 0.f;
+                float qv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
+                            const float d = y[nt][r][a][b] - mu;
+                            if (oy < p.OH && ox < p.OW) qv = fmaf(d, d, qv);
+                        }
+                qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
+                if (lane < 16) st[wave * 32 + nt * 16 + lane] = make_float2(mu, qv);
+            }
+            if (lane == 0) wn[wave] = nw;
+            __syncthreads();
+            if (t < 32) {
+                int n;
+                p.partials[(size_t)tile * 32 + t] = merge_rows(st, wn, t, &n);
+                if (t == 0) p.counts[tile] = n;
+            }
+        }
+        __syncthreads();            // the halo of the next tile is complete; red scratch free again
+    }
+#undef G_LOAD_HALO
+#undef G_STORE_HALO
+}
+
+template <int CR>
+int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
+{
+    const size_t lds = (size_t)(16 * conv_first2d_quads(CR) * 128 + CR * G_CPL + 8 * 64 + 8) * sizeof(float);
+    const int dv = cur_dev();
+    static int nblocks[MAX_DEVICES] = {};
+    if (!nblocks[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first2d_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipDeviceProp_t prop;
+        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        nblocks[dv] = prop.multiProcessorCount;
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int grid = std::max(1, nblocks[dv] - reserve_cus);
+    hipLaunchKernelGGL((conv_first2d_kernel<CR>), dim3(tiles < grid ? tiles : grid), dim3(512), lds, st, a);
+    FAV_LAUNCH_CHECK("conv_first2d_kernel");
+    return FAV_OK;
+}
+
 }  // namespace
 
 int conv_first_tiles(int OH, int OW) { return ((OH + F_TH - 1) / F_TH) * ((OW + F_TW - 1) / F_TW); }
@@ -265,6 +489,21 @@ int launch_conv_first(const ConvLaunch& c, int cin_real, const float* wpk, int* 
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW;
     a.tiles_x = (c.OW + F_TW - 1) / F_TW; a.tiles_y = (c.OH + F_TH - 1) / F_TH;
     return cin_real == 7 ? launch_first_t<7>(a, c.reserve_cus, st) : launch_first_t<3>(a, c.reserve_cus, st);
+}
+
+int conv_first2d_tiles(int OH, int OW) { return ((OH + G_TH - 1) / G_TH) * ((OW + G_TW - 1) / G_TW); }
+
+// same eligibility as launch_conv_first; wpk = conv_first2d_pack() (first2d_pack.h)
+int launch_conv_first2d(const ConvLaunch& c, int cin_real, const float* wpk, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(c.CIN == 8 && (cin_real == 7 || cin_real == 3) && c.COUTp == 32 && c.KH == 9 && c.KW == 9 && c.stride == 1 && c.pre.stages == 0 &&
+                c.ups == 0 && !c.final_mode && wpk, "first-layer conv (F(2x2,3x3) over the nine 3x3 blocks): not eligible");
+    FAV_REQUIRE((long long)c.IH * c.IWp * 8 < (1ll << 31), "first-layer conv: bad shape");
+    FirstArgs a;
+    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW;
+    a.tiles_x = (c.OW + G_TW - 1) / G_TW; a.tiles_y = (c.OH + G_TH - 1) / G_TH;
+    return cin_real == 7 ? launch_first2d_t<7>(a, c.reserve_cus, st) : launch_first2d_t<3>(a, c.reserve_cus, st);
 }
 
 }  // namespace fav

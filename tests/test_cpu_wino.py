@@ -261,6 +261,98 @@ def test_first_layer_pairing_and_transform_match_direct_convolution(first_packer
     assert err < 2e-3 * max(1.0, np.abs(ref).max() / 100), err
 
 
+# ---------------------------------------------------------------------------------------------- first layer: F(2x2,3x3) over the nine 3x3 blocks
+@pytest.fixture(scope="module")
+def first2d_packer(tmp_path_factory):
+    d = tmp_path_factory.mktemp("first2d")
+    src = d / "pack.cpp"
+    src.write_text('#include "first2d_pack.h"\n#include <cstring>\n'
+                   'extern "C" long pack(const float* w, int cin, int cout, float* out) {\n'
+                   '  std::vector<float> v; fav::conv_first2d_pack(w, cin, cout, v); if (out) memcpy(out, v.data(), v.size() * 4); return (long)v.size(); }\n'
+                   'extern "C" void combo(int cr, int q, int g, int* c) { fav::conv_first2d_combo(cr, q, g, c, c + 1, c + 2); }\n'
+                   'extern "C" int quads(int cr) { return fav::conv_first2d_quads(cr); }\n')
+    so = d / "libfirst2d.so"
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", CSRC, "-o", str(so), str(src)])
+    lib = ctypes.CDLL(str(so))
+    lib.pack.restype = ctypes.c_long
+    lib.pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("cin", [7, 3])
+def test_first_layer_2d_lane_level_restatement_matches_direct_convolution(first2d_packer, cin):
+    """csrc/first2d_pack.h + conv_first2d_kernel: every (channel, a, b) sits in exactly one (quad, lane group); one wave = 16 tiles of
+    2x2 outputs, lane = (tile column, lane group), v_mfma_f32_16x16x4_f32 operand / result layout (A[i = l % 16][k = l / 16],
+    B[k = l / 16][j = l % 16], D register r of lane l = D[4 (l / 16) + r][l % 16]), patch addresses in the plain-row halo planes, the
+    output transform inside the lane -- against the 9x9 correlation."""
+    lib = first2d_packer
+    NQ = lib.quads(cin)
+    assert NQ == (9 * cin + 3) // 4
+    seen = set()
+    combos = np.zeros((NQ, 4, 3), np.int32)
+    for q in range(NQ):
+        for g in range(4):
+            c = (ctypes.c_int * 3)()
+            lib.combo(cin, q, g, c)
+            combos[q, g] = list(c)
+            if c[0] >= 0:
+                assert tuple(c) not in seen
+                seen.add(tuple(c))
+    assert len(seen) == 9 * cin
+    rng = np.random.default_rng(40 + cin)
+    cout, HR, HC = 32, 24, 40                              # one block tile: 16 x 32 outputs from a 24 x 40 halo
+    CPL = HR * HC + 16
+    w = (rng.standard_normal((cout, cin, 9, 9)) / 20).astype(np.float32)
+    halo = rng.uniform(-120, 150, (cin, HR, HC)).astype(np.float32)
+    n = lib.pack(w.ctypes.data, cin, cout, None)
+    wpk = np.empty(n, np.float32)
+    lib.pack(w.ctypes.data, cin, cout, wpk.ctypes.data)
+    assert n == 16 * NQ * 128
+    Hs = np.full(cin * CPL, np.nan, np.float32)
+    for c in range(cin):
+        Hs[c * CPL: c * CPL + HR * HC] = halo[c].ravel()
+    ref = np.zeros((16, 32, cout))
+    for ky in range(9):
+        for kx in range(9):
+            ref += np.einsum("chw,oc->hwo", halo[:, ky:ky + 16, kx:kx + 32].astype(np.float64), w[:, :, ky, kx].astype(np.float64))
+    lanes = np.arange(64)
+    txl, g = lanes & 15, lanes >> 4
+    out = np.zeros((16, 32, cout), np.float32)
+    for wave in range(8):
+        acc = np.zeros((16, 2, 64, 4), np.float32)            # [position][nt][lane][register]
+        a_lane = 2 * wave * HC + 2 * txl
+        for q in range(NQ):
+            idx = 4 * q + g
+            c = idx // 9; a = (idx - 9 * c) // 3; b = idx - 9 * c - 3 * a
+            qoff = np.where(idx < 9 * cin, c * CPL + 3 * a * HC + 3 * b, 0)
+            assert all((combos[q, gg] == [c[gg * 16], a[gg * 16], b[gg * 16]]).all() for gg in range(4) if idx[gg * 16] < 9 * cin)
+            R = np.stack([[Hs[a_lane + qoff + r * HC + d] for d in range(4)] for r in range(4)])      # [r][d][lane]
+            assert not np.isnan(R).any()
+            for i in range(4):
+                L = (R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3])[i]                             # [d][lane]
+                V = (L[0] - L[2], L[1] + L[2], L[2] - L[1], L[1] - L[3])
+                for j in range(4):
+                    for nt in range(2):
+                        Bv = wpk[((((4 * i + j) * NQ + q) * 2 + nt) * 64) + lanes]
+                        A2 = V[j].reshape(4, 16)                # [k][i = tile]
+                        B2 = Bv.reshape(4, 16)                  # [k][j = channel]
+                        D = (A2.T.astype(np.float64) @ B2.astype(np.float64)).astype(np.float32)       # [tile][channel]
+                        for l in range(64):
+                            for r in range(4):
+                                acc[4 * i + j, nt, l, r] += D[4 * (l >> 4) + r, l & 15]
+        for l in range(64):
+            for nt in range(2):
+                ch = nt * 16 + (l & 15)
+                for r in range(4):
+                    M = acc[:, nt, l, r].reshape(4, 4)
+                    Q = np.stack([(M[:, 0] + M[:, 1]) + M[:, 2], (M[:, 1] - M[:, 2]) - M[:, 3]], axis=1)   # [i][b]
+                    for bcol in range(2):
+                        out[2 * wave + 0, 2 * (4 * (l >> 4) + r) + bcol, ch] = (Q[0, bcol] + Q[1, bcol]) + Q[2, bcol]
+                        out[2 * wave + 1, 2 * (4 * (l >> 4) + r) + bcol, ch] = (Q[1, bcol] - Q[2, bcol]) - Q[3, bcol]
+    err = np.abs(out - ref).max()
+    assert err < 3e-3 * max(1.0, np.abs(ref).max() / 100), err
+
+
 # ---------------------------------------------------------------------------------------------- U2 + c3s1-64: nine-position form
 UW_HW, UW_HP, UW_HPP = 34, 6 * 34, 288
 UW_HB = UW_HPP * LDSS
