@@ -647,7 +647,11 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i's kernels are already queued
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
         tr_mark(3);
-        if (loop_trace && done >= 100 && done < 112)
+        static const bool loop_trace_start = loop_trace && atoi(getenv("FAV_LOOP_TRACE")) == 2;       // 2: the first 48 frames instead (start-up)
+        if (loop_trace_start && done < 48)
+            fprintf(stderr, "loop trace frame %d: at %.3f ms since start: look-ahead %.3f  frame enqueued %.3f  encode enqueued %.3f  previous frame finished %.3f ms\n", i,
+                    std::chrono::duration<double, std::milli>(t0 - t_begin).count(), tr_ms[0], tr_ms[1], tr_ms[2], tr_ms[3]);
+        if (loop_trace && !loop_trace_start && done >= 100 && done < 112)
             fprintf(stderr, "loop trace frame %d: look-ahead %.3f  frame enqueued %.3f  encode enqueued %.3f  previous frame finished %.3f ms\n", i, tr_ms[0], tr_ms[1], tr_ms[2], tr_ms[3]);
         if (!quiet) {
             hipStreamWaitEvent(st_down, ev_out[now.ev], 0);  // ... and leaves on the download queue
