@@ -460,11 +460,11 @@ int launch_conv_t(const ConvArgs& a, hipStream_t st)
         // the runtime reports for this instantiation, capped at the 2 blocks per CU the hand-off buffers are sized for
         static int sk_per_cu[MAX_DEVICES] = {}, sk_cus[MAX_DEVICES] = {};
         if (!sk_per_cu[dv]) {
-            int occ = 0; hipDeviceProp_t prop;
-            FAV_HIP(hipGetDeviceProperties(&prop, dv));
+            int occ = 0; int prop_cus = 0;
+            FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
             FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_mfma_kernel<BN, WM, WN, SK>, 64 * WM * WN, lds));
             if (occ < 1) { set_error("stream-K conv: kernel does not fit on a CU"); return FAV_EHIP; }
-            sk_per_cu[dv] = occ >= 2 ? 2 : 1; sk_cus[dv] = prop.multiProcessorCount;
+            sk_per_cu[dv] = occ >= 2 ? 2 : 1; sk_cus[dv] = prop_cus;
         }
         int sk_blocks = sk_per_cu[dv] * std::max(1, sk_cus[dv] - a.reserve_cus);       // leave the reserved CUs to the side queues
         if (sk_blocks > SK_GRID) sk_blocks = SK_GRID;
@@ -643,9 +643,9 @@ int launch_conv_c8(const ConvLaunch& c, int* counts, hipStream_t st)
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        nblocks[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        nblocks[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int gridc8 = std::max(1, nblocks[dv] - c.reserve_cus);
@@ -838,9 +838,9 @@ static int launch_c8d_t(const C8Args& a, int reserve_cus, hipStream_t st)
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c8d_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        nblocks[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        nblocks[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::max(1, nblocks[dv] - reserve_cus);
@@ -1565,11 +1565,11 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, bool no_sk, h
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int occ = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        int occ = 0; int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
         if (occ < 1) { set_error("halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
-        cus[dv] = prop.multiProcessorCount;          // one block per CU
+        cus[dv] = prop_cus;          // one block per CU
     }
     int nres = std::max(1, cus[dv] - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
@@ -1968,11 +1968,11 @@ static int launch_s2_t(const S2Args& a, int cin, int reserve_cus, bool no_sk, hi
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int occ = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        int occ = 0; int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
         if (occ < 1) { set_error("stride-2 halo conv: kernel does not fit on a CU"); return FAV_EHIP; }
-        cus[dv] = prop.multiProcessorCount;
+        cus[dv] = prop_cus;
     }
     int nres = std::max(1, cus[dv] - reserve_cus);
     if (nres > SK_GRID) nres = SK_GRID;
@@ -2348,9 +2348,9 @@ int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_up2_kernel<CIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        cus[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        cus[dv] = prop_cus;
     }
     const int XO = 2 * FOLD2_M - (a.KW - 1);
     a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
@@ -2388,9 +2388,9 @@ int launch_fold_t(FoldArgs a, int reserve_cus, hipStream_t st)
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_kernel<CIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        cus[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        cus[dv] = prop_cus;
     }
     const int XO = FOLD_M - (a.KW - 1);
     a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;

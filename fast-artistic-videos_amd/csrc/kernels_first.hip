@@ -240,9 +240,9 @@ int launch_first_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        nblocks[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        nblocks[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::max(1, nblocks[dv] - reserve_cus);
@@ -463,9 +463,9 @@ int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first2d_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        nblocks[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        nblocks[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::max(1, nblocks[dv] - reserve_cus);

@@ -317,9 +317,9 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        cus[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        cus[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     // Next to the look-ahead side queues (reserve_cus > 0) a layer of many short tiles is launched one tile per block: a persistent

@@ -474,9 +474,9 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
-        cus[dv] = prop.multiProcessorCount;
+        int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
+        cus[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
     const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));

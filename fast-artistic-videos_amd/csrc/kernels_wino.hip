@@ -454,11 +454,11 @@ int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        int occ = 0; hipDeviceProp_t prop;
-        FAV_HIP(hipGetDeviceProperties(&prop, dv));
+        int occ = 0; int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 512, lds));
         if (occ < 1) { set_error("winograd conv: kernel does not fit on a CU"); return FAV_EHIP; }
-        cus[dv] = prop.multiProcessorCount;          // one block per CU
+        cus[dv] = prop_cus;          // one block per CU
     }
     const int units = a0.units_x * a0.units_y;
     const int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));

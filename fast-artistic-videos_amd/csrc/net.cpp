@@ -189,6 +189,8 @@ struct fav_net {
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
+    // ... carved out of a few large slabs: sixty hipMalloc calls cost the first frame of a run 10 ms (profiles/e2e_r04s_startup.log)
+    std::vector<void*> slabs; char* slab_cur = nullptr; size_t slab_left = 0;
     size_t cursor = 0, conv_cursor = 0, in_cursor = 0;
     hipStream_t st = nullptr;
     float* stage = nullptr; size_t stage_bytes = 0;   // NCHW-boundary staging (fav_net_forward)
@@ -204,7 +206,7 @@ struct fav_net {
         (void)hipFree(stage);
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wfirst2d); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
-        for (auto& b : bufs) (void)hipFree(b.p);
+        for (void* sp : slabs) (void)hipFree(sp);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
     }
     int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
@@ -371,8 +373,14 @@ int fav_net::alloc(size_t bytes, float** out)
         *out = static_cast<float*>(bufs[cursor++].p);
         return FAV_OK;
     }
-    DevBuf b; b.bytes = bytes;
-    FAV_HIP(hipMalloc(&b.p, bytes));
+    if (slab_left < bytes) {
+        const size_t sz = std::max(bytes, (size_t)256 << 20);
+        void* sp = nullptr;
+        FAV_HIP(hipMalloc(&sp, sz));
+        slabs.push_back(sp); slab_cur = static_cast<char*>(sp); slab_left = sz;
+    }
+    DevBuf b; b.bytes = bytes; b.p = slab_cur;
+    slab_cur += bytes; slab_left -= bytes;
     bufs.push_back(b); ++cursor;
     *out = static_cast<float*>(b.p);
     return FAV_OK;
@@ -671,7 +679,8 @@ int fav_net::forward_padded_unordered(const float* in8, int H, int W, float* out
     if (H != curH || W != curW) {
         if (!bufs.empty()) {
             FAV_HIP(hipDeviceSynchronize());
-            for (auto& b : bufs) (void)hipFree(b.p);
+            for (void* sp : slabs) (void)hipFree(sp);
+            slabs.clear(); slab_cur = nullptr; slab_left = 0;
             bufs.clear();
         }
         curH = H; curW = W;

@@ -539,7 +539,6 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     bool drained = false;
     next_to_issue = start + inc;
     for (int i = start; idx_ok(i) && cur.ok; i += inc) {                                                      // core:196-197
-        const bool first_iteration_of_run = first;
         if (first) {
             const int rW = -W, rH = -H;          // size of the reloaded PNG (-continue_with), if any
             W = cur.W; H = cur.H;
@@ -603,8 +602,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
             ahead.push_back(nxt);
         }
         };
-        if (first_iteration_of_run) top_up();            // (frame `start` is a single image: its successors' uploads start at once)
-        tr_mark(0);
+        tr_mark(0);      // (the look-ahead is topped up BEHIND the frame's enqueue, also for the first frame: its enqueue is 15 ms of one-time
+                         //  work -- activation arena, code objects -- that now runs while the loaders read and pin frames 2, 3, ...)
         if (quiet && wait_event_sleeping(ev_up[dset], 50) != hipSuccess) die("GPU error while uploading a frame");      // requested a frame ago: already there
         uint8_t* const d_out8 = gpu_png ? nullptr : d_out8s[done & 1];
         const bool teval = !o.s("temporal_eval_file").empty();
