@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wino_kernel(const WinoArgs p)
                            v_.z = fmaxf(fmaf(v_.z, sc.z, sh.z), lo1); v_.w = fmaxf(fmaf(v_.w, sc.w, sh.w), lo1); } }
         // MODE 2: skip rows straight into LDS (one instruction = one row of all 64 lanes, 1 KiB at the wave's place in the landing area)
 #define WG_LOAD_SKIP(slice_, ho_, lbase_, lrow_)                                                    \
-        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 4; ++a)                                 \
+        { if (JOIN) { asm volatile("" ::: "memory");      /* (never above the reads of the rows these loads replace) */ \
+              _Pragma("unroll") for (int a = 0; a < 4; ++a)                                         \
               __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)((lbase_) + a * (lrow_)), 16, ho_[a], (slice_) * 128, 0, 0); } }
         // MODE 2: z = fma(y, scale, shift) + skip (res_add_kernel's order), written where the mask says so (elsewhere the offset is out of
         // the buffer's range and the hardware drops the store), then transformed like any other input
