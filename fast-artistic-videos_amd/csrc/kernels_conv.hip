@@ -2300,6 +2300,20 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
         float* D = As;
         const size_t MO = (size_t)p.OH * p.OW;
         const int per_row = XO * p.COUT;
+        // an output (row group g, channel c, column xo) of a pass is the same for all four passes: its index arithmetic (two divisions
+        // by run-time values), bias and mean are formed once per tile instead of once per output
+        constexpr int NE = 3;                      // 4 * per_row = 1440 outputs per pass on 512 threads (COUT = 3, XO = 120)
+        int eg[NE], ec[NE], exo[NE]; float ebias[NE], emean[NE]; const float* ed[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = t + NT * k;
+            const bool ok = e < 4 * per_row;
+            const int g = ok ? e / per_row : 0, rem = ok ? e - g * per_row : 0;
+            const int c = rem / XO, xo = rem - c * XO;
+            eg[k] = ok && ox0 + xo < p.OW ? g : -1; ec[k] = c; exo[k] = xo;
+            ebias[k] = p.bias[c]; emean[k] = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+            ed[k] = D + g * FOLD2_M * 33 + c * p.KW;
+        }
 #pragma unroll
         for (int hh = 0; hh < RW; ++hh) {
 #pragma unroll
@@ -2308,6 +2322,19 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
                 D[(wrow * FOLD2_M + xr) * 33 + col] = acc[hh][r];
             }
             __syncthreads();
+            if (4 * per_row <= NE * NT) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const int oy = oy0 + eg[k] + 4 * hh;
+                    if (eg[k] < 0 || oy >= p.OH) continue;
+                    float v = ebias[k];
+                    for (int kx = 0; kx < p.KW; ++kx) v += ed[k][((exo[k] + kx) >> 1) * 33 + kx];
+                    v = tanhf(v) * p.tanh_mul;                                          // models_video.lua:135-136
+                    const size_t o = (size_t)oy * p.OW + ox0 + exo[k];
+                    if (p.out_raw) p.out_raw[(size_t)ec[k] * MO + o] = v;
+                    if (p.out_planar) p.out_planar[(size_t)(2 - ec[k]) * MO + o] = (v + emean[k]) / 255.f;      // preprocess.lua:66-71
+                }
+            } else {
             for (int e = t; e < 4 * per_row; e += NT) {
                 const int g = e / per_row, rem = e - g * per_row;
                 const int c = rem / XO, xo = rem - c * XO;
@@ -2323,6 +2350,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
                     const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
                     p.out_planar[(size_t)(2 - c) * MO + o] = (v + mean) / 255.f;          // preprocess.lua:66-71
                 }
+            }
             }
             __syncthreads();
         }

@@ -213,13 +213,17 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
                                                          const float2* bw_flo, const float* cert, int border, int H,
                                                          int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
 {
+    // image.load: byte / 255 -- a correctly rounded division (a dozen instructions); the 256 possible quotients are formed once per block
+    __shared__ float byte01[256];
+    byte01[threadIdx.x] = (float)threadIdx.x / 255.f;
+    __syncthreads();
     const int Wp = W + 2 * pad;
     const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
     if (xp >= Wp) return;
     const int y = reflect(yp - pad, H), x = reflect(xp - pad, W);
     const size_t i = (size_t)y * W + x;
     const uint8_t* px = frame_hwc + i * 3;
-    const float rgb[3] = {(float)px[0] / 255.f, (float)px[1] / 255.f, (float)px[2] / 255.f};   // image.load: byte/255
+    const float rgb[3] = {byte01[px[0]], byte01[px[1]], byte01[px[2]]};
     float4 lo, hi;
     lo.x = rgb[2] * 255.f - 103.939f;
     lo.y = rgb[1] * 255.f - 116.779f;
