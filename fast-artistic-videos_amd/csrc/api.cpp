@@ -123,6 +123,8 @@ extern "C" int fav_min_filter_f32(const float* cert, float* out, int H, int W, i
 extern "C" size_t fav_png_capacity(int W, int H) { return (W > 0 && H > 0) ? png_capacity(W, H) : 0; }
 extern "C" size_t fav_png_workspace_bytes(int W, int H) { return (W > 0 && H > 0) ? png_workspace_bytes(W, H) : 0; }
 
+extern "C" uint32_t fav_png_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint32_t len_b) { return png_crc32_combine_host(crc_a, crc_b, len_b); }
+
 extern "C" int fav_png_encode_rgb8(const uint8_t* rgb_hwc, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
                                    void* workspace, size_t workspace_bytes, fav_hipstream_t stream)
 {

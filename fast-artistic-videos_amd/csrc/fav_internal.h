@@ -234,6 +234,7 @@ struct PngTable {
 const std::vector<PngTable>& png_tables();
 size_t png_capacity(int W, int H);
 size_t png_workspace_bytes(int W, int H);
+uint32_t png_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint32_t len_b);
 int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,
                       void* workspace, size_t ws_bytes, hipStream_t st);
 int launch_check_cert(const float* backward_flo, const float* forward_flo, const float* structure, const float* avg, uint8_t* mask_out,

@@ -54,16 +54,20 @@ __device__ __host__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b)
     return p;
 }
 
-// x^(8 n) mod P for n < 2^24 from three 256-entry tables indexed by the bytes of n (host-computed once per device, 3 KB):
-// x^(8 n) = T0[n & 255] * T1[(n >> 8) & 255] * T2[(n >> 16) & 255]
-struct CrcTables { const uint32_t* t; };        // t[0..255] = T0, t[256..511] = T1, t[512..767] = T2
-__device__ inline uint32_t crc_xpow8(const CrcTables& tb, unsigned n)
+// x^(8 n) mod P for any 32-bit n from four 256-entry tables indexed by the bytes of n (host-computed once per device, 4 KB):
+// x^(8 n) = T0[n & 255] * T1[(n >> 8) & 255] * T2[(n >> 16) & 255] * T3[n >> 24]
+// (three tables stopped at n < 2^24 bytes: a 3840x2160 frame's IDAT is 25 MB -- its CRC was wrong; the capacity guard in
+//  launch_png_encode keeps n below 2^32)
+struct CrcTables { const uint32_t* t; };        // t[256 k .. 256 k + 255] = Tk
+__host__ __device__ inline uint32_t crc_xpow8_tab(const uint32_t* t, unsigned n)
 {
-    uint32_t p = tb.t[n & 255u];
-    if (n >> 8) p = crc_mulmod(p, tb.t[256 + ((n >> 8) & 255u)]);
-    if (n >> 16) p = crc_mulmod(p, tb.t[512 + ((n >> 16) & 255u)]);
+    uint32_t p = t[n & 255u];
+    if (n >> 8) p = crc_mulmod(p, t[256 + ((n >> 8) & 255u)]);
+    if (n >> 16) p = crc_mulmod(p, t[512 + ((n >> 16) & 255u)]);
+    if (n >> 24) p = crc_mulmod(p, t[768 + (n >> 24)]);
     return p;
 }
+__device__ inline uint32_t crc_xpow8(const CrcTables& tb, unsigned n) { return crc_xpow8_tab(tb.t, n); }
 
 // standard CRC-32 (init ~0, final ~) of a short byte string in LDS / registers, bitwise
 __device__ inline uint32_t crc_bytes(const uint8_t* s, int n)
@@ -129,12 +133,27 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         }
         raw = r8;
     } else {
+        // whole dwords around the row, aligned on the ADDRESS (a caller's buffer need not be dword-aligned); the dword that holds the
+        // image's last byte is assembled from bytes so that nothing past the caller's H*W*3 bytes is ever read
         const size_t base = (size_t)row * nraw;
-        const size_t a0 = base & ~(size_t)3;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb_hwc + a0);
-        const int nw = (int)((base + nraw - a0 + 3) / 4);
-        for (int i = tid; i < nw; i += NT) raww[i] = src[i];       // (the frame buffer is readable to the next dword boundary: hipMalloc granularity)
-        raw = reinterpret_cast<const uint8_t*>(raww) + (base - a0);
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(rgb_hwc) + base;
+        const unsigned lead = (size_t)(addr & 3u) <= base ? (unsigned)(addr & 3u) : 0u;
+        const uint8_t* a0 = rgb_hwc + base - lead;                  // (lead bytes of the previous row; 0 in row 0 even if the buffer is unaligned)
+        const int nw = (int)((lead + nraw + 3) / 4);
+        const bool ragged = row == H - 1 && ((lead + nraw) & 3);
+        if (((reinterpret_cast<uintptr_t>(a0)) & 3u) == 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a0);
+            for (int i = tid; i < nw - (ragged ? 1 : 0); i += NT) raww[i] = src[i];
+            if (ragged && tid == 0) {
+                uint32_t w = 0;
+                for (int b = 0; b < (int)((lead + nraw) & 3); ++b) w |= (uint32_t)a0[4 * (nw - 1) + b] << (8 * b);
+                raww[nw - 1] = w;
+            }
+        } else {                                                    // row 0 of an unaligned buffer: bytes
+            uint8_t* r8 = reinterpret_cast<uint8_t*>(raww);
+            for (int i = tid; i < (int)lead + nraw; i += NT) r8[i] = a0[i];
+        }
+        raw = reinterpret_cast<const uint8_t*>(raww) + lead;
     }
     for (int i = tid; i < out_words; i += NT) out[i] = 0u;
     for (int i = tid; i < PNG_ROW_WAVES * PNG_HIST; i += NT) (&hist[0][0])[i] = 0u;
@@ -479,22 +498,29 @@ const PngTable* png_tables_for_device(int device)
     return d;
 }
 
-// x^(8 n) tables (3 x 256 words), built once per device on the host with the same arithmetic the kernels use
+// x^(8 n) tables (4 x 256 words), built on the host with the same arithmetic the kernels use
+std::vector<uint32_t> crc_pow_tables()
+{
+    std::vector<uint32_t> t(1024);
+    uint32_t x8 = 1u << 31;                                         // x^0
+    for (int k = 0; k < 8; ++k) x8 = crc_mulmod(x8, 1u << 30);      // x^8: one byte
+    uint32_t step = x8;
+    for (int tbl = 0; tbl < 4; ++tbl) {
+        uint32_t p = 1u << 31;
+        for (int i = 0; i < 256; ++i) { t[tbl * 256 + i] = p; p = crc_mulmod(p, step); }
+        step = p;                                                   // step^256: the next table's unit
+    }
+    return t;
+}
+
+// ... uploaded once per device
 const uint32_t* crc_tables_for_device(int device)
 {
     static std::mutex mu;
     static std::vector<std::pair<int, uint32_t*>> cache;
     std::lock_guard<std::mutex> lock(mu);
     for (auto& kv : cache) if (kv.first == device) return kv.second;
-    std::vector<uint32_t> t(768);
-    uint32_t x8 = 1u << 31;                                         // x^0
-    for (int k = 0; k < 8; ++k) x8 = crc_mulmod(x8, 1u << 30);      // x^8: one byte
-    uint32_t step = x8;
-    for (int tbl = 0; tbl < 3; ++tbl) {
-        uint32_t p = 1u << 31;
-        for (int i = 0; i < 256; ++i) { t[tbl * 256 + i] = p; p = crc_mulmod(p, step); }
-        step = p;                                                   // step^256: the next table's unit
-    }
+    const std::vector<uint32_t> t = crc_pow_tables();
     uint32_t* d = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d), t.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
@@ -503,6 +529,14 @@ const uint32_t* crc_tables_for_device(int device)
 }
 }  // namespace
 
+// crc32(A || B) from crc32(A), crc32(B), |B| with the tables and the arithmetic the kernels use (host-only: the CPU suite pins the
+// combine against zlib beyond 2^24 bytes, where three tables used to end)
+uint32_t png_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint32_t len_b)
+{
+    static const std::vector<uint32_t> t = crc_pow_tables();
+    return crc_mulmod(crc_xpow8_tab(t.data(), len_b), crc_a) ^ crc_b;
+}
+
 int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes,
                       void* workspace, size_t ws_bytes, hipStream_t st)
 {
@@ -510,7 +544,7 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     FAV_REQUIRE(W >= 1 && H >= 1 && W <= 9000 && H <= 65535, "png: %dx%d is outside the encoder's range (width <= 9000, height <= 65535)", W, H);
     FAV_REQUIRE(png_out && png_bytes && workspace, "png: null argument");
     FAV_REQUIRE(capacity >= png_capacity(W, H), "png: output capacity %zu < fav_png_capacity = %zu", capacity, png_capacity(W, H));
-    FAV_REQUIRE(capacity < ((size_t)1 << 24) * 250, "png: image too large for the encoder's CRC tables");
+    FAV_REQUIRE(png_capacity(W, H) < ((size_t)1 << 32) - 64, "png: %dx%d needs a file of more than 4 GiB (IDAT length and the CRC combine are 32-bit)", W, H);
     FAV_REQUIRE(ws_bytes >= png_workspace_bytes(W, H), "png: workspace %zu < fav_png_workspace_bytes = %zu", ws_bytes, png_workspace_bytes(W, H));
     FAV_REQUIRE((reinterpret_cast<uintptr_t>(png_out) & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "png: output must be 4-byte, workspace 16-byte aligned");
     int device = 0; FAV_HIP(hipGetDevice(&device));
@@ -529,13 +563,20 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
     const int nraw = 3 * W, n = nraw + 1;
     const size_t lds1 = ((size_t)((nraw + 6) / 4 + 1) + (size_t)((n + 3) / 4 + 1) + (size_t)((n + 1) / 2 + 1) + (size_t)((n + 63) / 64 + 1) + (size_t)stride / 4) * 4;
     const size_t lds2 = (size_t)stride + 8;
-    static thread_local bool attr_set = false;
-    if (!attr_set && (lds1 > 48 * 1024 || lds2 > 48 * 1024)) {
-        // (rows wider than ~2600 pixels: raise the dynamic LDS limit once; 160 KB per CU on gfx950)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(png_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
-        attr_set = true;
+    if (lds1 > 48 * 1024 || lds2 > 48 * 1024) {
+        // (rows wider than ~2600 pixels: raise the dynamic LDS limit, once per DEVICE -- the attribute is the device's, not the
+        //  calling thread's; 160 KB per CU on gfx950)
+        static std::mutex mu;
+        static std::vector<int> done;
+        std::lock_guard<std::mutex> lock(mu);
+        bool have = false;
+        for (int d : done) have |= d == device;
+        if (!have) {
+            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
+            done.push_back(device);
+        }
     }
     if (rgb_planar)
         hipLaunchKernelGGL(png_rows_kernel<true>, dim3(H), dim3(64 * PNG_ROW_WAVES), lds1, st, nullptr, rgb_planar, W, H, stage, stride, sizes, adler, tabs);

@@ -103,17 +103,22 @@ int pow2_ceil(int c) { int p = 4; while (p < c) p <<= 1; return p; }
 // channel has zero weights and zero bias (identically 0), its InstanceNorm / BatchNorm gets scale 0 and shift 0 (stays 0 through ReLU,
 // residual joins and upsampling), and the next convolution has zero weights for it -- every real channel sees exactly the sums it saw
 // before (x + 0 * 0 = x).  `chan`: channels of the tensor flowing in (already padded).  The 3-channel last layer keeps its size.
-int pad_channel_counts(std::vector<Layer>& ls, int& chan, bool top)
+// `real`: the channel count the checkpoint itself gives that tensor (what a following InstanceNorm / BatchNorm / conv must match:
+// a malformed file -- IN(64) behind a real 128-channel conv -- is rejected, not run with its upper channels forced to zero);
+// `seen_conv`: false until the network's first convolution, whose 7 (3) inputs ride in an 8-channel pixel.
+int pad_channel_counts(std::vector<Layer>& ls, int& chan, int& real, bool& seen_conv, bool top)
 {
     for (size_t li = 0; li < ls.size(); ++li) {
         Layer& L = ls[li];
         if (L.type == L_CONV) {
-            const bool first_input = chan == 8 && L.cin <= 8;            // the 7 (3) network inputs ride in an 8-channel pixel
+            const bool first_input = !seen_conv && L.cin <= 8;           // the 7 (3) network inputs ride in an 8-channel pixel
+            seen_conv = true;
             const int cin_new = first_input ? L.cin : chan;
             bool has_tanh = false; float mul = 1.f;
             const bool is_final = top && L.cout == 3 && only_tail(ls, li + 1, has_tanh, mul) && has_tanh;
             const int cout_new = is_final ? L.cout : pow2_ceil(L.cout);
-            if (!first_input && L.cin > chan) { set_error("network: conv expects %d input channels, producer has fewer", L.cin); return FAV_EFORMAT; }
+            if (!first_input && L.cin != real) { set_error("network: conv expects %d input channels, its producer has %d", L.cin, real); return FAV_EFORMAT; }
+            const int cout_real = L.cout;
             if (cin_new != L.cin || cout_new != L.cout) {
                 std::vector<float> w((size_t)cout_new * cin_new * L.k * L.k, 0.f);
                 const size_t kk = (size_t)L.k * L.k;
@@ -127,17 +132,17 @@ int pad_channel_counts(std::vector<Layer>& ls, int& chan, bool top)
                 if (!L.b.empty()) L.b.resize((size_t)cout_new, 0.f);
                 L.cin = cin_new; L.cout = cout_new;
             }
-            chan = L.cout;
+            chan = L.cout; real = cout_real;
         } else if (L.type == L_IN) {
-            if ((int)L.gamma.size() > chan) { set_error("network: InstanceNormalization(%zu) after %d channels", L.gamma.size(), chan); return FAV_EFORMAT; }
+            if ((int)L.gamma.size() != real) { set_error("network: InstanceNormalization(%zu) after %d channels", L.gamma.size(), real); return FAV_EFORMAT; }
             L.gamma.resize((size_t)chan, 0.f); L.beta.resize((size_t)chan, 0.f);
         } else if (L.type == L_BN) {
-            if ((int)L.mean.size() > chan) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan); return FAV_EFORMAT; }
+            if ((int)L.mean.size() != real) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), real); return FAV_EFORMAT; }
             L.gamma.resize((size_t)chan, 0.f); L.beta.resize((size_t)chan, 0.f); L.mean.resize((size_t)chan, 0.f); L.var.resize((size_t)chan, 1.f);
         } else if (L.type == L_RES) {
-            int c = chan;
-            int rc = pad_channel_counts(L.block, c, false); if (rc) return rc;
-            if (c != chan) { set_error("network: residual branch changes the channel count"); return FAV_EUNSUPPORTED; }
+            int c = chan, r = real;
+            int rc = pad_channel_counts(L.block, c, r, seen_conv, false); if (rc) return rc;
+            if (c != chan || r != real) { set_error("network: residual branch changes the channel count"); return FAV_EUNSUPPORTED; }
         }
     }
     return FAV_OK;
@@ -349,7 +354,8 @@ int fav_net::upload()
         return FAV_EUNSUPPORTED; }
     exec = layers;
     int chan0 = 8;
-    int rc = pad_channel_counts(exec, chan0, true); if (rc) return rc;
+    int real0 = in_channels; bool seen_conv = false;
+    int rc = pad_channel_counts(exec, chan0, real0, seen_conv, true); if (rc) return rc;
     int chan = 8, maxc = 8;
     rc = upload_layers(exec, chan, maxc); if (rc) return rc;
     params = count_params(layers);
@@ -656,13 +662,30 @@ DeviceOrder& device_order(int device)
 }
 }  // namespace
 
+// the owner of `stream` is about to destroy it: drain it while the handle is still valid and forget it, so that the next forward
+// never synchronises a dead (or recycled) handle
+static void forget_stream(int device, hipStream_t stream)
+{
+    DeviceOrder& ord = device_order(device);
+    std::lock_guard<std::mutex> order_lock(ord.mu);
+    if (ord.valid && ord.last == stream) { (void)hipStreamSynchronize(stream); ord.valid = false; ord.last = nullptr; }
+}
+
+extern "C" int fav_net_forget_stream(fav_net* net, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(net, "fav_net_forget_stream: null network");
+    FAV_HIP(hipSetDevice(net->device));
+    forget_stream(net->device, static_cast<hipStream_t>(stream));
+    return FAV_OK;
+}
+
 int fav_net::forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream)
 {
     FAV_HIP(hipSetDevice(device));
     DeviceOrder& ord = device_order(device);
     std::lock_guard<std::mutex> order_lock(ord.mu);       // (handles are not thread-safe; this only keeps the bookkeeping consistent)
     if (ord.valid && ord.last != stream && hipStreamSynchronize(ord.last) != hipSuccess)
-        (void)hipGetLastError();       // the previous stream no longer exists (its owner synchronised and destroyed it): nothing to wait for
+        (void)hipGetLastError();       // (a handle destroyed without fav_net_forget_stream / fav_stream_destroy first: fav.h asks for either)
     ord.valid = true; ord.last = stream;
     return forward_padded_unordered(in8, H, W, out_planar, out_raw, stream);
 }
@@ -912,23 +935,32 @@ struct fav_stream {
     // look-ahead mask (fav_stream_prefetch_mask)
     // two side queues with their own structure workspaces: the masks of frames i+1 and i+2 are computed concurrently
     // (each 4-argument mask contains a ~3 ms sequential fp32 chain, CMatrix::avg), three look-ahead slots
-    static constexpr int NSIDE = 2, NPREF = 3;
+    static constexpr int NSIDE = 2, NPREF = 4;
     hipStream_t side[NSIDE] = {nullptr, nullptr}; void* side_ws[NSIDE] = {nullptr, nullptr}; hipEvent_t ev_in = nullptr;
     float* side_cert_tmp[NSIDE] = {nullptr, nullptr};      // scratch of the certainty preparation (erosion input) on each side queue
     struct Pref { uint8_t* mask = nullptr; float* cert = nullptr; hipEvent_t done = nullptr; bool valid = false;
-                  const void *frame = nullptr, *bw = nullptr, *fw = nullptr; int structure = 0; };
+                  const void *frame = nullptr, *bw = nullptr, *fw = nullptr; int structure = 0;
+                  uint32_t retired = 0; };       // host-ordered: retire sequence of the (mask, cert) buffers now in this slot (0: never read)
     Pref pref[NPREF]; int pref_next = 0, side_next = 0;
     // host-ordered look-ahead (fav_stream_set_host_ordered): no event ever enters the caller's queue or the side queues; a one-thread
     // kernel behind the mask pipeline stores a sequence number into host-mapped memory, which fav_stream_next_frame_flow polls
     bool host_ordered = false;
     uint32_t* done_host = nullptr;      // [NPREF], hipHostMalloc
-    uint32_t pref_seq[NPREF] = {0, 0, 0}; uint32_t seq_counter = 0;
+    uint32_t pref_seq[NPREF] = {0, 0, 0, 0}; uint32_t seq_counter = 0;
+    // ... and nothing orders a side queue behind the caller's queue either, so the buffers a consumed look-ahead swaps OUT of the stream
+    // (read by the previous frames' kernels on the caller's queue) must not be rewritten by a later look-ahead before those kernels are
+    // through: the consuming call first enqueues a one-thread kernel on the caller's queue that stores a retire sequence number into
+    // host-mapped memory (everything enqueued before it has then finished), and a look-ahead into a slot waits ON THE HOST for the
+    // sequence number of the buffers it holds (with NPREF slots and two frames of look-ahead that frame finished long ago: no wait)
+    uint32_t* retired_host = nullptr; uint32_t retire_counter = 0;
+    hipStream_t last_st = nullptr; bool ran = false;       // the HIP stream of the last forward (forgotten by the destructor)
     ~fav_stream()
     {
         if (net) (void)hipSetDevice(net->device);
+        if (net && ran) forget_stream(net->device, last_st);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); } (void)hipFree(side_ws[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
-        if (done_host) (void)hipHostFree(done_host);
+        if (done_host) (void)hipHostFree(done_host);       // (retired_host lives in the same allocation)
         for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); (void)hipFree(pf.cert); }
         for (int i = 0; i < NSIDE; ++i) (void)hipFree(side_cert_tmp[i]);
         (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws); (void)hipFree(png_ws);
@@ -1015,6 +1047,7 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     int rc = launch_prep_input(frame_rgb_hwc, nullptr, 0, 0, nullptr, nullptr, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
                                s->img_net ? 0 : s->opts.fill_random, s->opts.seed, s->frame_counter);
     if (rc) return rc;
+    s->last_st = st; s->ran = true;
     fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
     rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
     return stream_finish(s, out_rgb_f32, out_rgb8_hwc, st);
@@ -1050,6 +1083,7 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
                                s->opts.fill_random, s->opts.seed, s->frame_counter);
         if (rc) return rc;
     }
+    s->last_st = st; s->ran = true;
     { TraceRange tr_net("fav:network"); rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); }
     if (rc) return rc;
     return stream_finish(s, out_f32, out_u8, st);
@@ -1087,6 +1121,9 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
                     usleep(50);
                     if ((spins & 2047) == 2047) { const hipError_t e = hipStreamQuery(s->side[0]); if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "look-ahead queue"); }
                 }
+                // the buffers about to leave the stream were read by kernels already in the caller's queue: mark the point behind them
+                pf.retired = ++s->retire_counter;
+                int rcf = launch_store_flag(s->retired_host, pf.retired, st); if (rcf) return rcf;
             } else FAV_HIP(hipStreamWaitEvent(st, pf.done, 0));
             std::swap(s->mask, pf.mask);
             std::swap(s->cert, pf.cert);          // mask -> certainty (options, erosion) was done on the side queue as well
@@ -1121,7 +1158,15 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     if (!s->host_ordered) {
         FAV_HIP(hipEventRecord(s->ev_in, st));                 // inputs are complete at this point of the caller's stream
         FAV_HIP(hipStreamWaitEvent(sd, s->ev_in, 0));          // (work enqueued on `stream` AFTER this call is not waited for)
-    }                                                          // host-ordered: the caller has SEEN the inputs complete (fav.h)
+    } else if (pf.retired) {                                   // host-ordered: the caller has SEEN the inputs complete (fav.h) ...
+        // ... and the slot's buffers were read by frames on the caller's queue: those must be through before a side queue rewrites them
+        volatile uint32_t* flag = s->retired_host;
+        for (int spins = 0; (int32_t)(*flag - pf.retired) < 0; ++spins) {
+            usleep(50);
+            if ((spins & 2047) == 2047) { const hipError_t e = hipStreamQuery(st); if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "look-ahead: the caller's queue"); }
+        }
+        pf.retired = 0;
+    }
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
@@ -1172,10 +1217,11 @@ extern "C" int fav_stream_set_host_ordered(fav_stream* s, int on)
     FAV_REQUIRE(s, "fav_stream_set_host_ordered: null stream");
     FAV_HIP(hipSetDevice(s->net->device));
     if (on && !s->done_host) {
-        FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->done_host), 64, hipHostMallocDefault));
-        for (int i = 0; i < fav_stream::NPREF; ++i) s->done_host[i] = 0u;
+        FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->done_host), 128, hipHostMallocDefault));
+        for (int i = 0; i < 32; ++i) s->done_host[i] = 0u;
+        s->retired_host = s->done_host + 16;               // its own 64-byte line
     }
-    for (auto& pf : s->pref) pf.valid = false;          // look-aheads in flight in the other mode are dropped (their queues drain on their own)
+    for (auto& pf : s->pref) { pf.valid = false; pf.retired = 0; }     // look-aheads in flight in the other mode are dropped (their queues drain on their own)
     s->host_ordered = on != 0;
     return FAV_OK;
 }

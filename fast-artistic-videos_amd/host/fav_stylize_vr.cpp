@@ -194,6 +194,7 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
     if (img) check(fav_net_check(img), "stylising the video (image model)");
     (void)hipFree(d_frame); (void)hipFree(d_cert); (void)hipFree(d_flow); (void)hipFree(d_equi); (void)hipFree(d_cube);
     (void)hipFree(d_png_e); (void)hipFree(d_png_c); (void)hipFree(d_png_n); (void)hipFree(d_png_ws);
+    (void)fav_net_forget_stream(vid, st);      // the library must not wait on this handle before the next video's first forward
     hipStreamDestroy(st);
     *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
     return frames_done;

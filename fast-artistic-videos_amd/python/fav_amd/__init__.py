@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
     for f in (L.fav_png_capacity, L.fav_png_workspace_bytes):
         f.restype = C.c_size_t; f.argtypes = [C.c_int, C.c_int]
     L.fav_vr_destroy.argtypes = [C.c_void_p]; L.fav_vr_destroy.restype = None
+    L.fav_png_crc32_combine_host.restype = C.c_uint32; L.fav_png_crc32_combine_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     _lib = L
     return L
 
@@ -64,10 +65,10 @@ EXPORTS = [
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size", "fav_stream_set_host_ordered",
-    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_png_tables_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
+    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_png_tables_host", "fav_png_crc32_combine_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
-    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device",
+    "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device", "fav_net_forget_stream",
 ]
 
 

@@ -295,8 +295,14 @@ IMAGE_ARCH = "c9s1-32,d64,d128,R128,R128,R128,R128,R128,u64,u32,c9s1-3"        #
 
 
 def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
-                tanh_constant: float = 150.0, insert_pad: bool = True, use_instance_norm: bool = True) -> TorchObject:
-    """Mirror of models_video.lua:55-140 for padding_type='reflect-start', use_instance_norm=1."""
+                tanh_constant: float = 150.0, insert_pad: bool = True, use_instance_norm: bool = True,
+                recurrent_gain: float = 1.0) -> TorchObject:
+    """Mirror of models_video.lua:55-140 for padding_type='reflect-start', use_instance_norm=1.
+
+    recurrent_gain scales the first convolution's weights on input channels 4-7 (1-based: the warped, masked previous output and the
+    certainty plane, fast_artistic_video_core.lua:166-171).  Random-init weights make frame -> frame an expanding map (any perturbation
+    of the previous output grows ~3x per frame), which no trained model with the temporal-consistency loss does; a gain well below 1
+    gives a CONTRACTIVE synthetic checkpoint on which free-running whole-clip parity is a meaningful gate."""
     rng = np.random.default_rng(seed)
     mods = []
     prev = in_channels
@@ -308,6 +314,8 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
         if c0 == "c":
             f, s, nxt = int(v[1]), int(v[3]), int(v[5:])
             mods.append(_conv(rng, prev, nxt, f, s, (f - 1) // 2))          # :65-80 (zero pad stays)
+            if i == 0 and recurrent_gain != 1.0 and prev == 7:
+                mods[-1].fields["weight"][:, 3:7] *= np.float32(recurrent_gain)
         elif c0 == "d":
             nxt = int(v[1:]); mods.append(_conv(rng, prev, nxt, 3, 2, 1)); down *= 2   # :90-93
         elif c0 == "U":

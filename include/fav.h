@@ -20,8 +20,9 @@
  *     the library's own look-ahead queues) and hand partial tiles between co-resident blocks: two forwards must therefore not
  *     run CONCURRENTLY on one device.  Inside one process the library sees to that itself: when a forward is enqueued on another
  *     HIP stream than the previous forward on that device, the host first waits for that previous stream to drain (the ONE case in
- *     which an entry point synchronises), so several nets / streams are SERIALISED, never wrong.  A stream destroyed while it was
- *     the last one used must have been synchronised by its owner.  Across processes it cannot: one process per GPU (as
+ *     which an entry point synchronises), so several nets / streams are SERIALISED, never wrong.  Before a HIP stream that carried
+ *     forwards is destroyed, call fav_stream_destroy on the fav_streams that ran on it or fav_net_forget_stream (either drains it
+ *     and drops the library's note of the handle).  Across processes it cannot: one process per GPU (as
  *     bench.py and the launcher do), or fav_net_set_shared_device.  Handles are not locked: do not call into the same handle
  *     from two host threads at once.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
@@ -44,7 +45,7 @@ enum fav_status {
     FAV_EINVAL = -1,       /* bad argument (shape, null pointer, ...) */
     FAV_EIO = -2,          /* file could not be opened / read / written */
     FAV_EFORMAT = -3,      /* malformed .t7 / .flo / pnm */
-    FAV_EUNSUPPORTED = -4, /* valid input, but outside the hot-path scope (e.g. SpatialFullConvolution) */
+    FAV_EUNSUPPORTED = -4, /* valid input, but outside what the kernels cover (e.g. asymmetric reflection padding) */
     FAV_EHIP = -5,         /* HIP runtime error */
     FAV_ENODEVICE = -6     /* no HIP device: the product path has no CPU fallback */
 };
@@ -120,6 +121,9 @@ int fav_net_check(fav_net* net);
  * use data-parallel grids only -- one block per tile, nothing handed between blocks, no co-residency assumed -- at some cost in
  * load balance.  fav_net_check switches a network to this mode by itself after a hand-off has timed out. */
 int fav_net_set_shared_device(fav_net* net, int shared);
+/* `stream` (a hipStream_t that forwards of this network's device were enqueued on) is about to be destroyed by its owner: drains it
+ * if it is the one the library would otherwise wait on before the next forward on another stream (concurrency note above). */
+int fav_net_forget_stream(fav_net* net, fav_hipstream_t stream);
 /* human-readable layer list (one line per layer) -- used to cross-check the .t7 reader */
 int fav_net_describe_host(const fav_net* net, char* buf_host, size_t capacity);
 /* host-only (no device needed): parse a .t7 checkpoint and write the same layer list text */
@@ -213,8 +217,11 @@ int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_hwc, const 
  * fav_stream_next_frame_flow waits for the look-ahead on the HOST (a sequence number the mask pipeline's last kernel stores into
  * host-mapped memory; polled with short sleeps, normally already there) instead of making the compute queue wait on an event.
  * Why: on this runtime every event record behind long-running kernels and every dependency between queues keeps a runtime thread
- * spinning until it resolves -- one core per process ("quiet synchronisation").  Default: off (event-ordered, fully
- * asynchronous). */
+ * spinning until it resolves -- one core per process ("quiet synchronisation").  The look-ahead's OUTPUT buffers are the
+ * library's business in both modes: host-ordered, a look-ahead that would rewrite a mask / certainty buffer which frames still in the
+ * caller's queue read waits on the host until those frames are through (a retire sequence number stored by a one-thread kernel in the
+ * caller's queue; with up to two frames of look-ahead that is never a wait), so a caller may run any number of frames ahead.
+ * Default: off (event-ordered, fully asynchronous). */
 int fav_stream_set_host_ordered(fav_stream* s, int on);
 /* read / overwrite the recurrent state ([3][Ho][Wo] float RGB) -- for -continue_with */
 int fav_stream_get_state(fav_stream* s, float* state_rgb_f32, fav_hipstream_t stream);
@@ -299,7 +306,8 @@ void fav_free_host(void* p);
  *   workspace      fav_png_workspace_bytes(W, H) bytes of device memory, 16-byte aligned, owned by the caller, private to the call
  *                  until the stream has passed it.
  * fav_png_encode_rgb8: rgb_hwc = u8 [H][W][3];  fav_png_encode_f32: planar float RGB [3][H][W] (what fav_stream_get_state returns),
- * quantisation fused.  Width <= 9000. */
+ * quantisation fused.  Width <= 9000; any height whose file stays below 4 GiB.  rgb_hwc needs no padding or alignment:
+ * nothing outside its H*W*3 bytes is read. */
 size_t fav_png_capacity(int W, int H);
 size_t fav_png_workspace_bytes(int W, int H);
 int fav_png_encode_rgb8(const uint8_t* rgb_hwc, int W, int H, void* png_out, size_t capacity, uint32_t* png_bytes_out,
@@ -311,6 +319,9 @@ int fav_png_encode_f32(const float* rgb_planar, int W, int H, void* png_out, siz
  * dynamic-block header behind BFINAL / BTYPE, LSB first; uint32 hdr_bits, btype, dist_len, dist_code.  The last table is the
  * fixed code of RFC 1951 3.2.6.  out_host may be NULL to query count and table_bytes. */
 int fav_png_tables_host(void* out_host, size_t capacity, int* count, int* table_bytes);
+/* host-only (no device needed): crc32(A || B) from crc32(A), crc32(B) and |B| in bytes, by the table scheme the encoder's kernels use
+ * to raise a row's CRC to its position in the IDAT chunk (any 32-bit length) -- lets the CPU suite pin it against zlib */
+uint32_t fav_png_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint32_t len_b);
 /* the stream's current stylised frame (the recurrent state) as a PNG file, with the stream's own workspace */
 int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
 

@@ -13,6 +13,17 @@ Modes:
                               byte-identical
 
     python scripts/parity_clip.py --config 3 --frames 60 --out gpurun_out/parity_c3_freerun.json
+
+Whole clip on the contractive checkpoint (`--gain`, t7.build_model's recurrent_gain: frame -> frame then contracts, so free-running
+parity is a gate over ALL frames).  A 1280x720 oracle frame costs ~3 s on the GPU box's 16 CPUs (300 frames = 15 of the round's 90
+GPU-minutes spent waiting for a CPU), so config 3's 300 frames are split across the two machines -- both chains are deterministic
+functions of the seeded clip:
+    GPU box :  python scripts/parity_clip.py --config 3 --frames 300 --gain 0.05 --gpu-dump gpurun_out/c3_contractive_gpu.npz
+               (the GPU's free-running chain: 4096 fixed sample positions x 3 channels of EVERY frame as fp32, the full fp32 frame
+                at four check points, the mask's byte sum of every frame)
+    anywhere:  python scripts/parity_clip.py --config 3 --frames 300 --gain 0.05 --compare gpurun_out/c3_contractive_gpu.npz \
+                      --out profiles/parity_c3_freerun_contractive.json
+               (the oracle's own free-running chain on the same clip, compared at those positions / frames)
 """
 import argparse
 import json
@@ -27,6 +38,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fast-artistic-videos_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+CONTRACTIVE_GAIN = 0.05      # recurrent_gain of the contractive synthetic checkpoint (oracle-vs-perturbed-oracle control: x0.45-0.6 per frame
+                             # down to the fp32 noise floor at 640x360; tests/test_cpu_oracle.py gates the contraction)
 
 
 def psnr8(a, b):
@@ -62,6 +77,7 @@ def run_clip(fav, O, model_path, h, w, n_frames, mode="flow3", seed=1000, pool=8
     st = fav.Stream(net, h, w)
     tmp = tempfile.mkdtemp(prefix="parity_clip_")
     rows = []
+    prior_influence = None
     t_start = time.time()
     ref_free = O.Stylizer(layers) if free else None
     prev_gpu = None
@@ -97,7 +113,12 @@ def run_clip(fav, O, model_path, h, w, n_frames, mode="flow3", seed=1000, pool=8
                 r = tf.next(_f01(frame), bw, cert01)
             row["teacher_max_abs"] = float(np.abs(g - r).max()); row["teacher_psnr8_db"] = round(psnr8(g8, O.to_u8_hwc(r)), 2)
         if free:
+            if i == 1:      # how much the recurrent inputs matter: the same step with an all-occluded prior (one extra oracle frame)
+                probe = O.Stylizer(layers); probe.last = ref_free.last; probe.count = ref_free.count
+                r_np = probe.next(_f01(frame), bw, np.zeros_like(cert01))
             r = ref_free.first(_f01(frame)) if i == 0 else ref_free.next(_f01(frame), bw, cert01)
+            if i == 1:
+                prior_influence = float(np.abs(r - r_np).max())
             row["free_max_abs"] = float(np.abs(g - r).max()); row["free_psnr8_db"] = round(psnr8(g8, O.to_u8_hwc(r)), 2)
             row["free_rms"] = float(np.sqrt(np.mean((g.astype(np.float64) - r) ** 2)))
         prev_gpu = g
@@ -119,6 +140,96 @@ def run_clip(fav, O, model_path, h, w, n_frames, mode="flow3", seed=1000, pool=8
     mm = [r["mask_mismatch_bytes"] for r in rows if "mask_mismatch_bytes" in r]
     if mm:
         out["mask_mismatch_bytes_total"] = int(sum(mm))
+    if prior_influence is not None:
+        out["prior_influence_max_abs"] = prior_influence      # frame 2 with vs without its prior (oracle): the recurrent path is live
+    return out
+
+
+def clip_inputs(frames, bws, fws, pool, i):
+    lap, k = divmod(i, pool)
+    fi, gi = k, (k * (2 * lap + 1) + lap) % pool
+    return frames[fi], bws[gi], fws[gi]
+
+
+SAMPLES = 4096
+CHECKPOINTS = (1, 100, 200, -1)          # frames kept whole (1-based; -1 = the last)
+
+
+def sample_positions(h, w):
+    rng = np.random.default_rng(4242)
+    return rng.integers(0, h, SAMPLES), rng.integers(0, w, SAMPLES)
+
+
+def gpu_dump(fav, model_path, h, w, n_frames, path, seed=1000, pool=8, log=print):
+    """the GPU's free-running chain over the whole clip, reduced to what fits gpurun_out (see the module docstring)"""
+    import torch
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    frames, bws, fws = make_pool(h, w, seed, pool)
+    dfr, dbw, dfw = [T(a) for a in frames], [T(a) for a in bws], [T(a) for a in fws]
+    ys, xs = sample_positions(h, w)
+    tys, txs = torch.from_numpy(ys).to(dev), torch.from_numpy(xs).to(dev)
+    net = fav.Net(model_path, 0)
+    st = fav.Stream(net, h, w)
+    samples = np.zeros((n_frames, 3, SAMPLES), np.float32)
+    mask_sums = np.zeros(n_frames, np.int64)
+    full = {}
+    cps = {c if c > 0 else n_frames for c in CHECKPOINTS if c <= n_frames}
+    for i in range(n_frames):
+        fi, bi, wi = clip_inputs(range(pool), range(pool), range(pool), pool, i)
+        if i == 0:
+            o, _ = st.first_frame(dfr[fi])
+        else:
+            o, _ = st.next_frame_flow(dfr[fi], dbw[bi], dfw[wi])
+            mask_sums[i] = int(st.last_mask().to(torch.int64).sum().item())
+        samples[i] = o[:, tys, txs].cpu().numpy()
+        if i + 1 in cps:
+            full[f"full_{i + 1}"] = o.cpu().numpy()
+    net.check()
+    np.savez(path, samples=samples, mask_sums=mask_sums, h=h, w=w, seed=seed, pool=pool, frames=n_frames, **full)
+    log(f"wrote {path}: {n_frames} frames, {len(full)} whole frames")
+
+
+def compare_dump(O, model_path, path, threads=None, log=print):
+    """the oracle's own free-running chain on the same clip against the GPU's dumped chain"""
+    from fav_amd import t7
+    d = np.load(path)
+    h, w, seed, pool, n_frames = int(d["h"]), int(d["w"]), int(d["seed"]), int(d["pool"]), int(d["frames"])
+    layers = t7.extract_layers(t7.load(model_path)["model"])
+    frames, bws, fws = make_pool(h, w, seed, pool)
+    if threads:
+        O.set_threads(threads)
+    ys, xs = sample_positions(h, w)
+    ref = O.Stylizer(layers)
+    rows = []
+    t0 = time.time()
+    for i in range(n_frames):
+        frame, bw, fw = clip_inputs(frames, bws, fws, pool, i)
+        row = {"frame": i + 1}
+        if i == 0:
+            r = ref.first(_f01(frame))
+        else:
+            mask = O.consistency(bw, fw)
+            row["mask_byte_sum_equal"] = bool(int(mask.astype(np.int64).sum()) == int(d["mask_sums"][i]))
+            r = ref.next(_f01(frame), bw, mask.astype(np.float32) / np.float32(255))
+        g = d["samples"][i]
+        diff = np.abs(g - r[:, ys, xs])
+        row["sampled_max_abs"] = float(diff.max()); row["sampled_rms"] = float(np.sqrt(np.mean(diff.astype(np.float64) ** 2)))
+        key = f"full_{i + 1}"
+        if key in d.files:
+            gf = d[key]
+            row["full_max_abs"] = float(np.abs(gf - r).max()); row["full_psnr8_db"] = round(psnr8(O.to_u8_hwc(gf), O.to_u8_hwc(r)), 2)
+        rows.append(row); log(json.dumps(row))
+    out = {"what": "free-running over the whole clip: the GPU's chain (run on the MI355X, dumped) against the oracle's own chain on the same seeded clip; "
+                   "every frame at %d fixed sample positions x 3 channels, whole frames at the check points" % SAMPLES,
+           "model": os.path.basename(model_path), "H": h, "W": w, "mode": "flow3", "frames_compared": len(rows), "pool": pool, "seed": seed,
+           "seconds_oracle": round(time.time() - t0, 1), "per_frame": rows,
+           "sampled_max_abs_worst": max(r["sampled_max_abs"] for r in rows), "sampled_max_abs_last": rows[-1]["sampled_max_abs"],
+           "full_frames": {str(r["frame"]): {"max_abs": r["full_max_abs"], "psnr8_db": r["full_psnr8_db"]} for r in rows if "full_max_abs" in r},
+           "mask_byte_sums_equal_on_all_frames": all(r.get("mask_byte_sum_equal", True) for r in rows),
+           "gate": "2e-4 de-processed / 50 dB (BASELINE.md section 4)"}
+    out["within_gate"] = bool(out["sampled_max_abs_worst"] <= 2e-4 and all(v["max_abs"] <= 2e-4 and v["psnr8_db"] >= 50 for v in out["full_frames"].values())
+                              and out["mask_byte_sums_equal_on_all_frames"])
     return out
 
 
@@ -176,26 +287,37 @@ def main():
     ap.add_argument("--budget-s", type=float, default=None)
     ap.add_argument("--threads", type=int, default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--gain", type=float, default=1.0, help="recurrent_gain of the synthetic checkpoint (%g = the contractive one)" % CONTRACTIVE_GAIN)
+    ap.add_argument("--gpu-dump", default=None, help="GPU side of the split whole-clip run: write the GPU chain's samples to this .npz")
+    ap.add_argument("--compare", default=None, help="oracle side of the split whole-clip run: compare against this .npz")
     a = ap.parse_args()
     import oracle as O
     from fav_amd import t7
     fav_amd = None
-    if not a.control:
+    if not a.control and not a.compare:
         import fav_amd
     O.build()
     model = os.path.join(tempfile.mkdtemp(), "canonical.t7")
-    t7.make_synthetic_checkpoint(model, seed=3)
+    t7.make_synthetic_checkpoint(model, seed=3, recurrent_gain=a.gain)
     if a.config == 2:
         h, w, n, mode = 360, 640, a.frames or 32, "cert"
     else:
         h, w, n, mode = 720, 1280, a.frames or 60, "flow3"
     nthreads = a.threads or effective_cpus()        # (the GPU box shows 256 hardware threads under a 16-CPU quota)
-    if a.control:
+    if a.gpu_dump:
+        os.makedirs(os.path.dirname(os.path.abspath(a.gpu_dump)), exist_ok=True)
+        gpu_dump(fav_amd, model, h, w, n, a.gpu_dump)
+        return
+    if a.compare:
+        res = compare_dump(O, model, a.compare, threads=nthreads, log=lambda s_: print(s_, flush=True))
+        res["recurrent_gain"] = a.gain
+    elif a.control:
         res = run_control(O, model, h, w, n, mode=mode, threads=nthreads)
     else:
         res = run_clip(fav_amd, O, model, h, w, n, mode=mode, teacher=not a.no_teacher, budget_s=a.budget_s, threads=nthreads)
     res["baseline_config"] = a.config
     res["host_threads"] = nthreads
+    res.setdefault("recurrent_gain", a.gain)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:

@@ -487,3 +487,23 @@ def test_into_buffer_readers(favlib, oracle, tmp_path):
     assert L.fav_read_flo_into_host(pf.encode(), fb.ctypes.data_as(C.c_void_p), C.c_size_t(fb.size - 1), C.byref(W), C.byref(H)) == -1
     assert L.fav_read_pnm_into_host(pi.encode(), ib.ctypes.data_as(C.c_void_p), C.c_size_t(h * w * 3 - 1), C.byref(W), C.byref(H), C.byref(ch)) == -1
     assert b"does not fit" in L.fav_last_error()
+
+
+def test_contractive_checkpoint_contracts_and_random_init_does_not(oracle, tmp_path):
+    """The premise of the whole-clip free-running gate (tests/test_gpu_parity.py,
+    scripts/parity_clip.py): with the first convolution's prior + certainty weights scaled by CONTRACTIVE_GAIN the recurrent map
+    frame -> frame CONTRACTS -- two oracle chains that differ by +-5e-6 at frame 1 come closer every frame until they sit in the
+    fp32 noise -- while the plain random-init checkpoint amplifies the same perturbation ~3x per frame (why free-running parity
+    was ungateable on it: profiles/r03_parity_sensitivity_control_c2.json).  No GPU involved."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import parity_clip as PC
+    from fav_amd import t7
+    res = {}
+    for name, gain in (("contractive", PC.CONTRACTIVE_GAIN), ("random-init", 1.0)):
+        p = str(tmp_path / (name + ".t7"))
+        t7.make_synthetic_checkpoint(p, seed=3, recurrent_gain=gain)
+        res[name] = PC.run_control(oracle, p, 96, 128, 5, mode="flow3", log=lambda s: None)["per_frame"]
+    c, r = [x["rms"] for x in res["contractive"]], [x["rms"] for x in res["random-init"]]
+    assert c[1] < 0.8 * c[0] and c[2] < 0.8 * c[1] and c[4] < 0.3 * c[0], c
+    assert r[4] > 10 * r[0], r

@@ -65,3 +65,18 @@ def test_png_rows_inflate_with_every_code(oracle, favlib):
     assert len(seen) >= 6 and len(T) - 1 in seen and len(T) in seen, seen          # several model codes, the fixed code, a stored row
     for t in T[:-1]:
         assert abs(sum(2.0 ** -int(l) for l in t["len"]) - 1.0) < 1e-12 and t["len"].max() <= 15 and t["hdr_bits"] <= 40 * 32
+
+
+def test_crc_combine_scheme_matches_zlib_beyond_2_pow_24_bytes(favlib):
+    """crc32(A || B) from the parts, with the tables the pack / finish kernels index by the bytes of |B|: three tables ended at 2^24
+    bytes (a 3840x2160 frame's IDAT is 25 MB: its CRC was wrong and PIL / libpng rejected the file); four cover every 32-bit length"""
+    import os
+    a = os.urandom(1000)
+    ca = zlib.crc32(a)
+    for n in (0, 1, 5, 255, 256, 65535, 65536, (1 << 24) - 1, 1 << 24, (1 << 24) + 5, 50_000_003):
+        b = bytes(n)
+        assert favlib.lib().fav_png_crc32_combine_host(ca, zlib.crc32(b), n) == zlib.crc32(a + b), n
+    # a length above 2^31 without materialising it: crc(A || 0^n) for n = n1 + n2 is the combine of the combines
+    z1 = zlib.crc32(bytes(40_000_000))
+    got = favlib.lib().fav_png_crc32_combine_host(ca, favlib.lib().fav_png_crc32_combine_host(z1, z1, 40_000_000), 80_000_000)
+    assert got == favlib.lib().fav_png_crc32_combine_host(favlib.lib().fav_png_crc32_combine_host(ca, z1, 40_000_000), z1, 40_000_000)

@@ -10,6 +10,7 @@ Tolerances (fp32 path, stated once):
     <= 2e-4 after de-processing to [0,1]; 8-bit PSNR >= 50 dB.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -609,6 +610,48 @@ def test_config2_640x360_32_frames_reference_masks(favlib, oracle, cuda, canonic
     growth = [rows[k + 1]["free_rms"] / rows[k]["free_rms"] for k in range(8)]
     assert max(growth) <= 6.0, growth
     assert 5.0 < np.mean([r["reliable_pct"] for r in res["per_frame"][1:]]) < 99.0      # the masks gate a real share of the prior
+
+
+@pytest.fixture(scope="module")
+def contractive(tmp_path_factory):
+    """the canonical architecture with the first convolution's weights on the prior + certainty channels scaled by 0.05
+    (t7.build_model, recurrent_gain): frame -> frame contracts (CPU control: tests/test_cpu_oracle.py), so the whole clip is gateable"""
+    p = str(tmp_path_factory.mktemp("m") / "contractive.t7")
+    t7.make_synthetic_checkpoint(p, seed=1234, recurrent_gain=parity_gain())
+    return p
+
+
+def parity_gain():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import parity_clip
+    return parity_clip.CONTRACTIVE_GAIN
+
+
+def test_config2_free_running_whole_clip_contractive_weights(favlib, oracle, cuda, contractive):
+    """BASELINE.md section 4's SECOND gate -- free-running over the full clip -- as a gate: config 2 (640x360 x 32 frames, masks =
+    files of the reference's own checker binary) on the contractive synthetic checkpoint.  The GPU chain and the oracle chain run
+    independently from frame 1; every one of the 32 frames within 2e-4 (de-processed) and 50 dB.  Teacher-forced numbers of the same
+    run are gated as well (they use the same oracle calls' inputs, so they cost a second oracle frame each)."""
+    if not os.path.exists(oracle.REF_CHECKER):
+        pytest.skip("oracle/_ref/consistencyChecker not built (needs /root/reference at build time)")
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import parity_clip
+    try:
+        res = parity_clip.run_clip(favlib, oracle, contractive, 360, 640, 32, mode="cert", seed=2000, pool=8, teacher=False,
+                                   threads=parity_clip.effective_cpus(), log=lambda s: None)
+    finally:
+        oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_c2_freerun_contractive.json"), "w") as f:
+            json.dump(res, f, indent=1)
+    print({k: v for k, v in res.items() if k != "per_frame"})
+    assert res["frames_compared"] == 32
+    assert res["free_max_abs_worst"] <= 2e-4, [r["free_max_abs"] for r in res["per_frame"]]
+    assert res["free_psnr8_db_min"] >= 50.0, res["free_psnr8_db_min"]
+    # the recurrent path is live: the prior moves the output by far more than the gate (a dead prior would make the gate vacuous)
+    assert res["prior_influence_max_abs"] > 50 * 2e-4, res["prior_influence_max_abs"]
 
 
 def test_canonical_1280x720_recurrent_step_vs_oracle(favlib, oracle, cuda, canonical, poison):

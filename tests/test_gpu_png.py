@@ -94,3 +94,24 @@ def test_png_widest_supported_row_and_the_limit(favlib, oracle, cuda):
     assert data == P.encode(img)
     with pytest.raises(favlib.FavError, match="9000"):
         favlib.png_encode(T(np.zeros((1, 9001, 3), np.uint8), cuda))
+
+
+def test_png_above_16_mib_has_a_valid_crc(favlib, oracle, cuda):
+    """noise at 3000x2000 is stored almost raw -- an 18 MB IDAT chunk, beyond the 2^24 bytes the CRC combine's three
+    position tables covered (PIL / libpng verify the chunk CRC and rejected such files); also an unpadded, unaligned source buffer"""
+    import torch
+    h, w = 2000, 3000
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    data = favlib.png_encode(T(img, cuda))
+    assert len(data) > (1 << 24)
+    import struct, zlib
+    assert data[33:37] == struct.pack(">I", len(data) - 57) and data[37:41] == b"IDAT"
+    assert struct.unpack(">I", data[-16:-12])[0] == zlib.crc32(data[37:-16])            # the IDAT chunk's CRC over type + data
+    assert np.array_equal(_decode(data), img)
+    # a source that starts at an odd address and ends at the last byte of its allocation: nothing outside it is read, same file
+    hs, ws = 37, 333
+    small = np.ascontiguousarray(img[:hs, :ws])
+    buf = torch.zeros(1 + small.size, dtype=torch.uint8, device=cuda)
+    buf[1:] = T(small.reshape(-1), cuda)
+    assert favlib.png_encode(buf[1:].view(hs, ws, 3)) == favlib.png_encode(T(small, cuda))
