@@ -153,93 +153,133 @@ class ClockSampler:
                 "source": "rocm-smi --showclocks, 0.5 s period, while the leg ran"}
 
 
-def _make_clip_dir(d, name, frames_h, bw_h, fw_h, nframes, O):
-    """RAM-backed clip: `ring` distinct frames / flow pairs, the clip's files are symlinks onto them"""
-    os.makedirs(f"{d}/{name}/flow")
-    ring = len(frames_h)
-    if not os.path.isdir(d + "/src"):
-        os.makedirs(d + "/src")
-        for k in range(ring):
-            O.write_pnm(f"{d}/src/f{k}.ppm", frames_h[k]); O.write_flo(f"{d}/src/b{k}.flo", bw_h[k]); O.write_flo(f"{d}/src/w{k}.flo", fw_h[k])
-    for i in range(1, nframes + 1):
-        os.symlink(f"{d}/src/f{i % ring}.ppm", f"{d}/{name}/frame_{i:05d}.ppm")
-        if i > 1:
-            os.symlink(f"{d}/src/b{i % ring}.flo", f"{d}/{name}/flow/backward_{i}_{i-1}.flo"); os.symlink(f"{d}/src/w{i % ring}.flo", f"{d}/{name}/flow/forward_{i-1}_{i}.flo")
-
-
-def _cli_leg(base, d, name, extra_args, out_dir_glob, timeout=900, taskset=None):
-    cmd = (["taskset", "-c", taskset] if taskset else []) + base + extra_args
+def _cli_leg(base, extra_args, out_dirs, timeout=900, taskset=None, verify=None, prefix="out", exe_override=None):
+    """one run of the CLI; `verify` = (reference run, frames, pixel_frames or None): every PNG it wrote is compared byte for byte with
+    the in-process run of the same inputs (scripts/e2e_content.py) before the directory is removed -- `png_mismatch_frames` must be 0"""
+    import e2e_content as EC
+    cmd = (["taskset", "-c", taskset] if taskset else []) + (exe_override or []) + base + extra_args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
+        for od in out_dirs:
+            shutil.rmtree(od, ignore_errors=True)
         return {"error": (r.stderr or r.stdout)[-400:]}
     j = json.loads(lines[-1])
     res = {"fps": j["fps_end_to_end"], "seconds": j["seconds"], "frames": j["frames"]}
     for k in ("png_writers", "wait_loader_s", "wait_png_pool_s", "setup_s", "png_tail_s", "png_encoder", "host_cpu_ms_per_frame", "cpu_ms_per_frame_loaders", "cpu_ms_per_frame_writers", "cpu_ms_per_frame_writers_waiting_for_the_copy", "cpu_ms_per_frame_main", "png_mb_per_frame", "usable_cpus",
-              "gpus", "streams", "fps_per_gpu"):
+              "gpus", "streams", "fps_per_gpu", "weight_broadcast_ms", "rccl_comm_init_ms"):
         if k in j:
             res[k] = j[k]
     if "setup_s" in j:
         res["steady_state_fps"] = round(j["frames"] / max(1e-9, j["seconds"] - (j.get("setup_s") or 0.0) - (j.get("png_tail_s") or 0.0)), 3)
     n_png = 0
-    for od in out_dir_glob:
+    chk = {"png_checked": 0, "png_mismatch_frames": 0, "png_missing_frames": 0, "png_unexpected_files": 0}
+    for od in out_dirs:
         if os.path.isdir(od):
             n_png += len([f for f in os.listdir(od) if f.endswith(".png")])
+            if verify is not None:
+                ref, nfr, pixel_frames = verify
+                one = EC.verify_dir_pixels(od, prefix, ref, pixel_frames) if pixel_frames is not None else EC.verify_dir(od, prefix, ref, nfr)
+                for k, v in one.items():
+                    if isinstance(v, int) and k != "first_bad_frame":
+                        chk[k] = chk.get(k, 0) + v
+                if one.get("first_bad_frame"):
+                    chk.setdefault("first_bad_frame", one["first_bad_frame"])
             shutil.rmtree(od, ignore_errors=True)
+        elif verify is not None:
+            chk["png_missing_frames"] += verify[1]
     res["png_written"] = n_png
+    if verify is not None:
+        res.update(chk)
     return res
 
 
-def e2e_block(ckpt, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames=3000, quick=False):
+def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames=3000, quick=False):
     """File -> PNG rate of the drop-in CLI (fast_artistic_video.lua:93-97,160-170) -- BASELINE.json's "end-to-end": bin/fav_stylize
     over RAM-backed 1280x720 P6 frames + backward/forward .flo, fused on-GPU 3-argument check, PNG files written back to RAM.
     Everything the in-HBM `value` leaves out is inside: file reads, decode, H2D, D2H, file writes.  world > 1: the product's own
-    launcher (`-streams s0,.. -gpus N`: one worker process per GPU, RCCL broadcast of the weights), one clip per GPU."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    launcher (`-streams s0,.. -gpus N`: one worker process per GPU, RCCL broadcast of the weights), one clip per GPU.
+    EVERY leg's output is content-checked: each PNG byte for byte against the in-process fav_stream_* run of the same inputs
+    (`png_mismatch_frames`, `png_missing_frames`; the -png_encoder host legs, whose deflate streams differ by construction, by decoded
+    pixels on every 10th frame)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import oracle as O
-    exe = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "fav_stylize")
+    import e2e_content as EC
+    import fav_amd
+    pkg = os.path.join(ROOT, "fast-artistic-videos_amd")
+    exe = os.path.join(pkg, "bin", "fav_stylize")
     if not os.path.exists(exe) or not os.path.isdir("/dev/shm"):
         return {"error": "bin/fav_stylize or /dev/shm missing"}
     d = tempfile.mkdtemp(prefix="fav_e2e_", dir="/dev/shm")
     try:
+        have_ref_checker = os.path.exists(EC.REF_CHECKER)
         names = [f"s{k}" for k in range(world)]
         for nm in names:
-            _make_clip_dir(d, nm, frames_h, bw_h, fw_h, nframes, O)
+            EC.make_clip_dir(d, nm, frames_h, bw_h, fw_h, nframes, O, cert=have_ref_checker and world == 1 and not quick)
         pat = "%S" if world > 1 else names[0]
-        base = [exe, "-input_pattern", f"{d}/{pat}/frame_%05d.ppm", "-flow_pattern", f"{d}/{pat}/flow/backward_[%d]_{{%d}}.flo",
-                "-forward_flow_pattern", f"{d}/{pat}/flow/forward_{{%d}}_[%d].flo",
-                "-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1"]
+        flow_args = lambda p: ["-input_pattern", f"{d}/{p}/frame_%05d.ppm", "-flow_pattern", f"{d}/{p}/flow/backward_[%d]_{{%d}}.flo"]
+        tail = ["-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1"]
+        base = [exe] + flow_args(pat) + ["-forward_flow_pattern", f"{d}/{pat}/flow/forward_{{%d}}_[%d].flo"] + tail
         if world > 1:
             base += ["-streams", ",".join(names), "-gpus", str(world)]
         outp = lambda tag: ["-output_prefix", f"{d}/{pat}/o_{tag}/out"]
         outd = lambda tag: [f"{d}/{nm}/o_{tag}" for nm in names]
         out = {"frames_per_stream": nframes, "streams": world, "host_threads": os.cpu_count(), "usable_cpus": effective_cpus(),
                "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net + PNG encode (GPU) -> D2H (exact size) -> write() to /dev/shm",
-               "h2d_bytes_per_frame": H * W * (3 + 8 + 8)}
+               "h2d_bytes_per_frame": H * W * (3 + 8 + 8),
+               "content_check": "every PNG of every leg byte for byte against the in-process fav_stream_* run of the same inputs (bit-deterministic GPU path); "
+                                "png_mismatch_frames / png_missing_frames must be 0"}
+        # the in-process runs the legs are checked against (outside every timed region; this process is idle while a CLI leg runs)
+        n_long = sustained_frames if (sustained_frames and world == 1 and not quick) else nframes
+        every10 = list(range(10, nframes + 1, 10)) + ([nframes] if nframes % 10 else [])
+        t_ref = time.perf_counter()
+        ref3 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, max(n_long, nframes), "3arg", keep=every10)
+        out["reference_run_s"] = {"3arg_%d_frames" % max(n_long, nframes): round(time.perf_counter() - t_ref, 2)}
         # the headline leg: the defaults of the CLI (-png_encoder gpu), 3-argument check = the workload of `value`
         # (at --gpus N a launcher that cannot bring its RCCL communicator up must not hold the bench line back: 4 minutes)
-        out["gpu_png"] = _cli_leg(base, d, "gpu", ["-structure", "0"] + outp("gpu"), outd("gpu"), timeout=900 if world == 1 else 240)
+        out["gpu_png"] = _cli_leg(base, ["-structure", "0"] + outp("gpu"), outd("gpu"), timeout=900 if world == 1 else 240, verify=(ref3, nframes, None))
         if quick:
             return out
         if world == 1:
+            # the SAME job through the product's multi-GPU launcher (-streams s0 -gpus 1 -force_dist 1: worker process, RCCL communicator
+            # of one rank, ncclBroadcast of the packed weights): the exact command line the N > 1 runs issue, driver-run at N = 1
+            lb = [exe] + flow_args("%S") + ["-forward_flow_pattern", f"{d}/%S/flow/forward_{{%d}}_[%d].flo"] + tail + ["-streams", names[0], "-gpus", "1", "-force_dist", "1"]
+            out["gpu_png_via_launcher_rccl_world_1"] = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/%S/o_ln/out"], outd("ln"), timeout=300, verify=(ref3, nframes, None))
             # what the same job costs when the host deflates (round 2's path) and with the 4-argument (image-structure) check of
             # makeOptFlow_deepflow.sh:59; then the per-GPU share of a 16-CPU quota on an 8-GPU node: two cores
-            out["host_zlib_png_level_1"] = _cli_leg(base, d, "zl", ["-structure", "0", "-png_encoder", "host", "-png_level", "1"] + outp("zl"), outd("zl"))
-            out["gpu_png_4arg_check"] = _cli_leg(base, d, "g4", ["-structure", "1"] + outp("g4"), outd("g4"))
-            out["host_zlib_two_cores"] = _cli_leg(base, d, "z2", ["-structure", "0", "-png_encoder", "host", "-png_level", "1", "-num_frames", "100"] + outp("z2"), outd("z2"), taskset="0-1")
+            out["host_zlib_png_level_1"] = _cli_leg(base, ["-structure", "0", "-png_encoder", "host", "-png_level", "1"] + outp("zl"), outd("zl"), verify=(ref3, nframes, every10))
+            t_ref = time.perf_counter()
+            ref4 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, nframes, "4arg")
+            out["reference_run_s"]["4arg_%d_frames" % nframes] = round(time.perf_counter() - t_ref, 2)
+            out["gpu_png_4arg_check"] = _cli_leg(base, ["-structure", "1"] + outp("g4"), outd("g4"), verify=(ref4, nframes, None))
+            del ref4
+            if have_ref_checker:
+                # the certainty path exactly as stylizeVideo_deepflow.sh:87-96 calls it -- through the `th` shim, .pgm files written by the
+                # REFERENCE's checker binary (4-argument form, makeOptFlow_deepflow.sh:59-60) -- BASELINE config 2's data flow at config 3's size
+                masks = [O.read_pnm(f"{d}/src/r{k}.pgm") for k in range(len(frames_h))]
+                refc = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, nframes, "cert", masks_h=masks)
+                th = [os.path.join(pkg, "host", "th"), "fast_artistic_video.lua"] + flow_args(names[0]) + ["-occlusions_pattern", f"{d}/{names[0]}/flow/reliable_[%d]_{{%d}}.pgm",
+                      "-backend", "cuda", "-use_cudnn", "1"] + tail
+                out["gpu_png_cert_path_via_th_shim"] = _cli_leg(th, outp("ct"), outd("ct"), verify=(refc, nframes, None))
+                del refc
+            out["host_zlib_two_cores"] = _cli_leg(base, ["-structure", "0", "-png_encoder", "host", "-png_level", "1", "-num_frames", "100"] + outp("z2"), outd("z2"), taskset="0-1",
+                                                  verify=(ref3, 100, list(range(10, 101, 10))))
         # sustained leg: >= 3000 frames (same ring of inputs), shader clock sampled while it runs
         if sustained_frames and world == 1:
-            _make_clip_dir(d, "long", frames_h, bw_h, fw_h, sustained_frames, O)
+            EC.make_clip_dir(d, "long", frames_h, bw_h, fw_h, sustained_frames, O)
             lb = [a.replace(f"{d}/{names[0]}/", f"{d}/long/") for a in base]
             with ClockSampler() as cs:
-                leg = _cli_leg(lb, d, "long", ["-structure", "0", "-output_prefix", f"{d}/long/o/out"], [f"{d}/long/o"], timeout=1200)
+                leg = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/long/o/out"], [f"{d}/long/o"], timeout=1200, verify=(ref3, sustained_frames, None))
             leg["shader_clock"] = cs.summary()
             out["sustained"] = leg
             # the per-GPU share of a 16-CPU quota on an 8-GPU node: the whole process (loaders, submission, file writes, the HIP
             # runtime's own threads) confined to two CPUs
-            leg2 = _cli_leg(lb, d, "long2", ["-structure", "0", "-output_prefix", f"{d}/long/o2/out"], [f"{d}/long/o2"], timeout=1200, taskset="0-1")
+            leg2 = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/long/o2/out"], [f"{d}/long/o2"], timeout=1200, taskset="0-1", verify=(ref3, sustained_frames, None))
             leg2["note"] = "taskset -c 0-1 on the %d-frame clip" % sustained_frames
             out["sustained_two_cores"] = leg2
+        legs = [v for v in out.values() if isinstance(v, dict) and "png_written" in v]
+        out["png_mismatch_frames_all_legs"] = sum(v.get("png_mismatch_frames", 0) + v.get("png_missing_frames", 0) for v in legs)
+        out["png_checked_all_legs"] = sum(v.get("png_checked", 0) + v.get("png_checked_by_pixels", 0) for v in legs)
         return out
     except Exception as e:          # the e2e leg must never take the bench line with it
         return {"error": repr(e)[:400]}
@@ -567,9 +607,12 @@ def main():
         line["extra"]["png_bytes_per_frame_in_timed_region"] = int(png_n.item())
         if not args.no_e2e:
             del stream; torch.cuda.synchronize()
-            line["e2e"] = e2e_block(ckpt, frames_h, bw_h, fw_h, world=world, sustained_frames=args.sustained_frames, quick=args.quick_e2e)
+            line["e2e"] = e2e_block(ckpt, net, frames_h, bw_h, fw_h, world=world, sustained_frames=args.sustained_frames, quick=args.quick_e2e)
             head = line["e2e"].get("gpu_png", {}) if isinstance(line["e2e"], dict) else {}
             line["end_to_end_fps"] = head.get("fps")
+            # the bytes behind the end-to-end numbers: PNGs of ALL e2e legs that differ from (or are missing against) the in-process run
+            line["png_mismatch_frames"] = line["e2e"].get("png_mismatch_frames_all_legs", head.get("png_mismatch_frames")) if isinstance(line["e2e"], dict) else None
+            line["png_checked_frames"] = line["e2e"].get("png_checked_all_legs", head.get("png_checked")) if isinstance(line["e2e"], dict) else None
             line["end_to_end_note"] = ("file -> PNG, bin/fav_stylize%s, %d frames per stream from /dev/shm (BASELINE.json's end-to-end metric); `value` is the in-HBM "
                                        "rate the bench contract defines" % ("" if world == 1 else " -streams ... -gpus %d (one worker process per GPU)" % world, 300))
         print(json.dumps(line), flush=True)

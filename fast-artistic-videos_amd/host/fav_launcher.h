@@ -101,6 +101,42 @@ inline int writer_budget(int requested, int world, bool pinned = false)
 
 inline void ncheck(ncclResult_t r, const char* what) { if (r != ncclSuccess) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(r)); }
 
+// Watchdog of the job's only collectives.  The communicator is NON-BLOCKING (ncclConfig_t::blocking = 0): ncclCommInitRankConfig and
+// ncclBroadcast return at once and the worker polls ncclCommGetAsyncError (and the stream) with a deadline, so a rank that never shows
+// up or a half-up xGMI fabric ends the job with a message instead of a hang inside librccl (the launcher then stops the other workers).
+// FAV_RCCL_TIMEOUT_S overrides the 60 s deadline.
+inline double rccl_timeout_s()
+{
+    const char* e = getenv("FAV_RCCL_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0 ? v : 60.0;
+}
+
+inline void nccl_wait(ncclComm_t comm, ncclResult_t first, const char* what, int rank, hipStream_t st = nullptr, bool wait_stream = false)
+{
+    if (first != ncclSuccess && first != ncclInProgress) die(std::string("RCCL: ") + what + ": " + ncclGetErrorString(first));
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = rccl_timeout_s();
+    for (;;) {
+        ncclResult_t state = ncclSuccess;
+        ncheck(ncclCommGetAsyncError(comm, &state), "ncclCommGetAsyncError");
+        if (state != ncclSuccess && state != ncclInProgress) die(std::string("RCCL: ") + what + " failed: " + ncclGetErrorString(state));
+        if (state == ncclSuccess) {
+            if (!wait_stream) return;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return;
+            if (q != hipErrorNotReady) die(std::string("RCCL: ") + what + ": " + hipGetErrorString(q));
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            fprintf(stderr, "[rank %d] RCCL: %s did not complete within %.0f s -- a rank is missing or the GPU fabric is not fully up "
+                            "(see the other workers' messages; `rocm-smi --showtopo`); aborting the communicator\n", rank, what, limit);
+            (void)ncclCommAbort(comm);
+            exit(4);
+        }
+        usleep(500);
+    }
+}
+
 // rank 0 holds `blob`; on return every rank holds the same bytes.  ONE collective per model: ncclBroadcast of the packed
 // checkpoint (6.7 MB, latency-bound) preceded by its 8-byte size.
 inline void broadcast_blob(ncclComm_t comm, int rank, std::vector<uint8_t>& blob, hipStream_t st)
@@ -108,15 +144,13 @@ inline void broadcast_blob(ncclComm_t comm, int rank, std::vector<uint8_t>& blob
     unsigned long long n = rank == 0 ? blob.size() : 0, *d_n = nullptr;
     if (hipMalloc((void**)&d_n, 8) != hipSuccess) die("hipMalloc failed");
     hipMemcpy(d_n, &n, 8, hipMemcpyHostToDevice);
-    ncheck(ncclBroadcast(d_n, d_n, 8, ncclUint8, 0, comm, st), "ncclBroadcast(size)");
-    hipStreamSynchronize(st);
+    nccl_wait(comm, ncclBroadcast(d_n, d_n, 8, ncclUint8, 0, comm, st), "ncclBroadcast(size)", rank, st, true);
     hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost); hipFree(d_n);
     if (n == 0) { blob.clear(); return; }
     uint8_t* d_b = nullptr;
     if (hipMalloc((void**)&d_b, n) != hipSuccess) die("hipMalloc failed");
     if (rank == 0) hipMemcpy(d_b, blob.data(), n, hipMemcpyHostToDevice);
-    ncheck(ncclBroadcast(d_b, d_b, n, ncclUint8, 0, comm, st), "ncclBroadcast(blob)");
-    if (hipStreamSynchronize(st) != hipSuccess) die("RCCL broadcast failed");
+    nccl_wait(comm, ncclBroadcast(d_b, d_b, n, ncclUint8, 0, comm, st), "ncclBroadcast(blob)", rank, st, true);
     blob.resize(n);
     hipMemcpy(blob.data(), d_b, n, hipMemcpyDeviceToHost); hipFree(d_b);
 }
@@ -267,32 +301,35 @@ inline std::string host_ceiling_json(double cpu_ms_per_frame, const char* source
 inline void print_aggregate(const std::string& dir, int world, size_t nstreams)
 {
     const std::string idf = dir + "/id";
-    int frames = 0; double secs = 0, cpu = 0; std::string per = "";
+    int frames = 0; double secs = 0, cpu = 0, bcast_ms = 0, init_ms = 0; std::string per = "";
     for (int r = 0; r < world; ++r) {
         const std::string f = idf + ".rank" + std::to_string(r);
         FILE* fp = fopen(f.c_str(), "r");
-        int fr = 0; double sc = 0, cs = 0;
-        if (fp) { if (fscanf(fp, "%d %lf %lf", &fr, &sc, &cs) < 2) { fr = 0; sc = 0; cs = 0; } fclose(fp); unlink(f.c_str()); }
-        frames += fr; secs = std::max(secs, sc); cpu += cs;
+        int fr = 0; double sc = 0, cs = 0, bm = 0, im = 0;
+        if (fp) { if (fscanf(fp, "%d %lf %lf %lf %lf", &fr, &sc, &cs, &bm, &im) < 2) { fr = 0; sc = 0; cs = 0; } fclose(fp); unlink(f.c_str()); }
+        frames += fr; secs = std::max(secs, sc); cpu += cs; bcast_ms = std::max(bcast_ms, bm); init_ms = std::max(init_ms, im);
         per += (r ? ", " : "") + std::to_string(fr ? fr / std::max(sc, 1e-9) : 0.0);
     }
     const double ms = frames ? 1e3 * cpu / frames : 0.0;
     printf("{\"gpus\": %d, \"streams\": %zu, \"frames\": %d, \"seconds\": %.4f, \"fps_end_to_end\": %.3f, \"fps_per_gpu\": [%s], "
            "\"host_cpu_ms_per_frame\": %.3f, \"host_ceiling\": %s, "
-           "\"weights\": \"rank 0 parsed the .t7, ncclBroadcast of the packed blob\"}\n",
-           world, nstreams, frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str(), ms, host_ceiling_json(ms, "measured: CPU seconds of all workers / frames").c_str());
+           "\"weights\": \"rank 0 parsed the .t7, ncclBroadcast of the packed blob\", \"weight_broadcast_ms\": %.3f, \"rccl_comm_init_ms\": %.1f}\n",
+           world, nstreams, frames, secs, secs > 0 ? frames / secs : 0.0, per.c_str(), ms, host_ceiling_json(ms, "measured: CPU seconds of all workers / frames").c_str(),
+           bcast_ms, init_ms);
 }
 
-inline void write_worker_result(const std::string& idf, int rank, int frames, double seconds, double cpu_seconds = 0.0)
+struct DistTimes { double bcast_ms = 0, init_ms = 0; };      // the slowest rank's values end up in the aggregate line
+
+inline void write_worker_result(const std::string& idf, int rank, int frames, double seconds, double cpu_seconds = 0.0, DistTimes dt = DistTimes())
 {
     const std::string f = idf + ".rank" + std::to_string(rank);
-    char line[96]; const int n = snprintf(line, sizeof line, "%d %.6f %.6f\n", frames, seconds, cpu_seconds);
+    char line[160]; const int n = snprintf(line, sizeof line, "%d %.6f %.6f %.4f %.3f\n", frames, seconds, cpu_seconds, dt.bcast_ms, dt.init_ms);
     if (!write_private_file(f, line, (size_t)n)) fprintf(stderr, "cannot write %s\n", f.c_str());
 }
 
 // worker side: rank 0 parses + packs, everybody receives the blob(s) over RCCL and builds its network(s) on `device`
 inline void load_models_dist(int rank, int world, const std::string& idf, int device, const std::string& vid_path, const std::string& img_path,
-                             fav_net** net, fav_net** net_img, size_t nstreams, int nwriters)
+                             fav_net** net, fav_net** net_img, size_t nstreams, int nwriters, DistTimes* times = nullptr)
 {
     ncclUniqueId id;
     std::vector<uint8_t> blob, blob_img;
@@ -315,7 +352,11 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
         fclose(f);
     }
     ncclComm_t comm;
-    ncheck(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;                                           // every call returns at once; nccl_wait polls with a deadline
+    const auto ti = std::chrono::steady_clock::now();
+    nccl_wait(comm, ncclCommInitRankConfig(&comm, world, id, rank, &cfg), "ncclCommInitRank", rank);
+    const double ims = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count();
     hipStream_t bst; if (hipStreamCreate(&bst) != hipSuccess) die("hipStreamCreate failed");
     const auto tb = std::chrono::steady_clock::now();
     broadcast_blob(comm, rank, blob, bst);
@@ -323,8 +364,9 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
     const double bms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
     if (fav_net_create_from_blob(blob.data(), blob.size(), device, net)) die(fav_last_error());
     if (!blob_img.empty() && fav_net_create_from_blob(blob_img.data(), blob_img.size(), device, net_img)) die(fav_last_error());
-    printf("[rank %d/%d gpu %d] weights: %zu B%s via ncclBroadcast from rank 0 in %.2f ms; %zu stream(s), %d PNG writers\n", rank, world, device,
-           blob.size(), blob_img.empty() ? "" : " (+ image model)", bms, nstreams, nwriters);
+    printf("[rank %d/%d gpu %d] weights: %zu B%s via ncclBroadcast from rank 0 in %.2f ms (communicator up in %.0f ms); %zu stream(s), %d PNG writers\n", rank, world, device,
+           blob.size(), blob_img.empty() ? "" : " (+ image model)", bms, ims, nstreams, nwriters);
+    if (times) { times->bcast_ms = bms; times->init_ms = ims; }
     hipStreamDestroy(bst);
     ncclCommDestroy(comm);
 }

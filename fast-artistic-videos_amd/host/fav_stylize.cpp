@@ -793,10 +793,11 @@ int main(int argc, char** argv)
     if (hipSetDevice(device) != hipSuccess) die("cannot select GPU " + std::to_string(device));
     const bool want_img = o.s("model_img") != "self";
     fav_net* net = nullptr; fav_net* net_img = nullptr;                                                      // core.lua:39-66
+    favl::DistTimes dist_times;
     if (dist) {
         // rank 0 parses; the other ranks never open the .t7
         favl::load_models_dist(rank, world, o.s("rccl_id_file"), device, o.s("model_vid"), want_img ? o.s("model_img") : std::string(), &net, &net_img,
-                               mine.size(), nwriters);
+                               mine.size(), nwriters, &dist_times);
     } else {
         if (fav_net_create(o.s("model_vid").c_str(), device, &net)) die(fav_last_error());                   // core.lua:39-43
         if (want_img && fav_net_create(o.s("model_img").c_str(), device, &net_img)) die(fav_last_error());
@@ -825,7 +826,7 @@ int main(int argc, char** argv)
     check(fav_net_check(net), "at exit");
     if (net_img) check(fav_net_check(net_img), "at exit (image model)");
     if (o.i("timing")) printf("thread CPU seconds (live threads, whole process): %s\n", thread_cpu_report().c_str());
-    if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds, cpu_seconds);
+    if (dist && o.i("timing")) favl::write_worker_result(o.s("rccl_id_file"), rank, frames, seconds, cpu_seconds, dist_times);
     fflush(stdout);
     fav_net_destroy(net); fav_net_destroy(net_img);
     return 0;

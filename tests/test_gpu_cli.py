@@ -219,6 +219,111 @@ def test_fav_stylize_loop_flags(oracle, favlib, tmp_path, golden_dir):
     assert os.path.exists(tmp_path / "a" / "out-00004.png")
 
 
+def test_fav_stylize_backward(oracle, favlib, tmp_path, golden_dir):
+    """-backward (fast_artistic_video_core.lua:189-191): the loop runs i = num_frames-1, ..., 1 with the SAME file-name rule
+    ({i-1}, [i]); frame num_frames-1 has no previous output (the reference dereferences a nil last_frame_stylized there: here it is
+    stylised without a prior, as -continue_with without a saved frame), frame 1 is a single image by fast_artistic_video.lua:172."""
+    from PIL import Image
+    h, w, n = 48, 64, 4
+    frames, bws, fws = _write_clip(oracle, tmp_path, h, w, n, 90)
+    model = os.path.join(golden_dir, "tiny_model.t7")
+    layers = t7.extract_layers(t7.load(model)["model"])
+    f01 = lambda u8: np.transpose(u8, (2, 0, 1)).astype(np.float32) / np.float32(255)
+    r = subprocess.run([os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"), "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
+                        "-forward_flow_pattern", str(tmp_path / "flow" / "forward_{%d}_[%d].flo"), "-structure", "0", "-model_vid", model, "-model_img", "self", "-gpu", "0",
+                        "-output_prefix", str(tmp_path / "o" / "out"), "-backward", "-num_frames", str(n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(tmp_path / "o" / f"out-{n:05d}.png")                       # start index is num_frames - 1
+    order = [int(l.split("-")[-1].split(".")[0]) for l in r.stdout.splitlines() if l.startswith("Writing output image")]
+    assert order == [3, 2, 1], order
+    ref = oracle.Stylizer(layers)
+    want = {3: ref.first(f01(frames[2]))}
+    m = oracle.consistency(bws[1], fws[1])
+    want[2] = ref.next(f01(frames[1]), bws[1], m.astype(np.float32) / np.float32(255))
+    want[1] = oracle.Stylizer(layers).first(f01(frames[0]))
+    for i in (3, 2, 1):
+        got = np.asarray(Image.open(str(tmp_path / "o" / f"out-{i:05d}.png")))
+        assert np.abs(got.astype(int) - oracle.to_u8_hwc(want[i]).astype(int)).max() <= 1, i
+
+
+MODES = ["3arg", "4arg_lookahead", "cert_via_th_shim", "3arg_two_cpus"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_fav_stylize_config3_content_at_speed(oracle, favlib, cuda, mode):
+    """The bytes behind the end-to-end number (missing 1): BASELINE config 3 -- 300 frames of 1280x720 through
+    bin/fav_stylize at full rate, RAM-backed files, canonical architecture -- in the four ways the bench and the reference's drivers
+    run it: fused 3-argument check (the headline leg), -structure 1 with two frames of look-ahead, the certainty path with .pgm files
+    written by the REFERENCE's checker (what stylizeVideo_deepflow.sh:87-96 passes, through the `th` shim), and confined to two CPUs.
+    EVERY PNG the CLI wrote must equal, byte for byte, the file the in-process fav_stream_* run of the same inputs produces (the GPU
+    path is bit-deterministic), and frames sampled over the clip, the last one included, are decoded and compared with the oracle
+    teacher-forced from the GPU's own previous frame (<= 1 LSB; what the CLI replaces: fast_artistic_video.lua:160-170 inside the
+    loop of fast_artistic_video_core.lua:194-211)."""
+    import shutil, sys, tempfile, json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import e2e_content as EC
+    if mode == "cert_via_th_shim" and not os.path.exists(EC.REF_CHECKER):
+        pytest.skip("oracle/_ref/consistencyChecker not built (needs /root/reference at build time)")
+    if not os.path.isdir("/dev/shm"):
+        pytest.skip("no /dev/shm")
+    H, W, N, ring = 720, 1280, 300, 4
+    frames_h = [synth.random_frame(H, W, 1234 + i) for i in range(ring)]
+    bw_h = [synth.backward_flow(H, W, 1244 + i) for i in range(ring)]
+    fw_h = [synth.forward_flow_from_backward(bw_h[i], 1254 + i) for i in range(ring)]
+    d = tempfile.mkdtemp(prefix="fav_c3_", dir="/dev/shm")
+    try:
+        ckpt = os.path.join(d, "canonical.t7")
+        t7.make_synthetic_checkpoint(ckpt, seed=1234)
+        layers = t7.extract_layers(t7.load(ckpt)["model"])
+        EC.make_clip_dir(d, "s0", frames_h, bw_h, fw_h, N, oracle, cert=(mode == "cert_via_th_shim"))
+        pkg = os.path.join(ROOT, "fast-artistic-videos_amd")
+        common = ["-input_pattern", f"{d}/s0/frame_%05d.ppm", "-flow_pattern", f"{d}/s0/flow/backward_[%d]_{{%d}}.flo"]
+        tail = ["-model_vid", ckpt, "-model_img", "self", "-gpu", "0", "-timing", "1", "-output_prefix", f"{d}/s0/o/out"]
+        fused = ["-forward_flow_pattern", f"{d}/s0/flow/forward_{{%d}}_[%d].flo"]
+        masks = None
+        if mode == "3arg":
+            cmd, rmode = [os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "0"] + tail, "3arg"
+        elif mode == "4arg_lookahead":
+            cmd, rmode = [os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "1"] + tail, "4arg"
+        elif mode == "cert_via_th_shim":
+            cmd = [os.path.join(pkg, "host", "th"), "fast_artistic_video.lua"] + common + ["-occlusions_pattern", f"{d}/s0/flow/reliable_[%d]_{{%d}}.pgm",
+                                                                                            "-backend", "cuda", "-use_cudnn", "1"] + tail
+            rmode, masks = "cert", [oracle.read_pnm(f"{d}/src/r{k}.pgm") for k in range(ring)]
+        else:
+            cmd, rmode = ["taskset", "-c", "0-1", os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "0"] + tail, "3arg"
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["frames"] == N
+        sampled = [2, 3, 40, 77, 150, 151, 222, 299, 300] if mode == "3arg" else [2, 150, 300]
+        net = favlib.Net(ckpt, 0)
+        ref = EC.reference_run(favlib, net, frames_h, bw_h, fw_h, N, rmode, masks_h=masks, keep=sampled, keep_states=sampled)
+        chk = EC.verify_dir(f"{d}/s0/o", "out", ref, N)
+        print(mode, "fps", line["fps_end_to_end"], chk)
+        assert chk["png_mismatch_frames"] == 0 and chk["png_missing_frames"] == 0 and chk["png_unexpected_files"] == 0, chk
+        # sampled frames, teacher-forced against the oracle: the decoded FILE the CLI wrote vs the oracle's frame from the GPU's previous state
+        import parity_clip
+        oracle.set_threads(parity_clip.effective_cpus())
+        f01 = lambda u8: np.transpose(u8, (2, 0, 1)).astype(np.float32) / np.float32(255)
+        worst = 0
+        for i in sampled:
+            k = i % ring
+            before, after = ref.states[i]
+            st = oracle.Stylizer(layers); st.last = before
+            if rmode == "cert": m = masks[k]
+            else: m = oracle.consistency(bw_h[k], fw_h[k], frames_h[k] if rmode == "4arg" else None)
+            want = st.next(f01(frames_h[k]), bw_h[k], m.astype(np.float32) / np.float32(255))
+            assert np.abs(want - after).max() <= 2e-4, (i, float(np.abs(want - after).max()))
+            got = EC.decode_png(open(f"{d}/s0/o/out-{i:05d}.png", "rb").read())
+            lsb = int(np.abs(got.astype(int) - oracle.to_u8_hwc(want).astype(int)).max())
+            worst = max(worst, lsb)
+            assert lsb <= 1, (i, lsb)
+        print(mode, "sampled frames vs oracle: worst", worst, "LSB over", len(sampled), "frames")
+    finally:
+        oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def test_fav_stylize_vr_matches_oracle(oracle, favlib, tmp_path, golden_dir):
     """`th fast_artistic_video_vr.lua` contract (stylizeVRVideo_deepflow.sh:68-83 patterns): two frames of six faces, files named
     by face id in processing order {6,1,2,5,3,4}; the equirectangular and cube-map PNGs are compared with oracle/vr_oracle.py."""
