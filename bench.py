@@ -106,9 +106,36 @@ def reference_checker_baseline(bw, fw, frame):
             for _ in range(3):
                 t0 = time.perf_counter(); subprocess.check_call(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); ts.append(time.perf_counter() - t0)
             res[name] = min(ts)
-        return {"kind": "reference", "cores": 1, "unit": "masks/s", "value": round(1.0 / res["3arg"], 3), "value_4arg": round(1.0 / res["4arg"], 3),
-                "sample": "consistencyChecker (reference sources, g++ -O3) on one 1280x720 flow pair incl. .flo read + .pgm write on /dev/shm, "
-                          "min of 3: %.3f s (3-arg) / %.3f s (4-arg, image structure)" % (res["3arg"], res["4arg"])}
+        out = {"kind": "reference", "cores": 1, "unit": "masks/s", "value": round(1.0 / res["3arg"], 3), "value_4arg": round(1.0 / res["4arg"], 3),
+               "sample": "consistencyChecker (reference sources, g++ -O3) on one 1280x720 flow pair incl. .flo read + .pgm write on /dev/shm, "
+                         "min of 3: %.3f s (3-arg) / %.3f s (4-arg, image structure)" % (res["3arg"], res["4arg"])}
+        # the process-level drop-in timed the way the reference's driver calls it (makeOptFlow_deepflow.sh:59-60: one process per mask),
+        # and its list mode (one GPU context for N pairs); outputs compared byte for byte with the reference binary's
+        mine = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "consistencyChecker")
+        if os.path.exists(mine):
+            o2 = os.path.join(d, "out2.pgm")
+            drop, want = {}, {}
+            for name, extra in (("3arg", []), ("4arg", [i])):
+                subprocess.check_call([exe, a, b, o] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                want[name] = open(o, "rb").read()
+                ts = []
+                for _ in range(4):
+                    t0 = time.perf_counter(); subprocess.check_call([mine, a, b, o2] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); ts.append(time.perf_counter() - t0)
+                drop[name + "_s_per_call"] = round(min(ts[1:]), 4); drop[name + "_first_call_s"] = round(ts[0], 4)
+                drop[name + "_bytes_equal_reference"] = open(o2, "rb").read() == want[name]
+            npairs = 40
+            for name, extra in (("3arg", []), ("4arg", [i])):
+                lst = os.path.join(d, "pairs_%s.txt" % name)
+                with open(lst, "w") as f:
+                    for k in range(npairs):
+                        f.write(" ".join([a, b, os.path.join(d, "bo_%d.pgm" % k)] + extra) + "\n")
+                t0 = time.perf_counter(); subprocess.check_call([mine, "-batch", lst], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); dt = time.perf_counter() - t0
+                drop[name + "_batch_s_per_pair"] = round(dt / npairs, 5)
+                drop[name + "_batch_bytes_equal_reference"] = all(open(os.path.join(d, "bo_%d.pgm" % k), "rb").read() == want[name] for k in (0, npairs // 2, npairs - 1))
+            drop["note"] = ("bin/consistencyChecker (this repo, mask on the GPU) as a process: same argv, wall time per call incl. HIP context creation, file reads and the .pgm write on /dev/shm "
+                            "(min of 3 after one warm-up call); `-batch list.txt` = %d pairs in one process.  Reference binary beside it: %.3f / %.3f s per call" % (npairs, res["3arg"], res["4arg"]))
+            out["gpu_drop_in_process"] = drop
+        return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -6,10 +6,19 @@
 // once, atomically (the reference first writes an all-255 placeholder, :152, which races with the
 // polling consumer), and failures return a non-zero exit code instead of asserting.
 // Device selection: environment variable FAV_GPU (default 0).
+//
+// Additive: `consistencyChecker -batch <list.txt>` -- every line of the list is one call's arguments
+// (`<flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]`, blank-separated; `-` reads the list from stdin), processed in ONE process:
+// a single call pays for a HIP context (tens of milliseconds, more than the reference's whole CPU run of a 1280x720 pair), a list of
+// N pairs pays it once.  Each line's output path is printed as in the single-call form, one per line.  INTEGRATION.md section 1
+// shows the two-line change to makeOptFlow_deepflow.sh:45-66.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "../../include/fav.h"
@@ -20,10 +29,80 @@ static int fail(const char* what)
     return 1;
 }
 
+namespace {
+// one context, device buffers kept between pairs of the same size
+struct Batch {
+    int W = 0, H = 0; bool with_img = false;
+    float *d1 = nullptr, *d2 = nullptr; uint8_t *dimg = nullptr, *dout = nullptr; void* ws = nullptr; size_t wsb = 0;
+    std::vector<uint8_t> out;
+    void release() { hipFree(d1); hipFree(d2); hipFree(dimg); hipFree(dout); hipFree(ws); d1 = d2 = nullptr; dimg = dout = nullptr; ws = nullptr; }
+    int run(const std::vector<std::string>& a)
+    {
+        float *f1 = nullptr, *f2 = nullptr; uint8_t* img = nullptr;
+        int w1, h1, w2, h2;
+        if (fav_read_flo_host(a[0].c_str(), &f1, &w1, &h1)) return fail(a[0].c_str());
+        if (fav_read_flo_host(a[1].c_str(), &f2, &w2, &h2)) { fav_free_host(f1); return fail(a[1].c_str()); }
+        int rc = 0;
+        if (w1 != w2 || h1 != h2) { fprintf(stderr, "consistencyChecker: flow sizes differ\n"); rc = 1; }
+        if (!rc && a.size() >= 4) {
+            int wi, hi, ch;
+            if (fav_read_pnm_host(a[3].c_str(), &img, &wi, &hi, &ch)) rc = fail(a[3].c_str());
+            else if (wi != w1 || hi != h1 || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); rc = 1; }
+        }
+        const size_t n = (size_t)w1 * h1;
+        if (!rc && (w1 != W || h1 != H || (img != nullptr) != with_img)) {
+            release();
+            W = w1; H = h1; with_img = img != nullptr;
+            wsb = fav_consistency_workspace_bytes(W, H, with_img);
+            if (hipMalloc((void**)&d1, n * 8) || hipMalloc((void**)&d2, n * 8) || hipMalloc((void**)&dout, n) || hipMalloc((void**)&dimg, n * 3) ||
+                (wsb && hipMalloc(&ws, wsb))) { fprintf(stderr, "consistencyChecker: hipMalloc failed\n"); rc = 1; W = H = 0; }
+            out.resize(n);
+        }
+        if (!rc) {
+            hipMemcpy(d1, f1, n * 8, hipMemcpyHostToDevice);
+            hipMemcpy(d2, f2, n * 8, hipMemcpyHostToDevice);
+            if (img) hipMemcpy(dimg, img, n * 3, hipMemcpyHostToDevice);
+            if (fav_consistency_u8(d1, d2, img ? dimg : nullptr, dout, W, H, ws, wsb, nullptr)) rc = fail("fav_consistency_u8");
+            else if (hipMemcpy(out.data(), dout, n, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "consistencyChecker: device error\n"); rc = 1; }
+            else if (fav_write_pgm_host(a[2].c_str(), out.data(), W, H)) rc = fail(a[2].c_str());
+        }
+        fav_free_host(f1); fav_free_host(f2); fav_free_host(img);
+        return rc;
+    }
+};
+
+int batch_main(const char* list)
+{
+    FILE* f = strcmp(list, "-") == 0 ? stdin : fopen(list, "r");
+    if (!f) { fprintf(stderr, "consistencyChecker: cannot open %s\n", list); return 1; }
+    if (fav_device_count() <= 0) return fail("device");
+    const char* g = getenv("FAV_GPU");
+    if (hipSetDevice(g ? atoi(g) : 0) != hipSuccess) { fprintf(stderr, "consistencyChecker: cannot select GPU\n"); return 1; }
+    Batch b;
+    char line[16384];
+    int rc = 0, lineno = 0;
+    while (fgets(line, sizeof line, f)) {
+        ++lineno;
+        std::istringstream is(line);
+        std::vector<std::string> a; std::string tok;
+        while (is >> tok) a.push_back(tok);
+        if (a.empty() || a[0][0] == '#') continue;
+        if (a.size() < 3 || a.size() > 4) { fprintf(stderr, "consistencyChecker: %s:%d: expected <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n", list, lineno); rc = 2; break; }
+        if ((rc = b.run(a)) != 0) break;                          // as a sequence of single calls under `set -e`: stop at the first failure
+        printf("%s\n", a[2].c_str()); fflush(stdout);
+    }
+    if (f != stdin) fclose(f);
+    b.release();
+    return rc;
+}
+}  // namespace
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && strcmp(argv[1], "-batch") == 0) return batch_main(argv[2]);
     if (argc < 4) {
-        fprintf(stderr, "usage: consistencyChecker <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n");
+        fprintf(stderr, "usage: consistencyChecker <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n"
+                        "       consistencyChecker -batch <list.txt|->      (one such argument line per pair, one GPU context for all)\n");
         return 2;
     }
     float *f1 = nullptr, *f2 = nullptr;

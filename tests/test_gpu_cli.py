@@ -41,6 +41,16 @@ def test_consistency_checker_binary(oracle, favlib, tmp_path):
     assert r.returncode == 0
     assert open(o, "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw, img).tobytes()
     assert subprocess.run([exe, a, str(tmp_path / "missing.flo"), o]).returncode != 0
+    # list mode (additive): one argument line per pair, one GPU context; same bytes as the single calls, output paths echoed per line
+    lst = str(tmp_path / "pairs.txt")
+    o3, o4 = str(tmp_path / "b3.pgm"), str(tmp_path / "b4.pgm")
+    open(lst, "w").write(f"# pairs\n{a} {b} {o3}\n\n{a} {b} {o4} {i}\n")
+    r = subprocess.run([exe, "-batch", lst], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == [o3, o4], (r.stdout, r.stderr)
+    assert open(o3, "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw).tobytes()
+    assert open(o4, "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw, img).tobytes()
+    open(lst, "w").write(f"{a} {b} {o3}\n{a} {tmp_path / 'missing.flo'} {o4}\n")
+    assert subprocess.run([exe, "-batch", lst], capture_output=True).returncode != 0
 
 
 @pytest.mark.parametrize("fused", [False, True])
