@@ -10,11 +10,13 @@
 // flow2 (L2-served: the flow is locally smooth), one byte written.  17 algorithmic bytes / pixel.
 // 4-argument mode adds the image-structure term (computeCorners :39-78): gradient + second-moment
 // (parallel), the two recursive smoothing passes (one lane per row / per column, sequential along
-// the line exactly like CFilter.h:1416-1464), eigenvalue, CMatrix::normalize with its order
+// the line exactly like CFilter.h:1416-1464; iir_rows_kernel), eigenvalue, CMatrix::normalize with its order
 // dependent min/max quirk (CMatrix.h:721-737, reproduced with an exact parallel formulation) and
 // CMatrix::avg, an order-dependent fp32 running sum (CMatrix.h:1245-1251) evaluated exactly AND in parallel: inside one binade
 // the running sum is an integer multiple of its ulp, so every addend is a two-state (parity) transducer and the chain is a scan of
 // transducer compositions (avg_scan_kernel below; pinned against the scalar loop by test_sequential_sum_bit_exact).
+#include <mutex>
+
 #include "fav_internal.h"
 #include "consistency_pixel.h"
 
@@ -36,7 +38,8 @@ struct IIR { float k, pm, pp, e2, a2; };
 
 // gradient [-0.5,0,0.5] with edge-repeating mirror (CFilter.h:600-611,1499-1578), second-moment sums
 // over the 3 colour planes in plane order (consistencyChecker.cpp:54-60)
-__global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, float* dxx, float* dyy, float* dxy, int W, int H)
+// (the three planes are written with a row pitch `pw` that is a multiple of 4 floats: the smoothing passes read 16 bytes per lane)
+__global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, float* dxx, float* dyy, float* dxy, int W, int H, int pw)
 {
     const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
@@ -51,103 +54,171 @@ __global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, fl
         float dy = 0.f; dy += -0.5f * up; dy += 0.0f * mid; dy += 0.5f * dn;
         sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
     }
-    const size_t i = (size_t)y * W + x;
+    const size_t i = (size_t)y * pw + x;
     dxx[i] = sxx; dyy[i] = syy; dxy[i] = sxy;
 }
 
-// one lane per line; `n` samples with element stride `es`, line stride `ls`; scratch holds v1.
-// Arithmetic order exactly as CFilter.h:1426-1437 / 1451-1462.
-__global__ __launch_bounds__(256) void iir_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n,
-                                                 int es, int ls, IIR c)
+// recursiveSmoothX / recursiveSmoothY (CFilter.h:1416-1464): one LANE per line, the recurrences of :1426-1437 / :1451-1462 in their
+// exact order (they round at every step: nothing along a line can be re-associated), lines are independent.  Round 4: the line lies
+// CONTIGUOUS in memory (rows of the [H][pw] planes for the X pass, rows of the transposed [W][ph] planes for the Y pass) and travels
+// as 16-byte pieces per lane through a ring of NG register groups of 16 samples, requested NG-1 groups ahead.  Why: a pass is 34 / 60
+// waves, each alone on its SIMD -- a step is ~30 cycles of arithmetic, a memory round trip ~2000, and a wave may have at most 63
+// memory operations in flight (vmcnt).  With one dword per lane and step (the round-1..3 form, lanes side by side in the transposed
+// plane) that budget covers 63 steps; the compiler additionally consumed every group right behind its own loads (s_waitcnt
+// vmcnt(31), (30), ... in the ISA), so each group of 32 steps paid a full round trip: 130-240 us per pass where the arithmetic
+// needs ~40.  With four samples per operation the same budget reaches 250 steps ahead.  v1 (the causal half) goes to `scratch`.
+template <int NGF, int NGB>
+__global__ __launch_bounds__(64) void iir_rows_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n, int pitch, IIR c)
 {
-    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    const int line = blockIdx.x * 64 + threadIdx.x;
     if (line >= nlines || n < 2) return;
-    float* m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * ls;
-    float* v1 = scratch0 + (size_t)blockIdx.y * plane_stride + (size_t)line * ls;
-#define M_(i) m[(size_t)(i) * es]
-#define V1_(i) v1[(size_t)(i) * es]
-    float m0 = M_(0), m1 = M_(1);
-    float a0 = (0.5f - c.k * c.pm) * m0;
-    float a1 = c.k * (m1 + c.pm * m0) + (c.a2 - c.e2) * a0;
-    V1_(0) = a0; V1_(1) = a1;
-    float mp = m1;
-    int x = 2;
-    // The loads are independent of the recurrence, the kernel is latency-bound (one wave per 64 lines, ~35 waves in all):
-    // samples travel in groups of G, and the next group is already in flight while the chain runs over the current one.
-    constexpr int G = 32;
-    if (x + G <= n) {
-        float cur[G], nxt[G];
+    float* __restrict__ m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
+    float* __restrict__ v1 = scratch0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
+    constexpr int G = 16;
+    const float c0f = 0.5f - c.k * c.pm, cd = c.a2 - c.e2;
+    // ---------------------------------------------------------------- causal sweep, x = 0 .. n-1
+    {
+        const int ng = n / G;                                  // full groups [16 g, 16 g + 15]; the rest (< 16 samples) is the tail
+        float R[NGF][G];
+        float tl[G - 1];
 #pragma unroll
-        for (int q = 0; q < G; ++q) cur[q] = M_(x + q);
-        for (; x + G <= n; x += G) {
-            const bool more = x + 2 * G <= n;
-            if (more) {
+        for (int j = 0; j < G - 1; ++j) { const int x = ng * G + j; tl[j] = x < n ? m[x] : 0.f; }     // the tail, requested first
+        auto loadg = [&](float (&r)[G], int g) {
+            const float4* p = reinterpret_cast<const float4*>(m + (size_t)g * G);
 #pragma unroll
-                for (int q = 0; q < G; ++q) nxt[q] = M_(x + G + q);
+            for (int j = 0; j < 4; ++j) { const float4 q = p[j]; r[4 * j] = q.x; r[4 * j + 1] = q.y; r[4 * j + 2] = q.z; r[4 * j + 3] = q.w; }
+        };
+#pragma unroll
+        for (int k = 0; k < NGF; ++k) if (k < ng) loadg(R[k], k);
+        float a0 = 0.f, a1 = 0.f, mp = 0.f;
+        // x = 0: v1 = (0.5 - k pm) m0;  x = 1: v1 = k (m1 + pm m0) + (a2 - e2) v1(0);  then the three-term recurrence
+        auto step = [&](float mx) {
+            const float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+            a0 = a1; a1 = a; mp = mx;
+            return a;
+        };
+        auto step01 = [&](float mx, int x) {                   // positions that may be the line's first two
+            float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+            if (x < 2) a = x == 0 ? c0f * mx : c.k * (mx + c.pm * mp) + cd * a1;
+            a0 = a1; a1 = a; mp = mx;
+            return a;
+        };
+        auto chain = [&](const float (&r)[G], int g) {
+            float4* o = reinterpret_cast<float4*>(v1 + (size_t)g * G);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 w;
+                w.x = j ? step(r[4 * j]) : step01(r[0], g * G); w.y = j ? step(r[4 * j + 1]) : step01(r[1], g * G + 1);
+                w.z = step(r[4 * j + 2]); w.w = step(r[4 * j + 3]);
+                o[j] = w;
             }
+            // the sample the next group's first step needs must not LIVE in the ring: the slot is refilled right behind this chain, and a
+            // value left there is rescued by the compiler only after the refill -- behind a wait for the load just issued
+            asm volatile("v_mov_b32 %0, %1" : "=v"(mp) : "v"(r[G - 1]));
+        };
+        // whole rounds: the slot just consumed takes the group NGF further on -- UNCONDITIONALLY (the index is clamped; the last round
+        // re-requests the last group): a conditional refill makes the slot's registers a phi of "loaded" and "stale", which the
+        // compiler resolves with a copy behind the load, i.e. a wait for the load it has just issued (s_waitcnt vmcnt(3) in the ISA)
+        int gb = 0;
+        for (; gb + NGF <= ng; gb += NGF) {
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const float a = c.k * (cur[q] + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
-                V1_(x + q) = a; a0 = a1; a1 = a; mp = cur[q];
+            for (int k = 0; k < NGF; ++k) {
+                // (fences: left alone, the scheduler hoists the recurrence-free products of ALL slots to the top of the round -- and
+                //  with them a wait for the slot requested a moment ago)
+                __builtin_amdgcn_sched_barrier(0);
+                chain(R[k], gb + k);
+                __builtin_amdgcn_sched_barrier(0);
+                loadg(R[k], min(gb + k + NGF, ng - 1));
             }
-#pragma unroll
-            for (int q = 0; q < G; ++q) cur[q] = nxt[q];
         }
-    }
-    for (; x < n; ++x) {
-        const float mx = M_(x);
-        const float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
-        V1_(x) = a; a0 = a1; a1 = a; mp = mx;
-    }
-    // backward sweep: keep the ORIGINAL m(x+1), m(x+2) in registers while m is overwritten
-    const float ml = M_(n - 1);
-    float b1 = (0.5f + c.k * c.pm) * ml;                                   // v2(n-1)
-    float b0 = c.k * ((c.pp - c.e2) * ml) + (c.a2 - c.e2) * b1;            // v2(n-2)
-    float mo1 = M_(n - 2);                                                 // original m(n-2)
-    float mo2 = ml;                                                        // original m(n-1)
-    M_(n - 1) = V1_(n - 1) + b1;
-    M_(n - 2) = V1_(n - 2) + b0;
-    // now b0 = v2(x+1), b1 = v2(x+2) for x = n-3; mo1 = m(x+1), mo2 = m(x+2)
-    int xb = n - 3;
-    if (xb - (G - 1) >= 0) {
-        float cm[G], cv[G], nm[G], nv[G];
 #pragma unroll
-        for (int q = 0; q < G; ++q) { cm[q] = M_(xb - q); cv[q] = V1_(xb - q); }
-        for (; xb - (G - 1) >= 0; xb -= G) {
-            const bool more = xb - (2 * G - 1) >= 0;
-            if (more) {
+        for (int k = 0; k < NGF; ++k) if (gb + k < ng) chain(R[k], gb + k);
 #pragma unroll
-                for (int q = 0; q < G; ++q) { nm[q] = M_(xb - G - q); nv[q] = V1_(xb - G - q); }
+        for (int j = 0; j < G - 1; ++j) { const int x = ng * G + j; if (x < n) v1[x] = step01(tl[j], x); }
+    }
+    // ---------------------------------------------------------------- anti-causal sweep, x = n-1 .. 0; m is overwritten with v1 + v2
+    {
+        const int ng = (n - 2) / G;                            // full groups below the head; the head [16 ng, n) has 2 .. 17 samples
+        constexpr int HN = G + 2;
+        float hm[HN], hv[HN];
+#pragma unroll
+        for (int j = 0; j < HN; ++j) { const int x = n - 1 - j; const bool in = x >= ng * G; hm[j] = in ? m[x] : 0.f; hv[j] = in ? v1[x] : 0.f; }
+        float Rm[NGB][G], Rv[NGB][G];
+        auto loadg = [&](float (&rm)[G], float (&rv)[G], int g) {
+            const float4* p = reinterpret_cast<const float4*>(m + (size_t)g * G);
+            const float4* pv = reinterpret_cast<const float4*>(v1 + (size_t)g * G);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 q = p[j], u = pv[j];
+                rm[4 * j] = q.x; rm[4 * j + 1] = q.y; rm[4 * j + 2] = q.z; rm[4 * j + 3] = q.w;
+                rv[4 * j] = u.x; rv[4 * j + 1] = u.y; rv[4 * j + 2] = u.z; rv[4 * j + 3] = u.w;
             }
+        };
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
+        for (int k = 0; k < NGB; ++k) if (ng - 1 - k >= 0) loadg(Rm[k], Rv[k], ng - 1 - k);
+        // v2(n-1) = (0.5 + k pm) m(n-1);  v2(n-2) = k ((pp - e2) m(n-1)) + (a2 - e2) v2(n-1);  then the recurrence on the ORIGINAL m
+        float b0 = 0.f, b1 = 0.f, mo1 = 0.f, mo2 = 0.f;          // b0 = v2(x+1), b1 = v2(x+2), mo1 = m(x+1), mo2 = m(x+2)
+        const float c1f = 0.5f + c.k * c.pm, cpe = c.pp - c.e2;
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+            const int x = n - 1 - j;
+            if (x >= ng * G) {
+                float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
+                if (j == 0) bv = c1f * hm[0];
+                if (j == 1) bv = c.k * (cpe * mo1) + cd * b0;
+                m[x] = hv[j] + bv;
+                b1 = b0; b0 = bv; mo2 = mo1; mo1 = hm[j];
+            }
+        }
+        auto chain = [&](const float (&rm)[G], const float (&rv)[G], int g) {
+            float4* o = reinterpret_cast<float4*>(m + (size_t)g * G);
+            float out[G];
+#pragma unroll
+            for (int q = G - 1; q >= 0; --q) {
                 const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-                M_(xb - q) = cv[q] + bv;
-                b1 = b0; b0 = bv; mo2 = mo1; mo1 = cm[q];
+                out[q] = rv[q] + bv;
+                b1 = b0; b0 = bv; mo2 = mo1; mo1 = rm[q];
             }
 #pragma unroll
-            for (int q = 0; q < G; ++q) { cm[q] = nm[q]; cv[q] = nv[q]; }
+            for (int j = 3; j >= 0; --j) o[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mo1), "=&v"(mo2) : "v"(rm[0]), "v"(rm[1]));      // (as above)
+        };
+        int gb = 0;
+        for (; gb + NGB <= ng; gb += NGB) {
+#pragma unroll
+            for (int k = 0; k < NGB; ++k) {
+                const int g = ng - 1 - (gb + k);
+                __builtin_amdgcn_sched_barrier(0);
+                chain(Rm[k], Rv[k], g);
+                __builtin_amdgcn_sched_barrier(0);
+                loadg(Rm[k], Rv[k], max(g - NGB, 0));
+            }
         }
+#pragma unroll
+        for (int k = 0; k < NGB; ++k) if (ng - 1 - (gb + k) >= 0) chain(Rm[k], Rv[k], ng - 1 - (gb + k));
     }
-    for (; xb >= 0; --xb) {
-        const float mx = M_(xb);
-        const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-        M_(xb) = V1_(xb) + bv;
-        b1 = b0; b0 = bv; mo2 = mo1; mo1 = mx;
-    }
-#undef M_
-#undef V1_
 }
 
-__global__ __launch_bounds__(256) void eigen_kernel(const float* dxx, const float* dyy, const float* dxy, float* corners,
-                                                    size_t n)
+// eigenvalue (consistencyChecker.cpp:69-77) read from the TRANSPOSED smoothed planes [W][ph] (the Y pass runs on them) and written
+// in image order [H][W] -- the order CMatrix::normalize's scan and CMatrix::avg depend on: a 32x32 tile of the three planes through LDS
+__global__ __launch_bounds__(256) void eigen_t_kernel(const float* t3, size_t ps, float* corners, int H, int W, int ph)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float a = dxx[i], b = dxy[i], c = dyy[i];
-    const float temp = (float)(0.5 * (double)(a + c));                      // consistencyChecker.cpp:73
-    const float temp2 = temp * temp + b * b - a * c;
-    corners[i] = temp2 < 0.0f ? 0.0f : temp - sqrtf(temp2);
+    __shared__ float tl[3][32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;      // x (column) and y (row) origin of the tile
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = 0; p < 3; ++p)
+        for (int j = ty; j < 32; j += 8)
+            if (c0 + j < W && r0 + tx < H) tl[p][j][tx] = t3[(size_t)p * ps + (size_t)(c0 + j) * ph + r0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int y = r0 + j, x = c0 + tx;
+        if (y < H && x < W) {
+            const float a = tl[0][tx][j], c = tl[1][tx][j], b = tl[2][tx][j];        // dxx, dyy, dxy
+            const float temp = (float)(0.5 * (double)(a + c));                      // consistencyChecker.cpp:73
+            const float temp2 = temp * temp + b * b - a * c;
+            corners[(size_t)y * W + x] = temp2 < 0.0f ? 0.0f : temp - sqrtf(temp2);
+        }
+    }
 }
 
 // CMatrix::normalize's scan (CMatrix.h:727-729):
@@ -203,10 +274,20 @@ __global__ __launch_bounds__(256) void quirkmin_kernel(const float* v, size_t n,
     const size_t base = (size_t)blockIdx.x * NB;
     for (int j = threadIdx.x; j < NB; j += 256) sh[j] = base + j < n ? v[base + j] : -INFINITY;
     __syncthreads();
-    // each thread owns 4 consecutive elements; running max of everything before them
+    // each thread owns 4 consecutive elements; running max of everything before them: exclusive prefix max over the 256 threads'
+    // own maxima (max is exact and associative: wave scan by shuffles, then the waves before this one) -- the first version re-read
+    // up to 1020 LDS words per thread (0.15 ms per mask)
     const int j0 = threadIdx.x * 4;
-    float pre = -INFINITY;
-    for (int j = 0; j < j0; ++j) pre = fmaxf(pre, sh[j]);   // small (<= 1020 LDS reads); exactness over speed
+    __shared__ float wmax[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float inc = fmaxf(fmaxf(sh[j0], sh[j0 + 1]), fmaxf(sh[j0 + 2], sh[j0 + 3]));
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(inc, o); if (lane >= o) inc = fmaxf(inc, up); }
+    if (lane == 63) wmax[wv] = inc;
+    __syncthreads();
+    float pre = __shfl_up(inc, 1);
+    if (lane == 0) pre = -INFINITY;
+    for (int k = 0; k < wv; ++k) pre = fmaxf(pre, wmax[k]);
     pre = fmaxf(pre, bpre[blockIdx.x]);
     float mn = 30000.0f;
     for (int j = j0; j < j0 + 4; ++j) {
@@ -299,7 +380,9 @@ __device__ __forceinline__ Xd xd_shfl_up(const Xd& v, int off)
     return r;
 }
 
-__global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, float* avg_out, float* sum_out)
+// (`start`: optional {index, sum bits} left by avg_chunk_scan_kernel below -- this kernel then finishes from there; with the whole
+//  array behind it only the final store is left)
+__global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, float* avg_out, float* sum_out, const int* start)
 {
     constexpr int NT = 1024, E = 16, WIN = NT * E, NW = NT / 64;
     __shared__ int wD[2][NW], wPP[NW];                       // per-wave totals, then their exclusive scan
@@ -308,7 +391,7 @@ __global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, f
     __shared__ float s_sum;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const Xd ident = {0, 0, 2};                              // parity 0 -> 0, 1 -> 1
-    if (t == 0) { s_sum = 0.f; s_i = 0; s_stretch = 256; }
+    if (t == 0) { s_sum = start ? __int_as_float(start[1]) : 0.f; s_i = start ? start[0] : 0; s_stretch = 256; }
     __syncthreads();
     for (;;) {
         const float s = s_sum; const int i = s_i;
@@ -410,12 +493,194 @@ __global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, f
     if (t == 0) { const float s = s_sum; if (sum_out) *sum_out = s; if (avg_out) *avg_out = s / (float)n; }
 }
 
-// recursiveSmoothX through LDS: a block owns 64 rows; 64x64 tiles are moved with coalesced row-major accesses and each
-// lane walks ITS row inside the tile (LDS pitch 65: conflict-free column walk), so the sequential recurrences of
-// CFilter.h:1426-1437 keep their exact order while global memory sees full lines.
-// [R][C] -> [C][R] per plane (32x32 LDS tiles, both sides coalesced); lets the X smoothing pass run as the coalesced
-// one-lane-per-line kernel on the transposed planes without changing a single floating-point operation
-__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, size_t plane_stride, int R, int C)
+// ---- the same sum on MANY blocks (round 4) ---------------------------------------------------------------------------------------
+// The one-block scan above walks the array window by window: 57 dependent windows of ~14 us at 1280x720 = 0.8 ms on ONE CU, more
+// than half of a 4-argument mask.  What is sequential about the sum is only WHICH BINADE the running sum is in when an element
+// arrives (the element's transducer depends on the sum's exponent e) -- and that can be predicted: the exact prefix sums (fp64, per
+// chunk of 256 elements) tell the exponent at every chunk to within the running sum's own rounding drift.  So:
+//   1. avg_chunk_sum_kernel   (n/256 waves, all CUs): fp64 sum of every chunk + "has an element the transducer cannot take" flag;
+//   2. avg_chunk_class_kernel (n/256 waves): exclusive fp64 prefix P_c of the chunk sums (every block re-adds the sums before it:
+//      28 KB from L2), candidate exponents e_lo = exponent(0.97 P_c) and e_lo + 1 (if (P_c + T_c) * 1.03 reaches it), and the chunk's
+//      256 elements composed into ONE transducer per candidate (4 elements per lane, wave scan by shuffles);
+//   3. avg_chunk_scan_kernel  (one block): state = the exact running sum S.  1024 chunk transducers at a time for S's actual
+//      exponent, block-wide scan, first chunk whose end could leave the binade (or that has no transducer for this exponent): every
+//      chunk before it is absorbed in one step (S = ldexp(M + D)), that chunk is added natively (256 real fp32 additions by one
+//      lane), on to the next 1024.  ~15 rounds instead of 57 windows, each a scan of 1024 three-word items instead of 16384 elements;
+//   4. avg_scan_kernel (above) as the finisher from the state step 3 leaves: if step 3 met something outside its premise (negative /
+//      non-finite elements, a running sum that stays zero or stagnates far below the prediction) it stops THERE and the one-block
+//      kernel, whose every path is pinned by test_sequential_sum_bit_exact, takes over; otherwise it only stores the result.
+// A wrong prediction costs time, never bits: step 3 uses a chunk's transducer only for the exponent it was built for.  The scheme
+// (margins, crossing rule, hand-over) is pinned on the CPU by a numpy restatement: tests/test_cpu_oracle.py.
+constexpr int ACH = 256;                                      // elements per chunk (one wave, a float4 per lane)
+struct ChunkXd { int e_lo, flags, d0[2], d1[2], pp[2]; };     // flags: bit 0 slot 0 valid, bit 1 slot 1 valid, bit 8 bad element
+
+__global__ __launch_bounds__(256) void avg_chunk_sum_kernel(const float* v, int n, double* csum, int* cbad)
+{
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int base = chunk * ACH + lane * 4;
+    if (chunk * ACH >= n) return;
+    float x[4];
+    if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
+    else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }
+    double t = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
+    int bad = 0;
+    for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(x[j]); bad |= (int)(b >> 31) | (int)(((b >> 23) & 255u) == 255u); }
+    for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); bad |= __shfl_xor(bad, o); }
+    if (lane == 0) { csum[chunk] = t; cbad[chunk] = bad; }
+}
+
+__device__ __forceinline__ int f32_exponent_of(double p)     // exponent field of p rounded to fp32 (0 if zero / denormal / not finite)
+{
+    const float f = (float)p;
+    const int e = (int)(__float_as_uint(f) >> 23) & 255;
+    return (f > 0.f && e >= 1 && e <= 254) ? e : 0;
+}
+
+__global__ __launch_bounds__(256) void avg_chunk_class_kernel(const float* v, int n, const double* csum, const int* cbad, int nchunks, ChunkXd* out)
+{
+    __shared__ double red[4];
+    __shared__ double s_pre;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int chunk0 = blockIdx.x * 4;
+    // exclusive prefix of the chunk sums at this block's first chunk (the estimate only steers the choice of exponents)
+    double acc = 0.0;
+    for (int j = t; j < chunk0; j += 256) acc += csum[j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (t == 0) s_pre = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const int chunk = chunk0 + wave;
+    if (chunk >= nchunks) return;
+    double P = s_pre;
+    for (int j = 0; j < wave; ++j) P += csum[chunk0 + j];
+    const double T = csum[chunk];
+    const int e_lo = f32_exponent_of(P * 0.96875), e_hi = f32_exponent_of((P + T) * 1.03125);
+    const int base = chunk * ACH + lane * 4;
+    float x[4];
+    if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
+    else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }      // (padding zeros are identity transducers)
+    ChunkXd r; r.e_lo = e_lo; r.flags = cbad[chunk] ? 256 : 0;
+    const int nslots = (e_lo == 0 || cbad[chunk]) ? 0 : (e_hi > e_lo ? 2 : 1);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        r.d0[sl] = 0; r.d1[sl] = 0; r.pp[sl] = 2;
+        if (sl >= nslots) continue;                          // (wave-uniform)
+        const int e = e_lo + sl;
+        int d0 = 0, d1 = 0, p0 = 0, p1 = 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f, g, tie; elem_class(x[j], e, f, g, tie);
+            const int fo = f & 1;
+            const int dl0 = f + g + (tie & (p0 ^ fo)), dl1 = f + g + (tie & (p1 ^ fo));
+            d0 = sat_add(d0, dl0); p0 = (p0 + dl0) & 1;
+            d1 = sat_add(d1, dl1); p1 = (p1 + dl1) & 1;
+        }
+        Xd inc = {d0, d1, p0 | (p1 << 1)};
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const Xd a = xd_shfl_up(inc, off); if (lane >= off) inc = xd_then(a, inc); }
+        r.d0[sl] = __shfl(inc.d0, 63); r.d1[sl] = __shfl(inc.d1, 63); r.pp[sl] = __shfl(inc.pp, 63);
+        r.flags |= 1 << sl;
+    }
+    if (lane == 0) out[chunk] = r;
+}
+
+__global__ __launch_bounds__(1024) void avg_chunk_scan_kernel(const float* v, int n, const ChunkXd* cx, int nchunks, int* state_out)
+{
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ int wD[2][NW], wPP[NW];
+    __shared__ __attribute__((aligned(16))) float sX[ACH];
+    __shared__ int s_first, s_ci, s_stop, s_miss;
+    __shared__ float s_sum;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const Xd ident = {0, 0, 2};
+    if (t == 0) { s_sum = 0.f; s_ci = 0; s_stop = 0; s_miss = 0; }
+    __syncthreads();
+    for (;;) {
+        const float s = s_sum; const int ci = s_ci; const int stop = s_stop;
+        if (ci >= nchunks || stop) break;
+        __syncthreads();                                   // everyone has read the state
+        if (t == 0) s_first = NT;
+        const unsigned bits = __float_as_uint(s);
+        const int e = (int)(bits >> 23) & 255;
+        const bool ok = s > 0.f && e >= 1 && e <= 254;
+        const int M = (int)((bits & 0x7FFFFFu) | 0x800000u);
+        const int limit = (1 << 24) - M;
+        const int c = ci + t;
+        Xd me = ident; bool usable = false, bad = false;
+        if (c < nchunks) {
+            const ChunkXd q = cx[c];
+            const int sl = e - q.e_lo;
+            bad = (q.flags & 256) != 0;
+            usable = ok && !bad && sl >= 0 && sl < 2 && ((q.flags >> sl) & 1);
+            if (usable) { me.d0 = q.d0[sl]; me.d1 = q.d1[sl]; me.pp = q.pp[sl]; }
+        }
+        Xd inc = me;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const Xd a = xd_shfl_up(inc, off); if (lane >= off) inc = xd_then(a, inc); }
+        if (lane == 63) { wD[0][wave] = inc.d0; wD[1][wave] = inc.d1; wPP[wave] = inc.pp; }
+        __syncthreads();
+        if (wave == 0) {
+            const bool in = lane < NW;
+            Xd wi = ident;
+            if (in) { wi.d0 = wD[0][lane]; wi.d1 = wD[1][lane]; wi.pp = wPP[lane]; }
+#pragma unroll
+            for (int off = 1; off < NW; off <<= 1) { const Xd a = xd_shfl_up(wi, off); if (lane >= off) wi = xd_then(a, wi); }
+            Xd ex = xd_shfl_up(wi, 1);
+            if (lane == 0) ex = ident;
+            if (in) { wD[0][lane] = ex.d0; wD[1][lane] = ex.d1; wPP[lane] = ex.pp; }
+        }
+        __syncthreads();
+        const int par0 = M & 1;
+        Xd pre = {wD[0][wave], wD[1][wave], wPP[wave]};
+        { Xd exl = xd_shfl_up(inc, 1); if (lane == 0) exl = ident; pre = xd_then(pre, exl); }
+        const int dbefore = par0 ? pre.d1 : pre.d0;          // ulps added by the chunks ci .. c-1 (true start parity)
+        const int pin = (pre.pp >> par0) & 1;
+        const int dmine = pin ? me.d1 : me.d0;
+        // the chunk cannot be absorbed: no transducer for this exponent, or one of its elements might leave the binade
+        // (every prefix inside the chunk is <= dbefore + dmine: increments are non-negative)
+        const bool hit = c < nchunks && (!usable || sat_add(sat_add(dbefore, dmine), 1) >= limit);
+        if (hit) atomicMin(&s_first, t);
+        __syncthreads();
+        const int first = s_first;                         // window-relative index of the first chunk that needs native treatment
+        const int cnt = nchunks - ci < NT ? nchunks - ci : NT;
+        const int owner = first < cnt ? first : cnt - 1;
+        // the native chunk's elements into LDS (coalesced), while the owner forms the sum in front of it
+        const int nc = ci + first;
+        if (first < cnt && t < ACH) { const int idx = nc * ACH + t; sX[t] = idx < n ? v[idx] : 0.f; }
+        __syncthreads();
+        if (t == owner) {
+            const int dabs = first < cnt ? dbefore : sat_add(dbefore, dmine);
+            float sn = (ok && dabs > 0) ? ldexpf((float)(M + dabs), e - 150) : s;      // exact: M + dabs < 2^24
+            int next = ci + cnt, miss = 0, halt = 0;
+            if (first < cnt) {
+                // premise broken (negative / non-finite element) or no transducer round after round (a sum that stays zero -- a black
+                // frame's structure map: 3600 one-chunk rounds would be slower than the chain -- or stagnates below the prediction):
+                // leave the rest to the one-block kernel, from exactly here
+                miss = (!usable && !bad) ? s_miss + 1 : 0;
+                if (bad || miss > 8) halt = 1;
+                else {
+                    const int m = n - nc * ACH < ACH ? n - nc * ACH : ACH;
+                    int q = 0;
+#pragma unroll 4
+                    for (; q + 4 <= m; q += 4) { const float4 w = *reinterpret_cast<const float4*>(&sX[q]); sn += w.x; sn += w.y; sn += w.z; sn += w.w; }
+                    for (; q < m; ++q) sn += sX[q];
+                }
+                next = halt ? nc : nc + 1;
+            }
+            s_sum = sn; s_ci = next; s_stop = halt; s_miss = miss;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const long long i = (long long)s_ci * ACH;
+        state_out[0] = i < n ? (int)i : n; state_out[1] = __float_as_int(s_sum);
+    }
+}
+
+// [R][C] (row pitch pin) -> [C][R] (row pitch pout) per plane, 32x32 LDS tiles, both sides coalesced: the Y smoothing pass runs as
+// the same one-lane-per-contiguous-line kernel as the X pass, without changing a single floating-point operation
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, size_t plane_stride, int R, int C, int pin, int pout)
 {
     __shared__ float tl[32][33];
     const float* ip = in + (size_t)blockIdx.z * plane_stride;
@@ -423,22 +688,56 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < C) tl[j][tx] = ip[(size_t)(r0 + j) * C + c0 + tx];
+        if (r0 + j < R && c0 + tx < C) tl[j][tx] = ip[(size_t)(r0 + j) * pin + c0 + tx];
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
-        if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * R + r0 + tx] = tl[tx][j];
+        if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * pout + r0 + tx] = tl[tx][j];
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// scratch of the multi-block sequential sum: [state: 2 ints][chunk sums: double][bad flags: int][transducers: ChunkXd], 256-aligned parts
+size_t seqsum_workspace_bytes(size_t n)
+{
+    const size_t nc = (n + ACH - 1) / ACH;
+    return 256 + align_up(nc * 8, 256) + align_up(nc * 4, 256) + align_up(nc * sizeof(ChunkXd), 256);
+}
+
+// the four launches of the sum (see avg_chunk_sum_kernel): short arrays go straight to the one-block kernel
+static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st)
+{
+    static const bool one_block = getenv("FAV_AVG_ONE_BLOCK") != nullptr;       // (A/B: the round-3 form)
+    if (n < 65536 || one_block || !ws) {
+        hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(nullptr));
+        return;
+    }
+    const int nc = (int)((n + ACH - 1) / ACH);
+    char* w = static_cast<char*>(ws);
+    int* state = reinterpret_cast<int*>(w);
+    double* csum = reinterpret_cast<double*>(w + 256);
+    int* cbad = reinterpret_cast<int*>(w + 256 + align_up((size_t)nc * 8, 256));
+    ChunkXd* cx = reinterpret_cast<ChunkXd*>(w + 256 + align_up((size_t)nc * 8, 256) + align_up((size_t)nc * 4, 256));
+    hipLaunchKernelGGL(avg_chunk_sum_kernel, dim3((nc + 3) / 4), dim3(256), 0, st, v, (int)n, csum, cbad);
+    hipLaunchKernelGGL(avg_chunk_class_kernel, dim3((nc + 3) / 4), dim3(256), 0, st, v, (int)n, csum, cbad, nc, cx);
+    hipLaunchKernelGGL(avg_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, cx, nc, state);
+    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(state));
+}
+
+// floats per plane: the larger of the [H][pw] and the transposed [W][ph] layout (row pitches rounded up to 4 floats)
+static size_t structure_plane_floats(int W, int H)
+{
+    const size_t pw = ((size_t)W + 3) & ~(size_t)3, ph = ((size_t)H + 3) & ~(size_t)3;
+    return align_up(std::max((size_t)H * pw, (size_t)W * ph) * 4, 256) / 4;
+}
+
 size_t structure_workspace_bytes(int W, int H)
 {
     const size_t n = (size_t)W * H;
     const size_t nb = (n + NB - 1) / NB;
-    // 3 planes + 3 scratch planes + corners + 3 transposed planes + bmax + bpre + bmin + mm(2) + avg(1)
-    return align_up(n * 4, 256) * 10 + align_up(nb * 4, 256) * 3 + 256;
+    // 3 planes + 3 scratch planes (v1) + corners + 3 transposed planes + bmax + bpre + bmin + mm(2) + avg(1) + the sum's scratch
+    return structure_plane_floats(W, H) * 4 * 10 + align_up(nb * 4, 256) * 3 + 256 + seqsum_workspace_bytes(n);
 }
 
 static void iir_constants(float sigma, IIR& c)
@@ -460,7 +759,8 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
 {
     FAV_REQUIRE(ws != nullptr && ws_bytes >= structure_workspace_bytes(W, H), "consistency: workspace too small");
     FAV_REQUIRE(W >= 2 && H >= 2, "consistency: structure mode needs W,H >= 2");
-    const size_t n = (size_t)W * H, ps = align_up(n * 4, 256) / 4;
+    const size_t n = (size_t)W * H, ps = structure_plane_floats(W, H);
+    const int pw = (W + 3) & ~3, ph = (H + 3) & ~3;
     const int nb = (int)((n + NB - 1) / NB);
     float* planes = static_cast<float*>(ws);          // dxx, dyy, dxy
     float* scratch = planes + 3 * ps;
@@ -472,25 +772,20 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     float* mm = bmin + align_up((size_t)nb * 4, 256) / 4;   // [0]=cmax [1]=cmin [2]=avg
     IIR c; iir_constants(3.0f, c);                          // main(): computeCorners(image, &structure, 3.0f)
     const dim3 g2((W + 255) / 256, H);
-    hipLaunchKernelGGL(moments_kernel, g2, dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H);
-    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane
-    // recursiveSmoothX: transpose -> one lane per (former) row walking coalesced memory -> transpose back
-    hipLaunchKernelGGL(transpose_kernel, dim3((W + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, st, planes, tmp3, ps, H, W);
-    // One lane per line, so a pass is 34 / 60 waves of a 130-240 us dependent chain.  As blocks of ONE wave they spread over as many
-    // CUs as are free at that moment, and each of them then keeps a whole-CU block of the network's persistent grids waiting; as
-    // blocks of four waves (one per SIMD: the look-ahead register sets of the chain need more than 256 registers) they sit on 9 / 15 CUs
-    static const int ib = getenv("FAV_IIR_BLOCK") ? std::max(64, std::min(256, atoi(getenv("FAV_IIR_BLOCK")) / 64 * 64)) : 256;      // (tuning: read once)
-    hipLaunchKernelGGL(iir_kernel, dim3((H + ib - 1) / ib, 3), dim3(ib), 0, st, tmp3, ps, scratch, H, W, H, 1, c);
-    hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (W + 31) / 32, 3), dim3(256), 0, st, tmp3, planes, ps, W, H);
-    hipLaunchKernelGGL(iir_kernel, dim3((W + ib - 1) / ib, 3), dim3(ib), 0, st, planes, ps, scratch, W, H, W, 1, c);
-    hipLaunchKernelGGL(eigen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planes, planes + ps, planes + 2 * ps,
-                       corners, n);
+    hipLaunchKernelGGL(moments_kernel, g2, dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H, pw);
+    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane.  X pass on the rows of the planes,
+    // transpose, Y pass on the rows of the transposed planes, eigenvalue read back through a tile transpose (blocks of ONE wave: a pass is
+    // 34 / 60 waves, each gets a SIMD of its own)
+    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((H + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, H, W, pw, c);
+    hipLaunchKernelGGL(transpose_kernel, dim3((W + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, st, planes, tmp3, ps, H, W, pw, ph);
+    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((W + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, W, H, ph, c);
+    hipLaunchKernelGGL(eigen_t_kernel, dim3((W + 31) / 32, (H + 31) / 32), dim3(256), 0, st, tmp3, ps, corners, H, W, ph);
     hipLaunchKernelGGL(blockmax_kernel, dim3(nb), dim3(256), 0, st, corners, n, bmax);
     hipLaunchKernelGGL(prefixmax_kernel, dim3(1), dim3(1024), 0, st, bmax, nb, bpre, mm);
     hipLaunchKernelGGL(quirkmin_kernel, dim3(nb), dim3(256), 0, st, corners, n, bpre, bmin);
     hipLaunchKernelGGL(minreduce_kernel, dim3(1), dim3(256), 0, st, bmin, nb, mm);
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, corners, n, mm);
-    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, corners, (int)n, mm + 2, static_cast<float*>(nullptr));
+    launch_seqsum(corners, n, reinterpret_cast<char*>(mm) + 256, mm + 2, nullptr, st);
     FAV_LAUNCH_CHECK("structure kernels");
     *structure_out = corners;
     *avg_out = mm + 2;
@@ -499,9 +794,26 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
 
 int launch_sequential_sum(const float* x, size_t n, float* sum_out, hipStream_t st)
 {
-    FAV_REQUIRE(n > 0 && n < (1ull << 31), "sequential sum: bad length");
-    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, x, (int)n, static_cast<float*>(nullptr), sum_out);
-    FAV_LAUNCH_CHECK("avg_scan_kernel");
+    FAV_REQUIRE(n > 0 && n < (1ull << 31) - 1024, "sequential sum: bad length");
+    // operator-level entry (no workspace in its signature): one scratch buffer per device, grown on demand; calls on different
+    // streams are serialised by draining the previous one first (a test / tool entry point, not on the frame path)
+    struct Scratch { void* p = nullptr; size_t bytes = 0; hipStream_t last = nullptr; bool used = false; };
+    static std::mutex mu;
+    static Scratch scratch[64];
+    int device = 0; FAV_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(mu);
+    Scratch& sc = scratch[(device >= 0 && device < 64) ? device : 0];
+    const size_t need = seqsum_workspace_bytes(n);
+    if (sc.used && (sc.last != st || need > sc.bytes)) { if (hipStreamSynchronize(sc.last) != hipSuccess) (void)hipGetLastError(); }
+    if (need > sc.bytes) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.bytes = 0;
+        FAV_HIP(hipMalloc(&sc.p, need));
+        sc.bytes = need;
+    }
+    sc.last = st; sc.used = true;
+    launch_seqsum(x, n, sc.p, nullptr, sum_out, st);
+    FAV_LAUNCH_CHECK("sequential sum kernels");
     return FAV_OK;
 }
 

@@ -30,44 +30,60 @@ static int fail(const char* what)
 }
 
 namespace {
-// one context, device buffers kept between pairs of the same size
+// one context; device buffers and PINNED host staging kept between pairs of the same size (a pageable read + copy of 17.5 MB costs
+// more than the mask itself: 29 ms per pair against 6)
 struct Batch {
-    int W = 0, H = 0; bool with_img = false;
+    int W = 0, H = 0;
     float *d1 = nullptr, *d2 = nullptr; uint8_t *dimg = nullptr, *dout = nullptr; void* ws = nullptr; size_t wsb = 0;
-    std::vector<uint8_t> out;
-    void release() { hipFree(d1); hipFree(d2); hipFree(dimg); hipFree(dout); hipFree(ws); d1 = d2 = nullptr; dimg = dout = nullptr; ws = nullptr; }
+    float *h1 = nullptr, *h2 = nullptr; uint8_t *himg = nullptr, *hout = nullptr;
+    void release()
+    {
+        hipFree(d1); hipFree(d2); hipFree(dimg); hipFree(dout); hipFree(ws); d1 = d2 = nullptr; dimg = dout = nullptr; ws = nullptr;
+        hipHostFree(h1); hipHostFree(h2); hipHostFree(himg); hipHostFree(hout); h1 = h2 = nullptr; himg = hout = nullptr;
+        W = H = 0;
+    }
+    static bool flo_size(const char* path, int* w, int* h)      // the 12-byte header (consistencyChecker.cpp:16-36: tag, width, height)
+    {
+        FILE* f = fopen(path, "rb");
+        if (!f) return false;
+        unsigned char hd[12];
+        const bool ok = fread(hd, 1, 12, f) == 12;
+        fclose(f);
+        if (!ok) return false;
+        memcpy(w, hd + 4, 4); memcpy(h, hd + 8, 4);
+        return *w > 0 && *h > 0 && (long long)*w * *h < (1ll << 28);
+    }
     int run(const std::vector<std::string>& a)
     {
-        float *f1 = nullptr, *f2 = nullptr; uint8_t* img = nullptr;
-        int w1, h1, w2, h2;
-        if (fav_read_flo_host(a[0].c_str(), &f1, &w1, &h1)) return fail(a[0].c_str());
-        if (fav_read_flo_host(a[1].c_str(), &f2, &w2, &h2)) { fav_free_host(f1); return fail(a[1].c_str()); }
-        int rc = 0;
-        if (w1 != w2 || h1 != h2) { fprintf(stderr, "consistencyChecker: flow sizes differ\n"); rc = 1; }
-        if (!rc && a.size() >= 4) {
-            int wi, hi, ch;
-            if (fav_read_pnm_host(a[3].c_str(), &img, &wi, &hi, &ch)) rc = fail(a[3].c_str());
-            else if (wi != w1 || hi != h1 || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); rc = 1; }
-        }
-        const size_t n = (size_t)w1 * h1;
-        if (!rc && (w1 != W || h1 != H || (img != nullptr) != with_img)) {
+        int w1, h1s;
+        if (!flo_size(a[0].c_str(), &w1, &h1s)) { fprintf(stderr, "consistencyChecker: cannot read %s\n", a[0].c_str()); return 1; }
+        const size_t n = (size_t)w1 * h1s;
+        if (w1 != W || h1s != H) {
             release();
-            W = w1; H = h1; with_img = img != nullptr;
-            wsb = fav_consistency_workspace_bytes(W, H, with_img);
+            W = w1; H = h1s;
+            wsb = fav_consistency_workspace_bytes(W, H, 1);
             if (hipMalloc((void**)&d1, n * 8) || hipMalloc((void**)&d2, n * 8) || hipMalloc((void**)&dout, n) || hipMalloc((void**)&dimg, n * 3) ||
-                (wsb && hipMalloc(&ws, wsb))) { fprintf(stderr, "consistencyChecker: hipMalloc failed\n"); rc = 1; W = H = 0; }
-            out.resize(n);
+                (wsb && hipMalloc(&ws, wsb)) || hipHostMalloc((void**)&h1, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&h2, n * 8, hipHostMallocDefault) ||
+                hipHostMalloc((void**)&himg, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&hout, n, hipHostMallocDefault)) {
+                fprintf(stderr, "consistencyChecker: out of memory\n"); release(); return 1; }
         }
-        if (!rc) {
-            hipMemcpy(d1, f1, n * 8, hipMemcpyHostToDevice);
-            hipMemcpy(d2, f2, n * 8, hipMemcpyHostToDevice);
-            if (img) hipMemcpy(dimg, img, n * 3, hipMemcpyHostToDevice);
-            if (fav_consistency_u8(d1, d2, img ? dimg : nullptr, dout, W, H, ws, wsb, nullptr)) rc = fail("fav_consistency_u8");
-            else if (hipMemcpy(out.data(), dout, n, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "consistencyChecker: device error\n"); rc = 1; }
-            else if (fav_write_pgm_host(a[2].c_str(), out.data(), W, H)) rc = fail(a[2].c_str());
+        int w, h, ch;
+        if (fav_read_flo_into_host(a[0].c_str(), h1, n * 2, &w, &h)) return fail(a[0].c_str());
+        if (fav_read_flo_into_host(a[1].c_str(), h2, n * 2, &w, &h)) return fail(a[1].c_str());
+        if (w != W || h != H) { fprintf(stderr, "consistencyChecker: flow sizes differ\n"); return 1; }                  // :144-145
+        const bool img = a.size() >= 4;
+        if (img) {
+            if (fav_read_pnm_into_host(a[3].c_str(), himg, n * 3, &w, &h, &ch)) return fail(a[3].c_str());
+            if (w != W || h != H || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); return 1; }
         }
-        fav_free_host(f1); fav_free_host(f2); fav_free_host(img);
-        return rc;
+        hipMemcpyAsync(d1, h1, n * 8, hipMemcpyHostToDevice, nullptr);
+        hipMemcpyAsync(d2, h2, n * 8, hipMemcpyHostToDevice, nullptr);
+        if (img) hipMemcpyAsync(dimg, himg, n * 3, hipMemcpyHostToDevice, nullptr);
+        if (fav_consistency_u8(d1, d2, img ? dimg : nullptr, dout, W, H, ws, wsb, nullptr)) return fail("fav_consistency_u8");
+        if (hipMemcpyAsync(hout, dout, n, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+            fprintf(stderr, "consistencyChecker: device error\n"); return 1; }
+        if (fav_write_pgm_host(a[2].c_str(), hout, W, H)) return fail(a[2].c_str());
+        return 0;
     }
 };
 

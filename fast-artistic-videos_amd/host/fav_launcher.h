@@ -355,7 +355,8 @@ inline void load_models_dist(int rank, int world, const std::string& idf, int de
     ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
     cfg.blocking = 0;                                           // every call returns at once; nccl_wait polls with a deadline
     const auto ti = std::chrono::steady_clock::now();
-    nccl_wait(comm, ncclCommInitRankConfig(&comm, world, id, rank, &cfg), "ncclCommInitRank", rank);
+    const ncclResult_t ir = ncclCommInitRankConfig(&comm, world, id, rank, &cfg);      // (sets `comm` before it returns, also when in progress)
+    nccl_wait(comm, ir, "ncclCommInitRank", rank);
     const double ims = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count();
     hipStream_t bst; if (hipStreamCreate(&bst) != hipSuccess) die("hipStreamCreate failed");
     const auto tb = std::chrono::steady_clock::now();

@@ -12,7 +12,8 @@
 #   prof4                            the same with --structure 1 (4-argument checker mode)
 #   pmc                              scripts/gpu_pmc.sh <tag>  (separate --pmc passes)
 #   gaps                             scripts/gaps.sh
-#   ab:<env=val>[,<env=val>...]      quick bench alternating default / with the environment settings, two rounds
+#   ab:<env=val>[,<env=val>...][;<env=val>...]   quick bench alternating default / each ';'-separated set of environment settings, two rounds
+#   ab4:...                          the same in the 4-argument checker mode (--structure 1)
 #   ablib:<lib.so>[,<lib.so>...]     scripts/ab_lib.sh (alternating library builds)
 #   e2e[:<frames>]                   scripts/e2e.py (the CLI's own timing breakdown)
 #   c3dump                           GPU side of the 300-frame config-3 free-running parity run (contractive checkpoint)
@@ -55,10 +56,11 @@ PY
               ;;
     pmc)      bash scripts/gpu_pmc.sh $TAG 2>&1 | tail -40 ;;
     gaps)     bash scripts/gaps.sh 2>&1 | tail -70 ;;
-    ab)       for rep in 1 2; do
-                timeout 300 $QUICK 2>/dev/null | summ "default "
-                (export ${A//,/ }; timeout 300 $QUICK 2>/dev/null | summ "$A ")
-              done 2>&1 | tee $O/ab_${TAG}.log ;;
+    ab|ab4)   X=""; [ $K = ab4 ] && X="--structure 1"
+              for rep in 1 2; do
+                timeout 300 $QUICK $X 2>/dev/null | summ "default "
+                for V in ${A//;/ }; do (export ${V//,/ }; timeout 300 $QUICK $X 2>/dev/null | summ "$V "); done
+              done 2>&1 | tee $O/${K}_${TAG}.log ;;
     ablib)    bash scripts/ab_lib.sh ${A//,/ } 2>&1 | tee $O/ablib_${TAG}.log ;;
     e2e)      timeout 900 python scripts/e2e.py ${A:-300} 2>&1 | tee $O/e2e_${TAG}.log | tail -12 ;;
     c3dump)   timeout 600 python scripts/parity_clip.py --config 3 --frames 300 --gain 0.05 --gpu-dump $O/c3_contractive_gpu.npz 2>&1 | tail -3 ;;

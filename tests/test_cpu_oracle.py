@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -507,3 +508,29 @@ def test_contractive_checkpoint_contracts_and_random_init_does_not(oracle, tmp_p
     c, r = [x["rms"] for x in res["contractive"]], [x["rms"] for x in res["random-init"]]
     assert c[1] < 0.8 * c[0] and c[2] < 0.8 * c[1] and c[4] < 0.3 * c[0], c
     assert r[4] > 10 * r[0], r
+
+
+@pytest.mark.parametrize("case", ["uniform", "ties", "mixed", "zeros", "negatives", "structure-like", "stagnate"])
+def test_multi_block_sequential_sum_scheme(case):
+    """the scheme of the multi-block CMatrix::avg sum (round 4: predicted binades, chunk transducers, native crossings, hand-over to
+    the one-block finisher) restated in numpy (tests/util/seqsum_model.py) against the plain sequential fp32 loop -- bit for bit"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "util"))
+    import seqsum_model as SM
+    rng = np.random.default_rng(sum(map(ord, case))); n = 150001
+    if case == "uniform": x = rng.random(n, dtype=np.float32)
+    elif case == "ties": x = (rng.integers(0, 4096, n) * 2.0 ** -12).astype(np.float32)
+    elif case == "mixed": x = (10.0 ** rng.uniform(-9, 3, n)).astype(np.float32)
+    elif case == "zeros":
+        x = rng.random(n, dtype=np.float32); x[rng.random(n) < 0.7] = 0; x[:5000] = 0
+    elif case == "negatives":
+        x = rng.random(n, dtype=np.float32); x[rng.random(n) < 0.001] *= -1
+    elif case == "stagnate":
+        x = np.full(n, 1e-3, np.float32); x[0] = 60000.0
+    else: x = (rng.random(n) ** 6).astype(np.float32)
+    got, info = SM.model(x)
+    want = SM.seq_sum(x)
+    assert got.tobytes() == want.tobytes(), (case, got, want, info)
+    if case in ("uniform", "ties", "mixed", "structure-like"):
+        assert info["halted_at"] is None and info["rounds"] <= 20, info          # the fast path carries the whole array
+    if case in ("zeros", "negatives"):
+        assert info["halted_at"] is not None, info                               # the finisher takes over where the premise breaks

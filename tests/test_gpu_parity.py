@@ -140,7 +140,7 @@ def test_mask_bit_exact_vs_reference_golden(favlib, cuda, golden_dir, name):
     assert np.array_equal(m4, g["mask4"]), f"{(m4 != g['mask4']).sum()} bytes differ from the reference binary (4-arg)"
 
 
-@pytest.mark.parametrize("size", [(360, 640), (720, 1280), (5, 3), (130, 1029)])
+@pytest.mark.parametrize("size", [(360, 640), (720, 1280), (5, 3), (130, 1029), (2, 2), (17, 18), (98, 33), (53, 71), (480, 854)])
 def test_mask_bit_exact_vs_oracle(favlib, oracle, cuda, size):
     h, w = size
     bw = synth.backward_flow(h, w, 5) if h > 8 else synth.random_flow(h, w, 5, 0.5)
@@ -153,6 +153,20 @@ def test_mask_bit_exact_vs_oracle(favlib, oracle, cuda, size):
     assert np.array_equal(m4, ref4), f"{(m4 != ref4).sum()} of {m4.size} bytes differ (4-arg)"
     if h > 8:
         assert 0.2 < (m3 == 255).mean() < 0.98          # the fixture exercises both outcomes
+
+
+@pytest.mark.parametrize("kind", ["black", "constant", "half-black"])
+def test_mask_four_argument_mode_on_flat_frames(favlib, oracle, cuda, kind):
+    """a fade-in's black frame: the structure map is all zero, CMatrix::normalize divides by (max - min) = 0 -> 1, CMatrix::avg's sum
+    stays 0 and 4 / avg is infinite (consistencyChecker.cpp:122-124) -- the multi-block sum hands over to the one-block kernel there"""
+    h, w = 720, 1280
+    bw = synth.backward_flow(h, w, 15); fw = synth.forward_flow_from_backward(bw, 16)
+    img = np.zeros((h, w, 3), np.uint8)
+    if kind == "constant": img[:] = 77
+    if kind == "half-black": img[:, w // 2:] = synth.smooth_frame(h, w, 17)[:, w // 2:]
+    m4 = favlib.consistency(T(bw, cuda), T(fw, cuda), T(img, cuda)).cpu().numpy()
+    ref4 = oracle.consistency(bw, fw, img)
+    assert np.array_equal(m4, ref4), f"{(m4 != ref4).sum()} of {m4.size} bytes differ"
 
 
 # ---------------------------------------------------------------------------------------------- A5-A7
