@@ -327,7 +327,8 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
     // (d64 at 1280x720, 9 tiles per block: 175 us against 100 us alone and 154 us for the data-parallel kernel it replaced --
     // profiles/r02zg_4arg_s2w_ab.log); the hardware scheduler hands single tiles to whichever CU is free.  Same tiles, same partials.
     const int slots = std::max(1, cus[dv] - reserve_cus);
-    const int grid = (reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
+    static const bool tile_grid = !getenv("FAV_S2W_PERSISTENT");      // (A/B, round 4: the mask pipeline is 0.6 ms of short kernels now)
+    const int grid = (tile_grid && reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SwGeo<NTC, TR>::NTH), lds, st, a);
     FAV_LAUNCH_CHECK("conv3s2w_kernel");
     return FAV_OK;

@@ -987,7 +987,11 @@ int net_forward_padded(fav_net* n, const float* in8, int H, int W, float* out_pl
 // While look-ahead masks are in flight the persistent / stream-K convolution grids leave SIDE_CUS CUs unclaimed
 // (fav_net::reserve_cus): the side queues' kernels (among them a ~3 ms single-wave sequential chain) find free CUs, and a
 // statically scheduled network block is never kept off the chip by them.
-static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FAV_SIDE_CUS"))) : 8;      // (tuning: read once)
+static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FAV_SIDE_CUS"))) : 4;      // (tuning: read once; 8 until round 4, when a
+                                                                                                          //  mask was 1.5 ms of mostly sequential kernels: profiles/r4b_4arg_*)
+// one side queue carries every look-ahead since round 4 (a mask is 0.6 ms of short kernels, two in flight fit a 1.8 ms frame back to
+// back; two queues measured 541-543 frames/s against 546-548: profiles/r04c_4arg_knobs_ab.log)
+static const int NSIDE_USED = getenv("FAV_SIDE_QUEUES") ? std::max(1, std::min(2, atoi(getenv("FAV_SIDE_QUEUES")))) : 1;
 static hipError_t create_side_stream(hipStream_t* st)
 {
     // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free)
@@ -1153,7 +1157,7 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     if (use_structure) s->net->reserve_cus = SIDE_CUS;
     fav_stream::Pref& pf = s->pref[s->pref_next];
     s->pref_next = (s->pref_next + 1) % fav_stream::NPREF;
-    const int q = s->side_next; s->side_next = (s->side_next + 1) % fav_stream::NSIDE;
+    const int q = s->side_next; s->side_next = (s->side_next + 1) % NSIDE_USED;
     hipStream_t sd = s->side[q];
     if (!s->host_ordered) {
         FAV_HIP(hipEventRecord(s->ev_in, st));                 // inputs are complete at this point of the caller's stream

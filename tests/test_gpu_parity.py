@@ -151,7 +151,7 @@ def test_mask_bit_exact_vs_oracle(favlib, oracle, cuda, size):
     m4 = favlib.consistency(T(bw, cuda), T(fw, cuda), T(img, cuda)).cpu().numpy()
     ref4 = oracle.consistency(bw, fw, img)
     assert np.array_equal(m4, ref4), f"{(m4 != ref4).sum()} of {m4.size} bytes differ (4-arg)"
-    if h > 8:
+    if h >= 100:
         assert 0.2 < (m3 == 255).mean() < 0.98          # the fixture exercises both outcomes
 
 
