@@ -535,11 +535,16 @@ def main():
         # `achieved` may exceed the fp32 MFMA peak -- `executed_tflops` / `executed_frac` give the matrix-pipe view.
         # (kernel id 529 = the same kernel forming a pending residual join while it stages its input: three of the ten launches since
         #  round 3 -- they do the work of the three res_add launches they replace and are slower for it)
-        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid in (528, 529) and n > 0]
-        dom_plain = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 528 and n > 0]
-        dom_join = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 529 and n > 0]
-        dom_name = "conv3_wino_kernel (ten 3x3 128->128 residual convolutions, Winograd F(2x2,3x3), fp32 MFMA 32x32x2)"
-        exec_ratio = 16.0 / 36.0
+        # (round 4: kernel ids 728 / 729 = the same ten layers as Winograd F(4x4,3x3), kernels_wino4.hip -- 36 of the direct form's 144
+        #  multiply-adds per 4x4 outputs; ids 528 / 529 = F(2x2,3x3) behind FAV_WINO_F2)
+        f4 = any(kid in (728, 729) and n > 0 for (ms, n, macs, kid) in prof)
+        ids = (728, 729) if f4 else (528, 529)
+        dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid in ids and n > 0]
+        dom_plain = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == ids[0] and n > 0]
+        dom_join = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == ids[1] and n > 0]
+        dom_name = ("conv3_wino4_kernel (ten 3x3 128->128 residual convolutions, Winograd F(4x4,3x3), fp32 MFMA 16x16x4)" if f4 else
+                    "conv3_wino_kernel (ten 3x3 128->128 residual convolutions, Winograd F(2x2,3x3), fp32 MFMA 32x32x2)")
+        exec_ratio = 36.0 / 144.0 if f4 else 16.0 / 36.0
         if not dom:     # FAV_NO_WINO: the halo-resident direct form
             dom = [(ms, n, macs) for (ms, n, macs, kid) in prof if kid == 428 and n > 0]
             dom_name = "conv3_halo_kernel<128, false> (ten 3x3 128->128 residual convolutions, stream-K, halo-resident operand)"
@@ -593,6 +598,7 @@ def main():
                                  "(> 1: faster than any direct fp32 convolution could run)",
                          "avg_launch_us": round(secs / max(1, nl) * 1e6, 2), "launches": nl,
                          "launches_with_residual_join": sum(n for ms, n, macs in dom_join) if dom_name.startswith("conv3_wino") else 0,
+                         "executed_mults_per_direct_mult": "36/144 (F(4x4,3x3))" if f4 else "16/36 (F(2x2,3x3))",
                          "avg_launch_us_with_join": round(sum(ms for ms, n, macs in dom_join) / max(1, sum(n for ms, n, macs in dom_join)) * 1e3, 2) if dom_name.startswith("conv3_wino") and dom_join else None,
                          "avg_launch_us_without_join": round(sum(ms for ms, n, macs in dom_plain) / max(1, sum(n for ms, n, macs in dom_plain)) * 1e3, 2) if dom_name.startswith("conv3_wino") and dom_plain else None,
                          "frac_of_launches_without_join": (round(sum(2.0 * macs * n for ms, n, macs in dom_plain) / (sum(ms for ms, n, macs in dom_plain) / 1e3) / 1e12 * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4)

@@ -159,6 +159,10 @@ int launch_conv_first2d(const ConvLaunch& p, int cin_real, const float* wpk, int
 bool conv3_wino_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
 int conv3_wino_tiles(int OH, int OW);
 int launch_conv3_wino(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
+// the same layers as Winograd F(4x4,3x3), kernels_wino4.hip (round 4); wpk = conv_wino4_pack() (wino4_pack.h); partials per 16x16-pixel unit
+bool conv3_wino4_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);
+int conv3_wino4_tiles(int OH, int OW);
+int launch_conv3_wino4(const ConvLaunch& p, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 pad-1 64-channel layer on a x2 nearest-upsampled materialised input (U2 + c3s1-64): four 2x2 convolutions on the
 // physical pixels with merged weights, kernels_up2.hip; wpk = conv_up2_pack() (up2_pack.h); partials per 8x32 physical-pixel tile
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups);

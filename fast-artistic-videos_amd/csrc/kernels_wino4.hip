@@ -1,0 +1,425 @@
+// kernels_wino4.hip -- the residual 3x3 convolutions (128 -> 128, stride 1, no padding; models_video.lua:10-39) as Winograd
+// F(4x4, 3x3) minimal filtering on the fp32 matrix cores of gfx950 (round 4).
+//
+// Why: kernels_wino.hip (F(2x2, 3x3)) sits at 0.58 of the fp32 MFMA peak with 94 % matrix-pipe efficiency inside its K loop; what is
+// left there is clock, prologue and a cross-wave output transform.  The remaining lever is the NUMBER of matrix instructions:
+// F(4x4, 3x3) computes a 4x4 output patch from a 6x6 input patch with 36 multiplies per (input channel, output channel) -- 2.25 per
+// output against 4 (F(2x2)) and 9 (direct).  Its price is accuracy (larger transform constants): with the interpolation points
+// 0, +-3/4, +-3/2 (wino4_pack.h) a layer's fp32 error is ~3x the F(2x2) form's, still 2x a plain fp32 accumulation chain's.
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        (matrices in wino4_pack.h)
+//
+// Work unit = 4 x 4 tiles = 16 x 16 output pixels x 128 output channels, one block of FOUR waves per CU, one wave per SIMD with the
+// whole 512-register file of its SIMD:
+//   * v_mfma_f32_16x16x4_f32: M = the unit's 16 tiles, N = 16 output channels, K = 4 input channels.  Wave w owns output channels
+//     32 w .. 32 w + 31 for ALL 36 transform positions and all 16 tiles: 36 x 2 x 4 = 288 accumulator registers.  Every
+//     (tile, output channel) has its 36 position values in ONE lane, so the output transform A^T M A never leaves the lane -- no
+//     exchange between waves, no LDS pass (the F(2x2) kernel spends 4.9 of 39 us per unit there)
+//   * input: per 16-channel slice the 18 x 18 pixel halo is loaded once (16 bytes per thread and row), the producing layer's pending
+//     InstanceNorm / ReLU (or pending residual join) applied, and B^T d B formed in TWO passes through LDS by all four waves between
+//     their matrix instructions: rows (288 items of 6 -> 6) into L, columns (384 items) into V[position][tile][channel].  An A
+//     fragment is then ONE conflict-free ds_read_b128 per position and 16 channels (tile pitch 20 words = 5 sixteen-byte slots)
+//     -- 0.5 vector instructions per matrix instruction in all
+//   * weights: transformed in double and packed on the host in exactly the fragment order (wino4_pack.h); no two waves share a
+//     weight, so they go global -> registers directly (two contiguous 1 KiB loads per position), eight positions ahead through a
+//     ring of nine register pairs; 2.36 MB per layer, L2-resident
+//   * two barriers per slice (L complete, V complete); the slice's 288 matrix instructions per wave run between them
+// Units are independent (nothing handed over, nothing co-resident assumed): persistent blocks walk the units round-robin.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "fav_internal.h"
+#include "wino4_pack.h"
+
+namespace fav {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+
+constexpr int W4_TP = 20;                      // words per tile / pixel of a 16-channel slice (16 + 4: 5 sixteen-byte slots, odd)
+constexpr int W4_VPOS = 16 * W4_TP;            // 320: the 16 tiles of one transform position
+constexpr int W4_VBUF = 36 * W4_VPOS;          // 11520 words per V buffer
+constexpr int W4_LLINE = 18 * W4_TP;           // 360: one row-transformed line (18 columns) of a tile row
+constexpr int W4_LTY = 2180;                   // the six lines of a tile row (2160) padded to 545 slots = 1 (mod 16): see stage 2
+constexpr int W4_LBUF = 4 * W4_LTY;            // 8720 words
+constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF; // 31760 words = 127 040 B (+ 2 CIN words of pending scale / shift)
+static_assert(W4_LTY >= 6 * W4_LLINE && (W4_LTY / 4) % 16 == 1, "tile-row pitch of L");
+
+struct Wino4Args {
+    const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
+    float* out; float2* partials; int* counts;
+    const float* skip; float* zout;      // MODE 2 (pending residual join), as in kernels_wino.hip
+    int OWp;
+    int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
+    long long* dbg;
+};
+
+__device__ __forceinline__ void w4_bt(const v4f d[6], v4f v[6])      // B^T d (wino4_pack.h)
+{
+    const v4f e1 = d[4] - 2.25f * d[2], o1 = 0.75f * d[3] - 1.6875f * d[1];
+    const v4f e2 = d[4] - 0.5625f * d[2], o2 = 1.5f * d[3] - 0.84375f * d[1];
+    v[0] = 1.265625f * d[0] + (d[4] - 2.8125f * d[2]);
+    v[1] = e1 + o1; v[2] = e1 - o1; v[3] = e2 + o2; v[4] = e2 - o2;
+    v[5] = 1.265625f * d[1] + (d[5] - 2.8125f * d[3]);
+}
+
+// MODE 0: plain input; MODE 1: pending per-channel scale / shift (+ ReLU) of the producing convolution's InstanceNorm; MODE 2: pending
+// residual join z = skip + scale * y + shift (res_add_kernel's operations in its order), written out once as the next block's skip
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_wino4_kernel(const Wino4Args p)
+{
+    constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
+    constexpr int NT = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Vs = smem;                        // [2][W4_VBUF]
+    float* const Ls = smem + 2 * W4_VBUF;          // [4][W4_LTY]
+    float* const aff = Ls + W4_LBUF;               // [2][CIN]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int CIN = p.CIN, nslices = CIN >> 4;
+
+    int dbi = 0;
+#define DBG_T() { if (p.dbg && t == 0 && dbi < 21) p.dbg[blockIdx.x * 24 + dbi++] = wall_clock64(); }
+    DBG_T();
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
+    const float lo1 = (MODE == 1 && p.relu1) ? 0.f : -INFINITY;
+
+    // stage 1 (rows): item = (tile row ty, raw column x, 16-byte channel chunk cq) -> raw rows 4 ty .. 4 ty + 5 of column x, six
+    // transformed lines out.  4 x 18 x 4 = 288 items: item A = t (pixel t >> 2 = 0..63), item B = 256 + t for t < 32 (pixels 64..71:
+    // ty 3, x 10..17)
+    const int cq = t & 3;
+    const int pixA = t >> 2, tyA = (pixA * 3641) >> 16, xA = pixA - tyA * 18;
+    const int xB = 10 + (lane >> 2);
+    const bool hasB = t < 32;
+    float* const l1A = Ls + tyA * W4_LTY + xA * W4_TP + cq * 4;
+    float* const l1B = Ls + 3 * W4_LTY + xB * W4_TP + cq * 4;
+    const float* const affr = aff + cq * 4;
+    // stage 2 (columns): item = (tile m, line i, channel chunk kq) -> columns 4 tx .. 4 tx + 5 of line i, six positions out.
+    // 16 x 6 x 4 = 384 items: item C = t (i = wave), item D for waves 2, 3 (i = 4, 5; wave 0 already has the extra stage-1 item).  The 16 lanes of a read group are
+    // the 16 tiles of one (i, kq): slots ty * 545 + 20 tx (mod 16) = ty + 4 tx, all different; of a write group 5 m + kq, likewise
+    const int m2 = t & 15, kq2 = (t >> 4) & 3;
+    const bool hasD = t >= 128;
+    const float* const l2 = Ls + (m2 >> 2) * W4_LTY + 4 * (m2 & 3) * W4_TP + kq2 * 4;
+    float* const v2 = Vs + m2 * W4_TP + kq2 * 4;
+    // matrix operands: lane = (tile m = lane & 15, k quarter kq = lane >> 4): A = V[p][m][4 kq .. 4 kq + 3] -- step j of a slice
+    // multiplies channel 16 s + 4 kq + j; B likewise (wino4_pack.h): lane * 16 + [wave * 2048 + (s * 36 + p) * 8192] + nt * 1024
+    const float* const aA = Vs + (lane & 15) * W4_TP + (lane >> 4) * 4;
+    const int wlo = lane * 16, wso = wave * 2048;
+
+    // the weight ring lives across units: the last slice of a unit requests the first positions of slice 0 -- the next unit's
+    v4f fb[9][2];
+    bool ring_primed = false;
+    if (AFF) __syncthreads();
+    auto work = [&](const int u) {
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 4) * 36 * 8192, 0x00020000);
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(JOIN ? p.zout : const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
+        const int uy = u / p.units_x, ux = u - uy * p.units_x;
+        const int oy0 = uy * 16, ox0 = ux * 16;
+        DBG_T();   /* unit start */
+        // no padding: input pixel (oy0 + r, ox0 + c) for halo (r, c); coordinates past the image only feed outputs past the image
+        // (never stored), so they are clamped instead of masked
+        int hoA[6], hoB[6];
+        {
+            const int ixa = min(ox0 + xA, p.IW - 1), ixb = min(ox0 + xB, p.IW - 1);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                hoA[a] = ((min(oy0 + 4 * tyA + a, p.IH - 1) * p.IWp + ixa) * CIN + cq * 4) * 4;
+                hoB[a] = ((min(oy0 + 12 + a, p.IH - 1) * p.IWp + ixb) * CIN + cq * 4) * 4;
+            }
+        }
+        // MODE 2: which of an item's six rows this thread writes to the joined tensor (bits 0-5 item A, 8-13 item B): rows 4 ty ..
+        // 4 ty + 3 of columns 0..15 -- the unit's own 16 x 16 pixels -- plus the halo fringe (rows 16, 17 / columns 16, 17) where no
+        // other unit follows
+        int zm = 0;
+        const bool lastx = ux == p.units_x - 1, lasty = uy == p.units_y - 1;
+        if (JOIN) {
+            const bool ca = ox0 + xA < p.IW && (xA < 16 || lastx), cb = ox0 + xB < p.IW && (xB < 16 || lastx);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const bool ra = oy0 + 4 * tyA + a < p.IH && (a < 4 || (tyA == 3 && lasty));
+                const bool rb = oy0 + 12 + a < p.IH && (a < 4 || lasty);
+                zm |= (ca && ra ? 1 : 0) << a | (cb && rb ? 256 : 0) << a;
+            }
+        }
+
+        v4f sc, sh;
+#define W4_LOAD_RAW(q_, slice_, ho_)                                                                \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_[a], (slice_) * 64, 0)); }
+#define W4_LOAD_SKIP(x_, slice_, ho_)                                                               \
+        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho_[a], (slice_) * 64, 0)); } }
+#define W4_AFF(slice_)                                                                              \
+        { if (AFF) { sc = *reinterpret_cast<const v4f*>(affr + (slice_) * 16); sh = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 16); } }
+        // pending transform of the raw rows; MODE 2: z = fma(y, scale, shift) + skip, stored where the mask says so (elsewhere the offset is
+        // out of the buffer's range and the hardware drops the store)
+#define W4_PEND(q_, x_, slice_, ho_, zsh_)                                                          \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                           \
+            if (MODE == 1) { q_[a].x = fmaxf(fmaf(q_[a].x, sc.x, sh.x), lo1); q_[a].y = fmaxf(fmaf(q_[a].y, sc.y, sh.y), lo1);  \
+                             q_[a].z = fmaxf(fmaf(q_[a].z, sc.z, sh.z), lo1); q_[a].w = fmaxf(fmaf(q_[a].w, sc.w, sh.w), lo1); } \
+            if (JOIN) { q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x_[a].x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x_[a].y;            \
+                        q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x_[a].z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x_[a].w;            \
+                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << ((zsh_) + a))) ? ho_[a] : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
+#define W4_COMMIT1(q_, dst_)                                                                        \
+        { v4f l_[6]; w4_bt(q_, l_);                                                                 \
+          _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>((dst_) + i * W4_LLINE) = l_[i]; }
+#define W4_STAGE2(i_, nb_)                                                                          \
+        { v4f c_[6], o_[6];                                                                         \
+          _Pragma("unroll") for (int k = 0; k < 6; ++k) c_[k] = *reinterpret_cast<const v4f*>(l2 + (i_) * W4_LLINE + k * W4_TP); \
+          w4_bt(c_, o_);                                                                            \
+          _Pragma("unroll") for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(v2 + (nb_) * W4_VBUF + (6 * (i_) + j) * W4_VPOS) = o_[j]; }
+
+        v4f fa[3];
+#define W4_READ_A(slot_, par_, pos_) { fa[slot_] = *reinterpret_cast<const v4f*>(aA + (par_) * W4_VBUF + (pos_) * W4_VPOS); }
+#define W4_LOAD_B(slot_, sl_, pos_)                                                                 \
+        { const int so_ = wso + ((sl_) * 36 + (pos_)) * 8192;                                       \
+          fb[slot_][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so_, 0));          \
+          fb[slot_][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 1024, so_, 0)); }
+
+        // ---- prologue: slice 0 through both transform passes into V[0]
+        {
+            v4f qa[6], qb[6], xa[6], xb[6];
+            W4_LOAD_SKIP(xa, 0, hoA); if (hasB) { W4_LOAD_SKIP(xb, 0, hoB); }
+            W4_LOAD_RAW(qa, 0, hoA);
+            if (hasB) { W4_LOAD_RAW(qb, 0, hoB); }
+            if (!ring_primed) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { W4_LOAD_B(q, 0, q); }
+                ring_primed = true;
+            }
+            W4_AFF(0);
+            W4_PEND(qa, xa, 0, hoA, 0); W4_COMMIT1(qa, l1A);
+            if (hasB) { W4_PEND(qb, xb, 0, hoB, 8); W4_COMMIT1(qb, l1B); }
+            __syncthreads();
+            W4_STAGE2(wave, 0);
+            if (hasD) { W4_STAGE2(2 + wave, 0); }
+        }
+        v4f acc[36][2];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) { acc[q][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[q][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+        __syncthreads();
+        W4_READ_A(0, 0, 0); W4_READ_A(1, 0, 1);
+        DBG_T();   /* loop start */
+        const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
+
+        // ---- K loop: per 16-channel slice 36 positions of 8 matrix instructions; between them the NEXT slice is staged:
+        //   position 0      raw rows of item A requested          position 6   item A committed to L (pending transform, rows of B^T d),
+        //                                                                      raw rows of item B requested (wave 0, lanes 0..31)
+        //   position 10     item B committed                      position 12  barrier: L complete
+        //   positions 14, 22   column pass of items C, D into the other V buffer          after position 35   barrier: V complete
+        // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // positions [from_, to_) of the slice: A fragment two positions ahead, weights eight positions ahead, 8 matrix instructions
+        // (segments of a few positions each, so that every loop is small enough to be unrolled completely: the accumulators are
+        //  indexed by the position)
+#define W4_POSITIONS(from_, to_)                                                                    \
+        { _Pragma("unroll") for (int pos = (from_); pos < (to_); ++pos) {                          \
+            if (pos + 2 < 36) { W4_READ_A((pos + 2) % 3, par, pos + 2); }                            \
+            if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } \
+            W4_FENCE();                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos % 3][j], fb[pos % 9][0][j], acc[pos][0], 0, 0, 0); \
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos % 3][j], fb[pos % 9][1][j], acc[pos][1], 0, 0, 0); \
+            }                                                                                       \
+            W4_FENCE(); } }
+        for (int s = 0; s < nslices; ++s) {
+            const int par = s & 1;
+            const int sn = min(s + 1, nslices - 1);
+            const int sw = s + 1 < nslices ? s + 1 : 0;       // (weights: the next unit starts at slice 0 again)
+            v4f qa[6], xa[6];
+            W4_LOAD_SKIP(xa, sn, hoA); W4_LOAD_RAW(qa, sn, hoA);
+            W4_POSITIONS(0, 6);
+            W4_AFF(sn); W4_PEND(qa, xa, sn, hoA, 0); W4_COMMIT1(qa, l1A);
+            if (hasB) { W4_LOAD_SKIP(xa, sn, hoB); W4_LOAD_RAW(qa, sn, hoB); }
+            W4_POSITIONS(6, 10);
+            if (hasB) { W4_PEND(qa, xa, sn, hoB, 8); W4_COMMIT1(qa, l1B); }
+            W4_POSITIONS(10, 12);
+            __syncthreads();
+            W4_POSITIONS(12, 14);
+            W4_STAGE2(wave, par ^ 1);
+            W4_POSITIONS(14, 22);
+            if (hasD) { W4_STAGE2(2 + wave, par ^ 1); }
+            W4_POSITIONS(22, 36);
+            __syncthreads();
+            W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
+        }
+#undef W4_POSITIONS
+#undef W4_FENCE
+        DBG_T();   /* loop end */
+        if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
+        DBG_T();
+#undef W4_LOAD_RAW
+#undef W4_LOAD_SKIP
+#undef W4_AFF
+#undef W4_PEND
+#undef W4_COMMIT1
+#undef W4_STAGE2
+#undef W4_READ_A
+#undef W4_LOAD_B
+
+        // ---- output transform, in the lane.  acc[6 i + j][nt][r] = M[i][j] of tile 4 (lane >> 4) + r, output channel 32 wave + 16 nt +
+        // (lane & 15): Y = A^T M A (4 x 4), bias, NHWC store, per-unit InstanceNorm partials (mean, M2, count) like the other kernels
+        const int nl = lane & 15, g = lane >> 4;
+        const int nrows = max(0, min(16, p.OH - oy0)), ncols = max(0, min(16, p.OW - ox0));
+        const int nv = nrows * ncols;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * 512, 0x00020000);
+        const bool inside = nv == 256;         // (wave-uniform: nine units in ten lie wholly inside the image and skip every per-pixel test)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = wave * 32 + nt * 16 + nl;
+            const float bv = p.bias[co];
+            float y[4][4][4];                  // [r][row a][column b]
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float Q[4][6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float mcol[6] = {acc[j][nt][r], acc[6 + j][nt][r], acc[12 + j][nt][r], acc[18 + j][nt][r], acc[24 + j][nt][r], acc[30 + j][nt][r]};
+                    float o[4]; Wino4::at<float>(mcol, o);
+                    Q[0][j] = o[0]; Q[1][j] = o[1]; Q[2][j] = o[2]; Q[3][j] = o[3];
+                }
+                const int tile = 4 * g + r;
+                const int oyb = oy0 + 4 * (tile >> 2), oxb = ox0 + 4 * (tile & 3);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float o[4]; Wino4::at<float>(Q[a], o);
+                    const int ro = ((oyb + a) * p.OWp + oxb) * 512 + co * 4;      // byte offset of column 0; columns follow 512 B apart
+                    const bool rv = oyb + a < p.OH;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        y[r][a][b] = o[b] + bv;
+                        if (inside) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r][a][b]), ors, ro, b * 512, 0);
+                            sm += y[r][a][b];
+                        } else {
+                            const bool v = rv && oxb + b < p.OW;       // (outside the image: an offset past the buffer, the store is dropped)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r][a][b]), ors, v ? ro : (int)0xFFFFF000, b * 512, 0);
+                            sm += v ? y[r][a][b] : 0.f;
+                        }
+                    }
+                }
+            }
+            if (p.partials != nullptr) {
+                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                const float mu = nv ? sm / (float)nv : 0.f;
+                float m2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tile = 4 * g + r;
+                    const int oyb = oy0 + 4 * (tile >> 2), oxb = ox0 + 4 * (tile & 3);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const float d = y[r][a][b] - mu;
+                            if (inside || (oyb + a < p.OH && oxb + b < p.OW)) m2 = fmaf(d, d, m2);
+                        }
+                }
+                m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+                if (g == 0) p.partials[(size_t)u * 128 + co] = make_float2(mu, m2);
+            }
+        }
+        if (p.partials != nullptr && t == 0) p.counts[u] = nv;
+        // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
+        DBG_T();   /* epilogue end */
+    };
+    const int nunits = p.units_x * p.units_y;
+    for (int it = lb; it < nunits; it += gridDim.x) work(it);
+    if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
+#undef DBG_T
+}
+
+// FAV_WINO_DBG=n: in-kernel timeline of the n-th launch (same report as the F(2x2) kernel's)
+void wino4_debug_report(const long long* hbuf, int grid)
+{
+    long long t0 = hbuf[0];
+    for (int b = 0; b < grid; ++b) t0 = std::min(t0, hbuf[b * 24]);
+    double sum[4] = {0, 0, 0, 0}, tend = 0, ck = 0, wk = 0; int items = 0;
+    for (int b = 0; b < grid; ++b) {
+        const long long* r = &hbuf[b * 24]; const int n = (int)r[23];
+        for (int i = 1; i + 4 < n + 1 && i + 4 <= 20; i += 5) {
+            for (int q = 0; q < 4; ++q) sum[q] += (r[i + q + 1] - r[i + q]) * 0.01;
+            ++items; tend = std::max(tend, (r[i + 4] - t0) * 0.01);
+        }
+        ck += r[21]; wk += r[22];
+    }
+    fprintf(stderr, "WINO4DBG grid=%d units=%d  K loop: %.3f GHz;  per unit: prologue %.2f  loop %.2f  epilogue %.2f us;  last block ends at %.2f us\n",
+            grid, items, wk ? ck / (wk * 10.0) : 0.0, items ? sum[0] / items : 0.0, items ? sum[1] / items : 0.0, items ? sum[3] / items : 0.0, tend);
+}
+
+template <int MODE>
+int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
+{
+    const auto kern = conv3_wino4_kernel<MODE>;
+    const size_t lds = (size_t)(W4_SMEM + 2 * a0.CIN) * sizeof(float);
+    const int dv = cur_dev();
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dv]) {
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int occ = 0; int prop_cus = 0;
+        FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
+        if (occ < 1) { set_error("winograd F(4x4) conv: kernel does not fit on a CU"); return FAV_EHIP; }
+        cus[dv] = prop_cus;          // one block per CU
+    }
+    const int units = a0.units_x * a0.units_y;
+    const int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
+    Wino4Args a = a0; a.dbg = nullptr;
+    static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
+    static long long* dbuf = nullptr;
+    const bool dbg = dbg_n > 0 && --dbg_n == 0;
+    if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 24 * 8, st)); a.dbg = dbuf; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    FAV_LAUNCH_CHECK("conv3_wino4_kernel");
+    if (dbg) {
+        std::vector<long long> hb((size_t)512 * 24);
+        FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
+        wino4_debug_report(hb.data(), grid);
+    }
+    return FAV_OK;
+}
+
+}  // namespace
+
+bool conv3_wino4_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
+{
+    return k == 3 && stride == 1 && pad == 0 && ups == 0 && stages <= 1 && cin_pitch % 16 == 0 && cin_pitch >= 16 && cin_pitch <= 256 &&
+           cout == 128 && coutp == 128;
+}
+int conv3_wino4_tiles(int OH, int OW) { return ((OH + 15) / 16) * ((OW + 15) / 16); }
+
+int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
+{
+    FAV_REQUIRE(conv3_wino4_eligible(c.CIN, c.COUT, c.COUTp, c.KH, c.stride, c.pad, c.pre.stages, c.ups) && c.KH == c.KW && !c.final_mode && !c.stuff && wpk,
+                "winograd F(4x4) conv: not eligible");
+    FAV_REQUIRE((long long)(c.IH + 1) * c.IWp * c.CIN < (1ll << 29), "winograd F(4x4) conv: tensor too large for 32-bit byte offsets");
+    FAV_REQUIRE(c.OH == c.IH - 2 && c.OW == c.IW - 2, "winograd F(4x4) conv: bad geometry");
+    Wino4Args a;
+    a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.relu1 = c.pre.relu1;
+    a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
+    a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW;
+    a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 15) / 16;
+    a.dbg = nullptr;
+    a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
+    if (c.join_skip != nullptr) {
+        FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
+        return launch_wino4_t<2>(a, c.reserve_cus, st);
+    }
+    return c.pre.stages >= 1 ? launch_wino4_t<1>(a, c.reserve_cus, st) : launch_wino4_t<0>(a, c.reserve_cus, st);
+}
+
+}  // namespace fav

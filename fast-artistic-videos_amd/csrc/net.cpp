@@ -24,6 +24,7 @@
 
 #include "fav_internal.h"
 #include "wino_pack.h"
+#include "wino4_pack.h"
 #include "up2_pack.h"
 #include "s2_pack.h"
 #include "first_pack.h"
@@ -34,7 +35,7 @@ using namespace fav;
 namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
-struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wup2 = nullptr; float* ws2w = nullptr; float* wfirst = nullptr; float* wfirst2d = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
+struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wwino4 = nullptr; float* wup2 = nullptr; float* ws2w = nullptr; float* wfirst = nullptr; float* wfirst2d = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
 struct Act {
@@ -87,10 +88,11 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w, wino_f2; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr, getenv("FAV_NO_S2W") != nullptr};
+    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr, getenv("FAV_NO_S2W") != nullptr,
+                             getenv("FAV_WINO_F2") != nullptr};      // FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (rounds 2-3) instead of F(4x4,3x3)
     return t;
 }
 
@@ -190,7 +192,7 @@ struct fav_net {
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
-    bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_up2 = false, use_first = false, use_first2d = false, use_s2w = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
+    bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_wino4 = false, use_up2 = false, use_first = false, use_first2d = false, use_s2w = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
     int curH = 0, curW = 0;
     std::vector<DevBuf> bufs;
@@ -209,7 +211,7 @@ struct fav_net {
     {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
-        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wfirst2d); (void)hipFree(c.wgt16); }
+        for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wwino4); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wfirst2d); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (void* sp : slabs) (void)hipFree(sp);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
@@ -271,6 +273,11 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 std::vector<float> ww;
                 conv_wino_pack(L.w.data(), L.cin, L.cout, ww);
                 rc = dev_upload(ww, 0, &d.wwino); if (rc) return rc;
+                if (!tuning().wino_f2 && conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 0, 0)) {      // ... as F(4x4,3x3) (round 4)
+                    std::vector<float> w4;
+                    conv_wino4_pack(L.w.data(), L.cin, L.cout, w4);
+                    rc = dev_upload(w4, 0, &d.wwino4); if (rc) return rc;
+                }
             }
             if (!L.transposed && L.cin == d.cinp && conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 1)) {      // 3x3 after a x2 upsampling: merged 2x2 taps
                 std::vector<float> wu, wu9;
@@ -409,7 +416,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     ConvLaunch cg = cs;
     static const int side_sk_mode = getenv("FAV_SIDE_SK") ? atoi(getenv("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
     if (reserve_cus > 0 && side_sk_mode != 1) cg.no_sk = 1;
-    auto go = [&]() { return use_first ? (use_first2d ? launch_conv_first2d(cs, L.cin, convs[conv_index].wfirst2d, c8_counts, st) : launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st)) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cg, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
+    auto go = [&]() { return use_first ? (use_first2d ? launch_conv_first2d(cs, L.cin, convs[conv_index].wfirst2d, c8_counts, st) : launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st)) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? (use_wino4 ? launch_conv3_wino4(cs, convs[conv_index].wwino4, c8_counts, st) : launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st)) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cg, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
     char tag[96] = "";
     if (TraceRange::enabled()) snprintf(tag, sizeof tag, "fav:conv%d k%d s%d %d->%d %dx%d", conv_index, L.k, L.stride, L.cin, L.cout, c.OW, c.OH);
     TraceRange tr(tag);
@@ -425,7 +432,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     if ((int)prof_ms.size() <= conv_index) { prof_ms.resize(conv_index + 1, 0.0); prof_macs.resize(conv_index + 1, 0.0); prof_n.resize(conv_index + 1, 0); prof_tile.resize(conv_index + 1, 0); }
     prof_macs[conv_index] = (double)c.OH * c.OW * L.cout * L.cin * L.k * L.k;      // useful MACs only
     // kernel id: 16 first layer with F(2x2,3x3) over its nine 3x3 blocks, 6 first layer with F(2,3) along x, 500+N 3x3 on a x2-upsampled input (merged taps), 700+N stride-2 3x3 (fragment-order weights), 400+N Winograd 3x3 (+1: with a pending residual join as its input), 1 row-folded last layer, 8 first layer, 300+N halo 3x3 (N = 64|128), 200+N stride-2 halo 3x3, else the generic kernel's N tile
-    prof_tile[conv_index] = use_first ? (use_first2d ? 16 : 6) : use_s2w ? 700 + c.COUTp : use_up2 ? 500 + c.COUTp : use_wino ? 400 + c.COUTp + (c.join_skip ? 1 : 0) : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
+    prof_tile[conv_index] = use_first ? (use_first2d ? 16 : 6) : use_s2w ? 700 + c.COUTp : use_up2 ? 500 + c.COUTp : use_wino ? (use_wino4 ? 600 : 400) + c.COUTp + (c.join_skip ? 1 : 0) : wfold ? 1 : (use_c8 ? (c8d_w ? 7 : 8) : (use_h3 ? 300 + c.COUTp : (use_s2 ? 200 + c.COUTp : (c.COUTp % 128 == 0 ? 128 : (c.COUTp % 64 == 0 ? 64 : 32)))));
     return rc;
 }
 
@@ -503,11 +510,12 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                              conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
             const bool s2w = !L.transposed && d.ws2w != nullptr && !tuning().no_s2w &&
                              conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
+            const bool wino4 = wino && d.wwino4 != nullptr && conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
             const bool h3 = !wino && !up2 && !s2w && !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
             const bool s2 = !L.transposed && !s2w && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
             static const bool first_1d = getenv("FAV_FIRST_1D") != nullptr;      // (tuning: read once) the 1-D form of the first layer
             const bool first2d = first && d.wfirst2d != nullptr && !first_1d;
-            nxt.mblocks = first ? (first2d ? conv_first2d_tiles(c.OH, c.OW) : conv_first_tiles(c.OH, c.OW)) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? conv3_wino_tiles(c.OH, c.OW) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
+            nxt.mblocks = first ? (first2d ? conv_first2d_tiles(c.OH, c.OW) : conv_first_tiles(c.OH, c.OW)) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? (wino4 ? conv3_wino4_tiles(c.OH, c.OW) : conv3_wino_tiles(c.OH, c.OW)) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
             if (want_stats && (c8 || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
@@ -516,9 +524,9 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 c.join_skip = cur.join_skip; c.join_out = cur.join_out;
             }
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
-            c8_counts = (c8 || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_up2 = up2; use_first = first; use_first2d = first2d; use_s2w = s2w;
+            c8_counts = (c8 || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_wino4 = wino4; use_up2 = up2; use_first = first; use_first2d = first2d; use_s2w = s2w;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
-            use_c8 = false; use_h3 = false; use_s2 = false; use_wino = false; use_up2 = false; use_first = false; use_first2d = false; use_s2w = false;
+            use_c8 = false; use_h3 = false; use_s2 = false; use_wino = false; use_wino4 = false; use_up2 = false; use_first = false; use_first2d = false; use_s2w = false;
             cur = nxt;
             break;
         }

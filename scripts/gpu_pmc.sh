@@ -21,7 +21,9 @@ for f in sorted(glob.glob("$O/pmc_${TAG}_*/*counter_collection.csv")):
         for c, v in d.items():
             out.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
 json.dump(out, open("$O/pmc_$TAG.json", "w"), indent=1, sort_keys=True)
-dom = [k for k in out if k.startswith("fav::conv3_wino_kernel")]
+dom = [k for k in out if k.startswith("fav::conv3_wino4_kernel")]
+f4 = bool(dom)
+if not dom: dom = [k for k in out if k.startswith("fav::conv3_wino_kernel")]
 if dom and all("FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k] for k in dom):
     nl = sum(out[k]["FETCH_SIZE"]["n"] for k in dom)
     f = sum(out[k]["FETCH_SIZE"]["mean"] * out[k]["FETCH_SIZE"]["n"] for k in dom) / nl
@@ -29,8 +31,9 @@ if dom and all("FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k] for k in dom):
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of
     # 16-B/lane coalesced streams (this kernel's loads are all 16 B/lane) -> doubled; WRITE_SIZE taken as is (uncalibrated)
     import hashlib
-    sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/kernels_wino.hip", "rb").read()).hexdigest()[:16]
-    json.dump({"kernel": "conv3_wino_kernel", "source": "kernels_wino.hip", "source_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
+    srcf = "kernels_wino4.hip" if f4 else "kernels_wino.hip"
+    sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/" + srcf, "rb").read()).hexdigest()[:16]
+    json.dump({"kernel": "conv3_wino4_kernel" if f4 else "conv3_wino_kernel", "source": srcf, "source_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
                "launches_averaged": nl, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of all instances "
                        "(plain input / pending InstanceNorm / pending residual join) in bench.py; read side doubled per the gfx950 FETCH_SIZE "

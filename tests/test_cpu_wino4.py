@@ -1,0 +1,200 @@
+"""Winograd F(4x4,3x3) path of the residual convolutions (csrc/kernels_wino4.hip, round 4): the host-side weight transform / packing
+(csrc/wino4_pack.h, compiled here with g++) and a lane-level numpy restatement of the kernel's data movement -- the two transform
+passes through LDS (items, addresses, the padded tile-row pitch), the fragment address of every lane, the 16x16x4 MFMA operand /
+result layout, the in-lane output transform -- checked against a direct 3x3 correlation.  No GPU: this pins the index arithmetic the
+HIP kernel is written from; the kernel itself is compared with the oracle in tests/test_gpu_parity.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc")
+
+TP, VPOS, VBUF, LLINE, LTY, LBUF = 20, 320, 36 * 320, 360, 2180, 4 * 2180
+
+
+@pytest.fixture(scope="module")
+def packer(tmp_path_factory):
+    d = tmp_path_factory.mktemp("wino4")
+    src = d / "pack.cpp"
+    src.write_text('#include "wino4_pack.h"\n#include <cstring>\n'
+                   'extern "C" long pack(const float* w, int cin, int cout, float* out) {\n'
+                   '  std::vector<float> v; fav::conv_wino4_pack(w, cin, cout, v); if (out) memcpy(out, v.data(), v.size() * 4); return (long)v.size(); }\n'
+                   'extern "C" void bt(const double* d, double* v) { fav::Wino4::bt<double>(d, v); }\n'
+                   'extern "C" void at(const double* m, double* y) { fav::Wino4::at<double>(m, y); }\n')
+    so = d / "libpack4.so"
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", CSRC, "-o", str(so), str(src)])
+    lib = ctypes.CDLL(str(so))
+    lib.pack.restype = ctypes.c_long
+    lib.pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.bt.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; lib.at.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+
+    def pack(w):
+        cout, cin = w.shape[:2]
+        w = np.ascontiguousarray(w, np.float32)
+        n = lib.pack(w.ctypes.data, cin, cout, None)
+        out = np.empty(n, np.float32)
+        lib.pack(w.ctypes.data, cin, cout, out.ctypes.data)
+        return out
+
+    def bt(d):
+        d = np.ascontiguousarray(d, np.float64); v = np.empty(6)
+        lib.bt(d.ctypes.data, v.ctypes.data)
+        return v
+
+    def at(m):
+        m = np.ascontiguousarray(m, np.float64); y = np.empty(4)
+        lib.at(m.ctypes.data, y.ctypes.data)
+        return y
+    pack.bt, pack.at = bt, at
+    return pack
+
+
+BT = np.array([[81 / 64, 0, -45 / 16, 0, 1, 0], [0, -27 / 16, -9 / 4, 3 / 4, 1, 0], [0, 27 / 16, -9 / 4, -3 / 4, 1, 0],
+               [0, -27 / 32, -9 / 16, 3 / 2, 1, 0], [0, 27 / 32, -9 / 16, -3 / 2, 1, 0], [0, 81 / 64, 0, -45 / 16, 0, 1]])
+G = np.array([[64 / 81, 0, 0], [-128 / 243, -32 / 81, -8 / 27], [-128 / 243, 32 / 81, -8 / 27], [32 / 243, 16 / 81, 8 / 27], [32 / 243, -16 / 81, 8 / 27], [0, 0, 1]])
+AT = np.array([[1, 1, 1, 1, 1, 0], [0, 3 / 4, -3 / 4, 3 / 2, -3 / 2, 0], [0, 9 / 16, 9 / 16, 9 / 4, 9 / 4, 0], [0, 27 / 64, -27 / 64, 27 / 8, -27 / 8, 1]])
+
+
+def test_transform_matrices_are_a_minimal_filtering_algorithm(packer):
+    """Y = A^T [(G g G^T) (.) (B^T d B)] A is the 3x3 correlation of a 6x6 patch for ANY d, g (exactly, in rational arithmetic up to
+    double rounding), and the device forms of B^T / A^T (wino4_pack.h Wino4::bt / at) are those matrices"""
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        d, g = rng.standard_normal((6, 6)), rng.standard_normal((3, 3))
+        y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
+        ref = np.array([[(d[a:a + 3, b:b + 3] * g).sum() for b in range(4)] for a in range(4)])
+        assert np.abs(y - ref).max() < 1e-12
+        v = rng.standard_normal(6)
+        assert np.abs(packer.bt(v) - BT @ v).max() < 1e-13 and np.abs(packer.at(v) - AT @ v).max() < 1e-13
+
+
+def direct_conv(x, w, b):
+    IH, IW, _ = x.shape
+    OH, OW = IH - 2, IW - 2
+    y = np.zeros((OH, OW, w.shape[0]))
+    for ky in range(3):
+        for kx in range(3):
+            y += np.einsum("hwc,oc->hwo", x[ky:ky + OH, kx:kx + OW].astype(np.float64), w[:, :, ky, kx].astype(np.float64))
+    return y + b.astype(np.float64)
+
+
+def bt_rows(d):       # B^T applied to six [..]-shaped operands the way w4_bt does (operation order included)
+    e1, o1 = d[4] - 2.25 * d[2], 0.75 * d[3] - 1.6875 * d[1]
+    e2, o2 = d[4] - 0.5625 * d[2], 1.5 * d[3] - 0.84375 * d[1]
+    return [1.265625 * d[0] + (d[4] - 2.8125 * d[2]), e1 + o1, e1 - o1, e2 + o2, e2 - o2, 1.265625 * d[1] + (d[5] - 2.8125 * d[3])]
+
+
+def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
+    """One work unit (16 x 16 output pixels x 128 channels) the way conv3_wino4_kernel computes it.  Returns Y[16][16][128]."""
+    IH, IW, CIN = x.shape
+    ns = CIN // 16
+    wpk = wpk.reshape(ns, 36, 4, 2, 64, 4)
+    lanes = np.arange(64)
+    acc = np.zeros((4, 36, 2, 16, 16), f)                     # [wave][position][nt][tile][n]
+    for s in range(ns):
+        # stage 1: items (ty, x, cq) -> six row-transformed lines in L[ty][i][x][20]
+        L = np.full(LBUF, np.nan, f)
+        for e in range(288):
+            t = e if e < 256 else e - 256
+            cq = t & 3
+            if e < 256:
+                pix = t >> 2; ty = (pix * 3641) >> 16; xx = pix - ty * 18
+                assert ty == pix // 18
+            else:
+                assert t < 32
+                ty, xx = 3, 10 + ((t & 63) >> 2)
+            rows = []
+            for a in range(6):
+                iy, ix = min(oy0 + 4 * ty + a, IH - 1), min(ox0 + xx, IW - 1)
+                v = x[iy, ix, s * 16 + cq * 4: s * 16 + cq * 4 + 4].astype(f)
+                if scale is not None:
+                    v = v * scale[s * 16 + cq * 4: s * 16 + cq * 4 + 4] + shift[s * 16 + cq * 4: s * 16 + cq * 4 + 4]
+                    if relu:
+                        v = np.maximum(v, 0)
+                rows.append(v.astype(f))
+            dst = ty * LTY + xx * TP + cq * 4
+            for i, l in enumerate(bt_rows(rows)):
+                L[dst + i * LLINE: dst + i * LLINE + 4] = l.astype(f)
+        # stage 2: items (tile m, line i, kq) -> six positions in V[6 i + j][m][20]
+        V = np.full(VBUF, np.nan, f)
+        items = [(t & 15, (t >> 4) & 3, t >> 6) for t in range(256)] + [(t & 15, (t >> 4) & 3, 2 + (t >> 6)) for t in range(128, 256)]
+        assert sorted(items) == sorted((m, kq, i) for m in range(16) for kq in range(4) for i in range(6))
+        for m2, kq, i in items:
+            src = (m2 >> 2) * LTY + 4 * (m2 & 3) * TP + kq * 4 + i * LLINE
+            c = [L[src + k * TP: src + k * TP + 4] for k in range(6)]
+            assert not any(np.isnan(v).any() for v in c)
+            for j, o in enumerate(bt_rows(c)):
+                dst = (6 * i + j) * VPOS + m2 * TP + kq * 4
+                V[dst: dst + 4] = o.astype(f)
+        # matrix instructions: lane = (m = lane & 15, kq = lane >> 4); v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j], lane l
+        # holds A[l & 15][l >> 4] and B[l >> 4][l & 15]
+        aA = (lanes & 15) * TP + (lanes >> 4) * 4
+        for w in range(4):
+            for p in range(36):
+                A = V[(p * VPOS + aA)[:, None] + np.arange(4)[None, :]]          # [lane][step]
+                assert not np.isnan(A).any()
+                for nt in range(2):
+                    B = wpk[s, p, w, nt]                                          # [lane][step]
+                    for j in range(4):
+                        a2 = A[:, j].reshape(4, 16)          # [k][tile]
+                        b2 = B[:, j].reshape(4, 16)          # [k][n]
+                        acc[w, p, nt] += (a2.T.astype(np.float64) @ b2.astype(np.float64)).astype(f)
+    # output transform in the lane: register r of lane (g, n) = tile 4 g + r, channel 32 w + 16 nt + n
+    Y = np.zeros((16, 16, 128), f)
+    for w in range(4):
+        for nt in range(2):
+            for tile in range(16):
+                M = acc[w, :, nt, tile, :].reshape(6, 6, 16).astype(np.float64)     # [i][j][n]
+                Q = np.einsum("ai,ijn->ajn", AT, M)
+                Yt = np.einsum("ajn,bj->abn", Q, AT)
+                co = 32 * w + 16 * nt + np.arange(16)
+                Y[4 * (tile >> 2): 4 * (tile >> 2) + 4, 4 * (tile & 3): 4 * (tile & 3) + 4, co] = (Yt + bias[co][None, None, :]).astype(f)
+    return Y
+
+
+@pytest.mark.parametrize("cin,affine", [(32, False), (128, True)])
+def test_wino4_lane_level_restatement_matches_direct_convolution(packer, cin, affine):
+    rng = np.random.default_rng(11 + cin)
+    IH, IW = 21, 35                                   # 19 x 33 outputs: units (0, 0), (0, 1), (1, 2) incl. the clamped fringe
+    x = rng.standard_normal((IH, IW, cin)).astype(np.float32)
+    w = (rng.standard_normal((128, cin, 3, 3)) * np.sqrt(2 / (cin * 9))).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, 128).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cin).astype(np.float32) if affine else None
+    shift = rng.uniform(-0.5, 0.5, cin).astype(np.float32) if affine else None
+    xin = np.maximum(x * scale + shift, 0) if affine else x
+    ref = direct_conv(xin, w, b)
+    wpk = packer(w)
+    assert wpk.size == (cin // 16) * 36 * 4 * 2 * 64 * 4
+    for uy, ux in ((0, 0), (0, 1), (1, 2)):
+        Y = emulate_unit(x, wpk, b, scale, shift, affine, uy * 16, ux * 16)
+        oh, ow = min(16, 19 - uy * 16), min(16, 33 - ux * 16)
+        r = ref[uy * 16: uy * 16 + oh, ux * 16: ux * 16 + ow]
+        err = np.abs(Y[:oh, :ow] - r).max()
+        assert err < 2e-4, (uy, ux, err)
+
+
+def _slots(addr_words):
+    return (np.asarray(addr_words) // 4) % 16
+
+
+def test_wino4_lds_accesses_are_bank_conflict_free():
+    """a ds_read_b128 / ds_write_b128 is served in groups of 16 lanes; every group must touch 16 different sixteen-byte slots (mod 16):
+    the A-fragment read of every position, and both sides of the column pass (the reason for the 545-slot tile-row pitch of L)"""
+    lanes = np.arange(64)
+    aA = (lanes & 15) * TP + (lanes >> 4) * 4
+    for grp in range(4):
+        assert len(set(_slots(aA[grp * 16: grp * 16 + 16]))) == 16
+    t = np.arange(256)
+    m2, kq = t & 15, (t >> 4) & 3
+    l2 = (m2 >> 2) * LTY + 4 * (m2 & 3) * TP + kq * 4
+    v2 = m2 * TP + kq * 4
+    for grp in range(16):
+        sl = slice(grp * 16, grp * 16 + 16)
+        for k in range(6):
+            assert len(set(_slots(l2[sl] + k * TP))) == 16, ("stage-2 read", grp, k)
+        assert len(set(_slots(v2[sl]))) == 16, ("stage-2 write", grp)
+    assert (LTY // 4) % 16 == 1 and LTY >= 6 * LLINE

@@ -295,6 +295,13 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
     phases = np.load(tmp_path / "direct.npy")
     assert np.abs(phases - ref).max() <= 5e-2 and np.abs(got - phases).max() <= 2e-2, (np.abs(phases - ref).max(), np.abs(got - phases).max())
+    # FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (conv3_wino_kernel, the reference-accuracy form) instead of F(4x4,3x3)
+    env = dict(os.environ, FAV_WINO_F2="1")
+    subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
+    f2 = np.load(tmp_path / "direct.npy")
+    e2, e4 = np.abs(f2 - ref).max(), np.abs(got - ref).max()
+    print("canonical 88x120: F(2x2) max-abs %.3e, F(4x4) max-abs %.3e (150*tanh space)" % (e2, e4))
+    assert e2 <= 5e-2 and np.abs(got - f2).max() <= 2e-2 and not np.array_equal(got, f2)
 
 
 @pytest.mark.parametrize("size", [(88, 120), (90, 122), (360, 640), (720, 1280)])
