@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           w4_bt(c_, o_);                                                                            \
           _Pragma("unroll") for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(v2 + (nb_) * W4_VBUF + (6 * (i_) + j) * W4_VPOS) = o_[j]; }
 
-        v4f fa[3];
+        v4f fa[4];
 #define W4_READ_A(slot_, par_, pos_) { fa[slot_] = *reinterpret_cast<const v4f*>(aA + (par_) * W4_VBUF + (pos_) * W4_VPOS); }
 #define W4_LOAD_B(slot_, sl_, pos_)                                                                 \
         { const int so_ = wso + ((sl_) * 36 + (pos_)) * 8192;                                       \
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (hasB) { W4_LOAD_RAW(qb, 0, hoB); }
             if (!ring_primed) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { W4_LOAD_B(q, 0, q); }
+                for (int q = 0; q < 7; ++q) { W4_LOAD_B(q, 0, q); }
                 ring_primed = true;
             }
             W4_AFF(0);
@@ -222,17 +222,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //   positions 14, 22   column pass of items C, D into the other V buffer          after position 35   barrier: V complete
         // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-        // positions [from_, to_) of the slice: A fragment two positions ahead, weights eight positions ahead, 8 matrix instructions
+        // positions [from_, to_) of the slice, two at a time: A fragments of the pair after, weights seven / eight positions ahead, 16 matrix
+        // instructions interleaved over the pair's FOUR accumulators -- an accumulator is used again after three other instructions (a
+        // 16x16x4 result is ready ~11 passes after issue; with only the position's own two accumulators alternating every instruction
+        // waited ~3 passes for its predecessor: 51 us per unit's loop where the instructions need 35, profiles/r04d_wino4_first_run.log).
         // (segments of a few positions each, so that every loop is small enough to be unrolled completely: the accumulators are
         //  indexed by the position)
 #define W4_POSITIONS(from_, to_)                                                                    \
-        { _Pragma("unroll") for (int pos = (from_); pos < (to_); ++pos) {                          \
-            if (pos + 2 < 36) { W4_READ_A((pos + 2) % 3, par, pos + 2); }                            \
+        { _Pragma("unroll") for (int pos = (from_); pos < (to_); pos += 2) {                       \
+            if (pos + 2 < 36) { W4_READ_A((pos + 2) % 4, par, pos + 2); W4_READ_A((pos + 3) % 4, par, pos + 3); }    \
+            if (pos + 7 < 36) { W4_LOAD_B((pos + 7) % 9, s, pos + 7); } else { W4_LOAD_B((pos + 7) % 9, sw, pos + 7 - 36); } \
             if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } \
             W4_FENCE();                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos % 3][j], fb[pos % 9][0][j], acc[pos][0], 0, 0, 0); \
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos % 3][j], fb[pos % 9][1][j], acc[pos][1], 0, 0, 0); \
+                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][0][j], fa[pos % 4][j], acc[pos][0], 0, 0, 0); \
+                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][1][j], fa[pos % 4][j], acc[pos][1], 0, 0, 0); \
+                acc[pos + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][0][j], fa[(pos + 1) % 4][j], acc[pos + 1][0], 0, 0, 0); \
+                acc[pos + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][1][j], fa[(pos + 1) % 4][j], acc[pos + 1][1], 0, 0, 0); \
             }                                                                                       \
             W4_FENCE(); } }
         for (int s = 0; s < nslices; ++s) {
@@ -270,19 +276,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_READ_A
 #undef W4_LOAD_B
 
-        // ---- output transform, in the lane.  acc[6 i + j][nt][r] = M[i][j] of tile 4 (lane >> 4) + r, output channel 32 wave + 16 nt +
-        // (lane & 15): Y = A^T M A (4 x 4), bias, NHWC store, per-unit InstanceNorm partials (mean, M2, count) like the other kernels
-        const int nl = lane & 15, g = lane >> 4;
+        // ---- output transform, in the lane.  The matrix instructions were issued with the WEIGHTS as the M operand: acc[6 i + j][nt][r] =
+        // M[i][j] of tile (lane & 15), output channel 32 wave + 16 nt + 4 (lane >> 4) + r -- a lane holds FOUR CONSECUTIVE channels of one
+        // tile, i.e. 16 contiguous bytes of every output pixel.  Y = A^T M A (4 x 4), bias, NHWC store (b128), per-unit InstanceNorm
+        // partials (mean, M2, count) like the other kernels
+        const int tl = lane & 15, g = lane >> 4;
         const int nrows = max(0, min(16, p.OH - oy0)), ncols = max(0, min(16, p.OW - ox0));
         const int nv = nrows * ncols;
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * 512, 0x00020000);
         const bool inside = nv == 256;         // (wave-uniform: nine units in ten lie wholly inside the image and skip every per-pixel test)
+        const int oyb = oy0 + 4 * (tl >> 2), oxb = ox0 + 4 * (tl & 3);
+        const int cb = wave * 32 + 4 * g;      // first of this lane's four channels (+ 16 nt)
+        float y[2][4][4][4];                   // [nt][row a][column b][channel r]
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int co = wave * 32 + nt * 16 + nl;
-            const float bv = p.bias[co];
-            float y[4][4][4];                  // [r][row a][column b]
-            float sm = 0.f;
+            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb + 16 * nt);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float Q[4][6];
@@ -292,46 +300,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     float o[4]; Wino4::at<float>(mcol, o);
                     Q[0][j] = o[0]; Q[1][j] = o[1]; Q[2][j] = o[2]; Q[3][j] = o[3];
                 }
-                const int tile = 4 * g + r;
-                const int oyb = oy0 + 4 * (tile >> 2), oxb = ox0 + 4 * (tile & 3);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     float o[4]; Wino4::at<float>(Q[a], o);
-                    const int ro = ((oyb + a) * p.OWp + oxb) * 512 + co * 4;      // byte offset of column 0; columns follow 512 B apart
-                    const bool rv = oyb + a < p.OH;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        y[r][a][b] = o[b] + bv;
-                        if (inside) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r][a][b]), ors, ro, b * 512, 0);
-                            sm += y[r][a][b];
-                        } else {
-                            const bool v = rv && oxb + b < p.OW;       // (outside the image: an offset past the buffer, the store is dropped)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[r][a][b]), ors, v ? ro : (int)0xFFFFF000, b * 512, 0);
-                            sm += v ? y[r][a][b] : 0.f;
-                        }
-                    }
+                    for (int b = 0; b < 4; ++b) y[nt][a][b][r] = o[b] + bv[r];
                 }
             }
-            if (p.partials != nullptr) {
-                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-                const float mu = nv ? sm / (float)nv : 0.f;
-                float m2 = 0.f;
+        }
+        // both halves of a pixel's 128-byte line (this wave's 32 channels) leave back to back
+        unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ro = ((oyb + a) * p.OWp + oxb) * 512 + cb * 4;          // byte offset of column 0; columns follow 512 B apart
+            const bool rv = oyb + a < p.OH;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool v = inside || (rv && oxb + b < p.OW);               // (outside the image: an offset past the buffer, the store is dropped)
+                const int vo = v ? ro : (int)0xFFFFF000;
+                vmask |= (v ? 1u : 0u) << (4 * a + b);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const v4f w = {y[nt][a][b][0], y[nt][a][b][1], y[nt][a][b][2], y[nt][a][b][3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, vo, b * 512 + nt * 64, 0);
+                }
+            }
+        }
+        if (p.partials != nullptr) {
+            // per channel: the 16 lanes of a group hold its 16 tiles; sums by butterfly inside the group
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int tile = 4 * g + r;
-                    const int oyb = oy0 + 4 * (tile >> 2), oxb = ox0 + 4 * (tile & 3);
+                    float sm = 0.f;
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const float d = y[r][a][b] - mu;
-                            if (inside || (oyb + a < p.OH && oxb + b < p.OW)) m2 = fmaf(d, d, m2);
-                        }
+                        for (int b = 0; b < 4; ++b) sm += (inside || ((vmask >> (4 * a + b)) & 1u)) ? y[nt][a][b][r] : 0.f;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+                    const float mu = nv ? sm / (float)nv : 0.f;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) { const float d = y[nt][a][b][r] - mu; if (inside || ((vmask >> (4 * a + b)) & 1u)) m2 = fmaf(d, d, m2); }
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
+                    if (tl == 0) p.partials[(size_t)u * 128 + cb + 16 * nt + r] = make_float2(mu, m2);
                 }
-                m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
-                if (g == 0) p.partials[(size_t)u * 128 + co] = make_float2(mu, m2);
-            }
         }
         if (p.partials != nullptr && t == 0) p.counts[u] = nv;
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)

@@ -94,7 +94,7 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
     ns = CIN // 16
     wpk = wpk.reshape(ns, 36, 4, 2, 64, 4)
     lanes = np.arange(64)
-    acc = np.zeros((4, 36, 2, 16, 16), f)                     # [wave][position][nt][tile][n]
+    acc = np.zeros((4, 36, 2, 64, 4), f)                      # [wave][position][nt][lane][register r]: the MFMA result registers
     for s in range(ns):
         # stage 1: items (ty, x, cq) -> six row-transformed lines in L[ty][i][x][20]
         L = np.full(LBUF, np.nan, f)
@@ -130,29 +130,32 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
             for j, o in enumerate(bt_rows(c)):
                 dst = (6 * i + j) * VPOS + m2 * TP + kq * 4
                 V[dst: dst + 4] = o.astype(f)
-        # matrix instructions: lane = (m = lane & 15, kq = lane >> 4); v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j], lane l
-        # holds A[l & 15][l >> 4] and B[l >> 4][l & 15]
+        # matrix instructions: v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]
+        # and, in register r, D[4 (l >> 4) + r][l & 15].  The kernel passes the WEIGHTS as A (i = channel inside the 16-group) and the
+        # transformed input as B (j = tile): register r of lane l = tile l & 15, channel 4 (l >> 4) + r
         aA = (lanes & 15) * TP + (lanes >> 4) * 4
         for w in range(4):
             for p in range(36):
-                A = V[(p * VPOS + aA)[:, None] + np.arange(4)[None, :]]          # [lane][step]
-                assert not np.isnan(A).any()
+                Vf = V[(p * VPOS + aA)[:, None] + np.arange(4)[None, :]]         # [lane][step]
+                assert not np.isnan(Vf).any()
                 for nt in range(2):
-                    B = wpk[s, p, w, nt]                                          # [lane][step]
+                    Wf = wpk[s, p, w, nt]                                         # [lane][step]
                     for j in range(4):
-                        a2 = A[:, j].reshape(4, 16)          # [k][tile]
-                        b2 = B[:, j].reshape(4, 16)          # [k][n]
-                        acc[w, p, nt] += (a2.T.astype(np.float64) @ b2.astype(np.float64)).astype(f)
-    # output transform in the lane: register r of lane (g, n) = tile 4 g + r, channel 32 w + 16 nt + n
+                        a2 = Wf[:, j].reshape(4, 16)         # [k][channel i]   (lane = k * 16 + i)
+                        b2 = Vf[:, j].reshape(4, 16)         # [k][tile j]
+                        D = (a2.T.astype(np.float64) @ b2.astype(np.float64)).astype(f)      # [channel][tile]
+                        for r in range(4):
+                            acc[w, p, nt, :, r] += D[4 * (lanes >> 4) + r, lanes & 15]
+    # output transform in the lane: register r of lane l = tile l & 15, channel 32 w + 16 nt + 4 (l >> 4) + r
     Y = np.zeros((16, 16, 128), f)
     for w in range(4):
         for nt in range(2):
-            for tile in range(16):
-                M = acc[w, :, nt, tile, :].reshape(6, 6, 16).astype(np.float64)     # [i][j][n]
-                Q = np.einsum("ai,ijn->ajn", AT, M)
-                Yt = np.einsum("ajn,bj->abn", Q, AT)
-                co = 32 * w + 16 * nt + np.arange(16)
-                Y[4 * (tile >> 2): 4 * (tile >> 2) + 4, 4 * (tile & 3): 4 * (tile & 3) + 4, co] = (Yt + bias[co][None, None, :]).astype(f)
+            for lane in range(64):
+                tile, g = lane & 15, lane >> 4
+                for r in range(4):
+                    M = acc[w, :, nt, lane, r].reshape(6, 6).astype(np.float64)
+                    co = 32 * w + 16 * nt + 4 * g + r
+                    Y[4 * (tile >> 2): 4 * (tile >> 2) + 4, 4 * (tile & 3): 4 * (tile & 3) + 4, co] = (AT @ M @ AT.T + bias[co]).astype(f)
     return Y
 
 
