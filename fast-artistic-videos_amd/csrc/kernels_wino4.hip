@@ -49,7 +49,9 @@ constexpr int W4_VBUF = 36 * W4_VPOS;          // 11520 words per V buffer
 constexpr int W4_LLINE = 18 * W4_TP;           // 360: one row-transformed line (18 columns) of a tile row
 constexpr int W4_LTY = 2180;                   // the six lines of a tile row (2160) padded to 545 slots = 1 (mod 16): see stage 2
 constexpr int W4_LBUF = 4 * W4_LTY;            // 8720 words
-constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF; // 31760 words = 127 040 B (+ 2 CIN words of pending scale / shift)
+constexpr int W4_RA = 6 * 256 * 4;             // landing area of the raw rows (buffer_load ... lds): item A [row][thread] 16 bytes each
+constexpr int W4_RBUF = W4_RA + 6 * 32 * 4;    // ... and item B [row][lane < 32]: 6912 words
+constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF + W4_RBUF;      // 38672 words = 154 688 B (+ 2 CIN words of pending scale / shift)
 static_assert(W4_LTY >= 6 * W4_LLINE && (W4_LTY / 4) % 16 == 1, "tile-row pitch of L");
 
 struct Wino4Args {
@@ -72,7 +74,9 @@ __device__ __forceinline__ void w4_bt(const v4f d[6], v4f v[6])      // B^T d (w
 
 // MODE 0: plain input; MODE 1: pending per-channel scale / shift (+ ReLU) of the producing convolution's InstanceNorm; MODE 2: pending
 // residual join z = skip + scale * y + shift (res_add_kernel's operations in its order), written out once as the next block's skip
-template <int MODE>
+// (VAR: timing experiments only -- FAV_W4_VAR: bit 0 the K loop requests no weights, bit 1 stages nothing, bit 2 no barriers inside the slice;
+//  the results are garbage, the timeline of FAV_WINO_DBG says what each part costs)
+template <int MODE, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_wino4_kernel(const Wino4Args p)
 {
     constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
@@ -80,7 +84,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Vs = smem;                        // [2][W4_VBUF]
     float* const Ls = smem + 2 * W4_VBUF;          // [4][W4_LTY]
-    float* const aff = Ls + W4_LBUF;               // [2][CIN]
+    float* const Rs = Ls + W4_LBUF;                // landing area of the raw rows
+    float* const aff = Rs + W4_RBUF;               // [2][CIN]
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -158,8 +164,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 
         v4f sc, sh;
+        float* const landA = Rs + wave * 256;              // (wave-uniform: M0 of the LDS loads; lane i lands 16 i bytes further)
+        float* const landB = Rs + W4_RA;
+        const float* const readA = Rs + t * 4;
+        const float* const readB = Rs + W4_RA + lane * 4;
 #define W4_LOAD_RAW(q_, slice_, ho_)                                                                \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_[a], (slice_) * 64, 0)); }
+        // the NEXT slices' raw rows bypass the register file: buffer_load ... lds into the landing area, requested a whole slice before
+        // their use (a wave has no second wave on its SIMD to hide a round trip behind: rows requested six positions ahead cost the
+        // K loop 13 of its 57 us, profiles/r04e_wino4_variants.log), read back by the requesting thread behind an explicit s_waitcnt (the
+        // compiler does not see that dependency; loads return in order and at least `vm_` younger weight loads are in flight by then)
+#define W4_REQ_RAW(slice_, ho_, lbase_, lrow_)                                                      \
+        { asm volatile("" ::: "memory");      /* (never above the reads of the rows these loads replace) */ \
+          _Pragma("unroll") for (int a = 0; a < 6; ++a)                                             \
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)((lbase_) + a * (lrow_)), 16, ho_[a], (slice_) * 64, 0, 0); }
+#define W4_TAKE_RAW(q_, lread_, lrow_)                                                              \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>((lread_) + a * (lrow_)); }
 #define W4_LOAD_SKIP(x_, slice_, ho_)                                                               \
         { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho_[a], (slice_) * 64, 0)); } }
 #define W4_AFF(slice_)                                                                              \
@@ -176,11 +196,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_COMMIT1(q_, dst_)                                                                        \
         { v4f l_[6]; w4_bt(q_, l_);                                                                 \
           _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>((dst_) + i * W4_LLINE) = l_[i]; }
-#define W4_STAGE2(i_, nb_)                                                                          \
-        { v4f c_[6], o_[6];                                                                         \
-          _Pragma("unroll") for (int k = 0; k < 6; ++k) c_[k] = *reinterpret_cast<const v4f*>(l2 + (i_) * W4_LLINE + k * W4_TP); \
-          w4_bt(c_, o_);                                                                            \
+        // column pass in two halves: the six reads, and -- a segment of matrix instructions later -- transform and writes
+#define W4_S2_READ(c_, i_)                                                                          \
+        { _Pragma("unroll") for (int k = 0; k < 6; ++k) c_[k] = *reinterpret_cast<const v4f*>(l2 + (i_) * W4_LLINE + k * W4_TP); }
+#define W4_S2_DONE(c_, i_, nb_)                                                                     \
+        { v4f o_[6]; w4_bt(c_, o_);                                                                 \
           _Pragma("unroll") for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(v2 + (nb_) * W4_VBUF + (6 * (i_) + j) * W4_VPOS) = o_[j]; }
+#define W4_STAGE2(i_, nb_) { v4f c2_[6]; W4_S2_READ(c2_, i_); W4_S2_DONE(c2_, i_, nb_); }
 
         v4f fa[4];
 #define W4_READ_A(slot_, par_, pos_) { fa[slot_] = *reinterpret_cast<const v4f*>(aA + (par_) * W4_VBUF + (pos_) * W4_VPOS); }
@@ -203,6 +225,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_AFF(0);
             W4_PEND(qa, xa, 0, hoA, 0); W4_COMMIT1(qa, l1A);
             if (hasB) { W4_PEND(qb, xb, 0, hoB, 8); W4_COMMIT1(qb, l1B); }
+            W4_REQ_RAW(min(1, nslices - 1), hoA, landA, 1024);
+            if (hasB) { W4_REQ_RAW(min(1, nslices - 1), hoB, landB, 128); }
             __syncthreads();
             W4_STAGE2(wave, 0);
             if (hasD) { W4_STAGE2(2 + wave, 0); }
@@ -216,10 +240,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
 
         // ---- K loop: per 16-channel slice 36 positions of 8 matrix instructions; between them the NEXT slice is staged:
-        //   position 0      raw rows of item A requested          position 6   item A committed to L (pending transform, rows of B^T d),
-        //                                                                      raw rows of item B requested (wave 0, lanes 0..31)
-        //   position 10     item B committed                      position 12  barrier: L complete
-        //   positions 14, 22   column pass of items C, D into the other V buffer          after position 35   barrier: V complete
+        //   position 4      item A's raw rows (requested a slice ago) read back from the landing area
+        //   position 6      item A committed to L (pending transform, rows of B^T d); item B's rows read back (wave 0, lanes 0..31)
+        //   position 8      item B committed; the rows of the slice AFTER the next requested
+        //   position 12     barrier: L complete; column pass, item C: reads         position 14  ... transform + writes into the other V buffer
+        //   positions 14, 22   item D likewise (waves 2, 3)                             after position 35   barrier: V complete
         // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
         // positions [from_, to_) of the slice, two at a time: A fragments of the pair after, weights seven / eight positions ahead, 16 matrix
@@ -231,8 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_POSITIONS(from_, to_)                                                                    \
         { _Pragma("unroll") for (int pos = (from_); pos < (to_); pos += 2) {                       \
             if (pos + 2 < 36) { W4_READ_A((pos + 2) % 4, par, pos + 2); W4_READ_A((pos + 3) % 4, par, pos + 3); }    \
+            if (!(VAR & 1)) {                                                                       \
             if (pos + 7 < 36) { W4_LOAD_B((pos + 7) % 9, s, pos + 7); } else { W4_LOAD_B((pos + 7) % 9, sw, pos + 7 - 36); } \
-            if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } \
+            if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } } \
             W4_FENCE();                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
                 acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][0][j], fa[pos % 4][j], acc[pos][0], 0, 0, 0); \
@@ -245,21 +271,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int par = s & 1;
             const int sn = min(s + 1, nslices - 1);
             const int sw = s + 1 < nslices ? s + 1 : 0;       // (weights: the next unit starts at slice 0 again)
-            v4f qa[6], xa[6];
-            W4_LOAD_SKIP(xa, sn, hoA); W4_LOAD_RAW(qa, sn, hoA);
-            W4_POSITIONS(0, 6);
-            W4_AFF(sn); W4_PEND(qa, xa, sn, hoA, 0); W4_COMMIT1(qa, l1A);
-            if (hasB) { W4_LOAD_SKIP(xa, sn, hoB); W4_LOAD_RAW(qa, sn, hoB); }
-            W4_POSITIONS(6, 10);
-            if (hasB) { W4_PEND(qa, xa, sn, hoB, 8); W4_COMMIT1(qa, l1B); }
-            W4_POSITIONS(10, 12);
-            __syncthreads();
+            const int sn2 = min(s + 2, nslices - 1);
+            v4f qa[6], xa[6], c2[6];
+            if (!(VAR & 2)) { W4_LOAD_SKIP(xa, sn, hoA); }
+            W4_POSITIONS(0, 4);
+            if (!(VAR & 2)) {
+                // slice sn's rows were requested a slice ago (in the prologue for s = 0: eight weight loads have followed)
+                if (s == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                W4_TAKE_RAW(qa, readA, 1024);
+            }
+            W4_POSITIONS(4, 6);
+            if (!(VAR & 2)) {
+                W4_AFF(sn); W4_PEND(qa, xa, sn, hoA, 0); W4_COMMIT1(qa, l1A);
+                if (hasB) { W4_LOAD_SKIP(xa, sn, hoB); W4_TAKE_RAW(qa, readB, 128); }
+            }
+            W4_POSITIONS(6, 8);
+            if (!(VAR & 2)) {
+                if (hasB) { W4_PEND(qa, xa, sn, hoB, 8); W4_COMMIT1(qa, l1B); }
+                W4_REQ_RAW(sn2, hoA, landA, 1024);
+                if (hasB) { W4_REQ_RAW(sn2, hoB, landB, 128); }
+            }
+            W4_POSITIONS(8, 12);
+            if (!(VAR & 4)) __syncthreads();
+            if (!(VAR & 2)) { W4_S2_READ(c2, wave); }
             W4_POSITIONS(12, 14);
-            W4_STAGE2(wave, par ^ 1);
+            if (!(VAR & 2)) { W4_S2_DONE(c2, wave, par ^ 1); if (hasD) { W4_S2_READ(c2, 2 + wave); } }
             W4_POSITIONS(14, 22);
-            if (hasD) { W4_STAGE2(2 + wave, par ^ 1); }
+            if (!(VAR & 2)) { if (hasD) { W4_S2_DONE(c2, 2 + wave, par ^ 1); } }
             W4_POSITIONS(22, 36);
-            __syncthreads();
+            if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
         }
 #undef W4_POSITIONS
@@ -268,6 +308,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
         DBG_T();
 #undef W4_LOAD_RAW
+#undef W4_REQ_RAW
+#undef W4_TAKE_RAW
+#undef W4_S2_READ
+#undef W4_S2_DONE
 #undef W4_LOAD_SKIP
 #undef W4_AFF
 #undef W4_PEND
@@ -381,7 +425,9 @@ void wino4_debug_report(const long long* hbuf, int grid)
 template <int MODE>
 int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
 {
-    const auto kern = conv3_wino4_kernel<MODE>;
+    static const int var = getenv("FAV_W4_VAR") ? atoi(getenv("FAV_W4_VAR")) : 0;
+    const auto kern = (MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
+                      (MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> : conv3_wino4_kernel<MODE, 0>;
     const size_t lds = (size_t)(W4_SMEM + 2 * a0.CIN) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
@@ -389,7 +435,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int occ = 0; int prop_cus = 0;
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));
-        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds));
         if (occ < 1) { set_error("winograd F(4x4) conv: kernel does not fit on a CU"); return FAV_EHIP; }
         cus[dv] = prop_cus;          // one block per CU
     }
