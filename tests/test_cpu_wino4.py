@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc")
 
-TP, VPOS, VBUF, LLINE, LTY, LBUF = 20, 320, 36 * 320, 360, 2180, 4 * 2180
+VPOS, VBUF, LLINE, LTY, LKQ, LBUF = 256, 36 * 256, 72, 452, 1856, 4 * 1856       # words: kernels_wino4.hip, W4_*
 
 
 @pytest.fixture(scope="module")
@@ -96,17 +96,19 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
     lanes = np.arange(64)
     acc = np.zeros((4, 36, 2, 64, 4), f)                      # [wave][position][nt][lane][register r]: the MFMA result registers
     for s in range(ns):
-        # stage 1: items (ty, x, cq) -> six row-transformed lines in L[ty][i][x][20]
+        # stage 1: items (pixel = 18 ty + x, cq) -> six row-transformed lines in L[cq][ty][i][x] (one 16-byte slot each)
         L = np.full(LBUF, np.nan, f)
+        seen = set()
         for e in range(288):
             t = e if e < 256 else e - 256
-            cq = t & 3
+            cq = (t >> 3) & 3
             if e < 256:
-                pix = t >> 2; ty = (pix * 3641) >> 16; xx = pix - ty * 18
+                pix = (t >> 5) * 8 + (t & 7); ty = (pix * 3641) >> 16; xx = pix - ty * 18
                 assert ty == pix // 18
             else:
                 assert t < 32
-                ty, xx = 3, 10 + ((t & 63) >> 2)
+                ty, xx = 3, 10 + (t & 7)
+            assert (ty, xx, cq) not in seen; seen.add((ty, xx, cq))
             rows = []
             for a in range(6):
                 iy, ix = min(oy0 + 4 * ty + a, IH - 1), min(ox0 + xx, IW - 1)
@@ -116,24 +118,25 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
                     if relu:
                         v = np.maximum(v, 0)
                 rows.append(v.astype(f))
-            dst = ty * LTY + xx * TP + cq * 4
+            dst = cq * LKQ + ty * LTY + xx * 4
             for i, l in enumerate(bt_rows(rows)):
                 L[dst + i * LLINE: dst + i * LLINE + 4] = l.astype(f)
-        # stage 2: items (tile m, line i, kq) -> six positions in V[6 i + j][m][20]
+        assert len(seen) == 288
+        # stage 2: items (tile m, line i, kq) -> six positions in V[6 i + j][kq][m] (one slot each)
         V = np.full(VBUF, np.nan, f)
         items = [(t & 15, (t >> 4) & 3, t >> 6) for t in range(256)] + [(t & 15, (t >> 4) & 3, 2 + (t >> 6)) for t in range(128, 256)]
         assert sorted(items) == sorted((m, kq, i) for m in range(16) for kq in range(4) for i in range(6))
         for m2, kq, i in items:
-            src = (m2 >> 2) * LTY + 4 * (m2 & 3) * TP + kq * 4 + i * LLINE
-            c = [L[src + k * TP: src + k * TP + 4] for k in range(6)]
+            src = kq * LKQ + (m2 >> 2) * LTY + 4 * (m2 & 3) * 4 + i * LLINE
+            c = [L[src + k * 4: src + k * 4 + 4] for k in range(6)]
             assert not any(np.isnan(v).any() for v in c)
             for j, o in enumerate(bt_rows(c)):
-                dst = (6 * i + j) * VPOS + m2 * TP + kq * 4
+                dst = (6 * i + j) * VPOS + (kq * 16 + m2) * 4
                 V[dst: dst + 4] = o.astype(f)
         # matrix instructions: v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]
         # and, in register r, D[4 (l >> 4) + r][l & 15].  The kernel passes the WEIGHTS as A (i = channel inside the 16-group) and the
         # transformed input as B (j = tile): register r of lane l = tile l & 15, channel 4 (l >> 4) + r
-        aA = (lanes & 15) * TP + (lanes >> 4) * 4
+        aA = lanes * 4                                                       # V[p][kq = lane >> 4][m = lane & 15]
         for w in range(4):
             for p in range(36):
                 Vf = V[(p * VPOS + aA)[:, None] + np.arange(4)[None, :]]         # [lane][step]
@@ -180,24 +183,41 @@ def test_wino4_lane_level_restatement_matches_direct_convolution(packer, cin, af
         assert err < 2e-4, (uy, ux, err)
 
 
-def _slots(addr_words):
-    return (np.asarray(addr_words) // 4) % 16
+RGROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+RGROUPS += [[l + 32 for l in g] for g in RGROUPS]
 
 
 def test_wino4_lds_accesses_are_bank_conflict_free():
-    """a ds_read_b128 / ds_write_b128 is served in groups of 16 lanes; every group must touch 16 different sixteen-byte slots (mod 16):
-    the A-fragment read of every position, and both sides of the column pass (the reason for the 545-slot tile-row pitch of L)"""
+    """MI355X LDS (MI355X_MICROARCH.md): a ds_read_b128 is served in four NON-contiguous groups of 16 lanes over 16 sixteen-byte slots
+    (64 banks), a ds_write_b128 in eight contiguous groups of 8 lanes over 8 slots (32 banks).  Within a group all slots must differ:
+    the A-fragment read of every position, both sides of the column pass, the read-back of the landing area, and the row pass's
+    writes (where a group of eight consecutive pixels straddles two tile rows one 2-way conflict remains: at most 3 of the 36 groups)"""
     lanes = np.arange(64)
-    aA = (lanes & 15) * TP + (lanes >> 4) * 4
-    for grp in range(4):
-        assert len(set(_slots(aA[grp * 16: grp * 16 + 16]))) == 16
+    rslot = lambda words: (np.asarray(words) // 4) % 16
+    wslot = lambda words: (np.asarray(words) // 4) % 8
+    aA = lanes * 4
+    for g in RGROUPS:
+        assert len(set(rslot(aA[g]))) == 16
+    # landing area: 16 bytes per thread, consecutive
+    for g in RGROUPS:
+        assert len(set(rslot((lanes * 4)[g]))) == 16
+    for wave in range(4):
+        t = wave * 64 + lanes
+        m2, kq = t & 15, (t >> 4) & 3
+        l2 = kq * LKQ + (m2 >> 2) * LTY + 4 * (m2 & 3) * 4
+        for i in range(6):
+            for k in range(6):
+                for g in RGROUPS:
+                    assert len(set(rslot((l2 + i * LLINE + k * 4)[g]))) == 16, ("column pass read", wave, i, k)
+        v2 = lanes * 4
+        for g0 in range(0, 64, 8):
+            assert len(set(wslot(v2[g0: g0 + 8]))) == 8, ("column pass write", g0)
+    # row pass writes: item A of all 256 threads, line 0 (the other lines add the same constant to every lane)
     t = np.arange(256)
-    m2, kq = t & 15, (t >> 4) & 3
-    l2 = (m2 >> 2) * LTY + 4 * (m2 & 3) * TP + kq * 4
-    v2 = m2 * TP + kq * 4
-    for grp in range(16):
-        sl = slice(grp * 16, grp * 16 + 16)
-        for k in range(6):
-            assert len(set(_slots(l2[sl] + k * TP))) == 16, ("stage-2 read", grp, k)
-        assert len(set(_slots(v2[sl]))) == 16, ("stage-2 write", grp)
-    assert (LTY // 4) % 16 == 1 and LTY >= 6 * LLINE
+    cq = (t >> 3) & 3
+    pix = (t >> 5) * 8 + (t & 7)
+    ty, xx = pix // 18, pix % 18
+    l1 = cq * LKQ + ty * LTY + xx * 4
+    bad = sum(1 for g0 in range(0, 256, 8) if len(set(wslot(l1[g0: g0 + 8]))) != 8)
+    assert bad <= 3 * 4, bad                                  # (pixel groups 16..23, 32..39, 48..55 straddle a tile row, once per chunk)
+    assert (LTY // 4) % 16 == 1 and (LKQ // 4) % 16 == 0 and LTY >= 6 * LLINE and LKQ >= 4 * LTY
