@@ -58,8 +58,7 @@ constexpr int W4_LLINE = 18 * 4;               // 72: one row-transformed line (
 constexpr int W4_LTY = 113 * 4;                // 452: the six lines of a tile row (108 slots) padded to 113
 constexpr int W4_LKQ = 464 * 4;                // 1856: the four tile rows of a chunk plane (452 slots) padded to 464
 constexpr int W4_LBUF = 4 * W4_LKQ;            // 7424 words
-constexpr int W4_RA = 6 * 256 * 4;             // landing area of the raw rows (buffer_load ... lds): item A [row][thread] 16 bytes each
-constexpr int W4_RBUF = W4_RA + 6 * 32 * 4;    // ... and item B [row][lane < 32]: 6912 words
+constexpr int W4_RBUF = 6 * 288 * 4;           // landing area of the raw rows (buffer_load ... lds): [row][thread < 288] 16 bytes each: 6912 words
 constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF + W4_RBUF;      // 32768 words = 131 072 B (+ a second landing area for the skip rows of a
                                                               //  pending join, + 2 CIN words of pending scale / shift: 159 744 B)
 static_assert((W4_LTY / 4) % 16 == 1 && (W4_LKQ / 4) % 16 == 0 && W4_LTY >= 6 * W4_LLINE && W4_LKQ >= 4 * W4_LTY, "pitches of L");
@@ -102,13 +101,13 @@ __device__ __forceinline__ void w4_at(const float m[6], float y[4])
 // (VAR: timing experiments only -- FAV_W4_VAR: bit 0 the K loop requests no weights, bit 1 stages nothing, bit 2 no barriers inside the slice;
 //  the results are garbage, the timeline of FAV_WINO_DBG says what each part costs)
 template <int MODE, int VAR = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_wino4_kernel(const Wino4Args p)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_wino4_kernel(const Wino4Args p)
 {
     constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
-    constexpr int NT = 256;
+    constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Vs = smem;                        // [2][W4_VBUF]
-    float* const Ls = smem + 2 * W4_VBUF;          // [4][W4_LTY]
+    float* const Ls = smem + 2 * W4_VBUF;          // [W4_LBUF]
     float* const Rs = Ls + W4_LBUF;                // landing area of the raw rows
     float* const Ss = Rs + W4_RBUF;                // MODE 2: landing area of the skip rows (same shape)
     float* const aff = Ss + (MODE == 2 ? W4_RBUF : 0);      // [2][CIN]
@@ -130,30 +129,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float lo1 = (MODE == 1 && p.relu1) ? 0.f : -INFINITY;
 
     // stage 1 (rows): item = (pixel pix = 18 ty + x of the 4 x 18 (tile row, raw column) grid, 16-byte channel chunk cq) -> raw rows
-    // 4 ty .. 4 ty + 5 of column x, six transformed lines out.  288 items, numbered e = (pix >> 3) * 32 + cq * 8 + (pix & 7): eight
-    // consecutive lanes write eight consecutive pixels of one chunk plane.  Item A = t (pixels 0..63), item B = 256 + t for t < 32
-    // (pixels 64..71: ty 3, x 10..17)
+    // 4 ty .. 4 ty + 5 of column x, six transformed lines out.  288 items = threads 0..287 (waves 0-3 and half of wave 4), numbered
+    // t = (pix >> 3) * 32 + cq * 8 + (pix & 7): eight consecutive lanes write eight consecutive pixels of one chunk plane
+    const bool has1 = t < 288;
     const int cq = (t >> 3) & 3;
-    const int pixA = (t >> 5) * 8 + (t & 7), tyA = (pixA * 3641) >> 16, xA = pixA - tyA * 18;
-    const int xB = 10 + (t & 7);
-    const bool hasB = t < 32;
-    float* const l1A = Ls + cq * W4_LKQ + tyA * W4_LTY + xA * 4;
-    float* const l1B = Ls + cq * W4_LKQ + 3 * W4_LTY + xB * 4;
+    const int pix1 = min((t >> 5) * 8 + (t & 7), 71), ty1 = (pix1 * 3641) >> 16, x1 = pix1 - ty1 * 18;
+    float* const l1 = Ls + cq * W4_LKQ + ty1 * W4_LTY + x1 * 4;
     const float* const affr = aff + cq * 4;
     // stage 2 (columns): item = (tile m, line i, channel chunk kq) -> columns 4 tx .. 4 tx + 5 of line i, six positions out.
-    // 16 x 6 x 4 = 384 items: item C = t (i = wave), item D for waves 2, 3 (i = 4, 5; wave 0 already has the extra stage-1 item);
+    // 16 x 6 x 4 = 384 items = waves 2..7 (line i = wave - 2; waves 0, 1 carry the row pass only, waves 5..7 this pass only);
     // lane = (kq = lane >> 4, m = lane & 15), as the matrix operand
-    const int m2 = t & 15, kq2 = (t >> 4) & 3;
-    const bool hasD = t >= 128;
-    const float* const l2 = Ls + kq2 * W4_LKQ + (m2 >> 2) * W4_LTY + 4 * (m2 & 3) * 4;
-    float* const v2 = Vs + lane * 4;
+    const bool has2 = wave >= 2;
+    const int i2 = max(wave - 2, 0);
+    const int m2 = lane & 15, kq2 = lane >> 4;
+    const float* const l2 = Ls + kq2 * W4_LKQ + (m2 >> 2) * W4_LTY + 4 * (m2 & 3) * 4 + i2 * W4_LLINE;
+    float* const v2 = Vs + lane * 4 + 6 * i2 * W4_VPOS;
     // matrix operands: lane = (k quarter kq = lane >> 4, tile m = lane & 15): V[p][kq][m] -- step j of a slice multiplies channel
-    // 16 s + 4 kq + j; weights likewise (wino4_pack.h): lane * 16 + [wave * 2048 + (s * 36 + p) * 8192] + nt * 1024
+    // 16 s + 4 kq + j; weights likewise (wino4_pack.h: wave = 2 w + nt there): lane * 16 + [wave * 1024 + (s * 36 + p) * 8192]
     const float* const aA = Vs + lane * 4;
-    const int wlo = lane * 16, wso = wave * 2048;
+    const int wlo = lane * 16, wso = wave * 1024;
 
     // the weight ring lives across units: the last slice of a unit requests the first positions of slice 0 -- the next unit's
-    v4f fb[9][2];
+    v4f fb[9];
     bool ring_primed = false;
     if (AFF) __syncthreads();
     auto work = [&](const int u) {
@@ -166,122 +163,104 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         DBG_T();   /* unit start */
         // no padding: input pixel (oy0 + r, ox0 + c) for halo (r, c); coordinates past the image only feed outputs past the image
         // (never stored), so they are clamped instead of masked
-        int hoA[6], hoB[6];
+        int ho[6];
         {
-            const int ixa = min(ox0 + xA, p.IW - 1), ixb = min(ox0 + xB, p.IW - 1);
+            const int ix = min(ox0 + x1, p.IW - 1);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                hoA[a] = ((min(oy0 + 4 * tyA + a, p.IH - 1) * p.IWp + ixa) * CIN + cq * 4) * 4;
-                hoB[a] = ((min(oy0 + 12 + a, p.IH - 1) * p.IWp + ixb) * CIN + cq * 4) * 4;
-            }
+            for (int a = 0; a < 6; ++a) ho[a] = ((min(oy0 + 4 * ty1 + a, p.IH - 1) * p.IWp + ix) * CIN + cq * 4) * 4;
         }
-        // MODE 2: which of an item's six rows this thread writes to the joined tensor (bits 0-5 item A, 8-13 item B): rows 4 ty ..
-        // 4 ty + 3 of columns 0..15 -- the unit's own 16 x 16 pixels -- plus the halo fringe (rows 16, 17 / columns 16, 17) where no
-        // other unit follows
+        // MODE 2: which of the item's six rows this thread writes to the joined tensor: rows 4 ty .. 4 ty + 3 of columns 0..15 -- the
+        // unit's own 16 x 16 pixels -- plus the halo fringe (rows 16, 17 / columns 16, 17) where no other unit follows
         int zm = 0;
         const bool lastx = ux == p.units_x - 1, lasty = uy == p.units_y - 1;
         if (JOIN) {
-            const bool ca = ox0 + xA < p.IW && (xA < 16 || lastx), cb = ox0 + xB < p.IW && (xB < 16 || lastx);
+            const bool cv = ox0 + x1 < p.IW && (x1 < 16 || lastx);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const bool ra = oy0 + 4 * tyA + a < p.IH && (a < 4 || (tyA == 3 && lasty));
-                const bool rb = oy0 + 12 + a < p.IH && (a < 4 || lasty);
-                zm |= (ca && ra ? 1 : 0) << a | (cb && rb ? 256 : 0) << a;
-            }
+            for (int a = 0; a < 6; ++a) zm |= (cv && oy0 + 4 * ty1 + a < p.IH && (a < 4 || (ty1 == 3 && lasty)) ? 1 : 0) << a;
         }
 
         v4f sc, sh;
-        float* const landA = Rs + wave * 256;              // (wave-uniform: M0 of the LDS loads; lane i lands 16 i bytes further)
-        float* const landB = Rs + W4_RA;
-        const float* const readA = Rs + t * 4;
-        const float* const readB = Rs + W4_RA + lane * 4;
+        float* const land = Rs + wave * 256;               // (wave-uniform: M0 of the LDS loads; lane i lands 16 i bytes further)
+        const float* const rread = Rs + t * 4;
+        constexpr int RROW = 288 * 4;                       // words between the landing places of two rows
         constexpr int SKO = W4_RBUF;                        // skip rows: the same places one landing area further on
-#define W4_LOAD_RAW(q_, slice_, ho_)                                                                \
-        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_[a], (slice_) * 64, 0)); }
+#define W4_LOAD_RAW(q_, slice_)                                                                     \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[a], (slice_) * 64, 0)); }
+#define W4_LOAD_SKIP(x_, slice_)                                                                    \
+        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho[a], (slice_) * 64, 0)); } }
         // the NEXT slices' raw rows bypass the register file: buffer_load ... lds into the landing area, requested a whole slice before
-        // their use (a wave has no second wave on its SIMD to hide a round trip behind: rows requested six positions ahead cost the
-        // K loop 13 of its 57 us, profiles/r04e_wino4_variants.log), read back by the requesting thread behind an explicit s_waitcnt (the
-        // compiler does not see that dependency; loads return in order and at least `vm_` younger weight loads are in flight by then)
-#define W4_REQ_RAW(slice_, ho_, lbase_, lrow_)                                                      \
+        // their use, read back by the requesting thread behind an explicit s_waitcnt (the compiler does not see that dependency;
+        // loads return in order and the ring's younger weight loads are in flight by then)
+#define W4_REQ_RAW(slice_)                                                                          \
         { asm volatile("" ::: "memory");      /* (never above the reads of the rows these loads replace) */ \
           if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a)     /* the skip rows first: the rows' arrival implies theirs */ \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)((lbase_) + SKO + a * (lrow_)), 16, ho_[a], (slice_) * 64, 0, 0); } \
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(land + SKO + a * RROW), 16, ho[a], (slice_) * 64, 0, 0); } \
           _Pragma("unroll") for (int a = 0; a < 6; ++a)                                             \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)((lbase_) + a * (lrow_)), 16, ho_[a], (slice_) * 64, 0, 0); }
-#define W4_TAKE_RAW(q_, x_, lread_, lrow_)                                                          \
-        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>((lread_) + a * (lrow_));  \
-          if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = *reinterpret_cast<const v4f*>((lread_) + SKO + a * (lrow_)); } }
-#define W4_LOAD_SKIP(x_, slice_, ho_)                                                               \
-        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho_[a], (slice_) * 64, 0)); } }
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, ho[a], (slice_) * 64, 0, 0); }
+#define W4_TAKE_RAW(q_, x_)                                                                         \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rread + a * RROW);    \
+          if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = *reinterpret_cast<const v4f*>(rread + SKO + a * RROW); } }
 #define W4_AFF(slice_)                                                                              \
         { if (AFF) { sc = *reinterpret_cast<const v4f*>(affr + (slice_) * 16); sh = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 16); } }
         // pending transform of the raw rows; MODE 2: z = fma(y, scale, shift) + skip, stored where the mask says so (elsewhere the offset is
         // out of the buffer's range and the hardware drops the store)
-#define W4_PEND(q_, x_, slice_, ho_, zsh_)                                                          \
+#define W4_PEND(q_, x_, slice_)                                                                     \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                           \
             if (MODE == 1) { q_[a].x = fmaxf(fmaf(q_[a].x, sc.x, sh.x), lo1); q_[a].y = fmaxf(fmaf(q_[a].y, sc.y, sh.y), lo1);  \
                              q_[a].z = fmaxf(fmaf(q_[a].z, sc.z, sh.z), lo1); q_[a].w = fmaxf(fmaf(q_[a].w, sc.w, sh.w), lo1); } \
             if (JOIN) { q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x_[a].x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x_[a].y;            \
                         q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x_[a].z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x_[a].w;            \
-                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << ((zsh_) + a))) ? ho_[a] : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
-#define W4_COMMIT1(q_, dst_)                                                                        \
+                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << a)) ? ho[a] : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
+#define W4_COMMIT1(q_)                                                                              \
         { v4f l_[6]; w4_bt(q_, l_);                                                                 \
-          _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>((dst_) + i * W4_LLINE) = l_[i]; }
+          _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>(l1 + i * W4_LLINE) = l_[i]; }
         // column pass in two halves: the six reads, and -- a segment of matrix instructions later -- transform and writes
-#define W4_S2_READ(c_, i_)                                                                          \
-        { _Pragma("unroll") for (int k = 0; k < 6; ++k) c_[k] = *reinterpret_cast<const v4f*>(l2 + (i_) * W4_LLINE + k * 4); }
-#define W4_S2_DONE(c_, i_, nb_)                                                                     \
+#define W4_S2_READ(c_)                                                                              \
+        { _Pragma("unroll") for (int k = 0; k < 6; ++k) c_[k] = *reinterpret_cast<const v4f*>(l2 + k * 4); }
+#define W4_S2_DONE(c_, nb_)                                                                         \
         { v4f o_[6]; w4_bt(c_, o_);                                                                 \
-          _Pragma("unroll") for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(v2 + (nb_) * W4_VBUF + (6 * (i_) + j) * W4_VPOS) = o_[j]; }
-#define W4_STAGE2(i_, nb_) { v4f c2_[6]; W4_S2_READ(c2_, i_); W4_S2_DONE(c2_, i_, nb_); }
+          _Pragma("unroll") for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(v2 + (nb_) * W4_VBUF + j * W4_VPOS) = o_[j]; }
 
         v4f fa[4];
 #define W4_READ_A(slot_, par_, pos_) { fa[slot_] = *reinterpret_cast<const v4f*>(aA + (par_) * W4_VBUF + (pos_) * W4_VPOS); }
 #define W4_LOAD_B(slot_, sl_, pos_)                                                                 \
-        { const int so_ = wso + ((sl_) * 36 + (pos_)) * 8192;                                       \
-          fb[slot_][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, so_, 0));          \
-          fb[slot_][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo + 1024, so_, 0)); }
+        { fb[slot_] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, wso + ((sl_) * 36 + (pos_)) * 8192, 0)); }
 
         // ---- prologue: slice 0 through both transform passes into V[0]
         {
-            v4f qa[6], qb[6], xa[6], xb[6];
-            W4_LOAD_SKIP(xa, 0, hoA); if (hasB) { W4_LOAD_SKIP(xb, 0, hoB); }
-            W4_LOAD_RAW(qa, 0, hoA);
-            if (hasB) { W4_LOAD_RAW(qb, 0, hoB); }
+            v4f qa[6], xa[6];
+            if (has1) { W4_LOAD_SKIP(xa, 0); W4_LOAD_RAW(qa, 0); }
             if (!ring_primed) {
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { W4_LOAD_B(q, 0, q); }
                 ring_primed = true;
             }
-            W4_AFF(0);
-            W4_PEND(qa, xa, 0, hoA, 0); W4_COMMIT1(qa, l1A);
-            if (hasB) { W4_PEND(qb, xb, 0, hoB, 8); W4_COMMIT1(qb, l1B); }
-            W4_REQ_RAW(min(1, nslices - 1), hoA, landA, 1024);
-            if (hasB) { W4_REQ_RAW(min(1, nslices - 1), hoB, landB, 128); }
+            if (has1) {
+                W4_AFF(0);
+                W4_PEND(qa, xa, 0); W4_COMMIT1(qa);
+                W4_REQ_RAW(min(1, nslices - 1));
+            }
             __syncthreads();
-            W4_STAGE2(wave, 0);
-            if (hasD) { W4_STAGE2(2 + wave, 0); }
+            if (has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, 0); }
         }
-        v4f acc[36][2];
+        v4f acc[36];
 #pragma unroll
-        for (int q = 0; q < 36; ++q) { acc[q][0] = v4f{0.f, 0.f, 0.f, 0.f}; acc[q][1] = v4f{0.f, 0.f, 0.f, 0.f}; }
+        for (int q = 0; q < 36; ++q) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         W4_READ_A(0, 0, 0); W4_READ_A(1, 0, 1);
         DBG_T();   /* loop start */
         const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
 
-        // ---- K loop: per 16-channel slice 36 positions of 8 matrix instructions; between them the NEXT slice is staged:
-        //   position 4      item A's raw rows (requested a slice ago) read back from the landing area
-        //   position 6      item A committed to L (pending transform, rows of B^T d); item B's rows read back (wave 0, lanes 0..31)
-        //   position 8      item B committed; the rows of the slice AFTER the next requested
-        //   position 12     barrier: L complete; column pass, item C: reads         position 14  ... transform + writes into the other V buffer
-        //   positions 14, 22   item D likewise (waves 2, 3)                             after position 35   barrier: V complete
+        // ---- K loop: per 16-channel slice 36 positions of 4 matrix instructions per wave; between them the NEXT slice is staged:
+        //   position 4      the raw rows (requested a slice ago) read back from the landing area      (threads 0..287)
+        //   position 6      committed to L (pending transform, rows of B^T d)
+        //   position 8      the rows of the slice AFTER the next requested
+        //   position 12     barrier: L complete; column pass: reads                                   (waves 2..7)
+        //   position 14     ... transform + writes into the other V buffer          after position 35   barrier: V complete
         // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-        // positions [from_, to_) of the slice, two at a time: A fragments of the pair after, weights seven / eight positions ahead, 16 matrix
-        // instructions interleaved over the pair's FOUR accumulators -- an accumulator is used again after three other instructions (a
-        // 16x16x4 result is ready ~11 passes after issue; with only the position's own two accumulators alternating every instruction
-        // waited ~3 passes for its predecessor: 51 us per unit's loop where the instructions need 35, profiles/r04d_wino4_first_run.log).
+        // positions [from_, to_) of the slice, two at a time: A fragments of the pair after, weights seven / eight positions ahead, 8 matrix
+        // instructions alternating between the pair's two accumulators (the SIMD's other wave fills the gaps a dependent pair leaves)
         // (segments of a few positions each, so that every loop is small enough to be unrolled completely: the accumulators are
         //  indexed by the position)
 #define W4_POSITIONS(from_, to_)                                                                    \
@@ -292,10 +271,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } } \
             W4_FENCE();                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-                acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][0][j], fa[pos % 4][j], acc[pos][0], 0, 0, 0); \
-                acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][1][j], fa[pos % 4][j], acc[pos][1], 0, 0, 0); \
-                acc[pos + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][0][j], fa[(pos + 1) % 4][j], acc[pos + 1][0], 0, 0, 0); \
-                acc[pos + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][1][j], fa[(pos + 1) % 4][j], acc[pos + 1][1], 0, 0, 0); \
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][j], fa[pos % 4][j], acc[pos], 0, 0, 0); \
+                acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][j], fa[(pos + 1) % 4][j], acc[pos + 1], 0, 0, 0); \
             }                                                                                       \
             W4_FENCE(); } }
         for (int s = 0; s < nslices; ++s) {
@@ -305,30 +282,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int sn2 = min(s + 2, nslices - 1);
             v4f qa[6], xa[6], c2[6];
             W4_POSITIONS(0, 4);
-            if (!(VAR & 2)) {
-                // slice sn's rows were requested a slice ago (in the prologue for s = 0: eight weight loads have followed)
-                if (s == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-                W4_TAKE_RAW(qa, xa, readA, 1024);
+            if (!(VAR & 2) && has1) {
+                // slice sn's rows were requested a slice ago (in the prologue for s = 0: four weight loads have followed)
+                if (s == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                W4_TAKE_RAW(qa, xa);
             }
             W4_POSITIONS(4, 6);
-            if (!(VAR & 2)) {
-                W4_AFF(sn); W4_PEND(qa, xa, sn, hoA, 0); W4_COMMIT1(qa, l1A);
-                if (hasB) { W4_TAKE_RAW(qa, xa, readB, 128); }
-            }
+            if (!(VAR & 2) && has1) { W4_AFF(sn); W4_PEND(qa, xa, sn); W4_COMMIT1(qa); }
             W4_POSITIONS(6, 8);
-            if (!(VAR & 2)) {
-                if (hasB) { W4_PEND(qa, xa, sn, hoB, 8); W4_COMMIT1(qa, l1B); }
-                W4_REQ_RAW(sn2, hoA, landA, 1024);
-                if (hasB) { W4_REQ_RAW(sn2, hoB, landB, 128); }
-            }
+            if (!(VAR & 2) && has1) { W4_REQ_RAW(sn2); }
             W4_POSITIONS(8, 12);
             if (!(VAR & 4)) __syncthreads();
-            if (!(VAR & 2)) { W4_S2_READ(c2, wave); }
+            if (!(VAR & 2) && has2) { W4_S2_READ(c2); }
             W4_POSITIONS(12, 14);
-            if (!(VAR & 2)) { W4_S2_DONE(c2, wave, par ^ 1); if (hasD) { W4_S2_READ(c2, 2 + wave); } }
-            W4_POSITIONS(14, 22);
-            if (!(VAR & 2)) { if (hasD) { W4_S2_DONE(c2, 2 + wave, par ^ 1); } }
-            W4_POSITIONS(22, 36);
+            if (!(VAR & 2) && has2) { W4_S2_DONE(c2, par ^ 1); }
+            W4_POSITIONS(14, 36);
             if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
         }
@@ -346,13 +314,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_AFF
 #undef W4_PEND
 #undef W4_COMMIT1
-#undef W4_STAGE2
 #undef W4_READ_A
 #undef W4_LOAD_B
 
-        // ---- output transform, in the lane.  The matrix instructions were issued with the WEIGHTS as the M operand: acc[6 i + j][nt][r] =
-        // M[i][j] of tile (lane & 15), output channel 32 wave + 16 nt + 4 (lane >> 4) + r -- a lane holds FOUR CONSECUTIVE channels of one
-        // tile, i.e. 16 contiguous bytes of every output pixel.  Y = A^T M A (4 x 4), bias, NHWC store (b128), per-unit InstanceNorm
+        // ---- output transform, in the lane.  The matrix instructions were issued with the WEIGHTS as the M operand: acc[6 i + j][r] =
+        // M[i][j] of tile (lane & 15), output channel 16 wave + 4 (lane >> 4) + r -- a lane holds FOUR CONSECUTIVE channels of one tile,
+        // i.e. 16 contiguous bytes of every output pixel.  Y = A^T M A (4 x 4), bias, NHWC store (b128), per-unit InstanceNorm
         // partials (mean, M2, count) like the other kernels
         const int tl = lane & 15, g = lane >> 4;
         const int nrows = max(0, min(16, p.OH - oy0)), ncols = max(0, min(16, p.OW - ox0));
@@ -360,17 +327,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * 512, 0x00020000);
         const bool inside = nv == 256;         // (wave-uniform: nine units in ten lie wholly inside the image and skip every per-pixel test)
         const int oyb = oy0 + 4 * (tl >> 2), oxb = ox0 + 4 * (tl & 3);
-        const int cb = wave * 32 + 4 * g;      // first of this lane's four channels (+ 16 nt)
-        float y[2][4][4][4];                   // [nt][row a][column b][channel r]
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb + 16 * nt);
+        const int cb = wave * 16 + 4 * g;      // first of this lane's four channels
+        float y[4][4][4];                      // [row a][column b][channel r]
+        {
+            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float Q[4][6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float mcol[6] = {acc[j][nt][r], acc[6 + j][nt][r], acc[12 + j][nt][r], acc[18 + j][nt][r], acc[24 + j][nt][r], acc[30 + j][nt][r]};
+                    const float mcol[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
                     float o[4]; w4_at(mcol, o);
                     Q[0][j] = o[0]; Q[1][j] = o[1]; Q[2][j] = o[2]; Q[3][j] = o[3];
                 }
@@ -378,11 +344,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int a = 0; a < 4; ++a) {
                     float o[4]; w4_at(Q[a], o);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) y[nt][a][b][r] = o[b] + bv[r];
+                    for (int b = 0; b < 4; ++b) y[a][b][r] = o[b] + bv[r];
                 }
             }
         }
-        // both halves of a pixel's 128-byte line (this wave's 32 channels) leave back to back
         unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -391,38 +356,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const bool v = inside || (rv && oxb + b < p.OW);               // (outside the image: an offset past the buffer, the store is dropped)
-                const int vo = v ? ro : (int)0xFFFFF000;
                 vmask |= (v ? 1u : 0u) << (4 * a + b);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const v4f w = {y[nt][a][b][0], y[nt][a][b][1], y[nt][a][b][2], y[nt][a][b][3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, vo, b * 512 + nt * 64, 0);
-                }
+                const v4f w = {y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, v ? ro : (int)0xFFFFF000, b * 512, 0);
             }
         }
         if (p.partials != nullptr) {
             // per channel: the 16 lanes of a group hold its 16 tiles; sums by butterfly inside the group
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int r = 0; r < 4; ++r) {
+                float sm = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sm = 0.f;
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) sm += (inside || ((vmask >> (4 * a + b)) & 1u)) ? y[a][b][r] : 0.f;
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) sm += (inside || ((vmask >> (4 * a + b)) & 1u)) ? y[nt][a][b][r] : 0.f;
+                for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+                const float mu = nv ? sm / (float)nv : 0.f;
+                float m2 = 0.f;
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
-                    const float mu = nv ? sm / (float)nv : 0.f;
-                    float m2 = 0.f;
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) { const float d = y[a][b][r] - mu; if (inside || ((vmask >> (4 * a + b)) & 1u)) m2 = fmaf(d, d, m2); }
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) { const float d = y[nt][a][b][r] - mu; if (inside || ((vmask >> (4 * a + b)) & 1u)) m2 = fmaf(d, d, m2); }
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
-                    if (tl == 0) p.partials[(size_t)u * 128 + cb + 16 * nt + r] = make_float2(mu, m2);
-                }
+                for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
+                if (tl == 0) p.partials[(size_t)u * 128 + cb + r] = make_float2(mu, m2);
+            }
         }
         if (p.partials != nullptr && t == 0) p.counts[u] = nv;
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
@@ -465,7 +424,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int occ = 0; int prop_cus = 0;
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));
-        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds));
+        FAV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 512, lds));
         if (occ < 1) { set_error("winograd F(4x4) conv: kernel does not fit on a CU"); return FAV_EHIP; }
         cus[dv] = prop_cus;          // one block per CU
     }
@@ -476,7 +435,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 24 * 8, st)); a.dbg = dbuf; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_wino4_kernel");
     if (dbg) {
         std::vector<long long> hb((size_t)512 * 24);
