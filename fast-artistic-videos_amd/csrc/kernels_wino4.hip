@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wlo = lane * 16, wso = wave * 1024;
 
     // the weight ring lives across units: the last slice of a unit requests the first positions of slice 0 -- the next unit's
-    v4f fb[9];
+    v4f fb[6];
     bool ring_primed = false;
     if (AFF) __syncthreads();
     auto work = [&](const int u) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (has1) { W4_LOAD_SKIP(xa, 0); W4_LOAD_RAW(qa, 0); }
             if (!ring_primed) {
 #pragma unroll
-                for (int q = 0; q < 7; ++q) { W4_LOAD_B(q, 0, q); }
+                for (int q = 0; q < 4; ++q) { W4_LOAD_B(q, 0, q); }
                 ring_primed = true;
             }
             if (has1) {
@@ -252,11 +252,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const long long ck0 = p.dbg ? clock64() : 0, wk0 = p.dbg ? wall_clock64() : 0;
 
         // ---- K loop: per 16-channel slice 36 positions of 4 matrix instructions per wave; between them the NEXT slice is staged:
-        //   position 4      the raw rows (requested a slice ago) read back from the landing area      (threads 0..287)
-        //   position 6      committed to L (pending transform, rows of B^T d)
-        //   position 8      the rows of the slice AFTER the next requested
-        //   position 12     barrier: L complete; column pass: reads                                   (waves 2..7)
-        //   position 14     ... transform + writes into the other V buffer          after position 35   barrier: V complete
+        //   position 6      the raw rows (requested a slice ago) read back from the landing area, committed to L (pending transform, rows
+        //                   of B^T d), the rows of the slice AFTER the next requested                  (threads 0..287)
+        //   position 12     barrier: L complete
+        //   position 14     column pass into the other V buffer (waves 2..7)        after position 35   barrier: V complete
         // (the last slice stages a copy of itself into the idle buffer: no branches inside the loop body)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
         // positions [from_, to_) of the slice, two at a time: A fragments of the pair after, weights seven / eight positions ahead, 8 matrix
@@ -267,12 +266,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         { _Pragma("unroll") for (int pos = (from_); pos < (to_); pos += 2) {                       \
             if (pos + 2 < 36) { W4_READ_A((pos + 2) % 4, par, pos + 2); W4_READ_A((pos + 3) % 4, par, pos + 3); }    \
             if (!(VAR & 1)) {                                                                       \
-            if (pos + 7 < 36) { W4_LOAD_B((pos + 7) % 9, s, pos + 7); } else { W4_LOAD_B((pos + 7) % 9, sw, pos + 7 - 36); } \
-            if (pos + 8 < 36) { W4_LOAD_B((pos + 8) % 9, s, pos + 8); } else { W4_LOAD_B((pos + 8) % 9, sw, pos + 8 - 36); } } \
+            if (pos + 4 < 36) { W4_LOAD_B((pos + 4) % 6, s, pos + 4); } else { W4_LOAD_B((pos + 4) % 6, sw, pos + 4 - 36); } \
+            if (pos + 5 < 36) { W4_LOAD_B((pos + 5) % 6, s, pos + 5); } else { W4_LOAD_B((pos + 5) % 6, sw, pos + 5 - 36); } } \
             W4_FENCE();                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 9][j], fa[pos % 4][j], acc[pos], 0, 0, 0); \
-                acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 9][j], fa[(pos + 1) % 4][j], acc[pos + 1], 0, 0, 0); \
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 6][j], fa[pos % 4][j], acc[pos], 0, 0, 0); \
+                acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 6][j], fa[(pos + 1) % 4][j], acc[pos + 1], 0, 0, 0); \
             }                                                                                       \
             W4_FENCE(); } }
         for (int s = 0; s < nslices; ++s) {
@@ -280,22 +279,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int sn = min(s + 1, nslices - 1);
             const int sw = s + 1 < nslices ? s + 1 : 0;       // (weights: the next unit starts at slice 0 again)
             const int sn2 = min(s + 2, nslices - 1);
-            v4f qa[6], xa[6], c2[6];
-            W4_POSITIONS(0, 4);
+            W4_POSITIONS(0, 6);
             if (!(VAR & 2) && has1) {
-                // slice sn's rows were requested a slice ago (in the prologue for s = 0: four weight loads have followed)
-                if (s == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                // slice sn's rows were requested a slice ago (in the prologue for s = 0: six weight loads have followed): read back, pending
+                // transform, rows of B^T d, into L -- in one piece (nothing is held across matrix instructions: the registers are the
+                // accumulators'; the SIMD's other wave covers the LDS round trip)
+                v4f qa[6], xa[6];
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 W4_TAKE_RAW(qa, xa);
+                W4_AFF(sn); W4_PEND(qa, xa, sn); W4_COMMIT1(qa);
+                W4_REQ_RAW(sn2);
             }
-            W4_POSITIONS(4, 6);
-            if (!(VAR & 2) && has1) { W4_AFF(sn); W4_PEND(qa, xa, sn); W4_COMMIT1(qa); }
-            W4_POSITIONS(6, 8);
-            if (!(VAR & 2) && has1) { W4_REQ_RAW(sn2); }
-            W4_POSITIONS(8, 12);
+            W4_POSITIONS(6, 12);
             if (!(VAR & 4)) __syncthreads();
-            if (!(VAR & 2) && has2) { W4_S2_READ(c2); }
             W4_POSITIONS(12, 14);
-            if (!(VAR & 2) && has2) { W4_S2_DONE(c2, par ^ 1); }
+            if (!(VAR & 2) && has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
             W4_POSITIONS(14, 36);
             if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
