@@ -69,8 +69,20 @@ struct Wino4Args {
     const float* skip; float* zout;      // MODE 2 (pending residual join), as in kernels_wino.hip
     int OWp;
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
+    // the units of a thin LAST round are cut along K: units 0 .. nfull-1 are computed whole, every later unit as four items of a
+    // quarter of the input channels each; their partial outputs meet in ks_ws, the last of the four to arrive adds them up (in the
+    // fixed order 0, 1, 2, 3: the result does not depend on who that is) -- see launch_wino4_t
+    int nfull; float* ks_ws; int* ks_cnt;
     long long* dbg;
 };
+
+// 16-byte write-through store (sc1), as in kernels_conv.hip: the partial outputs of a K-split unit are published with these +
+// `s_waitcnt vmcnt(0)` + a relaxed agent-scope counter instead of plain stores + a release fence (which would write back the whole
+// XCD L2's dirty lines, i.e. the output tiles of the round before)
+__device__ __forceinline__ void w4_store16_wt(void* ptr, v4f v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
 
 // B^T d and A^T m (wino4_pack.h) with every multiply-add WRITTEN as one: the three instantiations of the kernel (plain input, pending
 // normalisation, pending join) must round alike -- a network computes the same bits whether a residual join is launched or left pending
@@ -153,7 +165,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v4f fb[6];
     bool ring_primed = false;
     if (AFF) __syncthreads();
-    auto work = [&](const int u) {
+    // one work item: KS = 1: a whole unit; KS = 4: quarter kq of its input channels (slices kq * nslices / 4 ...)
+    auto work = [&](auto ks_c, const int u, const int kq) {
+        constexpr int KS = decltype(ks_c)::value;
+        const int nsl = nslices / KS, s0 = kq * nsl, s1 = s0 + nsl;
+        if (KS > 1) ring_primed = false;
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 4) * 36 * 8192, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
@@ -163,12 +179,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         DBG_T();   /* unit start */
         // no padding: input pixel (oy0 + r, ox0 + c) for halo (r, c); coordinates past the image only feed outputs past the image
         // (never stored), so they are clamped instead of masked
-        int ho[6];
-        {
-            const int ix = min(ox0 + x1, p.IW - 1);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) ho[a] = ((min(oy0 + 4 * ty1 + a, p.IH - 1) * p.IWp + ix) * CIN + cq * 4) * 4;
-        }
+        // (two registers instead of six offsets -- row a = row 0 + min(a, rows before the image ends) * row pitch: the accumulators leave
+        //  no room, and a spilled value's reload inside the K loop is a `s_waitcnt vmcnt(0)` that drains the weight prefetch)
+        const int ho0 = ((min(oy0 + 4 * ty1, p.IH - 1) * p.IWp + min(ox0 + x1, p.IW - 1)) * CIN + cq * 4) * 4;
+        const int hrmax = max(p.IH - 1 - (oy0 + 4 * ty1), 0);
+        const int hrow = p.IWp * CIN * 4;
+#define ho_(a_) (ho0 + min((a_), hrmax) * hrow)
         // MODE 2: which of the item's six rows this thread writes to the joined tensor: rows 4 ty .. 4 ty + 3 of columns 0..15 -- the
         // unit's own 16 x 16 pixels -- plus the halo fringe (rows 16, 17 / columns 16, 17) where no other unit follows
         int zm = 0;
@@ -185,32 +201,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int RROW = 288 * 4;                       // words between the landing places of two rows
         constexpr int SKO = W4_RBUF;                        // skip rows: the same places one landing area further on
 #define W4_LOAD_RAW(q_, slice_)                                                                     \
-        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho[a], (slice_) * 64, 0)); }
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(irs, ho_(a), (slice_) * 64, 0)); }
 #define W4_LOAD_SKIP(x_, slice_)                                                                    \
-        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho[a], (slice_) * 64, 0)); } }
+        { if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(srs, ho_(a), (slice_) * 64, 0)); } }
         // the NEXT slices' raw rows bypass the register file: buffer_load ... lds into the landing area, requested a whole slice before
         // their use, read back by the requesting thread behind an explicit s_waitcnt (the compiler does not see that dependency;
         // loads return in order and the ring's younger weight loads are in flight by then)
 #define W4_REQ_RAW(slice_)                                                                          \
         { asm volatile("" ::: "memory");      /* (never above the reads of the rows these loads replace) */ \
           if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a)     /* the skip rows first: the rows' arrival implies theirs */ \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(land + SKO + a * RROW), 16, ho[a], (slice_) * 64, 0, 0); } \
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(land + SKO + a * RROW), 16, ho_(a), (slice_) * 64, 0, 0); } \
           _Pragma("unroll") for (int a = 0; a < 6; ++a)                                             \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, ho[a], (slice_) * 64, 0, 0); }
-#define W4_TAKE_RAW(q_, x_)                                                                         \
-        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rread + a * RROW);    \
-          if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a) x_[a] = *reinterpret_cast<const v4f*>(rread + SKO + a * RROW); } }
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, ho_(a), (slice_) * 64, 0, 0); }
+#define W4_TAKE_RAW(q_)                                                                             \
+        { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rread + a * RROW); }
+        // (the skip rows of a pending join are read one at a time where they are added: six more live rows would not fit the registers)
+#define W4_SKIP_LDS(a_) (*reinterpret_cast<const v4f*>(rread + SKO + (a_) * RROW))
 #define W4_AFF(slice_)                                                                              \
         { if (AFF) { sc = *reinterpret_cast<const v4f*>(affr + (slice_) * 16); sh = *reinterpret_cast<const v4f*>(affr + CIN + (slice_) * 16); } }
         // pending transform of the raw rows; MODE 2: z = fma(y, scale, shift) + skip, stored where the mask says so (elsewhere the offset is
         // out of the buffer's range and the hardware drops the store)
-#define W4_PEND(q_, x_, slice_)                                                                     \
+#define W4_PEND(q_, xs_, slice_)                                                                    \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                           \
             if (MODE == 1) { q_[a].x = fmaxf(fmaf(q_[a].x, sc.x, sh.x), lo1); q_[a].y = fmaxf(fmaf(q_[a].y, sc.y, sh.y), lo1);  \
                              q_[a].z = fmaxf(fmaf(q_[a].z, sc.z, sh.z), lo1); q_[a].w = fmaxf(fmaf(q_[a].w, sc.w, sh.w), lo1); } \
-            if (JOIN) { q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x_[a].x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x_[a].y;            \
-                        q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x_[a].z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x_[a].w;            \
-                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << a)) ? ho[a] : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
+            if (JOIN) { const v4f x1_ = xs_(a);                                                     \
+                        q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x1_.x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x1_.y;                \
+                        q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x1_.z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x1_.w;                \
+                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << a)) ? ho_(a) : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
 #define W4_COMMIT1(q_)                                                                              \
         { v4f l_[6]; w4_bt(q_, l_);                                                                 \
           _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>(l1 + i * W4_LLINE) = l_[i]; }
@@ -226,19 +244,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W4_LOAD_B(slot_, sl_, pos_)                                                                 \
         { fb[slot_] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlo, wso + ((sl_) * 36 + (pos_)) * 8192, 0)); }
 
-        // ---- prologue: slice 0 through both transform passes into V[0]
+        // ---- prologue: the item's first slice through both transform passes into V[0]
         {
             v4f qa[6], xa[6];
-            if (has1) { W4_LOAD_SKIP(xa, 0); W4_LOAD_RAW(qa, 0); }
+            if (has1) { W4_LOAD_SKIP(xa, s0); W4_LOAD_RAW(qa, s0); }
             if (!ring_primed) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { W4_LOAD_B(q, 0, q); }
-                ring_primed = true;
+                for (int q = 0; q < 4; ++q) { W4_LOAD_B(q, s0, q); }
+                ring_primed = KS == 1;
             }
             if (has1) {
-                W4_AFF(0);
-                W4_PEND(qa, xa, 0); W4_COMMIT1(qa);
-                W4_REQ_RAW(min(1, nslices - 1));
+                W4_AFF(s0);
+#define W4_SKIP_REG(a_) xa[a_]
+                W4_PEND(qa, W4_SKIP_REG, s0); W4_COMMIT1(qa);
+#undef W4_SKIP_REG
+                W4_REQ_RAW(min(s0 + 1, s1 - 1));
             }
             __syncthreads();
             if (has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, 0); }
@@ -274,20 +294,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 6][j], fa[(pos + 1) % 4][j], acc[pos + 1], 0, 0, 0); \
             }                                                                                       \
             W4_FENCE(); } }
-        for (int s = 0; s < nslices; ++s) {
-            const int par = s & 1;
-            const int sn = min(s + 1, nslices - 1);
-            const int sw = s + 1 < nslices ? s + 1 : 0;       // (weights: the next unit starts at slice 0 again)
-            const int sn2 = min(s + 2, nslices - 1);
+        for (int sl = 0; sl < nsl; ++sl) {
+            const int s = s0 + sl, par = sl & 1;
+            const int sn = min(s + 1, s1 - 1);
+            const int sw = s + 1 < s1 ? s + 1 : s0;           // (weights: a whole unit's successor starts at slice 0 again)
+            const int sn2 = min(s + 2, s1 - 1);
             W4_POSITIONS(0, 6);
             if (!(VAR & 2) && has1) {
                 // slice sn's rows were requested a slice ago (in the prologue for s = 0: six weight loads have followed): read back, pending
                 // transform, rows of B^T d, into L -- in one piece (nothing is held across matrix instructions: the registers are the
                 // accumulators'; the SIMD's other wave covers the LDS round trip)
-                v4f qa[6], xa[6];
+                v4f qa[6];
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                W4_TAKE_RAW(qa, xa);
-                W4_AFF(sn); W4_PEND(qa, xa, sn); W4_COMMIT1(qa);
+                W4_TAKE_RAW(qa);
+                W4_AFF(sn); W4_PEND(qa, W4_SKIP_LDS, sn); W4_COMMIT1(qa);
                 W4_REQ_RAW(sn2);
             }
             W4_POSITIONS(6, 12);
@@ -303,9 +323,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         DBG_T();   /* loop end */
         if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
         DBG_T();
+#undef ho_
 #undef W4_LOAD_RAW
 #undef W4_REQ_RAW
 #undef W4_TAKE_RAW
+#undef W4_SKIP_LDS
 #undef W4_S2_READ
 #undef W4_S2_DONE
 #undef W4_LOAD_SKIP
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cb = wave * 16 + 4 * g;      // first of this lane's four channels
         float y[4][4][4];                      // [row a][column b][channel r]
         {
-            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
+            const v4f bv = KS == 1 ? *reinterpret_cast<const v4f*>(p.bias + cb) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float Q[4][6];
@@ -345,6 +367,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int b = 0; b < 4; ++b) y[a][b][r] = o[b] + bv[r];
                 }
             }
+        }
+        if (KS > 1) {
+            // a quarter of the input channels: the output transform is linear, so this is a PARTIAL output.  Publish it (write-through,
+            // drained), count; the last of the unit's four items reads all four back and adds them in the order 0, 1, 2, 3 (+ bias)
+            const int ul = u - p.nfull;
+            float* const slot = p.ks_ws + ((size_t)(ul * 4) * 256 + (4 * (tl >> 2)) * 16 + 4 * (tl & 3)) * 128 + cb;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    w4_store16_wt(slot + ((size_t)kq * 256 + a * 16 + b) * 128, v4f{y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int* const flag = reinterpret_cast<int*>(aff + 2 * CIN);
+            __syncthreads();
+            if (t == 0) *flag = __hip_atomic_fetch_add(p.ks_cnt + ul, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == KS - 1;
+            __syncthreads();                   // (the flag word is free again)
+            if (!last) { DBG_T(); return; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (t == 0) __hip_atomic_store(p.ks_cnt + ul, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    v4f q4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) q4[q] = *reinterpret_cast<const v4f*>(slot + ((size_t)q * 256 + a * 16 + b) * 128);
+                    const v4f sum = ((q4[0] + q4[1]) + q4[2]) + q4[3] + bv;
+                    y[a][b][0] = sum.x; y[a][b][1] = sum.y; y[a][b][2] = sum.z; y[a][b][3] = sum.w;
+                }
         }
         unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
 #pragma unroll
@@ -385,8 +439,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
         DBG_T();   /* epilogue end */
     };
-    const int nunits = p.units_x * p.units_y;
-    for (int it = lb; it < nunits; it += gridDim.x) work(it);
+    const int nitems = p.nfull + 4 * (p.units_x * p.units_y - p.nfull);
+    for (int it = lb; it < nitems; it += gridDim.x) {
+        if (it < p.nfull) work(std::integral_constant<int, 1>{}, it, 0);
+        else work(std::integral_constant<int, 4>{}, p.nfull + ((it - p.nfull) >> 2), (it - p.nfull) & 3);
+    }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
 #undef DBG_T
 }
@@ -415,7 +472,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     static const int var = getenv("FAV_W4_VAR") ? atoi(getenv("FAV_W4_VAR")) : 0;
     const auto kern = (MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
                       (MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> : conv3_wino4_kernel<MODE, 0>;
-    const size_t lds = (size_t)(W4_SMEM + (MODE == 2 ? W4_RBUF : 0) + 2 * a0.CIN) * sizeof(float);
+    const size_t lds = (size_t)(W4_SMEM + (MODE == 2 ? W4_RBUF : 0) + 2 * a0.CIN + 4) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
@@ -429,6 +486,13 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     const int units = a0.units_x * a0.units_y;
     const int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
     Wino4Args a = a0; a.dbg = nullptr;
+    // A CU holds one unit at a time, so a launch takes ceil(units / grid) rounds of one unit time -- and three of the ten layers at
+    // 1280x720 have 273-286 units for 256 CUs (a unit is 256 pixels, the layers 64.8-66.9 k).  When the last round has at most
+    // grid / 4 units, each of them is cut into FOUR items along K (two of the eight 16-channel slices each): four times as many CUs
+    // work on that round, it takes a third of a unit time instead of a whole one (prologue, two slices, hand-over through ks_ws)
+    static const bool no_ksplit = getenv("FAV_W4_NO_KSPLIT") != nullptr;
+    const int rounds = (units + grid - 1) / grid, rem = units - (rounds - 1) * grid;
+    a.nfull = (rounds >= 2 && rem * 4 <= grid && rem <= 64 && (a0.CIN >> 4) % 4 == 0 && a0.ks_ws && a0.ks_cnt && !no_ksplit) ? (rounds - 1) * grid : units;
     static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
@@ -465,6 +529,7 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 15) / 16;
     a.dbg = nullptr;
     a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
+    a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.nfull = a.units_x * a.units_y;
     if (c.join_skip != nullptr) {
         FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
         return launch_wino4_t<2>(a, c.reserve_cus, st);

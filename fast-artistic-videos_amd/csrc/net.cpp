@@ -186,6 +186,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
+    float* ks_ws = nullptr; int* ks_cnt = nullptr;                                    // K-split units of the F(4x4) Winograd kernel
     // a residual block whose join stays pending (run(), L_RES): its last convolution lays its output out under the skip tensor
     struct LazyOut { bool active = false; int pitch = 0, rows = 0, shave = 0, conv_index = -1; } lazy;
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
@@ -214,7 +215,7 @@ struct fav_net {
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wwino4); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wfirst2d); (void)hipFree(c.wgt16); }
         for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
         for (void* sp : slabs) (void)hipFree(sp);
-        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); if (sk_err_host) (void)hipHostFree(sk_err_host);
+        (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); (void)hipFree(ks_ws); (void)hipFree(ks_cnt); if (sk_err_host) (void)hipHostFree(sk_err_host);
     }
     int upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc);
     int upload();
@@ -372,6 +373,9 @@ int fav_net::upload()
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_ws), conv_streamk_workspace_bytes()));
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_flags), conv_streamk_grid() * sizeof(unsigned)));
     FAV_HIP(hipMemset(sk_flags, 0, conv_streamk_grid() * sizeof(unsigned)));
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&ks_ws), conv3_wino4_ksplit_bytes()));
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&ks_cnt), 64 * sizeof(int)));
+    FAV_HIP(hipMemset(ks_cnt, 0, 64 * sizeof(int)));
     FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&sk_err_host), sizeof(unsigned), hipHostMallocMapped));
     *sk_err_host = 0;
     FAV_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&sk_err_dev), sk_err_host, 0));
@@ -408,6 +412,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     cs.no_sk = shared_device ? 1 : 0;
     cs.sk_ws = sk_ws; cs.sk_flags = sk_flags; cs.sk_epoch = ++sk_epoch;      // launches of one net are stream-ordered
     cs.sk_err = sk_err_dev;
+    cs.ks_ws = ks_ws; cs.ks_cnt = ks_cnt;
     if (sk_epoch == 0xffffffffu) sk_epoch = 0;
     // generic kernel while look-ahead masks are in flight: its stream-K hand-off assumes that all blocks are resident at once, and the
     // side queues' kernels land on any CU -- owners then wait for blocks that have not started (d128: 186 us against 115 us alone,
