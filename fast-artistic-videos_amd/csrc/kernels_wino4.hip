@@ -83,14 +83,6 @@ __device__ __forceinline__ void w4_store16_wt(void* ptr, v4f v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
 }
-// ... and read back past this XCD's L2 (sc0 sc1: the same addresses held last frame's partial outputs; an agent-scope acquire fence would
-// do, by invalidating the whole L2 under the blocks still computing next to this one)
-__device__ __forceinline__ v4f w4_load16_coherent(const void* ptr)
-{
-    v4f v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
-}
 
 // B^T d and A^T m (wino4_pack.h) with every multiply-add WRITTEN as one: the three instantiations of the kernel (plain input, pending
 // normalisation, pending join) must round alike -- a network computes the same bits whether a residual join is launched or left pending
@@ -394,23 +386,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool last = *flag == KS - 1;
             __syncthreads();                   // (the flag word is free again)
             if (!last) { DBG_T(); return; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (t == 0) __hip_atomic_store(p.ks_cnt + ul, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
-            // (the loads are opaque to the compiler -- inline asm, no wait inserted: all sixteen of a row are issued, ONE explicit wait, then the sums)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                v4f part[4][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) part[q][b] = w4_load16_coherent(slot + ((size_t)q * 256 + a * 16 + b) * 128);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const v4f sum = ((part[0][b] + part[1][b]) + part[2][b]) + part[3][b] + bv;
+                    v4f q4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) q4[q] = *reinterpret_cast<const v4f*>(slot + ((size_t)q * 256 + a * 16 + b) * 128);
+                    const v4f sum = ((q4[0] + q4[1]) + q4[2]) + q4[3] + bv;
                     y[a][b][0] = sum.x; y[a][b][1] = sum.y; y[a][b][2] = sum.z; y[a][b][3] = sum.w;
                 }
-            }
         }
         unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
 #pragma unroll
