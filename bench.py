@@ -580,6 +580,8 @@ def main():
             "metric": "stylized frames/sec @1280x720, per-frame hot path (mask + warp + assembly + net + deprocess + PNG encode on the GPU) with inputs "
                       "resident in HBM; file->PNG rate of the product CLI (BASELINE.json's end-to-end) in `end_to_end_fps` / `e2e`, PSNR vs CPU ref in `parity`",
             "value": round(fps, 3), "unit": "frames/s",
+            "value_note": "`value` = in-HBM rate of the whole per-frame hot path (contract: inputs resident when the timed region starts); "
+                          "the rate BASELINE.json's end-to-end wording means (files in -> PNG files out through bin/fav_stylize) is `end_to_end_fps`",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "1280x720 fused on-GPU consistency check (%s) + min-filter + warp + assemble + transformer net "
