@@ -111,6 +111,9 @@ __device__ __forceinline__ void w4_at(const float m[6], float y[4])
 // MODE 0: plain input; MODE 1: pending per-channel scale / shift (+ ReLU) of the producing convolution's InstanceNorm; MODE 2: pending
 // residual join z = skip + scale * y + shift (res_add_kernel's operations in its order), written out once as the next block's skip
 // (VAR: timing experiments only -- FAV_W4_VAR: bit 0 the K loop requests no weights, bit 1 stages nothing, bit 2 no barriers inside the slice;
+//  16 (MODE 2): the joined tensor is not stored -- K loop 55.5 us instead of 65.5: what its stores cost.  Tried against that in round 4
+//  (profiles/r4p_*, r4q_*, r4r_*): the stores in an epilogue pass over the unit (re-read, add, store: 80 -> 92 us per launch, the traffic of
+//  all CUs in one burst), behind the slice's first barrier out of LDS (-> 88 us), with the non-temporal hint (-1.5 us);
 //  the results are garbage, the timeline of FAV_WINO_DBG says what each part costs)
 template <int MODE, int VAR = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_wino4_kernel(const Wino4Args p)
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (JOIN) { const v4f x1_ = xs_(a);                                                     \
                         q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x1_.x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x1_.y;                \
                         q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x1_.z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x1_.w;                \
-                        if (a < 4 || lasty) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << a)) ? ho_(a) : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
+                        if (!(VAR & 16) && (a < 4 || lasty)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q_[a]), zrs, (zm & (1 << a)) ? ho_(a) : (int)0xFFFFFFF0, (slice_) * 64, 0); } } }
 #define W4_COMMIT1(q_)                                                                              \
         { v4f l_[6]; w4_bt(q_, l_);                                                                 \
           _Pragma("unroll") for (int i = 0; i < 6; ++i) *reinterpret_cast<v4f*>(l1 + i * W4_LLINE) = l_[i]; }
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // FAV_WINO_DBG=n: in-kernel timeline of the n-th launch (same report as the F(2x2) kernel's)
-void wino4_debug_report(const long long* hbuf, int grid)
+void wino4_debug_report(const long long* hbuf, int grid, int mode)
 {
     long long t0 = hbuf[0];
     for (int b = 0; b < grid; ++b) t0 = std::min(t0, hbuf[b * 24]);
@@ -462,8 +465,8 @@ void wino4_debug_report(const long long* hbuf, int grid)
         }
         ck += r[21]; wk += r[22];
     }
-    fprintf(stderr, "WINO4DBG grid=%d units=%d  K loop: %.3f GHz;  per unit: prologue %.2f  loop %.2f  epilogue %.2f us;  last block ends at %.2f us\n",
-            grid, items, wk ? ck / (wk * 10.0) : 0.0, items ? sum[0] / items : 0.0, items ? sum[1] / items : 0.0, items ? sum[3] / items : 0.0, tend);
+    fprintf(stderr, "WINO4DBG mode=%d grid=%d units=%d  K loop: %.3f GHz;  per unit: prologue %.2f  loop %.2f  epilogue %.2f us;  last block ends at %.2f us\n",
+            mode, grid, items, wk ? ck / (wk * 10.0) : 0.0, items ? sum[0] / items : 0.0, items ? sum[1] / items : 0.0, items ? sum[3] / items : 0.0, tend);
 }
 
 template <int MODE>
@@ -471,7 +474,8 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
 {
     static const int var = getenv("FAV_W4_VAR") ? atoi(getenv("FAV_W4_VAR")) : 0;
     const auto kern = (MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
-                      (MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> : conv3_wino4_kernel<MODE, 0>;
+                      (MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
+                      (MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> : conv3_wino4_kernel<MODE, 0>;
     const size_t lds = (size_t)(W4_SMEM + (MODE == 2 ? W4_RBUF : 0) + 2 * a0.CIN + 4) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
@@ -502,7 +506,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     if (dbg) {
         std::vector<long long> hb((size_t)512 * 24);
         FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
-        wino4_debug_report(hb.data(), grid);
+        wino4_debug_report(hb.data(), grid, MODE);
     }
     return FAV_OK;
 }
