@@ -125,11 +125,12 @@ struct ConvLaunch {
     // join_skip = the skip tensor's pixel under y's pixel (0, 0) at the SAME row pitch IWp, join_out = where the joined tensor is
     // written (pitch IWp as well).  OWp > 0: row pitch of `out` in pixels (the output is laid out under a later join's skip tensor).
     const float* join_skip = nullptr; float* join_out = nullptr; int OWp = 0;
-    // F(4x4) Winograd kernel only: meeting place of the K-split units of a thin last round (conv3_wino4_ksplit_bytes() bytes) and their
-    // arrival counters (64 ints, zero between launches); null => whole units only
+    // F(4x4) Winograd kernel only: meeting places of the two parts of a unit that a stream-K share boundary cuts (conv3_wino4_ksplit_bytes()
+    // bytes: 256 boundaries x 2 parts x 16 x 16 pixels x 128 channels) and their arrival counters (256 ints, zero between launches);
+    // null => whole units only
     float* ks_ws = nullptr; int* ks_cnt = nullptr;
 };
-inline size_t conv3_wino4_ksplit_bytes() { return (size_t)64 * 4 * 256 * 128 * sizeof(float); }
+inline size_t conv3_wino4_ksplit_bytes() { return (size_t)256 * 2 * 256 * 128 * sizeof(float); }
 size_t conv_streamk_workspace_bytes();
 int conv_streamk_grid();
 constexpr int CONV_BM = 128;

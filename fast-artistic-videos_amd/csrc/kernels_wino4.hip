@@ -41,6 +41,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MAX_DEVICES = 64;
+constexpr int W4_MEET_MAX = 256;             // meeting places of ks_ws / ks_cnt (conv3_wino4_ksplit_bytes): one per block of a stream-K launch
 inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
 
 // LDS layouts, in 16-byte SLOTS (4 words).  A ds_read_b128 is served in four NON-contiguous groups of 16 lanes -- {0-3, 12-15, 20-27},
@@ -69,10 +70,10 @@ struct Wino4Args {
     const float* skip; float* zout;      // MODE 2 (pending residual join), as in kernels_wino.hip
     int OWp;
     int IH, IW, IWp, CIN, OH, OW, units_x, units_y, relu1;
-    // the units of a thin LAST round are cut along K: units 0 .. nfull-1 are computed whole, every later unit as four items of a
-    // quarter of the input channels each; their partial outputs meet in ks_ws, the last of the four to arrive adds them up (in the
-    // fixed order 0, 1, 2, 3: the result does not depend on who that is) -- see launch_wino4_t
-    int nfull; float* ks_ws; int* ks_cnt;
+    // stream != 0: the launch's units x slices are dealt out as ONE sequence of 16-channel slices, an equal share per block (launch_wino4_t);
+    // a unit cut by a share boundary is computed in two parts -- the slices before the cut by one block, those behind it by the next --
+    // whose partial outputs meet in ks_ws: whichever part is finished second adds the other's to its own (+ bias) and stores the unit
+    int stream; float* ks_ws; int* ks_cnt;
     long long* dbg;
 };
 
@@ -168,11 +169,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v4f fb[6];
     bool ring_primed = false;
     if (AFF) __syncthreads();
-    // one work item: KS = 1: a whole unit; KS = 4: quarter kq of its input channels (slices kq * nslices / 4 ...)
-    auto work = [&](auto ks_c, const int u, const int kq) {
-        constexpr int KS = decltype(ks_c)::value;
-        const int nsl = nslices / KS, s0 = kq * nsl, s1 = s0 + nsl;
-        if (KS > 1) ring_primed = false;
+    // one work item: slices s0 .. s1 - 1 of unit u -- all of them (meet < 0), or one of the two parts of a unit that a share boundary
+    // cuts (meet = the boundary's meeting place in ks_ws / ks_cnt, part = 0: the slices before the cut, 1: behind it)
+    auto work = [&](const int u, const int s0, const int s1, const int meet, const int part) {
+        const int nsl = s1 - s0;
+        const bool whole = meet < 0;
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 4) * 36 * 8192, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (!ring_primed) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { W4_LOAD_B(q, s0, q); }
-                ring_primed = KS == 1;
+                ring_primed = true;
             }
             if (has1) {
                 W4_AFF(s0);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int sl = 0; sl < nsl; ++sl) {
             const int s = s0 + sl, par = sl & 1;
             const int sn = min(s + 1, s1 - 1);
-            const int sw = s + 1 < s1 ? s + 1 : s0;           // (weights: a whole unit's successor starts at slice 0 again)
+            const int sw = s + 1 < s1 ? s + 1 : 0;            // (weights: whatever this block computes next starts at a slice 0)
             const int sn2 = min(s + 2, s1 - 1);
             W4_POSITIONS(0, 6);
             if (!(VAR & 2) && has1) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cb = wave * 16 + 4 * g;      // first of this lane's four channels
         float y[4][4][4];                      // [row a][column b][channel r]
         {
-            const v4f bv = KS == 1 ? *reinterpret_cast<const v4f*>(p.bias + cb) : v4f{0.f, 0.f, 0.f, 0.f};
+            const v4f bv = whole ? *reinterpret_cast<const v4f*>(p.bias + cb) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float Q[4][6];
@@ -371,36 +372,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        if (KS > 1) {
-            // a quarter of the input channels: the output transform is linear, so this is a PARTIAL output.  Publish it (write-through,
-            // drained), count; the last of the unit's four items reads all four back and adds them in the order 0, 1, 2, 3 (+ bias)
-            const int ul = u - p.nfull;
-            float* const slot = p.ks_ws + ((size_t)(ul * 4) * 256 + (4 * (tl >> 2)) * 16 + 4 * (tl & 3)) * 128 + cb;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    w4_store16_wt(slot + ((size_t)kq * 256 + a * 16 + b) * 128, v4f{y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]});
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!whole) {
+            // a part of the unit's input channels: the output transform is linear, so this is a PARTIAL output.  If the other part is
+            // there already, add it; otherwise publish this one (write-through, drained) and count -- and add the other's after all
+            // if it arrived in the meantime.  a + b = b + a: the sum does not depend on who adds
+            const size_t pix = (size_t)(4 * (tl >> 2)) * 16 + 4 * (tl & 3);
+            float* const mine = p.ks_ws + (((size_t)meet * 2 + part) * 256 + pix) * 128 + cb;
+            const float* const other = p.ks_ws + (((size_t)meet * 2 + (part ^ 1)) * 256 + pix) * 128 + cb;
             int* const flag = reinterpret_cast<int*>(aff + 2 * CIN);
+            if (t == 0) *flag = __hip_atomic_load(p.ks_cnt + meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (t == 0) *flag = __hip_atomic_fetch_add(p.ks_cnt + ul, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const bool last = *flag == KS - 1;
+            bool second = *flag == 1;
             __syncthreads();                   // (the flag word is free again)
-            if (!last) { DBG_T(); return; }
+            if (!second) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        w4_store16_wt(mine + (size_t)(a * 16 + b) * 128, v4f{y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t == 0) *flag = __hip_atomic_fetch_add(p.ks_cnt + meet, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                second = *flag == 1;
+                __syncthreads();
+                if (!second) { DBG_T(); return; }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (t == 0) __hip_atomic_store(p.ks_cnt + ul, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            if (t == 0) __hip_atomic_store(p.ks_cnt + meet, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    v4f q4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) q4[q] = *reinterpret_cast<const v4f*>(slot + ((size_t)q * 256 + a * 16 + b) * 128);
-                    const v4f sum = ((q4[0] + q4[1]) + q4[2]) + q4[3] + bv;
-                    y[a][b][0] = sum.x; y[a][b][1] = sum.y; y[a][b][2] = sum.z; y[a][b][3] = sum.w;
+                    const v4f o = *reinterpret_cast<const v4f*>(other + (size_t)(a * 16 + b) * 128);
+                    y[a][b][0] = (y[a][b][0] + o.x) + bv.x; y[a][b][1] = (y[a][b][1] + o.y) + bv.y;
+                    y[a][b][2] = (y[a][b][2] + o.z) + bv.z; y[a][b][3] = (y[a][b][3] + o.w) + bv.w;
                 }
         }
         unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
@@ -442,10 +449,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
         DBG_T();   /* epilogue end */
     };
-    const int nitems = p.nfull + 4 * (p.units_x * p.units_y - p.nfull);
-    for (int it = lb; it < nitems; it += gridDim.x) {
-        if (it < p.nfull) work(std::integral_constant<int, 1>{}, it, 0);
-        else work(std::integral_constant<int, 4>{}, p.nfull + ((it - p.nfull) >> 2), (it - p.nfull) & 3);
+    const int units = p.units_x * p.units_y;
+    if (!p.stream) {
+        for (int u = lb; u < units; u += gridDim.x) work(u, 0, nslices, -1, 0);
+    } else {
+        // block lb's share of the units x nslices slices: [g, g1); every share is at least a unit long, so a unit has at most two parts:
+        // the slices before the cut close block lb's share (meeting place lb), those behind it open block lb + 1's
+        const long long tot = (long long)units * nslices;
+        int g = (int)(tot * lb / gridDim.x);
+        const int g1 = (int)(tot * (lb + 1) / gridDim.x);
+        while (g < g1) {
+            const int u = g / nslices, s0 = g - u * nslices, s1 = min(nslices, s0 + (g1 - g));
+            const bool whole = s0 == 0 && s1 == nslices;
+            work(u, s0, s1, whole ? -1 : (s0 == 0 ? lb : lb - 1), s0 == 0 ? 0 : 1);
+            g += s1 - s0;
+        }
     }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
 #undef DBG_T
@@ -488,15 +506,20 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
         cus[dv] = prop_cus;          // one block per CU
     }
     const int units = a0.units_x * a0.units_y;
-    const int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
+    int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
     Wino4Args a = a0; a.dbg = nullptr;
     // A CU holds one unit at a time, so a launch takes ceil(units / grid) rounds of one unit time -- and three of the ten layers at
-    // 1280x720 have 273-286 units for 256 CUs (a unit is 256 pixels, the layers 64.8-66.9 k).  When the last round has at most
-    // grid / 4 units, each of them is cut into FOUR items along K (two of the eight 16-channel slices each): four times as many CUs
-    // work on that round, it takes a third of a unit time instead of a whole one (prologue, two slices, hand-over through ks_ws)
-    static const bool no_ksplit = getenv("FAV_W4_NO_KSPLIT") != nullptr;
+    // 1280x720 have 273-286 units for 256 CUs (a unit is 256 pixels, the layers 64.8-66.9 k): two rounds for 1.07-1.12 rounds of work.
+    // When the last round is that thin the units x slices are dealt out as one sequence instead, an equal share of 16-channel
+    // slices per block ("stream-K"): a share boundary inside a unit makes two parts of it, computed by two neighbouring blocks, the
+    // second to finish adds them (ks_ws / ks_cnt: one meeting place per boundary).  Costs a second prologue and output transform per
+    // block and the hand-over, i.e. ~0.3 unit times: worth it when the last round is less than ~0.6 full
+    // (FAV_W4_GRID: fewer blocks than CUs -- the tests reach the many-shares case with small images through it)
+    static const bool no_stream = getenv("FAV_W4_NO_STREAM") != nullptr;
+    static const int grid_cap = getenv("FAV_W4_GRID") ? atoi(getenv("FAV_W4_GRID")) : 0;
+    if (grid_cap > 0) grid = std::min(grid, std::max(1, grid_cap));
     const int rounds = (units + grid - 1) / grid, rem = units - (rounds - 1) * grid;
-    a.nfull = (rounds >= 2 && rem * 4 <= grid && rem <= 64 && (a0.CIN >> 4) % 4 == 0 && a0.ks_ws && a0.ks_cnt && !no_ksplit) ? (rounds - 1) * grid : units;
+    a.stream = (rounds >= 2 && rem * 5 <= grid * 3 && grid <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
     static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
@@ -533,7 +556,7 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 15) / 16;
     a.dbg = nullptr;
     a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
-    a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.nfull = a.units_x * a.units_y;
+    a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.stream = 0;
     if (c.join_skip != nullptr) {
         FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
         return launch_wino4_t<2>(a, c.reserve_cus, st);

@@ -186,7 +186,7 @@ struct fav_net {
     std::vector<DevIN> ins;
     float* ones = nullptr; float* zeros = nullptr;
     float* sk_ws = nullptr; unsigned* sk_flags = nullptr; unsigned sk_epoch = 0;   // stream-K hand-off state
-    float* ks_ws = nullptr; int* ks_cnt = nullptr;                                    // K-split units of the F(4x4) Winograd kernel
+    float* ks_ws = nullptr; int* ks_cnt = nullptr;                                    // meeting places of the F(4x4) Winograd kernel's stream-K launches
     // a residual block whose join stays pending (run(), L_RES): its last convolution lays its output out under the skip tensor
     struct LazyOut { bool active = false; int pitch = 0, rows = 0, shave = 0, conv_index = -1; } lazy;
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
@@ -374,8 +374,8 @@ int fav_net::upload()
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&sk_flags), conv_streamk_grid() * sizeof(unsigned)));
     FAV_HIP(hipMemset(sk_flags, 0, conv_streamk_grid() * sizeof(unsigned)));
     FAV_HIP(hipMalloc(reinterpret_cast<void**>(&ks_ws), conv3_wino4_ksplit_bytes()));
-    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&ks_cnt), 64 * sizeof(int)));
-    FAV_HIP(hipMemset(ks_cnt, 0, 64 * sizeof(int)));
+    FAV_HIP(hipMalloc(reinterpret_cast<void**>(&ks_cnt), 256 * sizeof(int)));
+    FAV_HIP(hipMemset(ks_cnt, 0, 256 * sizeof(int)));
     FAV_HIP(hipHostMalloc(reinterpret_cast<void**>(&sk_err_host), sizeof(unsigned), hipHostMallocMapped));
     *sk_err_host = 0;
     FAV_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&sk_err_dev), sk_err_host, 0));
@@ -597,9 +597,13 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             // (models_video.lua:41-53, R128 x 5): the 15 us res_add launch (88 MB at the HBM roofline) becomes 33 MB of extra reads and
             // 33 MB of writes inside a kernel that is bound by its matrix instructions.  The skip must be a plain tensor (the first
             // block's skip still carries d128's InstanceNorm + ReLU: its join stays a launch).
+            // Since round 4 only with the F(2x2) kernels (FAV_WINO_F2), or on request (FAV_LAZY_JOIN): inside the F(4x4) kernel the joined
+            // rows' stores cost 10 us of its K loop (the weight ring runs dry behind them) on top of 8 us of staging -- more than the
+            // 16 us launch they replace (639 against 634 frames/s, profiles/r4s_stream_k_and_joins_ab.log)
             static const bool no_lazy = getenv("FAV_NO_LAZY_JOIN") != nullptr;      // (tuning: read once)
+            static const bool want_lazy = getenv("FAV_LAZY_JOIN") != nullptr;
             const int nconv = count_convs(L.block);
-            const bool lazy_out = !no_lazy && precision == 0 && li + 1 < ls.size() && ls[li + 1].type == L_RES && skip.pre.stages == 0 && skip.ups == 0 &&
+            const bool lazy_out = !no_lazy && (tuning().wino_f2 || want_lazy) && precision == 0 && li + 1 < ls.size() && ls[li + 1].type == L_RES && skip.pre.stages == 0 && skip.ups == 0 &&
                                   res_block_is_winograd(L, conv_cursor) && res_block_is_winograd(ls[li + 1], conv_cursor + (size_t)nconv);
             if (lazy_out) { lazy.active = true; lazy.pitch = skip.P(); lazy.rows = skip.Hp; lazy.shave = L.shave; lazy.conv_index = (int)conv_cursor + nconv - 1; }
             rc = run(L.block, br, false, nullptr, nullptr);

@@ -304,6 +304,36 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     assert e2 <= 5e-2 and np.abs(got - f2).max() <= 2e-2 and not np.array_equal(got, f2)
 
 
+@pytest.mark.parametrize("size,grid,lazy", [((88, 120), 4, 0), ((88, 120), 7, 1), ((90, 122), 5, 0), ((360, 640), 37, 1), ((720, 1280), 0, 0)])
+def test_stream_k_shares_of_the_winograd_layers(favlib, cuda, canonical, tmp_path, size, grid, lazy):
+    """conv3_wino4_kernel deals a launch with a thin last round out as one sequence of 16-channel slices, an equal share per block; a unit
+    cut by a share boundary is computed in two parts by two blocks and whichever finishes second adds them (kernels_wino4.hip, `stream`).
+    FAV_W4_GRID caps the number of blocks, so small images reach the many-shares case (pending joins included: their joined rows are
+    written slice by slice by whichever part stages them); FAV_W4_NO_STREAM computes whole units only.  Not the same bits -- a cut unit's
+    channels are summed in two pieces -- but the same numbers to rounding, and the same bits from run to run whoever arrives second."""
+    import subprocess, sys
+    H, W = size
+    rng = np.random.default_rng(3 * H + W)
+    x = (rng.standard_normal((7, H, W)) * 60).astype(np.float32)
+    np.save(tmp_path / "x.npy", x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "x = torch.from_numpy(np.load(%r)).cuda(); net = fav_amd.Net(%r, 0)\n"
+             "a = net.forward(x).cpu().numpy(); b = net.forward(x).cpu().numpy(); c = net.forward(x).cpu().numpy()\n"
+             "assert np.array_equal(a, b) and np.array_equal(a, c)\n"
+             "np.save(sys.argv[1], a)\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical))
+    envg = {"FAV_W4_GRID": str(grid)} if grid else {}
+    if lazy: envg["FAV_LAZY_JOIN"] = "1"           # residual joins pending in the next convolution (conv3_wino4_kernel<2>) instead of launched
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(os.environ, FAV_W4_NO_STREAM="1", **envg), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(os.environ, **envg), timeout=300)
+    whole, stream = np.load(tmp_path / "whole.npy"), np.load(tmp_path / "stream.npy")
+    assert np.isfinite(stream).all()
+    d = np.abs(stream - whole).max()
+    print("stream-K vs whole units at %dx%d, grid cap %d: max-abs %.3e (150*tanh space)" % (H, W, grid, d))
+    assert d <= 5e-3, d
+    assert not np.array_equal(stream, whole)       # (the shares really cut units at these sizes)
+
+
 @pytest.mark.parametrize("size", [(88, 120), (90, 122), (360, 640), (720, 1280)])
 def test_pending_residual_joins_give_the_bits_of_the_launched_ones(favlib, cuda, canonical, tmp_path, size):
     """The joins of residual blocks 2-4 (models_video.lua:41-53) are not launched: the next block's first Winograd convolution forms
@@ -319,13 +349,22 @@ def test_pending_residual_joins_give_the_bits_of_the_launched_ones(favlib, cuda,
              "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
              "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "eager.npy")))
-    subprocess.check_call([sys.executable, "-c", child], env=dict(os.environ, FAV_NO_LAZY_JOIN="1"), timeout=300)
-    eager = np.load(tmp_path / "eager.npy")
+    # (launched joins are the default again since round 4: FAV_LAZY_JOIN asks for the pending form -- in the F(4x4) kernel here, and in the
+    #  F(2x2) kernel, whose default it still is, with FAV_WINO_F2)
     net = favlib.Net(canonical, 0)
-    got = net.forward(T(x, cuda)).cpu().numpy()
-    assert np.isfinite(got).all()
-    assert np.array_equal(got, eager), np.abs(got - eager).max()
-    assert np.array_equal(got, net.forward(T(x, cuda)).cpu().numpy())
+    eager = net.forward(T(x, cuda)).cpu().numpy()
+    assert np.isfinite(eager).all()
+    assert np.array_equal(eager, net.forward(T(x, cuda)).cpu().numpy())
+    for extra in ({"FAV_LAZY_JOIN": "1"}, {"FAV_WINO_F2": "1"}):
+        ref_env = dict(os.environ, **extra)
+        subprocess.check_call([sys.executable, "-c", child], env=ref_env, timeout=300)
+        pending = np.load(tmp_path / "eager.npy")
+        if "FAV_WINO_F2" in extra:      # the F(2x2) kernels: pending (their default) against launched, both in children
+            subprocess.check_call([sys.executable, "-c", child], env=dict(ref_env, FAV_NO_LAZY_JOIN="1"), timeout=300)
+            launched = np.load(tmp_path / "eager.npy")
+        else:
+            launched = eager
+        assert np.array_equal(pending, launched), (extra, np.abs(pending - launched).max())
 
 
 @pytest.mark.parametrize("inorm", [True, False])
