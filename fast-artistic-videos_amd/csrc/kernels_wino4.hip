@@ -73,7 +73,9 @@ struct Wino4Args {
     // stream != 0: the launch's units x slices are dealt out as ONE sequence of 16-channel slices, an equal share per block (launch_wino4_t);
     // a unit cut by a share boundary is computed in two parts -- the slices before the cut by one block, those behind it by the next --
     // whose partial outputs meet in ks_ws: whichever part is finished second adds the other's to its own (+ bias) and stores the unit
-    int stream; float* ks_ws; int* ks_cnt;
+    // (shares: how many -- a function of the layer and the device alone, NOT of how many blocks this launch may use: the look-ahead mode
+    //  leaves the side queues a few CUs, and both modes must produce the same bits)
+    int stream, shares; float* ks_ws; int* ks_cnt;
     long long* dbg;
 };
 
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto work = [&](const int u, const int s0, const int s1, const int meet, const int part) {
         const int nsl = s1 - s0;
         const bool whole = meet < 0;
+        if (s0 != 0) ring_primed = false;                   // (the ring holds the first positions of a slice 0)
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 4) * 36 * 8192, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
@@ -453,16 +456,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (!p.stream) {
         for (int u = lb; u < units; u += gridDim.x) work(u, 0, nslices, -1, 0);
     } else {
-        // block lb's share of the units x nslices slices: [g, g1); every share is at least a unit long, so a unit has at most two parts:
-        // the slices before the cut close block lb's share (meeting place lb), those behind it open block lb + 1's
+        // share sh of the units x nslices slices: [g, g1); every share is at least a unit long, so a unit has at most two parts: the
+        // slices before the cut close share sh (meeting place sh), those behind it open share sh + 1
         const long long tot = (long long)units * nslices;
-        int g = (int)(tot * lb / gridDim.x);
-        const int g1 = (int)(tot * (lb + 1) / gridDim.x);
-        while (g < g1) {
-            const int u = g / nslices, s0 = g - u * nslices, s1 = min(nslices, s0 + (g1 - g));
-            const bool whole = s0 == 0 && s1 == nslices;
-            work(u, s0, s1, whole ? -1 : (s0 == 0 ? lb : lb - 1), s0 == 0 ? 0 : 1);
-            g += s1 - s0;
+        for (int sh = lb; sh < p.shares; sh += gridDim.x) {
+            int g = (int)(tot * sh / p.shares);
+            const int g1 = (int)(tot * (sh + 1) / p.shares);
+            while (g < g1) {
+                const int u = g / nslices, s0 = g - u * nslices, s1 = min(nslices, s0 + (g1 - g));
+                const bool whole = s0 == 0 && s1 == nslices;
+                work(u, s0, s1, whole ? -1 : (s0 == 0 ? sh : sh - 1), s0 == 0 ? 0 : 1);
+                g += s1 - s0;
+            }
         }
     }
     if (p.dbg && t == 0) p.dbg[blockIdx.x * 24 + 23] = dbi;
@@ -515,11 +520,17 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     // second to finish adds them (ks_ws / ks_cnt: one meeting place per boundary).  Costs a second prologue and output transform per
     // block and the hand-over, i.e. ~0.3 unit times: worth it when the last round is less than ~0.6 full
     // (FAV_W4_GRID: fewer blocks than CUs -- the tests reach the many-shares case with small images through it)
+    // The number of shares depends on the layer and the device only (CUs - 4: what the look-ahead mode leaves the network's grids,
+    // fav_net::reserve_cus) -- with all 256 CUs four blocks of such a launch stay idle (1.6 %), and both modes cut the same units at the
+    // same slices: same bits
     static const bool no_stream = getenv("FAV_W4_NO_STREAM") != nullptr;
     static const int grid_cap = getenv("FAV_W4_GRID") ? atoi(getenv("FAV_W4_GRID")) : 0;
     if (grid_cap > 0) grid = std::min(grid, std::max(1, grid_cap));
-    const int rounds = (units + grid - 1) / grid, rem = units - (rounds - 1) * grid;
-    a.stream = (rounds >= 2 && rem * 5 <= grid * 3 && grid <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
+    const int shares = std::max(1, grid_cap > 0 ? std::min(cus[dv] - 4, grid_cap) : cus[dv] - 4);
+    const int rounds = (units + shares - 1) / shares, rem = units - (rounds - 1) * shares;
+    a.stream = (rounds >= 2 && rem * 5 <= shares * 3 && shares <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
+    a.shares = shares;
+    if (a.stream) grid = std::min(grid, shares);
     static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
@@ -556,7 +567,7 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
     a.units_x = (c.OW + 15) / 16; a.units_y = (c.OH + 15) / 16;
     a.dbg = nullptr;
     a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
-    a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.stream = 0;
+    a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.stream = 0; a.shares = 1;
     if (c.join_skip != nullptr) {
         FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
         return launch_wino4_t<2>(a, c.reserve_cus, st);
