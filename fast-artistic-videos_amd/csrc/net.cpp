@@ -949,6 +949,13 @@ struct fav_stream {
     uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
     void* ws = nullptr; size_t ws_bytes = 0;
     void* png_ws = nullptr; size_t png_ws_bytes = 0;      // workspace of fav_stream_encode_png (allocated on first use)
+    // fav_stream_encode_png_async: the encoder's kernels run on a queue of their own, next to the NEXT frame's network (they fill the
+    // tails of its grids instead of standing in front of it).  The state is double-buffered from then on: frame i + 1 is written into
+    // the other buffer while frame i's is being encoded, and the frame that comes back to a buffer waits for that buffer's encoder
+    hipStream_t png_q = nullptr; hipEvent_t ev_png_in = nullptr;
+    float* state_other = nullptr;                         // the buffer `state` is not (null until the first asynchronous encode)
+    hipEvent_t png_done = nullptr, png_done_other = nullptr;      // the last encode that read `state` / `state_other` ...
+    bool png_pending = false, png_pending_other = false;          // ... if nothing has waited for it yet
     // look-ahead mask (fav_stream_prefetch_mask)
     // two side queues with their own structure workspaces: the masks of frames i+1 and i+2 are computed concurrently
     // (each 4-argument mask contains a ~3 ms sequential fp32 chain, CMatrix::avg), three look-ahead slots
@@ -975,6 +982,11 @@ struct fav_stream {
     {
         if (net) (void)hipSetDevice(net->device);
         if (net && ran) forget_stream(net->device, last_st);
+        if (png_q) { (void)hipStreamSynchronize(png_q); (void)hipStreamDestroy(png_q); }
+        if (ev_png_in) (void)hipEventDestroy(ev_png_in);
+        if (png_done) (void)hipEventDestroy(png_done);
+        if (png_done_other) (void)hipEventDestroy(png_done_other);
+        (void)hipFree(state_other);
         for (int i = 0; i < NSIDE; ++i) { if (side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); } (void)hipFree(side_ws[i]); }
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (done_host) (void)hipHostFree(done_host);       // (retired_host lives in the same allocation)
@@ -1048,6 +1060,19 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
 
 extern "C" void fav_stream_destroy(fav_stream* s) { delete s; }
 
+// the buffer the next frame is written into becomes `state`.  Synchronous encodes only: the one buffer, in place (the frame's own
+// input was assembled from it before the network starts).  With an asynchronous encode possibly reading `state`: the other buffer,
+// behind the encode that read THAT one two frames ago (long finished)
+static int state_for_writing(fav_stream* s, hipStream_t st)
+{
+    if (!s->state_other) return FAV_OK;
+    std::swap(s->state, s->state_other);
+    std::swap(s->png_done, s->png_done_other);
+    std::swap(s->png_pending, s->png_pending_other);
+    if (s->png_pending) { FAV_HIP(hipStreamWaitEvent(st, s->png_done, 0)); s->png_pending = false; }
+    return FAV_OK;
+}
+
 static int stream_finish(fav_stream* s, float* out_rgb_f32, uint8_t* out_rgb8_hwc, hipStream_t st)
 {
     const size_t n = (size_t)s->Ho * s->Wo;
@@ -1070,6 +1095,7 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     if (rc) return rc;
     s->last_st = st; s->ran = true;
     fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
+    rc = state_for_writing(s, st); if (rc) return rc;
     rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
     return stream_finish(s, out_rgb_f32, out_rgb8_hwc, st);
 }
@@ -1105,6 +1131,7 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
         if (rc) return rc;
     }
     s->last_st = st; s->ran = true;
+    rc = state_for_writing(s, st); if (rc) return rc;       // (the prior was read from the previous state above)
     { TraceRange tr_net("fav:network"); rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); }
     if (rc) return rc;
     return stream_finish(s, out_f32, out_u8, st);
@@ -1217,8 +1244,19 @@ extern "C" int fav_stream_set_state(fav_stream* s, const float* state_rgb_f32, f
 {
     FAV_REQUIRE(s && state_rgb_f32, "fav_stream_set_state: null argument");
     FAV_HIP(hipSetDevice(s->net->device));
+    if (s->png_pending) { FAV_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), s->png_done, 0)); s->png_pending = false; }
     FAV_HIP(hipMemcpyAsync(s->state, state_rgb_f32, (size_t)3 * s->Ho * s->Wo * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     s->has_state = true;
+    return FAV_OK;
+}
+
+extern "C" int fav_stream_wait_png(fav_stream* s, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s, "fav_stream_wait_png: null stream");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (s->png_pending) FAV_HIP(hipStreamWaitEvent(st, s->png_done, 0));
+    if (s->png_pending_other) FAV_HIP(hipStreamWaitEvent(st, s->png_done_other, 0));
     return FAV_OK;
 }
 
@@ -1230,7 +1268,34 @@ extern "C" int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capaci
         s->png_ws_bytes = png_workspace_bytes(s->Wo, s->Ho);
         FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
     }
+    if (s->png_q) { int rc = fav_stream_wait_png(s, stream); if (rc) return rc; }      // (one workspace: behind the asynchronous encodes)
     return launch_png_encode(nullptr, s->state, s->Wo, s->Ho, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fav_stream_encode_png_async(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream)
+{
+    FAV_REQUIRE(s && s->has_state, "fav_stream_encode_png_async: no stylised frame yet");
+    FAV_HIP(hipSetDevice(s->net->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!s->png_ws) {
+        s->png_ws_bytes = png_workspace_bytes(s->Wo, s->Ho);
+        FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
+    }
+    if (!s->png_q) {
+        const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
+        FAV_HIP(hipStreamCreateWithFlags(&s->png_q, hipStreamNonBlocking));
+        FAV_HIP(hipEventCreateWithFlags(&s->ev_png_in, ef));
+        FAV_HIP(hipEventCreateWithFlags(&s->png_done, ef));
+        FAV_HIP(hipEventCreateWithFlags(&s->png_done_other, ef));
+        FAV_HIP(hipMalloc(reinterpret_cast<void**>(&s->state_other), (size_t)3 * s->Ho * s->Wo * 4));
+    }
+    FAV_HIP(hipEventRecord(s->ev_png_in, st));                 // the frame is complete at this point of the caller's queue
+    FAV_HIP(hipStreamWaitEvent(s->png_q, s->ev_png_in, 0));
+    int rc = launch_png_encode(nullptr, s->state, s->Wo, s->Ho, png_out, capacity, png_bytes_out, s->png_ws, s->png_ws_bytes, s->png_q);
+    if (rc) return rc;
+    FAV_HIP(hipEventRecord(s->png_done, s->png_q));
+    s->png_pending = true;
+    return FAV_OK;
 }
 
 extern "C" int fav_stream_set_host_ordered(fav_stream* s, int on)

@@ -11,6 +11,8 @@
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
 // makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>,
+// -png_overlap <0|1> (1, default: with -png_encoder gpu the encoder's kernels run on a queue of their own next to the following frame's
+//   network -- fav_stream_encode_png_async -- instead of in front of it)
 // -png_encoder <gpu|host> (gpu, default: the PNG file's bytes are produced on the device, the host only write()s them -- fixed-Huffman
 // deflate, larger files; host: zlib on the writer threads at -png_level <0..9>, ~25 ms per 1280x720 frame and core),
 // -precision <fp32|bf16> (fp32 = parity mode, default; bf16 = optional fast mode, see include/fav.h),
@@ -335,6 +337,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     // run-length deflate per row + Adler-32 / CRC-32 combine), leave as ONE exact-size DMA and the writer thread only write()s them;
     // -png_encoder host: the 8-bit frame is downloaded and deflated by zlib on the writer threads (-png_level; ~25 ms per frame and core)
     const bool gpu_png = o.s("png_encoder") == "gpu";
+    const bool png_overlap = o.i("png_overlap") != 0;
     // QUIET synchronisation (gpu_png, no 4-argument look-ahead): nothing but kernels ever enters the compute queue.  On this runtime
     // a marker behind long-running kernels (hipEventRecord on the compute stream) or a device-side dependency between queues
     // (hipStreamWaitEvent, a copy in front of kernels in one stream) is resolved by a runtime thread that SPINS until the marker
@@ -637,7 +640,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
                 else hipStreamWaitEvent(st, png_copy_ev[now.ev], 0);
             }
             if (quiet) h_png_size[now.ev] = 0u;          // the frame's last kernel overwrites it with the file size (host-mapped)
-            check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, quiet ? &h_png_size[now.ev] : d_png_size[now.ev], st), "fav_stream_encode_png");
+            // quiet mode: on the stream's encoder queue, next to frame i + 1's network (-png_overlap 1, default) -- the host learns of the
+            // file through its size word either way; with events in the queues the encode stays in front of the next frame
+            if (quiet && png_overlap) check(fav_stream_encode_png_async(fs, d_png[now.ev], png_cap, &h_png_size[now.ev], st), "fav_stream_encode_png_async");
+            else check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, quiet ? &h_png_size[now.ev] : d_png_size[now.ev], st), "fav_stream_encode_png");
         }
         if (!quiet) hipEventRecord(ev_out[now.ev], st);  // the frame's 8-bit image / PNG is complete on the compute queue ...
         tr_mark(2);                                      // PNG encode enqueued
@@ -715,7 +721,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"png_encoder", "gpu"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
+           {"png_level", "1"}, {"png_encoder", "gpu"}, {"png_overlap", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
            {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"}, {"pin_workers", "1"},
            // internal (set by the launcher for its workers)
            {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};

@@ -65,7 +65,7 @@ EXPORTS = [
     "fav_stream_set_image_net", "fav_stream_first_frame", "fav_stream_next_frame_cert", "fav_stream_next_frame_flow", "fav_stream_prefetch_mask",
     "fav_stream_get_state",
     "fav_stream_set_state", "fav_stream_last_mask", "fav_stream_get_input_f32", "fav_stream_output_size", "fav_stream_set_host_ordered",
-    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_png_tables_host", "fav_png_crc32_combine_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
+    "fav_png_capacity", "fav_png_workspace_bytes", "fav_png_encode_rgb8", "fav_png_encode_f32", "fav_stream_encode_png", "fav_stream_encode_png_async", "fav_stream_wait_png", "fav_png_tables_host", "fav_png_crc32_combine_host", "fav_read_flo_host", "fav_read_pnm_host", "fav_write_pgm_host",
     "fav_write_png_rgb8_host", "fav_free_host",
     "fav_vr_create", "fav_vr_destroy", "fav_vr_face", "fav_vr_finish_frame", "fav_vr_output_sizes", "fav_vr_get_f32",
     "fav_vr_map_host", "fav_temporal_loss_host", "fav_sequential_sum_f32", "fav_read_flo_into_host", "fav_read_pnm_into_host", "fav_net_set_precision", "fav_net_check", "fav_net_set_shared_device", "fav_net_forget_stream",
@@ -351,6 +351,14 @@ class Stream:
     def encode_png_into(self, out, nbytes):
         """fav_stream_encode_png: the current stylised frame as the bytes of a PNG file, enqueued on the current stream (no sync)"""
         _check(lib().fav_stream_encode_png(self.h, _p(out), C.c_size_t(out.numel()), _p(nbytes), _stream()))
+
+    def encode_png_async_into(self, out, nbytes):
+        """fav_stream_encode_png_async: the same bytes, produced on the stream's own encoder queue next to the following frame"""
+        _check(lib().fav_stream_encode_png_async(self.h, _p(out), C.c_size_t(out.numel()), _p(nbytes), _stream()))
+
+    def wait_png(self):
+        """fav_stream_wait_png: the current stream waits for the asynchronous encodes issued so far"""
+        _check(lib().fav_stream_wait_png(self.h, _stream()))
 
     def last_input(self):
         """[7][H][W] network input of the last frame (content | prior | certainty), un-padded copy of the fused kernel's output"""

@@ -324,6 +324,16 @@ int fav_png_tables_host(void* out_host, size_t capacity, int* count, int* table_
 uint32_t fav_png_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint32_t len_b);
 /* the stream's current stylised frame (the recurrent state) as a PNG file, with the stream's own workspace */
 int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
+/* the same file, produced NEXT TO whatever `stream` is given afterwards (normally the next frame's network: the encoder's short kernels
+ * fill the tails of its grids instead of standing in front of it): enqueued on a queue the fav_stream owns, behind everything `stream`
+ * holds at the time of the call.  The stream's state is double-buffered from the first such call on -- the next frame is written
+ * next to the one being encoded, and the frame after it waits (on the device) for the encoder of the buffer it returns to -- so the
+ * fav_stream_* calls may follow immediately.  png_out / png_bytes_out are complete when *png_bytes_out (set it to 0 first; e.g.
+ * host-mapped memory) becomes the file's size, or behind fav_stream_wait_png on a queue of the caller's.  One encode per frame;
+ * successive encodes run in order.  Same bytes as fav_stream_encode_png. */
+int fav_stream_encode_png_async(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
+/* makes `stream` wait (on the device) for the asynchronous encodes issued so far */
+int fav_stream_wait_png(fav_stream* s, fav_hipstream_t stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,47 @@ def test_png_from_float_state_and_stream(favlib, oracle, cuda, golden_dir):
     assert png == favlib.png_encode(u8.contiguous())          # the u8 and the float source give the same file
 
 
+@pytest.mark.parametrize("size", [(48, 64), (180, 320)])
+def test_png_encoded_next_to_the_following_frames(favlib, oracle, cuda, golden_dir, size):
+    """fav_stream_encode_png_async: every frame's file produced on the stream's encoder queue while the NEXT frames are already being
+    stylised (double-buffered state: frame i + 1 is written next to the one being encoded, frame i + 2 waits for that buffer's encoder)
+    -- same bytes as the encode on the compute queue of a second stream fed the same inputs, same recurrent states, and
+    set_state / a synchronous encode in between stay ordered."""
+    import torch
+    net = favlib.Net(os.path.join(golden_dir, "tiny_model.t7"), 0)
+    H, W = size
+    N = 9
+    fr = [T(synth.random_frame(H, W, 40 + i), cuda) for i in range(N)]
+    bw = [T(synth.backward_flow(H, W, 50 + i), cuda) for i in range(N)]
+    fw = [T(synth.forward_flow_from_backward(bw[i].cpu().numpy(), 60 + i), cuda) for i in range(N)]
+    a, b = favlib.Stream(net, H, W), favlib.Stream(net, H, W)
+    want, states = [], []
+    b.first_frame(fr[0], want_f32=False)
+    for i in range(N):
+        if i: b.next_frame_flow(fr[i], bw[i], fw[i], use_structure=False, want_f32=False)
+        want.append(favlib.png_encode(None, from_stream=b)); states.append(b.state().cpu().numpy())
+    bufs = [a.png_buffers() for _ in range(N)]
+    a.first_frame(fr[0], want_f32=False)
+    for i in range(N):                                   # nothing waits between the frames
+        if i: a.next_frame_flow(fr[i], bw[i], fw[i], use_structure=False, want_f32=False)
+        a.encode_png_async_into(*bufs[i])
+    a.wait_png()
+    torch.cuda.synchronize()
+    for i in range(N):
+        n = int(bufs[i][1].item())
+        assert bufs[i][0][:n].cpu().numpy().tobytes() == want[i], "frame %d" % i
+    assert np.array_equal(a.state().cpu().numpy(), states[-1])
+    # a synchronous encode and set_state after asynchronous ones
+    assert favlib.png_encode(None, from_stream=a) == want[-1]
+    a.encode_png_async_into(*bufs[0])
+    a.set_state(T(states[3], cuda))                      # (into the buffer the encoder is reading: waits for it on the device)
+    a.next_frame_flow(fr[4], bw[4], fw[4], use_structure=False, want_f32=False)
+    a.encode_png_async_into(*bufs[1])
+    a.wait_png(); torch.cuda.synchronize()
+    assert bufs[0][0][:int(bufs[0][1].item())].cpu().numpy().tobytes() == want[-1]
+    assert bufs[1][0][:int(bufs[1][1].item())].cpu().numpy().tobytes() == want[4]
+
+
 def test_png_full_size_1280x720_decodes_exactly(favlib, oracle, cuda):
     """BASELINE config 3 size: decodes (PIL) to the exact bytes, every repeated call gives the same file, size within the capacity"""
     import png_model as P
