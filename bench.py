@@ -519,7 +519,9 @@ def main():
         def step4(i):
             k2 = (i + 2) % ring
             stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)
-            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=True, want_f32=False, out_u8=out8)
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=True, want_f32=False, want_u8=False)
+            if args.png_sync: stream.encode_png_into(png_out, png_n)        # (the timed step's own ending: the two rates compare like with like)
+            else: stream.encode_png_async_into(png_out, png_n)
         stream.prefetch_mask(frames[0], bws[0], fws[0], use_structure=True)
         stream.prefetch_mask(frames[1], bws[1], fws[1], use_structure=True)
         for i in range(4):
@@ -623,8 +625,10 @@ def main():
                          "avg_launch_us_without_join": round(sum(ms for ms, n, macs in dom_plain) / max(1, sum(n for ms, n, macs in dom_plain)) * 1e3, 2) if dom_name.startswith("conv3_wino") and dom_plain else None,
                          "frac_of_launches_without_join": (round(sum(2.0 * macs * n for ms, n, macs in dom_plain) / (sum(ms for ms, n, macs in dom_plain) / 1e3) / 1e12 * exec_ratio / FP32_MFMA_PEAK_TFLOPS, 4)
                                                            if dom_name.startswith("conv3_wino") and dom_plain else None),
-                         "join_note": "three of the ten launches form the residual join z = skip + IN(branch) of the previous block while staging their input and write it out "
-                                      "(the work of the res_add launches they replace: 33 MB more to read, 33 MB to write, one more operand transform); `frac` is over all ten",
+                         "join_note": ("residual joins are launches of their own next to the F(4x4) kernel (since r4s: a join formed inside the convolution costs more than "
+                                       "its launch); three of the ten launches have 273-286 units for 252 shares and run as stream-K (a cut unit in two parts)" if f4 else
+                                       "three of the ten launches form the residual join z = skip + IN(branch) of the previous block while staging their input and write it out "
+                                       "(the work of the res_add launches they replace: 33 MB more to read, 33 MB to write, one more operand transform); `frac` is over all ten"),
                          "timed_with": "HIP events (no system fence) around every convolution launch of every %d-th step of the timed region (%d of %d steps)" % (max(1, pe), n_prof_steps, args.steps),
                          "conv_stack_ms_per_frame": round(conv_ms, 4),
                          "conv_stack_tflops": round(FLOP_PER_FRAME / (conv_ms * 1e-3) / 1e12, 3) if conv_ms > 0 else None,
@@ -632,6 +636,9 @@ def main():
                          "per_kernel_ms_tflops": {k: [round(v[0], 4), round(v[1] / (v[0] * 1e-3) / 1e12, 1)] for k, v in per_kernel.items()}},
         }
         line["extra"] = extra
+        if "frames_per_s_4arg_structure_mode_lookahead" in extra:      # `value`'s sibling: the checker mode makeOptFlow_deepflow.sh:59-60 runs
+            line["config"]["value_in_4arg_structure_mode"] = extra["frames_per_s_4arg_structure_mode_lookahead"]
+            line["config"]["value_in_4arg_structure_mode_over_value"] = round(extra["frames_per_s_4arg_structure_mode_lookahead"] / fps, 4)
         # the launch path is not the limiter: host enqueue time per frame vs GPU time per frame (why a HIP graph would not help:
         # kernel boundaries cost the same GPU-side in a replayed graph, MI355X_MICROARCH.md "boundary" row)
         line["extra"]["host_enqueue_ms_per_frame"] = round(t_enq / args.steps * 1e3, 4)
