@@ -35,10 +35,8 @@ if dom and all("FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k] for k in dom):
     sha = hashlib.sha256(open("$R/fast-artistic-videos_amd/csrc/" + srcf, "rb").read()).hexdigest()[:16]
     json.dump({"kernel": "conv3_wino4_kernel" if f4 else "conv3_wino_kernel", "source": srcf, "source_sha16": sha, "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w,
                "launches_averaged": nl, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
-               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of all instances "
-                       "(plain input / pending InstanceNorm / pending residual join) in bench.py; read side doubled per the gfx950 FETCH_SIZE "
-                       "calibration; algorithmic bytes per launch: ~68 MB (33-35 MB in + 32-34 MB out + 1 MB packed weights), plus 33 MB of skip "
-                       "read and 33 MB of joined tensor written in the three launches that form a residual join (mean over ten: ~88 MB)"},
+               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, mean over the launches of all instances in bench.py; read side doubled per the gfx950 "
+                       "FETCH_SIZE calibration; algorithmic bytes per launch: ~69 MB (33.5 MB in + 33 MB out + 2.4 MB packed weights; F(2x2) kernel with pending joins: +66 MB in three of ten)"},
               open("$O/pmc_traffic_$TAG.json", "w"), indent=1)
 for k in sorted(out):
     print(k[:80], {c: round(v["mean"], 1) for c, v in out[k].items()})
