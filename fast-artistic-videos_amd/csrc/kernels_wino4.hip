@@ -526,7 +526,8 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     static const bool no_stream = getenv("FAV_W4_NO_STREAM") != nullptr;
     static const int grid_cap = getenv("FAV_W4_GRID") ? atoi(getenv("FAV_W4_GRID")) : 0;
     if (grid_cap > 0) grid = std::min(grid, std::max(1, grid_cap));
-    const int shares = std::max(1, grid_cap > 0 ? std::min(cus[dv] - 4, grid_cap) : cus[dv] - 4);
+    const int free_cus = std::max(4, reserve_cus);        // (more than the default four reserved -- FAV_SIDE_CUS: that many fewer shares, other bits)
+    const int shares = std::max(1, grid_cap > 0 ? std::min(cus[dv] - free_cus, grid_cap) : cus[dv] - free_cus);
     const int rounds = (units + shares - 1) / shares, rem = units - (rounds - 1) * shares;
     a.stream = (rounds >= 2 && rem * 5 <= shares * 3 && shares <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
     a.shares = shares;
