@@ -387,8 +387,8 @@ def main():
                     "world size 1 (exercises the N>1 launch path on a 1-GPU box)")
     ap.add_argument("--sustained-frames", type=int, default=3000, help="length of the sustained file->PNG leg (0 = skip)")
     ap.add_argument("--quick-e2e", action="store_true", help="only the headline file->PNG leg")
-    ap.add_argument("--png-sync", action="store_true", help="PNG encode on the compute queue in front of the next frame (fav_stream_encode_png, the form "
-                    "of rounds 3-4) instead of on the stream's encoder queue next to it (fav_stream_encode_png_async)")
+    ap.add_argument("--png-async", action="store_true", help="PNG encode on the stream's encoder queue next to the following frame (fav_stream_encode_png_async) "
+                    "instead of on the compute queue in front of it (fav_stream_encode_png, the default: what bin/fav_stylize does)")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational 4-argument-mode pass after the timed region "
                     "(used for the rocprofv3 runs, so that the per-kernel averages cover the timed configuration only)")
     args = ap.parse_args()
@@ -455,7 +455,7 @@ def main():
             k2 = (i + 2) % ring  # on the side queues BEFORE frame i's network so they overlap it (two in flight)
             stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=bool(args.structure))
         stream.next_frame_flow(frames[k], bws[k], fws[k], use_structure=bool(args.structure), want_f32=False, want_u8=False)
-        if args.png_sync:
+        if not args.png_async:
             stream.encode_png_into(png_out, png_n)
         else:   # the encoder's kernels on the stream's own queue, next to frame i + 1's network (every frame is still encoded in full)
             stream.encode_png_async_into(png_out, png_n)
@@ -504,23 +504,24 @@ def main():
             stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
         torch.cuda.synchronize()
         extra["frames_per_s_without_png_encode"] = round(n0 / (time.perf_counter() - t1), 3)
-        if not args.png_sync:    # ... and with the encode on the compute queue, in front of the next frame (`value` until r4u)
-            def step_sync(i):
-                stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
-                stream.encode_png_into(png_out, png_n)
-            for i in range(4):
-                step_sync(i)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for i in range(4, 4 + n0):
-                step_sync(i)
-            torch.cuda.synchronize()
-            extra["frames_per_s_png_encode_on_the_compute_queue"] = round(n0 / (time.perf_counter() - t1), 3)
+        # ... and with the encode on the other queue (informational: the form `value` does not use)
+        def step_other(i):
+            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+            if args.png_async: stream.encode_png_into(png_out, png_n)
+            else: stream.encode_png_async_into(png_out, png_n)
+        for i in range(4):
+            step_other(i)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for i in range(4, 4 + n0):
+            step_other(i)
+        torch.cuda.synchronize()
+        extra["frames_per_s_png_encode_on_the_compute_queue" if args.png_async else "frames_per_s_png_encode_on_the_streams_encoder_queue"] = round(n0 / (time.perf_counter() - t1), 3)
     if world == 1 and not args.structure and not args.no_extra:
         def step4(i):
             k2 = (i + 2) % ring
             stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)
             stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=True, want_f32=False, want_u8=False)
-            if args.png_sync: stream.encode_png_into(png_out, png_n)        # (the timed step's own ending: the two rates compare like with like)
+            if not args.png_async: stream.encode_png_into(png_out, png_n)        # (the timed step's own ending: the two rates compare like with like)
             else: stream.encode_png_async_into(png_out, png_n)
         stream.prefetch_mask(frames[0], bws[0], fws[0], use_structure=True)
         stream.prefetch_mask(frames[1], bws[1], fws[1], use_structure=True)
@@ -605,7 +606,7 @@ def main():
             "config": {"workload": "1280x720 fused on-GPU consistency check (%s) + min-filter + warp + assemble + transformer net "
                                    "(c9s1-32,d64,d128,R128x5,U2,c3s1-64,U2,c9s1-3, reflect-start pad 40) + deprocess, inputs in HBM, "
                                    "1 independent stream per GPU" % ("4-arg" if args.structure else "3-arg"),
-                       "png_encode": ("compute queue, in front of the next frame" if args.png_sync else
+                       "png_encode": ("compute queue, in front of the next frame (as bin/fav_stylize)" if not args.png_async else
                                       "every frame, on the stream's encoder queue next to the next frame's network (fav_stream_encode_png_async)"),
                        "frame": [W, H], "streams": world, "parallelism": f"{world} independent streams, no data-path collective"},
             # `achieved` / `frac`: the MATRIX-PIPE view -- FLOPs the kernel actually executes on the fp32 MFMA pipe (16/36 of the direct

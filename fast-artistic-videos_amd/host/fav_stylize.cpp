@@ -11,8 +11,9 @@
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
 // makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>,
-// -png_overlap <0|1> (1, default: with -png_encoder gpu the encoder's kernels run on a queue of their own next to the following frame's
-//   network -- fav_stream_encode_png_async -- instead of in front of it)
+// -png_overlap <0|1> (0, default; 1: with -png_encoder gpu the encoder's kernels run on a queue of their own next to the following frame's
+//   network -- fav_stream_encode_png_async -- instead of in front of it: +0.5 % in HBM, but the events between the queues cost this
+//   process 1.6 ms of CPU per frame and the file -> PNG rate does not move, profiles/bench_r5e.log against bench_r5f.log)
 // -png_encoder <gpu|host> (gpu, default: the PNG file's bytes are produced on the device, the host only write()s them -- fixed-Huffman
 // deflate, larger files; host: zlib on the writer threads at -png_level <0..9>, ~25 ms per 1280x720 frame and core),
 // -precision <fp32|bf16> (fp32 = parity mode, default; bf16 = optional fast mode, see include/fav.h),
@@ -640,8 +641,8 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
                 else hipStreamWaitEvent(st, png_copy_ev[now.ev], 0);
             }
             if (quiet) h_png_size[now.ev] = 0u;          // the frame's last kernel overwrites it with the file size (host-mapped)
-            // quiet mode: on the stream's encoder queue, next to frame i + 1's network (-png_overlap 1, default) -- the host learns of the
-            // file through its size word either way; with events in the queues the encode stays in front of the next frame
+            // -png_overlap 1 (quiet mode): on the stream's encoder queue, next to frame i + 1's network -- the host learns of the file
+            // through its size word either way
             if (quiet && png_overlap) check(fav_stream_encode_png_async(fs, d_png[now.ev], png_cap, &h_png_size[now.ev], st), "fav_stream_encode_png_async");
             else check(fav_stream_encode_png(fs, d_png[now.ev], png_cap, quiet ? &h_png_size[now.ev] : d_png_size[now.ev], st), "fav_stream_encode_png");
         }
@@ -721,7 +722,7 @@ int main(int argc, char** argv)
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
            {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
-           {"png_level", "1"}, {"png_encoder", "gpu"}, {"png_overlap", "1"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
+           {"png_level", "1"}, {"png_encoder", "gpu"}, {"png_overlap", "0"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
            {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"}, {"pin_workers", "1"},
            // internal (set by the launcher for its workers)
            {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
