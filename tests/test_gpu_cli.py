@@ -256,7 +256,7 @@ def test_fav_stylize_backward(oracle, favlib, tmp_path, golden_dir):
         assert np.abs(got.astype(int) - oracle.to_u8_hwc(want[i]).astype(int)).max() <= 1, i
 
 
-MODES = ["3arg", "4arg_lookahead", "cert_via_th_shim", "3arg_two_cpus"]
+MODES = ["3arg", "4arg_lookahead", "cert_via_th_shim", "3arg_two_cpus", "4arg_png_overlap"]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -295,6 +295,8 @@ def test_fav_stylize_config3_content_at_speed(oracle, favlib, cuda, mode):
             cmd, rmode = [os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "0"] + tail, "3arg"
         elif mode == "4arg_lookahead":
             cmd, rmode = [os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "1"] + tail, "4arg"
+        elif mode == "4arg_png_overlap":       # the PNG encoder on the stream's own queue next to the following frame (fav_stream_encode_png_async)
+            cmd, rmode = [os.path.join(BIN, "fav_stylize")] + common + fused + ["-structure", "1", "-png_overlap", "1"] + tail, "4arg"
         elif mode == "cert_via_th_shim":
             cmd = [os.path.join(pkg, "host", "th"), "fast_artistic_video.lua"] + common + ["-occlusions_pattern", f"{d}/s0/flow/reliable_[%d]_{{%d}}.pgm",
                                                                                             "-backend", "cuda", "-use_cudnn", "1"] + tail
