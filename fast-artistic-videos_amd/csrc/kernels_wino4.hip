@@ -192,6 +192,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int hrmax = max(p.IH - 1 - (oy0 + 4 * ty1), 0);
         const int hrow = p.IWp * CIN * 4;
 #define ho_(a_) (ho0 + min((a_), hrmax) * hrow)
+        // the row REQUESTS use another item numbering than the row pass: request lane d asks for pixel d >> 2, chunk d & 3 -- four
+        // adjacent lanes = the 64 contiguous bytes of one pixel's slice, one request instead of four 16-byte ones -- and lands it in slot d;
+        // the row pass's thread reads slot 4 pix + cq (another wave's request: a wait + barrier lie between, see the K loop)
+        const int dpix = min(t >> 2, 71), dty = (dpix * 3641) >> 16, dx = dpix - dty * 18;
+        const int hd0 = ((min(oy0 + 4 * dty, p.IH - 1) * p.IWp + min(ox0 + dx, p.IW - 1)) * CIN + (t & 3) * 4) * 4;
+        const int hdmax = max(p.IH - 1 - (oy0 + 4 * dty), 0);
+#define hd_(a_) (hd0 + min((a_), hdmax) * hrow)
         // MODE 2: which of the item's six rows this thread writes to the joined tensor: rows 4 ty .. 4 ty + 3 of columns 0..15 -- the
         // unit's own 16 x 16 pixels -- plus the halo fringe (rows 16, 17 / columns 16, 17) where no other unit follows
         int zm = 0;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
         v4f sc, sh;
         float* const land = Rs + wave * 256;               // (wave-uniform: M0 of the LDS loads; lane i lands 16 i bytes further)
-        const float* const rread = Rs + t * 4;
+        const float* const rread = Rs + (pix1 * 4 + cq) * 4;
         constexpr int RROW = 288 * 4;                       // words between the landing places of two rows
         constexpr int SKO = W4_RBUF;                        // skip rows: the same places one landing area further on
 #define W4_LOAD_RAW(q_, slice_)                                                                     \
@@ -217,9 +224,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W4_REQ_RAW(slice_)                                                                          \
         { asm volatile("" ::: "memory");      /* (never above the reads of the rows these loads replace) */ \
           if (JOIN) { _Pragma("unroll") for (int a = 0; a < 6; ++a)     /* the skip rows first: the rows' arrival implies theirs */ \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(land + SKO + a * RROW), 16, ho_(a), (slice_) * 64, 0, 0); } \
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(land + SKO + a * RROW), 16, hd_(a), (slice_) * 64, 0, 0); } \
           _Pragma("unroll") for (int a = 0; a < 6; ++a)                                             \
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, ho_(a), (slice_) * 64, 0, 0); }
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, hd_(a), (slice_) * 64, 0, 0); }
 #define W4_TAKE_RAW(q_)                                                                             \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rread + a * RROW); }
         // (the skip rows of a pending join are read one at a time where they are added: six more live rows would not fit the registers)
@@ -307,12 +314,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int sw = s + 1 < s1 ? s + 1 : 0;            // (weights: whatever this block computes next starts at a slice 0)
             const int sn2 = min(s + 2, s1 - 1);
             W4_POSITIONS(0, 6);
+            if (sl == 0) {      // the rows requested in the prologue (by other waves): landed, and everybody knows
+                if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                __syncthreads();
+            }
             if (!(VAR & 2) && has1) {
                 // slice sn's rows were requested a slice ago (in the prologue for s = 0: six weight loads have followed): read back, pending
                 // transform, rows of B^T d, into L -- in one piece (nothing is held across matrix instructions: the registers are the
                 // accumulators'; the SIMD's other wave covers the LDS round trip)
                 v4f qa[6];
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 W4_TAKE_RAW(qa);
                 W4_AFF(sn); W4_PEND(qa, W4_SKIP_LDS, sn); W4_COMMIT1(qa);
                 W4_REQ_RAW(sn2);
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             W4_POSITIONS(12, 14);
             if (!(VAR & 2) && has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
             W4_POSITIONS(14, 36);
+            if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this slice's row requests (30 weight loads ago) have landed: the barrier tells the readers
             if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
         }
@@ -331,6 +342,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (p.dbg && t == 0) { p.dbg[blockIdx.x * 24 + 21] += clock64() - ck0; p.dbg[blockIdx.x * 24 + 22] += wall_clock64() - wk0; }
         DBG_T();
 #undef ho_
+#undef hd_
 #undef W4_LOAD_RAW
 #undef W4_REQ_RAW
 #undef W4_TAKE_RAW
