@@ -391,9 +391,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // a part of the unit's input channels: the output transform is linear, so this is a PARTIAL output.  If the other part is
             // there already, add it; otherwise publish this one (write-through, drained) and count -- and add the other's after all
             // if it arrived in the meantime.  a + b = b + a: the sum does not depend on who adds
-            const size_t pix = (size_t)(4 * (tl >> 2)) * 16 + 4 * (tl & 3);
-            float* const mine = p.ks_ws + (((size_t)meet * 2 + part) * 256 + pix) * 128 + cb;
-            const float* const other = p.ks_ws + (((size_t)meet * 2 + (part ^ 1)) * 256 + pix) * 128 + cb;
+            // (the meeting place is laid out in the order the threads hold the values -- [pixel (a, b) of the tile][wave][lane] x 16 bytes: every
+            //  store / load instruction of a wave is one contiguous KiB; the other part's thread of the same index holds the same outputs)
+            float* const mine = p.ks_ws + ((size_t)meet * 2 + part) * 32768 + (wave * 64 + lane) * 4;
+            const float* const other = p.ks_ws + ((size_t)meet * 2 + (part ^ 1)) * 32768 + (wave * 64 + lane) * 4;
             int* const flag = reinterpret_cast<int*>(aff + 2 * CIN);
             if (t == 0) *flag = __hip_atomic_load(p.ks_cnt + meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        w4_store16_wt(mine + (size_t)(a * 16 + b) * 128, v4f{y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]});
+                        w4_store16_wt(mine + (a * 4 + b) * 2048, v4f{y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (t == 0) *flag = __hip_atomic_fetch_add(p.ks_cnt + meet, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const v4f o = *reinterpret_cast<const v4f*>(other + (size_t)(a * 16 + b) * 128);
+                    const v4f o = *reinterpret_cast<const v4f*>(other + (a * 4 + b) * 2048);
                     y[a][b][0] = (y[a][b][0] + o.x) + bv.x; y[a][b][1] = (y[a][b][1] + o.y) + bv.y;
                     y[a][b][2] = (y[a][b][2] + o.z) + bv.z; y[a][b][3] = (y[a][b][3] + o.w) + bv.w;
                 }
