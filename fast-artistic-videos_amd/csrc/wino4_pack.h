@@ -8,8 +8,8 @@
 //
 // Interpolation points 0, +-3/4, +-3/2, infinity instead of the textbook 0, +-1, +-2: every entry of B^T and A^T is still a dyadic
 // rational (exact in fp32), the largest are 45/16 and 27/8 instead of 5 and 8, and the fp32 error of a 128 -> 128 layer measured
-// 9.2e-7 rms / 7.3e-6 max against 1.9e-6 / 3.0e-5 for the textbook points (F(2x2, 3x3): 3.1e-7 / 1.7e-6; a plain fp32 accumulation
-// chain: 4.3e-7 / 4.7e-6) -- profiles/r04_wino4_points.txt.
+// 9.0e-7 rms / 9.0e-6 max against 1.9e-6 / 3.2e-5 for the textbook points (F(2x2, 3x3): 3.1e-7 / 1.7e-6; a plain fp32 accumulation
+// chain: 4.3e-7 / 4.1e-6) -- scripts/wino4_points.py, profiles/r04_wino4_points.txt.
 //
 //   B^T = | 81/64    0    -45/16    0     1   0 |     G = |  64/81     0       0   |    A^T = | 1    1      1      1     1    0 |
 //         |   0   -27/16   -9/4    3/4    1   0 |         | -128/243 -32/81  -8/27 |          | 0   3/4   -3/4    3/2  -3/2   0 |
