@@ -599,7 +599,9 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             // block's skip still carries d128's InstanceNorm + ReLU: its join stays a launch).
             // Since round 4 only with the F(2x2) kernels (FAV_WINO_F2), or on request (FAV_LAZY_JOIN): inside the F(4x4) kernel the joined
             // rows' stores cost 10 us of its K loop (the weight ring runs dry behind them) on top of 8 us of staging -- more than the
-            // 16 us launch they replace (639 against 634 frames/s, profiles/r4s_stream_k_and_joins_ab.log)
+            // 16 us launch they replace (639 against 634 frames/s, profiles/r4s_stream_k_and_joins_ab.log).  (The F(4x4) kernel's pending-join
+            // instantiation is kept for FAV_LAZY_JOIN and the tests that pin its bits against the launched joins; since the row requests carry
+            // their own offsets it spills inside its K loop -- nobody tuned it further)
             static const bool no_lazy = getenv("FAV_NO_LAZY_JOIN") != nullptr;      // (tuning: read once)
             static const bool want_lazy = getenv("FAV_LAZY_JOIN") != nullptr;
             const int nconv = count_convs(L.block);
