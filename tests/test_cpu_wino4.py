@@ -221,3 +221,70 @@ def test_wino4_lds_accesses_are_bank_conflict_free():
     bad = sum(1 for g0 in range(0, 256, 8) if len(set(wslot(l1[g0: g0 + 8]))) != 8)
     assert bad <= 3 * 4, bad                                  # (pixel groups 16..23, 32..39, 48..55 straddle a tile row, once per chunk)
     assert (LTY // 4) % 16 == 1 and (LKQ // 4) % 16 == 0 and LTY >= 6 * LLINE and LKQ >= 4 * LTY
+
+
+def test_wino4_row_requests_and_their_read_back():
+    """The raw-row requests (buffer_load ... lds, kernels_wino4.hip `hd_`): request lane d < 288 asks for pixel d >> 2, chunk d & 3 -- four
+    ADJACENT lanes = the 64 contiguous bytes of one pixel's 16-channel slice -- and lands it in slot d; the row pass's thread
+    t = (pix >> 3) * 32 + cq * 8 + (pix & 7) reads slot 4 pix + cq.  Every (pixel, chunk) of the 4 x 18 item grid is requested once, read
+    by the thread that owns it, and the read-back is bank-conflict-free for the true ds_read_b128 lane groups."""
+    d = np.arange(288)
+    dpix, dchunk = d >> 2, d & 3
+    assert dpix.max() == 71 and len(set(zip(dpix.tolist(), dchunk.tolist()))) == 288
+    # four adjacent request lanes: one pixel, chunks 0..3 = byte offsets 0, 16, 32, 48 of its slice
+    for q in range(0, 288, 4):
+        assert len(set(dpix[q:q + 4])) == 1 and list(dchunk[q:q + 4]) == [0, 1, 2, 3]
+    t = np.arange(288)
+    cq = (t >> 3) & 3
+    pix = np.minimum((t >> 5) * 8 + (t & 7), 71)
+    slot = pix * 4 + cq                                            # rread = Rs + (pix1 * 4 + cq) * 4 words
+    assert sorted(slot.tolist()) == list(range(288))               # every landed piece has exactly one reader
+    assert np.array_equal(dpix[slot], pix) and np.array_equal(dchunk[slot], cq)       # ... the thread whose item it is
+    for w0 in range(0, 256, 64):                                   # whole waves of the row pass (the fifth is half empty)
+        s = slot[w0:w0 + 64]
+        for g in RGROUPS:
+            assert len(set((s[g] % 16).tolist())) == 16, ("read-back", w0)
+
+
+def _shares(units, nslices, shares):
+    """restatement of the stream-K dealing in conv3_wino4_kernel (`p.stream`): share sh = slices [tot sh / shares, tot (sh + 1) / shares) of the
+    launch's units x nslices; returns per share its segments (unit, s0, s1, meeting place or -1, part)"""
+    tot = units * nslices
+    out = []
+    for sh in range(shares):
+        g, g1 = tot * sh // shares, tot * (sh + 1) // shares
+        segs = []
+        while g < g1:
+            u = g // nslices; s0 = g - u * nslices; s1 = min(nslices, s0 + (g1 - g))
+            whole = s0 == 0 and s1 == nslices
+            segs.append((u, s0, s1, -1 if whole else (sh if s0 == 0 else sh - 1), 0 if s0 == 0 else 1))
+            g += s1 - s0
+        out.append(segs)
+    return out
+
+
+@pytest.mark.parametrize("units,shares", [(286, 252), (273, 252), (625, 252), (576, 252), (9, 4), (9, 7), (84, 37), (253, 252), (504, 252), (1000, 252)])
+def test_stream_k_shares_cover_every_slice_once_and_cut_a_unit_in_two(units, shares):
+    """launch_wino4_t deals a launch with a thin last round out as `shares` equal runs of 16-channel slices (shares = CUs - 4: a function
+    of the layer and the device only).  Every (unit, slice) is computed exactly once; a share is at least a unit long, so a unit has at
+    most two parts; the two parts of a cut unit name the same meeting place (the boundary's index) as part 0 (the slices before the cut,
+    closing a share) and part 1 (those behind it, opening the next), and no meeting place is used by two units."""
+    nslices = 8
+    sh = _shares(units, nslices, shares)
+    seen = np.zeros((units, nslices), np.int32)
+    meet = {}
+    for k, segs in enumerate(sh):
+        assert sum(s1 - s0 for _, s0, s1, _, _ in segs) >= nslices                  # a share is at least a unit long ...
+        for i, (u, s0, s1, m, part) in enumerate(segs):
+            seen[u, s0:s1] += 1
+            if m >= 0:
+                assert 0 <= m < shares - 1 + 1 and part == (0 if s0 == 0 else 1)
+                assert (part == 0 and i == len(segs) - 1 and m == k) or (part == 1 and i == 0 and m == k - 1)     # ... cut only at its ends
+                meet.setdefault(m, []).append((u, part, s0, s1))
+    assert (seen == 1).all()
+    for m, parts in meet.items():
+        assert len(parts) == 2 and parts[0][0] == parts[1][0], (m, parts)            # one unit per meeting place, both of its parts
+        (u, p0, a0, a1), (_, p1, b0, b1) = sorted(parts, key=lambda x: x[1])
+        assert (p0, p1) == (0, 1) and a0 == 0 and a1 == b0 and b1 == nslices
+    cut_units = {parts[0][0] for parts in meet.values()}
+    assert len(cut_units) == len(meet)                                                # no unit in three parts
