@@ -1284,12 +1284,26 @@ extern "C" int fav_stream_encode_png_async(fav_stream* s, void* png_out, size_t 
         FAV_HIP(hipMalloc(&s->png_ws, s->png_ws_bytes));
     }
     if (!s->png_q) {
+        // all or nothing: a stream with the queue but without the second state buffer would let the next frame overwrite what is being encoded
         const unsigned ef = hipEventDisableTiming | hipEventDisableSystemFence;
-        FAV_HIP(hipStreamCreateWithFlags(&s->png_q, hipStreamNonBlocking));
-        FAV_HIP(hipEventCreateWithFlags(&s->ev_png_in, ef));
-        FAV_HIP(hipEventCreateWithFlags(&s->png_done, ef));
-        FAV_HIP(hipEventCreateWithFlags(&s->png_done_other, ef));
-        FAV_HIP(hipMalloc(reinterpret_cast<void**>(&s->state_other), (size_t)3 * s->Ho * s->Wo * 4));
+        hipStream_t q = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr; float* other = nullptr;
+        const hipError_t e = [&]() -> hipError_t {
+            hipError_t r;
+            if ((r = hipStreamCreateWithFlags(&q, hipStreamNonBlocking)) != hipSuccess) return r;
+            if ((r = hipEventCreateWithFlags(&e0, ef)) != hipSuccess) return r;
+            if ((r = hipEventCreateWithFlags(&e1, ef)) != hipSuccess) return r;
+            if ((r = hipEventCreateWithFlags(&e2, ef)) != hipSuccess) return r;
+            return hipMalloc(reinterpret_cast<void**>(&other), (size_t)3 * s->Ho * s->Wo * 4);
+        }();
+        if (e != hipSuccess) {
+            if (q) (void)hipStreamDestroy(q);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (e2) (void)hipEventDestroy(e2);
+            (void)hipFree(other);
+            return hip_fail(e, "fav_stream_encode_png_async: encoder queue / second state buffer");
+        }
+        s->png_q = q; s->ev_png_in = e0; s->png_done = e1; s->png_done_other = e2; s->state_other = other;
     }
     FAV_HIP(hipEventRecord(s->ev_png_in, st));                 // the frame is complete at this point of the caller's queue
     FAV_HIP(hipStreamWaitEvent(s->png_q, s->ev_png_in, 0));
