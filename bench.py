@@ -546,6 +546,21 @@ def main():
         extra["frames_per_s_bf16_operand_fast_mode_3arg"] = round(n4 / (time.perf_counter() - t1), 3)
         net.set_precision(False)
 
+    # not part of `value` either: the same step on checkpoints with MORE FILTERS (README.md:141: the published VR models; the reference
+    # builds any architecture string) -- every filter count doubled / x1.5; scripts/wide_bench.py.  Their layers must stay on the
+    # minimal-filtering kernels (`fallback_layers` empty) at a conv-stack rate close to the canonical network's
+    if world == 1 and not args.no_extra and not args.structure:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import wide_bench
+        try:
+            wb = wide_bench.run(wide_bench.WIDE2, steps=max(6, args.steps // 4), warmup=2, h=H, w=W, frames=frames, bws=bws, fws=fws)
+            extra["wide_arch"] = wb
+            extra["wide_arch_frames_per_s"] = wb["frames_per_s"]
+            wb15 = wide_bench.run(wide_bench.WIDE15, steps=max(6, args.steps // 4), warmup=2, h=H, w=W, frames=frames, bws=bws, fws=fws)
+            extra["wide_arch_x1_5"] = {k: wb15[k] for k in ("arch", "frames_per_s", "ms_per_frame", "conv_stack_algorithmic_tflops", "kernel_ids", "fallback_layers")}
+        except Exception as e:      # informational block: never takes the bench line down
+            extra["wide_arch"] = {"error": repr(e)[:300]}
+
     if rank == 0:
         fps = world * args.steps / dt
         # roofline of the dominant kernel: the ten 3x3 128->128 residual convolutions (91.7 of the 152.8 GMAC per frame).  Round 2:

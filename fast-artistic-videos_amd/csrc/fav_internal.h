@@ -138,6 +138,7 @@ inline int conv_mblocks(int OH, int OW) { return (OH * OW + CONV_BM - 1) / CONV_
 int launch_conv(const ConvLaunch& p, hipStream_t st);
 // last layer with few output channels: kx taps folded into N (see kernels_conv.hip); wfold = [KH][32][CIN]
 bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride);
+bool conv_fold_launchable(int cin_pitch, int k, int pad, int ups, int IH, int IW);      // 128 / 256 input channels: on a x2-upsampled input only
 int launch_conv_fold(const ConvLaunch& p, const float* wfold, hipStream_t st);
 
 // per-channel finalize of (mean, M2) partials -> scale/shift:  scale = gamma/sqrt(var+eps)
@@ -157,6 +158,7 @@ int conv_first_tiles(int OH, int OW);
 int launch_conv_first(const ConvLaunch& p, int cin_real, const float* wpk, int* counts, hipStream_t st);
 // ... and with 2-D minimal filtering F(2x2,3x3) over its nine 3x3 blocks (conv_first2d_kernel); wpk = conv_first2d_pack() (first2d_pack.h);
 // partials per 16x32-pixel tile
+bool conv_first2d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups);      // any number of 32-filter groups
 int conv_first2d_tiles(int OH, int OW);
 int launch_conv_first2d(const ConvLaunch& p, int cin_real, const float* wpk, int* counts, hipStream_t st);
 // 3x3 stride-1 UNPADDED 128-channel layers (the residual blocks): Winograd F(2x2,3x3), kernels_wino.hip; wpk = conv_wino_pack()

@@ -59,4 +59,17 @@ inline void conv_first2d_pack(const float* w, int cin, int cout, std::vector<flo
             }
 }
 
+// layers with more than 32 filters: computed in groups of 32 output channels, each with the packed block conv_first2d_pack() makes
+// of its (up to) 32 filters -- the blocks follow each other; coutp = the padded filter count (a multiple of 32)
+inline void conv_first2d_pack_groups(const float* w, int cin, int cout, int coutp, std::vector<float>& out)
+{
+    out.clear();
+    std::vector<float> one;
+    for (int g = 0; g < coutp / 32; ++g) {
+        const int n = cout - 32 * g < 0 ? 0 : (cout - 32 * g > 32 ? 32 : cout - 32 * g);
+        conv_first2d_pack(w + (size_t)g * 32 * cin * 81, cin, n, one);
+        out.insert(out.end(), one.begin(), one.end());
+    }
+}
+
 }  // namespace fav

@@ -2189,10 +2189,15 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_kernel(const FoldArgs p)
 // wave two or three 32-MFMA blocks per staged row (consecutive rows per wave would leave half the waves idle at each barrier).
 constexpr int FOLD2_M = 64;      // physical input columns per tile
 
-template <int CIN>
+// NH > 1 (input pitch CT = NH * CIN channels, e.g. 128 behind a c3s1-128 of a checkpoint with more filters): the merged slices of all
+// channels do not fit the LDS next to the staging buffers, so a tile is computed in NH passes over its rows, one per block of CIN
+// channels, into the same accumulators; the pass's slices (87 KB for CIN = 64) are reloaded from L2 at its start -- ~1 us against the
+// ~50 us a pass takes
+template <int CIN, int NH = 1>
 __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs p)
 {
     constexpr int NT = 512;
+    constexpr int CT = CIN * NH;               // channel pitch of the input tensor
     constexpr int RW = FOLD_R / 4;             // output rows per wave (rows g + 4 yy)
     constexpr int S = CIN + 4;
     constexpr int NV = CIN / 32;               // float4 per thread per staged row (8 threads per column)
@@ -2207,17 +2212,22 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
     const int XO = 2 * FOLD2_M - (p.KW - 1);   // output columns per tile (120)
     const int PH = p.IH >> 1, PW = p.IW >> 1;  // physical input size
 
-    for (int i = t; i < CIN; i += NT) {
-        aff[i] = p.stages >= 1 ? p.scale1[i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[i] : 0.f;
-        aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[i] : 0.f;
-    }
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float lo2 = (p.stages >= 2 && p.relu2) ? 0.f : -INFINITY;
-    const float* wm = p.wfold + (size_t)p.KH * 32 * CIN;           // merged slices follow the plain ones
-    for (int e = t; e < (p.KH + 1) * 32 * (CIN / 4); e += NT) {
-        const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);
-        *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(wm + (size_t)row * CIN + c4 * 4);
+    const float* wm = p.wfold + (size_t)p.KH * 32 * CT;            // merged slices follow the plain ones
+    // the transform table and the merged slices of channels hoff .. hoff + CIN - 1 (NH == 1: once per block; else once per pass)
+#define FOLD_RESIDENT(hoff_)                                                                        \
+    {                                                                                               \
+        for (int i = t; i < CIN; i += NT) {                                                         \
+            aff[i] = p.stages >= 1 ? p.scale1[(hoff_) + i] : 1.f; aff[CIN + i] = p.stages >= 1 ? p.shift1[(hoff_) + i] : 0.f; \
+            aff[2 * CIN + i] = p.stages >= 2 ? p.scale2[(hoff_) + i] : 1.f; aff[3 * CIN + i] = p.stages >= 2 ? p.shift2[(hoff_) + i] : 0.f; \
+        }                                                                                           \
+        for (int e = t; e < (p.KH + 1) * 32 * (CIN / 4); e += NT) {                                 \
+            const int row = e / (CIN / 4), c4 = e - row * (CIN / 4);                                \
+            *reinterpret_cast<v4f*>(Bs + row * S + c4 * 4) = *reinterpret_cast<const v4f*>(wm + (size_t)row * CT + (hoff_) + c4 * 4); \
+        }                                                                                           \
     }
+    if (NH == 1) FOLD_RESIDENT(0);
     const int xl = t >> 3, ch0 = (t & 7) * (CIN / 8);
     const int frag = (lane & 31) * S + (lane >> 5) * 4;
     const int col = lane & 31, rbase = 4 * (lane >> 5);
@@ -2232,11 +2242,12 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
         const int pc = pxs + xl;
         const bool colv = pc >= 0 && pc < PW;
         const float colm = colv ? 1.f : 0.f;
-        const int coloff = colv ? pc * CIN + ch0 : 0;
+        const int coloff = colv ? pc * CT + ch0 : 0;
+        int hoff = 0;                              // first channel of the current pass
 
 #define FOLD_LOAD(pr_)                                                                              \
         {                                                                                           \
-            const float* src_ = p.in + (size_t)(pr_) * p.IWp * CIN + coloff;                        \
+            const float* src_ = p.in + (size_t)(pr_) * p.IWp * CT + coloff + hoff;                  \
             _Pragma("unroll") for (int i = 0; i < NV; ++i) ra[i] = *reinterpret_cast<const float4*>(src_ + 4 * i); \
         }
 #define FOLD_STORE(buf_)                                                                            \
@@ -2257,11 +2268,16 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
             for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
 
         const long long w0 = p.dbg ? wall_clock64() : 0;
+        long long w1 = 0;
+#pragma unroll 1
+        for (int half = 0; half < NH; ++half) {
+        hoff = half * CIN;
         FOLD_LOAD(pr_lo);
-        __syncthreads();               // affine tables + weights visible; the previous tile's epilogue is done with the staging memory
+        __syncthreads();               // affine tables + weights visible; the previous tile's epilogue (the previous pass's last row) is done with the LDS
+        if (NH > 1) { FOLD_RESIDENT(hoff); __syncthreads(); }
         FOLD_STORE(0);
         __syncthreads();
-        const long long w1 = p.dbg ? wall_clock64() : 0;
+        if (half == 0) w1 = p.dbg ? wall_clock64() : 0;
 
         int cur = 0;
         for (int pr = pr_lo; pr <= pr_hi; ++pr) {
@@ -2291,8 +2307,10 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
             __syncthreads();
             cur ^= 1;
         }
+        }
 #undef FOLD_LOAD
 #undef FOLD_STORE
+#undef FOLD_RESIDENT
 
         const long long w2 = p.dbg ? wall_clock64() : 0;
         // ---- epilogue in four passes (pass hh: output rows oy0 + g + 4 hh of the four row groups): D tiles -> LDS [4][64][33],
@@ -2361,7 +2379,7 @@ __global__ __launch_bounds__(512, 2) void conv_rowfold_up2_kernel(const FoldArgs
     }
 }
 
-template <int CIN>
+template <int CIN, int NH = 1>
 int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
 {
     const int S = CIN + 4;
@@ -2374,7 +2392,7 @@ int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_up2_kernel<CIN>),
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rowfold_up2_kernel<CIN, NH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int prop_cus = 0;
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
@@ -2389,7 +2407,7 @@ int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
     static long long* dbuf = nullptr;
     a.dbg = nullptr;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 8 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 8 * 8, st)); a.dbg = dbuf; }
-    hipLaunchKernelGGL((conv_rowfold_up2_kernel<CIN>), dim3(tiles < nres ? tiles : nres), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_rowfold_up2_kernel<CIN, NH>), dim3(tiles < nres ? tiles : nres), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_rowfold_up2_kernel");
     if (dbg) {
         std::vector<long long> hb((size_t)512 * 8);
@@ -2433,7 +2451,15 @@ int launch_fold_t(FoldArgs a, int reserve_cus, hipStream_t st)
 
 bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride)
 {
-    return stride == 1 && cout * k <= 32 && k <= 9 && (cin_pitch == 16 || cin_pitch == 32 || cin_pitch == 64);
+    return stride == 1 && cout * k <= 32 && k <= 9 && (cin_pitch == 16 || cin_pitch == 32 || cin_pitch == 64 || cin_pitch == 128 || cin_pitch == 256);
+}
+// 128 / 256 input channels (checkpoints with more filters, README.md:141): only the form for a x2-upsampled input exists (U2 + c9s1-3,
+// every architecture string of the reference ends that way); anything else with that many channels takes the generic kernel
+bool conv_fold_launchable(int cin_pitch, int k, int pad, int ups, int IH, int IW)
+{
+    static const bool no_up2 = getenv("FAV_NO_FOLD_UP2") != nullptr;
+    if (cin_pitch <= 64) return true;
+    return ups == 1 && !no_up2 && (pad & 1) == 0 && (k & 1) == 1 && (IH & 1) == 0 && (IW & 1) == 0 && k + 1 <= 10;
 }
 
 int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
@@ -2450,9 +2476,12 @@ int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
     // x2 nearest-upsampled input: physical columns, merged ky slices (wfold carries them after the plain slices)
     static const bool no_up2 = getenv("FAV_NO_FOLD_UP2") != nullptr;
     if (c.ups == 1 && !no_up2 && (c.pad & 1) == 0 && (c.KW & 1) == 1 && (c.IH & 1) == 0 && (c.IW & 1) == 0 && c.KH + 1 <= 10) {
+        if (c.CIN == 256) return launch_fold_up2_t<64, 4>(a, c.reserve_cus, st);
+        if (c.CIN == 128) return launch_fold_up2_t<64, 2>(a, c.reserve_cus, st);
         if (c.CIN == 64) return launch_fold_up2_t<64>(a, c.reserve_cus, st);
         if (c.CIN == 32) return launch_fold_up2_t<32>(a, c.reserve_cus, st);
     }
+    FAV_REQUIRE(c.CIN <= 64, "row-folded conv: %d input channels are supported on a x2-upsampled input only", c.CIN);
     if (c.CIN == 64) return launch_fold_t<64>(a, c.reserve_cus, st);
     if (c.CIN == 32) return launch_fold_t<32>(a, c.reserve_cus, st);
     return launch_fold_t<16>(a, c.reserve_cus, st);

@@ -42,6 +42,10 @@ struct FirstArgs {
     const float* in; const float* wpk; const float* bias;
     float* out; float2* partials; int* counts;
     int IH, IW, IWp, COUT, pad, OH, OW, tiles_x, tiles_y;
+    // conv_first2d_kernel<CR, true> only (more than 32 filters): the output channels are computed in `groups` groups of 32; a block
+    // keeps ONE group's transformed weights in LDS and walks the tiles (gridDim.x % groups == 0); COUTP = the channel pitch of partials;
+    // wpk holds one packed block (conv_first2d_pack) per group
+    int COUTP, groups;
 };
 
 __device__ __forceinline__ float2 merge_rows(const float2* st, const int* wn, int c, int* n_out)
@@ -271,7 +275,7 @@ constexpr int G_CPL = G_HR * G_HC + 16;             // words per channel plane (
 constexpr int G_HP = G_HR * G_HC;                   // 960 halo pixels
 constexpr int G_NH = (G_HP + 511) / 512;            // 2 halo pixels per thread
 
-template <int CR>
+template <int CR, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
 {
     constexpr int NQ = (9 * CR + 3) / 4;
@@ -281,7 +285,10 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
     float* const red = Hs + CR * G_CPL;            // [8][32] float2 + [8] int
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    for (int e = t; e < 16 * NQ * 32; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(p.wpk + e * 4);
+    const int grp = WIDE ? blockIdx.x % p.groups : 0, tstep = WIDE ? gridDim.x / p.groups : gridDim.x;
+    const int PITCH = WIDE ? p.COUTP : 32;
+    const float* const wsrc = p.wpk + (WIDE ? (size_t)grp * (16 * NQ * 128) : 0);
+    for (int e = t; e < 16 * NQ * 32; e += 512) *reinterpret_cast<v4f*>(Ws + e * 4) = *reinterpret_cast<const v4f*>(wsrc + e * 4);
 
     const int ntiles = p.tiles_x * p.tiles_y;
     float4 hlo[G_NH], hhi[G_NH];
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
         }                                                                                           \
     }
 
-    int tile = blockIdx.x;
+    int tile = WIDE ? blockIdx.x / p.groups : blockIdx.x;
     if (tile < ntiles) G_LOAD_HALO(tile);
     G_STORE_HALO();
 
@@ -331,8 +338,8 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
     const float* const b_hi = b_lo + hi_words;                               // positions 8..15 (their offsets would not fit a DS immediate)
     __syncthreads();
 
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int nxt = tile + gridDim.x;
+    for (; tile < ntiles; tile += tstep) {
+        const int nxt = tile + tstep;
         if (nxt < ntiles) G_LOAD_HALO(nxt);
         v4f acc[16][2];
 #pragma unroll
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
         float sm[2] = {0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int ch = nt * 16 + txl;
+            const int ch = grp * 32 + nt * 16 + txl;
             const float bv = p.bias[ch];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -445,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
             __syncthreads();
             if (t < 32) {
                 int n;
-                p.partials[(size_t)tile * 32 + t] = merge_rows(st, wn, t, &n);
-                if (t == 0) p.counts[tile] = n;
+                p.partials[(size_t)tile * PITCH + grp * 32 + t] = merge_rows(st, wn, t, &n);
+                if (t == 0 && grp == 0) p.counts[tile] = n;
             }
         }
         __syncthreads();            // the halo of the next tile is complete; red scratch free again
@@ -455,21 +462,24 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
 #undef G_STORE_HALO
 }
 
-template <int CR>
+template <int CR, bool WIDE = false>
 int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
 {
     const size_t lds = (size_t)(16 * conv_first2d_quads(CR) * 128 + CR * G_CPL + 8 * 64 + 8) * sizeof(float);
     const int dv = cur_dev();
     static int nblocks[MAX_DEVICES] = {};
     if (!nblocks[dv]) {
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first2d_kernel<CR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_first2d_kernel<CR, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int prop_cus = 0;
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         nblocks[dv] = prop_cus;
     }
     const int tiles = a.tiles_x * a.tiles_y;
-    const int grid = std::max(1, nblocks[dv] - reserve_cus);
-    hipLaunchKernelGGL((conv_first2d_kernel<CR>), dim3(tiles < grid ? tiles : grid), dim3(512), lds, st, a);
+    const int ngrp = WIDE ? a.groups : 1;
+    int grid = std::max(1, nblocks[dv] - reserve_cus);
+    grid = std::min(grid, tiles * ngrp);
+    if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block keeps one group's weights
+    hipLaunchKernelGGL((conv_first2d_kernel<CR, WIDE>), dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_first2d_kernel");
     return FAV_OK;
 }
@@ -491,18 +501,25 @@ int launch_conv_first(const ConvLaunch& c, int cin_real, const float* wpk, int* 
     return cin_real == 7 ? launch_first_t<7>(a, c.reserve_cus, st) : launch_first_t<3>(a, c.reserve_cus, st);
 }
 
+// the 2-D form takes any number of 32-filter groups (c9s1-32: one; c9s1-64, the "more filters" checkpoints of README.md:141: two)
+bool conv_first2d_eligible(int cin_pitch, int cin_real, int coutp, int k, int stride, int stages, int ups)
+{
+    return cin_pitch == 8 && (cin_real == 7 || cin_real == 3) && k == 9 && stride == 1 && stages == 0 && ups == 0 && coutp % 32 == 0 && coutp >= 32 && coutp <= 256;
+}
 int conv_first2d_tiles(int OH, int OW) { return ((OH + G_TH - 1) / G_TH) * ((OW + G_TW - 1) / G_TW); }
 
 // same eligibility as launch_conv_first; wpk = conv_first2d_pack() (first2d_pack.h)
 int launch_conv_first2d(const ConvLaunch& c, int cin_real, const float* wpk, int* counts, hipStream_t st)
 {
-    FAV_REQUIRE(c.CIN == 8 && (cin_real == 7 || cin_real == 3) && c.COUTp == 32 && c.KH == 9 && c.KW == 9 && c.stride == 1 && c.pre.stages == 0 &&
-                c.ups == 0 && !c.final_mode && wpk, "first-layer conv (F(2x2,3x3) over the nine 3x3 blocks): not eligible");
+    FAV_REQUIRE(conv_first2d_eligible(c.CIN, cin_real, c.COUTp, c.KH, c.stride, c.pre.stages, c.ups) && c.KW == 9 && !c.final_mode && wpk,
+                "first-layer conv (F(2x2,3x3) over the nine 3x3 blocks): not eligible");
     FAV_REQUIRE((long long)c.IH * c.IWp * 8 < (1ll << 31), "first-layer conv: bad shape");
     FirstArgs a;
     a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW;
     a.tiles_x = (c.OW + G_TW - 1) / G_TW; a.tiles_y = (c.OH + G_TH - 1) / G_TH;
+    a.COUTP = c.COUTp; a.groups = c.COUTp / 32;
+    if (a.groups > 1) return cin_real == 7 ? launch_first2d_t<7, true>(a, c.reserve_cus, st) : launch_first2d_t<3, true>(a, c.reserve_cus, st);
     return cin_real == 7 ? launch_first2d_t<7>(a, c.reserve_cus, st) : launch_first2d_t<3>(a, c.reserve_cus, st);
 }
 

@@ -39,6 +39,10 @@ struct S2wArgs {
     const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
     float* out; float2* partials; int* counts;
     int IH, IW, IWp, CIN, OH, OW, pad, tiles_x, tiles_y, stages, relu1;
+    // WIDE instantiations only (more than 128 filters): the output channels are computed in `groups` groups of 32 NTC, a work item =
+    // (tile, group), group-minor; COUTP = the channel pitch of out / partials; wpk holds one packed block (conv_s2w_pack) per group.
+    // The grid is a multiple of `groups`: a persistent block stays with one group (its weight prefetch runs across tiles)
+    int COUTP, groups;
 };
 
 template <int NTC, int TR> struct SwGeo {
@@ -52,7 +56,7 @@ template <int NTC, int TR> struct SwGeo {
     static constexpr int HB = NPC * PS * SW_P;              // floats per buffer (pixels HP .. NPC * PS - 1 are scratch)
 };
 
-template <int NTC, int TR>
+template <int NTC, int TR, bool WIDE = false>
 __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(const S2wArgs p)
 {
     using G = SwGeo<NTC, TR>;
@@ -70,7 +74,14 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
     const int nt = wave % NTC, row = wave / NTC;
     const int m = lane & 31, h = lane >> 5;
     const int CIN = p.CIN, nch = CIN >> 4;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, nch * 18 * NTC * 1024, 0x00020000);
+    int lb;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ngrp = WIDE ? p.groups : 1, grp = WIDE ? lb % p.groups : 0;      // (gridDim.x % groups == 0: every item of this block is of group grp)
+    const int PITCH = WIDE ? p.COUTP : COUT;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk) + (size_t)grp * (nch * 18 * NTC * 256), 0, nch * 18 * NTC * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * CIN * 4, 0x00020000);
     const int wlo = lane * 16, wnt = nt * 1024;                         // weights: lane * 16 + [((chunk * 2 + kg) * 9 + tap) * NTC * 1024 + nt * 1024]
 
@@ -97,12 +108,7 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
     const float lo1 = (p.stages >= 1 && p.relu1) ? 0.f : -INFINITY;
     const float* const affr = aff + c4 * 4;
 
-    int lb;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int ntiles = p.tiles_x * p.tiles_y;
+    const int ntiles = p.tiles_x * p.tiles_y * ngrp;      // work items: tile = (pixel tile) * groups + group
     int tile = lb;
     if (tile >= ntiles) return;
 
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
     // interior tiles (the halo lies inside the image: all but the frame of border tiles): one add per piece, no masks
     bool hmask = false;
 #define SW_TILE_SETUP(tile_)                                                                        \
-    {   const int ty_ = (tile_) / p.tiles_x, tx_ = (tile_) - ty_ * p.tiles_x;                       \
+    {   const int pt_ = WIDE ? (tile_) / ngrp : (tile_);                                            \
+        const int ty_ = pt_ / p.tiles_x, tx_ = pt_ - ty_ * p.tiles_x;                               \
         const int iy0_ = 2 * ty_ * TR - p.pad, ix0_ = 2 * tx_ * 32 - p.pad;                         \
         hmask = iy0_ < 0 || ix0_ < 0 || iy0_ + 2 * TR >= p.IH || ix0_ + 64 >= p.IW;                  \
         if (!hmask) {                                                                               \
@@ -174,9 +181,10 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
 
     SW_READ_A_DYN(0, 0, 0, 0); SW_READ_A_DYN(1, 1, 0, 0);
     int par = 0, pend = -1;
-    int oy0 = (tile / p.tiles_x) * TR, ox0 = (tile - (tile / p.tiles_x) * p.tiles_x) * 32;
+    int ptile = WIDE ? tile / ngrp : tile;
+    int oy0 = (ptile / p.tiles_x) * TR, ox0 = (ptile - (ptile / p.tiles_x) * p.tiles_x) * 32;
     const int n = lane & 31, co = nt * 32 + n;
-    const float bv = p.bias[co];
+    const float bv = p.bias[grp * COUT + co];
     for (;;) {
         const int ntile = tile + (int)gridDim.x;
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
                     const float mean = cnt ? s1 / (float)cnt : 0.f;
                     float m2 = 0.f;
                     for (int w = 0; w < TR; ++w) { const float d = stt[w * COUT + t].x - mean; m2 += stt[w * COUT + t].y + (float)wn[w] * d * d; }
-                    p.partials[(size_t)pend * COUT + t] = make_float2(mean, m2);
-                    if (t == 0) p.counts[pend] = cnt;
+                    p.partials[(size_t)pend * PITCH + grp * COUT + t] = make_float2(mean, m2);
+                    if (t == 0 && grp == 0) p.counts[pend] = cnt;
                 }
                 pend = -1;
             }
@@ -234,14 +242,14 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
         {
             const int oy = oy0 + row;
             float sm = 0.f; int nv = 0;
-            float* const ob = p.out + ((size_t)oy * p.OW + ox0 + 4 * h) * COUT + co;
+            float* const ob = p.out + ((size_t)oy * p.OW + ox0 + 4 * h) * PITCH + grp * COUT + co;
             const bool full = oy0 + TR <= p.OH && ox0 + 32 <= p.OW;
             if (full) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[r] + bv;
                     acc[r] = v;
-                    ob[(size_t)((r & 3) + 8 * (r >> 2)) * COUT] = v;
+                    ob[(size_t)((r & 3) + 8 * (r >> 2)) * PITCH] = v;
                     sm += v;
                 }
                 nv = 16;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
                     const int mi = (r & 3) + 8 * (r >> 2);
                     const float v = acc[r] + bv;
                     acc[r] = v;
-                    if (oy < p.OH && ox0 + 4 * h + mi < p.OW) { ob[(size_t)mi * COUT] = v; sm += v; ++nv; }
+                    if (oy < p.OH && ox0 + 4 * h + mi < p.OW) { ob[(size_t)mi * PITCH] = v; sm += v; ++nv; }
                 }
             }
             if (p.partials != nullptr) {
@@ -273,14 +281,15 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
                 q += __shfl_xor(q, 32);
                 if (lane < 32) stt[row * COUT + co] = make_float2(mu, q);
                 if (lane == 0 && nt == 0) wn[row] = nw;
-                pend = tile;
+                pend = ptile;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         }
         tile = ntile;
         if (tile >= ntiles) break;
-        oy0 = (tile / p.tiles_x) * TR; ox0 = (tile - (tile / p.tiles_x) * p.tiles_x) * 32;
+        ptile = WIDE ? tile / ngrp : tile;
+        oy0 = (ptile / p.tiles_x) * TR; ox0 = (ptile - (ptile / p.tiles_x) * p.tiles_x) * 32;
     }
     if (pend >= 0) {
         __syncthreads();
@@ -290,8 +299,8 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
             const float mean = cnt ? s1 / (float)cnt : 0.f;
             float m2 = 0.f;
             for (int w = 0; w < TR; ++w) { const float d = stt[w * COUT + t].x - mean; m2 += stt[w * COUT + t].y + (float)wn[w] * d * d; }
-            p.partials[(size_t)pend * COUT + t] = make_float2(mean, m2);
-            if (t == 0) p.counts[pend] = cnt;
+            p.partials[(size_t)pend * PITCH + grp * COUT + t] = make_float2(mean, m2);
+            if (t == 0 && grp == 0) p.counts[pend] = cnt;
         }
     }
 #undef SW_AOFF
@@ -308,10 +317,10 @@ __global__ __launch_bounds__(64 * NTC * TR, NTC * TR / 4) void conv3s2w_kernel(c
 #undef SW_READ_A_DYN
 }
 
-template <int NTC, int TR>
+template <int NTC, int TR, bool WIDE = false>
 int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
 {
-    const auto kern = conv3s2w_kernel<NTC, TR>;
+    const auto kern = conv3s2w_kernel<NTC, TR, WIDE>;
     const size_t lds = (size_t)(2 * SwGeo<NTC, TR>::HB + 2 * a.CIN) * sizeof(float) + (size_t)TR * NTC * 32 * sizeof(float2) + 16 * sizeof(int);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
@@ -321,14 +330,16 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         cus[dv] = prop_cus;
     }
-    const int tiles = a.tiles_x * a.tiles_y;
+    const int ngrp = WIDE ? a.groups : 1;
+    const int tiles = a.tiles_x * a.tiles_y * ngrp;
     // Next to the look-ahead side queues (reserve_cus > 0) a layer of many short tiles is launched one tile per block: a persistent
     // block that shares its CU with a side-queue kernel falls behind and its statically assigned tiles become the launch's tail
     // (d64 at 1280x720, 9 tiles per block: 175 us against 100 us alone and 154 us for the data-parallel kernel it replaced --
     // profiles/r02zg_4arg_s2w_ab.log); the hardware scheduler hands single tiles to whichever CU is free.  Same tiles, same partials.
     const int slots = std::max(1, cus[dv] - reserve_cus);
     static const bool tile_grid = !getenv("FAV_S2W_PERSISTENT");      // (A/B, round 4: the mask pipeline is 0.6 ms of short kernels now)
-    const int grid = (tile_grid && reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
+    int grid = (tile_grid && reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
+    if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block stays with one group
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SwGeo<NTC, TR>::NTH), lds, st, a);
     FAV_LAUNCH_CHECK("conv3s2w_kernel");
     return FAV_OK;
@@ -339,11 +350,11 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
 bool conv3s2w_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
 {
     return k == 3 && stride == 2 && pad <= 1 && ups == 0 && stages <= 1 && cin_pitch % 16 == 0 && cin_pitch >= 32 && cin_pitch <= 512 &&
-           cout == coutp && (coutp == 64 || coutp == 128);
+           cout == coutp && (coutp == 64 || (coutp % 128 == 0 && coutp <= 1024));      // 64, or any number of 128-filter groups
 }
 // tile rows: d64 4 (8 waves); d128 3 (12 waves: 737 tiles = 3 rounds on 256 CUs at 1280x720; with 2 rows 1100 tiles = 5 rounds where 4.3 would do)
 // (measured and not kept: d64 with 6 rows on 12 waves -- 104 us against 98.8 us with 4 rows on 8: profiles/r02y_s2w_rows_ab.log)
-static int s2w_rows(int coutp) { static const int r128 = getenv("FAV_S2W_ROWS128") ? atoi(getenv("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 ? 2 : 3); }      // (tuning: read once)
+static int s2w_rows(int coutp) { static const int r128 = getenv("FAV_S2W_ROWS128") ? atoi(getenv("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 && coutp == 128 ? 2 : 3); }      // (tuning: read once)
 int conv3s2w_tiles(int OH, int OW, int coutp) { const int tr = s2w_rows(coutp); return ((OH + tr - 1) / tr) * ((OW + 31) / 32); }
 
 int launch_conv3s2w(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
@@ -357,6 +368,9 @@ int launch_conv3s2w(const ConvLaunch& c, const float* wpk, int* counts, hipStrea
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.CIN = c.CIN; a.OH = c.OH; a.OW = c.OW; a.pad = c.pad;
     const int tr = s2w_rows(c.COUTp);
     a.tiles_x = (c.OW + 31) / 32; a.tiles_y = (c.OH + tr - 1) / tr;
+    a.COUTP = c.COUTp; a.groups = c.COUTp > 128 ? c.COUTp / 128 : 1;
+    FAV_REQUIRE((long long)(c.OH + 1) * c.OW * c.COUTp < (1ll << 31), "stride-2 conv: output too large");
+    if (a.groups > 1) return launch_s2w_t<4, 3, true>(a, c.reserve_cus, st);
     return c.COUTp == 64 ? launch_s2w_t<2, 4>(a, c.reserve_cus, st) : tr == 2 ? launch_s2w_t<4, 2>(a, c.reserve_cus, st) : launch_s2w_t<4, 3>(a, c.reserve_cus, st);
 }
 

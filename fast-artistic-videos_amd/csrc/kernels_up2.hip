@@ -44,6 +44,9 @@ struct Up2Args {
     const float* in; const float* wpk; const float* bias; const float* scale1; const float* shift1;
     float* out; float2* partials; int* counts;
     int PH, PW, IWp, CIN, tiles_x, tiles_y, relu1;
+    // conv3_up2w_kernel<true> only (more than 64 filters): the output channels are computed in `groups` groups of 64, a work item =
+    // (tile, group), group-minor; COUTP = the channel pitch of out / partials; wpk holds one packed block (conv_up2w_pack) per group
+    int COUTP, groups;
 };
 
 // AFF: the input carries a pending per-channel scale/shift (+ReLU) -- U2 is followed by InstanceNormalization + ReLU in the reference's
@@ -248,6 +251,7 @@ constexpr int UW_HB = UW_HPP * LDSS;
 static_assert(2 * 288 * LDSS <= 8 * 64 * 2 * LDSS, "halo buffers inside the exchange area");
 constexpr int UW_ZS = 8 * 64 * 2 * LDSS;       // exchange: [kind 0|3 x 4 rows][64 channels][2 folds][36] floats (147 KB)
 
+template <bool WIDE>
 __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -258,9 +262,10 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
     const int kind = wave >> 2, row = wave & 3;                            // kind 0, 1, 2 <-> transform row i = 0, 1, 3
     const int CIN = p.CIN, nslices = CIN >> 5, nkg = CIN >> 3;
     const int m = lane & 31, h = lane >> 5;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, nkg * 18 * 1024, 0x00020000);
+    const int ngrp = WIDE ? p.groups : 1, PITCH = WIDE ? p.COUTP : 64;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, nkg * 18 * 1024 * ngrp, 0x00020000);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.PH * p.IWp * CIN * 4, 0x00020000);
-    const int wlo = lane * 16, wso = kind * 3 * 2048;                      // weights: lane * 16 + [kg * 18432 + (3 kind + jj) * 2048 + nt * 1024]
+    const int wlo = lane * 16, wso0 = kind * 3 * 2048;                     // weights: lane * 16 + [group * nkg * 18432 + kg * 18432 + (3 kind + jj) * 2048 + nt * 1024]
     // operand rows: kind 0: halo rows (row, row + 1), L = Ra - Rb;  kind 1: (row + 1, row + 1), L = Ra;  kind 2: (row + 1, row + 2), L = Ra - Rb
     const float kap = kind == 1 ? 0.f : 1.f;
     const float* const ra = Hs + ((row + (kind == 0 ? 0 : 1)) * UW_HW + m) * LDSS + 4 * h;
@@ -272,8 +277,10 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
     const float lo1 = p.relu1 ? 0.f : -INFINITY;
     const float* const affr = aff + c4 * 4;
 
-    const int ntiles = p.tiles_x * p.tiles_y;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ntiles = p.tiles_x * p.tiles_y * ngrp;      // work items: (pixel tile) * groups + group
+    for (int item = blockIdx.x; item < ntiles; item += gridDim.x) {
+        const int tile = WIDE ? item / ngrp : item, grp = WIDE ? item - tile * ngrp : 0;
+        const int wso = wso0 + grp * nkg * 18432;
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         const int sy0 = ty * 4, sx0 = tx * 32;
         int ho[3];
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
             float y3[2][16];                   // the fourth output of every pixel (the other three replace the accumulators)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int co = nt * 32 + n;
+                const int co = grp * 64 + nt * 32 + n;
                 const float bv = p.bias[co];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -403,8 +410,8 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
                         const float y00 = a0[e] + b0 + bv, y01 = a1[e] + b1 + bv, y10 = b0 - c0[e] + bv, y11 = b1 - c1[e] + bv;
                         acc[0][nt][r] = y00; acc[1][nt][r] = y01; acc[2][nt][r] = y10; y3[nt][r] = y11;      // kept for the statistics
                         if (sy < p.PH && sx < p.PW) {
-                            float* o = p.out + ((size_t)(2 * sy) * OW + 2 * sx) * 64 + co;
-                            o[0] = y00; o[64] = y01; o[(size_t)OW * 64] = y10; o[(size_t)OW * 64 + 64] = y11;
+                            float* o = p.out + ((size_t)(2 * sy) * OW + 2 * sx) * PITCH + co;
+                            o[0] = y00; o[PITCH] = y01; o[(size_t)OW * PITCH] = y10; o[(size_t)OW * PITCH + PITCH] = y11;
                             sm[nt] += (y00 + y01) + (y10 + y11);
                             if (nt == 0) nv += 4;
                         }
@@ -439,8 +446,8 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
             const float mean = cnt ? s1 / (float)cnt : 0.f;
             float m2 = 0.f;
             for (int w = 0; w < 4; ++w) { const float d = stt[w * 64 + t].x - mean; m2 += stt[w * 64 + t].y + (float)wn[w] * d * d; }
-            p.partials[(size_t)tile * 64 + t] = make_float2(mean, m2);
-            if (t == 0) p.counts[tile] = cnt;
+            p.partials[(size_t)tile * PITCH + grp * 64 + t] = make_float2(mean, m2);
+            if (t == 0 && grp == 0) p.counts[tile] = cnt;
         }
         __syncthreads();            // the exchange area / statistics scratch are free for the next tile's halo
     }
@@ -448,12 +455,12 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
 
 }  // namespace
 
+static bool up2_winograd() { static const bool w = getenv("FAV_UP2_PHASES") == nullptr; return w; }      // (tuning: read once)
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
 {
     return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&
-           cout == 64 && coutp == 64;
+           cout == coutp && (cout == 64 || (up2_winograd() && cout % 64 == 0 && cout <= 512));      // the nine-position kernel: any number of 64-filter groups
 }
-static bool up2_winograd() { static const bool w = getenv("FAV_UP2_PHASES") == nullptr; return w; }      // (tuning: read once)
 int conv3_up2_tiles(int OH, int OW) { return ((OH / 2 + (up2_winograd() ? 3 : 7)) / (up2_winograd() ? 4 : 8)) * ((OW / 2 + 31) / 32); }
 
 int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)
@@ -473,15 +480,19 @@ int launch_conv3_up2(const ConvLaunch& c, const float* wpk, int* counts, hipStre
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {
         FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_up2w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int prop_cus = 0;
         FAV_HIP(hipDeviceGetAttribute(&prop_cus, hipDeviceAttributeMultiprocessorCount, dv));      // (hipGetDeviceProperties costs a millisecond or two per call)
         cus[dv] = prop_cus;
     }
-    const int tiles = a.tiles_x * a.tiles_y;
+    a.COUTP = c.COUTp; a.groups = c.COUTp / 64;
+    FAV_REQUIRE((long long)(c.OH + 1) * c.OW * c.COUTp < (1ll << 31), "upsampled 3x3 conv: output too large");
+    const int tiles = a.tiles_x * a.tiles_y * a.groups;
     const int grid = std::min(tiles, std::max(1, cus[dv] - c.reserve_cus));
     // (every U2 of the reference's builder is followed by a normalisation: stages == 1)
-    if (wg) { a.wpk = wpk + conv_up2_packed_floats(c.CIN); hipLaunchKernelGGL(conv3_up2w_kernel, dim3(grid), dim3(768), lds, st, a); }
+    if (wg && a.groups > 1) { hipLaunchKernelGGL(conv3_up2w_kernel<true>, dim3(grid), dim3(768), lds, st, a); }      // (wpk: the groups' nine-position blocks only)
+    else if (wg) { a.wpk = wpk + conv_up2_packed_floats(c.CIN); hipLaunchKernelGGL(conv3_up2w_kernel<false>, dim3(grid), dim3(768), lds, st, a); }
     else hipLaunchKernelGGL(conv3_up2_kernel<true>, dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv3_up2_kernel");
     return FAV_OK;

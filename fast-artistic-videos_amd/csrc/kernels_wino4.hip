@@ -77,6 +77,10 @@ struct Wino4Args {
     //  leaves the side queues a few CUs, and both modes must produce the same bits)
     int stream, shares; float* ks_ws; int* ks_cnt;
     long long* dbg;
+    // WIDE instantiations only (layers with more than 128 filters: the VR checkpoints "have more filters", README.md:141): the output
+    // channels are computed in `groups` groups of 128, a work unit = (pixel unit, group); COUT = 128 * groups is the channel pitch of
+    // out / partials, wpk holds one packed block (conv_wino4_pack of 128 filters) per group
+    int COUT, groups;
 };
 
 // 16-byte write-through store (sc1), as in kernels_conv.hip: the partial outputs of a K-split unit are published with these +
@@ -118,7 +122,7 @@ __device__ __forceinline__ void w4_at(const float m[6], float y[4])
 //  (profiles/r4p_*, r4q_*, r4r_*): the stores in an epilogue pass over the unit (re-read, add, store: 80 -> 92 us per launch, the traffic of
 //  all CUs in one burst), behind the slice's first barrier out of LDS (-> 88 us), with the non-temporal hint (-1.5 us);
 //  the results are garbage, the timeline of FAV_WINO_DBG says what each part costs)
-template <int MODE, int VAR = 0>
+template <int MODE, int VAR = 0, bool WIDE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_wino4_kernel(const Wino4Args p)
 {
     constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
@@ -170,14 +174,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the weight ring lives across units: the last slice of a unit requests the first positions of slice 0 -- the next unit's
     v4f fb[6];
     bool ring_primed = false;
+    int ring_grp = 0;                  // WIDE: the output group whose weights the ring holds
+    const int upix = p.units_x * p.units_y;
     if (AFF) __syncthreads();
     // one work item: slices s0 .. s1 - 1 of unit u -- all of them (meet < 0), or one of the two parts of a unit that a share boundary
     // cuts (meet = the boundary's meeting place in ks_ws / ks_cnt, part = 0: the slices before the cut, 1: behind it)
-    auto work = [&](const int u, const int s0, const int s1, const int meet, const int part) {
+    auto work = [&](const int ug, const int s0, const int s1, const int meet, const int part) {
         const int nsl = s1 - s0;
         const bool whole = meet < 0;
         if (s0 != 0) ring_primed = false;                   // (the ring holds the first positions of a slice 0)
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (p.CIN >> 4) * 36 * 8192, 0x00020000);
+        // WIDE: ug = (pixel unit u, output group grp) -- group-minor when whole units are walked (the groups of a pixel unit run on
+        // neighbouring blocks of one XCD and share its input in L2), group-major in a stream-K sequence (a share stays inside a group)
+        int u = ug, grp = 0;
+        if (WIDE) {
+            if (p.stream) { grp = ug / upix; u = ug - grp * upix; } else { u = ug / p.groups; grp = ug - u * p.groups; }
+            if (grp != ring_grp) { ring_primed = false; ring_grp = grp; }
+        }
+        const int wgb = (p.CIN >> 4) * 36 * 8192;           // bytes of one group's packed weights
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk) + (WIDE ? (size_t)grp * (wgb >> 2) : 0), 0, wgb, 0x00020000);
         const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(JOIN ? p.skip : p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(JOIN ? p.zout : const_cast<float*>(p.in), 0, p.IH * p.IWp * p.CIN * 4, 0x00020000);
@@ -363,10 +377,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tl = lane & 15, g = lane >> 4;
         const int nrows = max(0, min(16, p.OH - oy0)), ncols = max(0, min(16, p.OW - ox0));
         const int nv = nrows * ncols;
-        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * 512, 0x00020000);
+        const int cpb = WIDE ? p.COUT * 4 : 512;             // bytes per output pixel
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * cpb, 0x00020000);
         const bool inside = nv == 256;         // (wave-uniform: nine units in ten lie wholly inside the image and skip every per-pixel test)
         const int oyb = oy0 + 4 * (tl >> 2), oxb = ox0 + 4 * (tl & 3);
-        const int cb = wave * 16 + 4 * g;      // first of this lane's four channels
+        const int cb = (WIDE ? grp * 128 : 0) + wave * 16 + 4 * g;      // first of this lane's four channels
         float y[4][4][4];                      // [row a][column b][channel r]
         {
             const v4f bv = whole ? *reinterpret_cast<const v4f*>(p.bias + cb) : v4f{0.f, 0.f, 0.f, 0.f};
@@ -429,14 +444,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int ro = ((oyb + a) * p.OWp + oxb) * 512 + cb * 4;          // byte offset of column 0; columns follow 512 B apart
+            const int ro = ((oyb + a) * p.OWp + oxb) * cpb + cb * 4;          // byte offset of column 0; columns follow one pixel (512 B) apart
             const bool rv = oyb + a < p.OH;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const bool v = inside || (rv && oxb + b < p.OW);               // (outside the image: an offset past the buffer, the store is dropped)
                 vmask |= (v ? 1u : 0u) << (4 * a + b);
                 const v4f w = {y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, v ? ro : (int)0xFFFFF000, b * 512, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, v ? ro : (int)0xFFFFF000, b * cpb, 0);
             }
         }
         if (p.partials != nullptr) {
@@ -458,14 +473,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int b = 0; b < 4; ++b) { const float d = y[a][b][r] - mu; if (inside || ((vmask >> (4 * a + b)) & 1u)) m2 = fmaf(d, d, m2); }
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
-                if (tl == 0) p.partials[(size_t)u * 128 + cb + r] = make_float2(mu, m2);
+                if (tl == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb + r] = make_float2(mu, m2);
             }
         }
-        if (p.partials != nullptr && t == 0) p.counts[u] = nv;
+        if (p.partials != nullptr && t == 0 && grp == 0) p.counts[u] = nv;
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
         DBG_T();   /* epilogue end */
     };
-    const int units = p.units_x * p.units_y;
+    const int units = WIDE ? upix * p.groups : upix;
     if (!p.stream) {
         for (int u = lb; u < units; u += gridDim.x) work(u, 0, nslices, -1, 0);
     } else {
@@ -505,13 +520,18 @@ void wino4_debug_report(const long long* hbuf, int grid, int mode)
             mode, grid, items, wk ? ck / (wk * 10.0) : 0.0, items ? sum[0] / items : 0.0, items ? sum[1] / items : 0.0, items ? sum[3] / items : 0.0, tend);
 }
 
-template <int MODE>
+template <int MODE, bool WIDE>
 int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
 {
+#ifdef FAV_DIAG
+    // timing experiments (make DIAG=1 only): these instantiations skip parts of the kernel and produce garbage
     static const int var = getenv("FAV_W4_VAR") ? atoi(getenv("FAV_W4_VAR")) : 0;
-    const auto kern = (MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
-                      (MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
-                      (MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> : conv3_wino4_kernel<MODE, 0>;
+    const auto kern = (!WIDE && MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (!WIDE && MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (!WIDE && MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
+                      (!WIDE && MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (!WIDE && MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
+                      (!WIDE && MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> : conv3_wino4_kernel<MODE, 0, WIDE>;
+#else
+    const auto kern = conv3_wino4_kernel<MODE, 0, WIDE>;
+#endif
     const size_t lds = (size_t)(W4_SMEM + (MODE == 2 ? W4_RBUF : 0) + 2 * a0.CIN + 4) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
@@ -523,7 +543,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
         if (occ < 1) { set_error("winograd F(4x4) conv: kernel does not fit on a CU"); return FAV_EHIP; }
         cus[dv] = prop_cus;          // one block per CU
     }
-    const int units = a0.units_x * a0.units_y;
+    const int units = a0.units_x * a0.units_y * (WIDE ? a0.groups : 1);
     int grid = std::min(units, std::max(1, cus[dv] - reserve_cus));
     Wino4Args a = a0; a.dbg = nullptr;
     // A CU holds one unit at a time, so a launch takes ceil(units / grid) rounds of one unit time -- and three of the ten layers at
@@ -561,10 +581,11 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
 
 }  // namespace
 
+// any number of 128-filter groups (the canonical network has one; checkpoints with more filters -- README.md:141 -- two or more)
 bool conv3_wino4_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
 {
-    return k == 3 && stride == 1 && pad == 0 && ups == 0 && stages <= 1 && cin_pitch % 16 == 0 && cin_pitch >= 16 && cin_pitch <= 256 &&
-           cout == 128 && coutp == 128;
+    return k == 3 && stride == 1 && pad == 0 && ups == 0 && stages <= 1 && cin_pitch % 16 == 0 && cin_pitch >= 16 && cin_pitch <= 512 &&
+           cout == coutp && cout % 128 == 0 && cout >= 128 && cout <= 1024;
 }
 int conv3_wino4_tiles(int OH, int OW) { return ((OH + 15) / 16) * ((OW + 15) / 16); }
 
@@ -574,6 +595,7 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
                 "winograd F(4x4) conv: not eligible");
     FAV_REQUIRE((long long)(c.IH + 1) * c.IWp * c.CIN < (1ll << 29), "winograd F(4x4) conv: tensor too large for 32-bit byte offsets");
     FAV_REQUIRE(c.OH == c.IH - 2 && c.OW == c.IW - 2, "winograd F(4x4) conv: bad geometry");
+    FAV_REQUIRE((long long)(c.OH + 1) * (c.OWp > 0 ? c.OWp : c.OW) * c.COUT < (1ll << 29), "winograd F(4x4) conv: output too large for 32-bit byte offsets");
     Wino4Args a;
     a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.scale1 = c.pre.scale1; a.shift1 = c.pre.shift1; a.relu1 = c.pre.relu1;
     a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
@@ -582,11 +604,14 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
     a.dbg = nullptr;
     a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
     a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.stream = 0; a.shares = 1;
+    a.COUT = c.COUT; a.groups = c.COUT / 128;
     if (c.join_skip != nullptr) {
         FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
-        return launch_wino4_t<2>(a, c.reserve_cus, st);
+        FAV_REQUIRE(a.groups == 1, "winograd F(4x4) conv: a pending residual join is formed by 128-filter layers only");
+        return launch_wino4_t<2, false>(a, c.reserve_cus, st);
     }
-    return c.pre.stages >= 1 ? launch_wino4_t<1>(a, c.reserve_cus, st) : launch_wino4_t<0>(a, c.reserve_cus, st);
+    if (a.groups > 1) return c.pre.stages >= 1 ? launch_wino4_t<1, true>(a, c.reserve_cus, st) : launch_wino4_t<0, true>(a, c.reserve_cus, st);
+    return c.pre.stages >= 1 ? launch_wino4_t<1, false>(a, c.reserve_cus, st) : launch_wino4_t<0, false>(a, c.reserve_cus, st);
 }
 
 }  // namespace fav

@@ -269,27 +269,33 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
                 std::vector<float> wf2;                                            // ... and with F(2x2,3x3) over its nine 3x3 blocks
                 conv_first2d_pack(L.w.data(), L.cin, L.cout, wf2);
                 rc = dev_upload(wf2, 0, &d.wfirst2d); if (rc) return rc;
+            } else if (!L.transposed && conv_first2d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, 0, 0)) {      // first layer with more than 32 filters: groups of 32 on the 2-D form
+                std::vector<float> wf2;
+                conv_first2d_pack_groups(L.w.data(), L.cin, L.cout, d.coutp, wf2);
+                rc = dev_upload(wf2, 0, &d.wfirst2d); if (rc) return rc;
             }
             if (!L.transposed && L.cin == d.cinp && conv3_wino_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 0, 0)) {      // residual 3x3: Winograd
                 std::vector<float> ww;
                 conv_wino_pack(L.w.data(), L.cin, L.cout, ww);
                 rc = dev_upload(ww, 0, &d.wwino); if (rc) return rc;
-                if (!tuning().wino_f2 && conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 0, 0)) {      // ... as F(4x4,3x3) (round 4)
-                    std::vector<float> w4;
-                    conv_wino4_pack(L.w.data(), L.cin, L.cout, w4);
-                    rc = dev_upload(w4, 0, &d.wwino4); if (rc) return rc;
-                }
+            }
+            if (!L.transposed && L.cin == d.cinp && !tuning().wino_f2 && conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 0, 0)) {      // ... as F(4x4,3x3) (round 4), any number of 128-filter groups (round 5)
+                std::vector<float> w4;
+                conv_wino4_pack_groups(L.w.data(), L.cin, L.cout, w4);
+                rc = dev_upload(w4, 0, &d.wwino4); if (rc) return rc;
             }
             if (!L.transposed && L.cin == d.cinp && conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 1)) {      // 3x3 after a x2 upsampling: merged 2x2 taps
                 std::vector<float> wu, wu9;
-                conv_up2_pack(L.w.data(), L.cin, wu);
-                conv_up2w_pack(L.w.data(), L.cin, wu9);                            // the nine-position form follows the phase-merged one
-                wu.insert(wu.end(), wu9.begin(), wu9.end());
+                if (L.cout == 64) {
+                    conv_up2_pack(L.w.data(), L.cin, wu);
+                    conv_up2w_pack(L.w.data(), L.cin, wu9);                        // the nine-position form follows the phase-merged one
+                    wu.insert(wu.end(), wu9.begin(), wu9.end());
+                } else conv_up2w_pack_groups(L.w.data(), L.cin, L.cout, wu);      // more than 64 filters: the nine-position form only, one block per group of 64
                 rc = dev_upload(wu, 0, &d.wup2); if (rc) return rc;
             }
             if (!L.transposed && L.cin == d.cinp && conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, 1, 0)) {      // 3x3 stride 2: fragment order
                 std::vector<float> ws;
-                conv_s2w_pack(L.w.data(), L.cin, L.cout, ws);
+                conv_s2w_pack_groups(L.w.data(), L.cin, L.cout, ws);
                 rc = dev_upload(ws, 0, &d.ws2w); if (rc) return rc;
             }
             if (!L.transposed && conv_fold_eligible(d.cinp, L.cout, L.k, L.stride)) {
@@ -405,7 +411,7 @@ int fav_net::alloc(size_t bytes, float** out)
 
 int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
-    const float* wfold = (c.final_mode && !tuning().no_fold) ? convs[conv_index].wfold : nullptr;
+    const float* wfold = (c.final_mode && !tuning().no_fold && conv_fold_launchable(c.CIN, c.KH, c.pad, c.ups, c.IH, c.IW)) ? convs[conv_index].wfold : nullptr;
     const float* c8d_w = (use_c8 && !tuning().no_c8d && conv_c8d_eligible(c.CIN, L.cin, c.COUTp, L.k, c.stride, c.pre.stages, c.ups)) ? convs[conv_index].wc8d : nullptr;
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
@@ -508,28 +514,32 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             } else { rc = alloc((size_t)c.OH * c.OW * L.cout * sizeof(float), &nxt.data); if (rc) return rc; }
             const bool want_stats = li + 1 < ls.size() && ls[li + 1].type == L_IN;
             const bool c8 = !L.transposed && conv_c8_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_c8;
-            const bool wino = !L.transposed && d.wwino != nullptr && precision == 0 && !tuning().no_wino &&
-                              conv3_wino_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
-            const bool first = c8 && d.wfirst != nullptr && !tuning().no_first && !tuning().no_c8d && conv_c8d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups);
+            const bool wino4 = !L.transposed && d.wwino4 != nullptr && precision == 0 && !tuning().no_wino &&
+                               conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
+            const bool wino = wino4 || (!L.transposed && d.wwino != nullptr && precision == 0 && !tuning().no_wino &&
+                                        conv3_wino_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups));
+            // (a first layer with more than 32 filters: the 2-D minimal-filtering kernel in groups of 32; no other special kernel takes it)
+            const bool first_wide = !c8 && !L.transposed && d.wfirst2d != nullptr && !tuning().no_first && !tuning().no_c8d &&
+                                    conv_first2d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups);
+            const bool first = first_wide || (c8 && d.wfirst != nullptr && !tuning().no_first && !tuning().no_c8d && conv_c8d_eligible(d.cinp, L.cin, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups));
             const bool up2 = !L.transposed && d.wup2 != nullptr && precision == 0 && !tuning().no_up2 &&
                              conv3_up2_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
             const bool s2w = !L.transposed && d.ws2w != nullptr && !tuning().no_s2w &&
                              conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
-            const bool wino4 = wino && d.wwino4 != nullptr && conv3_wino4_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
             const bool h3 = !wino && !up2 && !s2w && !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
             const bool s2 = !L.transposed && !s2w && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
             static const bool first_1d = getenv("FAV_FIRST_1D") != nullptr;      // (tuning: read once) the 1-D form of the first layer
-            const bool first2d = first && d.wfirst2d != nullptr && !first_1d;
+            const bool first2d = first_wide || (first && d.wfirst2d != nullptr && !first_1d);
             nxt.mblocks = first ? (first2d ? conv_first2d_tiles(c.OH, c.OW) : conv_first_tiles(c.OH, c.OW)) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? (wino4 ? conv3_wino4_tiles(c.OH, c.OW) : conv3_wino_tiles(c.OH, c.OW)) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
-            if (want_stats && (c8 || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
+            if (want_stats && (c8 || first || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
             if (cur.join_skip != nullptr || pitched_out) {
                 if (!wino) { set_error("internal: a pending residual join next to a convolution that is not the Winograd kernel's"); return FAV_EINVAL; }
                 c.join_skip = cur.join_skip; c.join_out = cur.join_out;
             }
             if (h3 && precision == 1) c.wgt16 = d.wgt16;
-            c8_counts = (c8 || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_wino4 = wino4; use_up2 = up2; use_first = first; use_first2d = first2d; use_s2w = s2w;
+            c8_counts = (c8 || first || h3 || s2 || wino || up2 || s2w) ? (nxt.counts ? nxt.counts : reinterpret_cast<int*>(zeros)) : nullptr; use_c8 = c8; use_h3 = h3; use_s2 = s2; use_wino = wino; use_wino4 = wino4; use_up2 = up2; use_first = first; use_first2d = first2d; use_s2w = s2w;
             rc = timed_conv(c, (int)conv_cursor - 1, L); if (rc) return rc;
             use_c8 = false; use_h3 = false; use_s2 = false; use_wino = false; use_wino4 = false; use_up2 = false; use_first = false; use_first2d = false; use_s2w = false;
             cur = nxt;

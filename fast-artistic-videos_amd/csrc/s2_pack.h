@@ -28,4 +28,17 @@ inline void conv_s2w_pack(const float* w, int cin, int cout, std::vector<float>&
         }
 }
 
+// layers with more than 128 filters (cout % 128 == 0): computed in groups of 128 output channels, each with the packed block
+// conv_s2w_pack() makes of its 128 filters -- the blocks follow each other
+inline void conv_s2w_pack_groups(const float* w, int cin, int cout, std::vector<float>& out)
+{
+    if (cout <= 128) { conv_s2w_pack(w, cin, cout, out); return; }
+    out.clear();
+    std::vector<float> one;
+    for (int g = 0; g < cout / 128; ++g) {
+        conv_s2w_pack(w + (size_t)g * 128 * cin * 9, cin, 128, one);
+        out.insert(out.end(), one.begin(), one.end());
+    }
+}
+
 }  // namespace fav

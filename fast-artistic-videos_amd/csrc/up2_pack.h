@@ -75,4 +75,16 @@ inline void conv_up2w_pack(const float* w, int cin, std::vector<float>& out)
         }
 }
 
+// layers with more than 64 filters (cout % 64 == 0): computed in groups of 64 output channels by the nine-position kernel, each
+// group with the packed block conv_up2w_pack() makes of its 64 filters -- the blocks follow each other
+inline void conv_up2w_pack_groups(const float* w, int cin, int cout, std::vector<float>& out)
+{
+    out.clear();
+    std::vector<float> one;
+    for (int g = 0; g < cout / 64; ++g) {
+        conv_up2w_pack(w + (size_t)g * 64 * cin * 9, cin, one);
+        out.insert(out.end(), one.begin(), one.end());
+    }
+}
+
 }  // namespace fav

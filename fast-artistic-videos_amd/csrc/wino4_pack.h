@@ -87,4 +87,16 @@ inline void conv_wino4_pack(const float* w, int cin, int cout, std::vector<float
         }
 }
 
+// layers with more than 128 filters (cout % 128 == 0): the kernel computes them in groups of 128 output channels, a work unit =
+// (pixel unit, group), each group with the packed block conv_wino4_pack() makes of its 128 filters -- the blocks follow each other
+inline void conv_wino4_pack_groups(const float* w, int cin, int cout, std::vector<float>& out)
+{
+    out.clear();
+    std::vector<float> one;
+    for (int g = 0; g < cout / 128; ++g) {
+        conv_wino4_pack(w + (size_t)g * 128 * cin * 9, cin, 128, one);
+        out.insert(out.end(), one.begin(), one.end());
+    }
+}
+
 }  // namespace fav

@@ -18,7 +18,9 @@
 #   e2e[:<frames>]                   scripts/e2e.py (the CLI's own timing breakdown)
 #   c3dump                           GPU side of the 300-frame config-3 free-running parity run (contractive checkpoint)
 #   parity:<config>:<frames>[:gain]  scripts/parity_clip.py on the box (teacher-forced + free-running)
-#   vr                               scripts/vr_bench.py
+#   vr[:<flags>]                     scripts/vr_bench.py (e.g. vr:--arch+2x)
+#   wide[:<flags>]                   scripts/wide_bench.py (a checkpoint with more filters; e.g. wide:--arch+1.5x)
+#   profwide[:<flags>]               rocprofv3 --kernel-trace --stats of scripts/wide_bench.py -> <tag>_wide_kernel_stats.csv
 #   sh:<command>                     anything else ('+' for spaces)
 TAG=${1:-x}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
@@ -66,7 +68,17 @@ PY
     c3dump)   timeout 600 python scripts/parity_clip.py --config 3 --frames 300 --gain 0.05 --gpu-dump $O/c3_contractive_gpu.npz 2>&1 | tail -3 ;;
     parity)   IFS=: read C N G <<< "$A"
               timeout 2400 python scripts/parity_clip.py --config $C --frames $N --gain ${G:-1.0} --out $O/parity_c${C}_${TAG}.json 2>&1 | tail -2 ;;
-    vr)       timeout 900 python scripts/vr_bench.py 2>&1 | tee $O/vr_${TAG}.log | tail -5 ;;
+    vr)       timeout 900 python scripts/vr_bench.py $A 2>&1 | tee -a $O/vr_${TAG}.log | tail -5 ;;
+    wide)     timeout 900 python scripts/wide_bench.py $A 2>&1 | tee -a $O/wide_${TAG}.log | tail -5 ;;
+    profwide) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_wide -o p -- python $R/scripts/wide_bench.py --steps 10 --warmup 3 $A > $O/prof_${TAG}_wide.log 2>&1)
+              cp $(ls $O/prof_${TAG}_wide/*kernel_stats.csv | head -1) $O/${TAG}_wide_kernel_stats.csv 2>/dev/null
+              python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/${TAG}_wide_kernel_stats.csv")))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
+    print("%-90s calls %5s avg %9.2f us  %5.1f %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+PY
+              tail -1 $O/prof_${TAG}_wide.log | cut -c1-600 ;;
     sh)       bash -c "$A" 2>&1 | tail -40 ;;
     *)        echo "unknown step $K" ;;
   esac

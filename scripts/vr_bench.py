@@ -1,6 +1,7 @@
 """BASELINE config 5 on one GPU: 360-degree cube-map path, 6 x 1504x1504 faces per frame (overlap 128, equirect 2560x1440 as in
 stylizeVRVideo_deepflow.sh:76-83), canonical architecture with synthetic weights, inputs resident in HBM.
-usage: python scripts/vr_bench.py [--frames 6] [--face 1504]"""
+usage: python scripts/vr_bench.py [--frames 6] [--face 1504] [--arch 2x|1.5x|<architecture string>]
+(--arch: a checkpoint with more filters, as the reference's published VR models have -- README.md:141)"""
 import argparse, json, os, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +15,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=6)
 ap.add_argument("--face", type=int, default=1504)
 ap.add_argument("--overlap", type=int, default=128)
+ap.add_argument("--arch", default="", help="2x | 1.5x | an architecture string of models_video.lua (default: the canonical one)")
 a = ap.parse_args()
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import wide_bench
+arch = {"": t7.CANONICAL_ARCH, "2x": wide_bench.WIDE2, "1.5x": wide_bench.WIDE15}.get(a.arch, a.arch)
 dev = torch.device("cuda:0")
 with tempfile.TemporaryDirectory() as d:
-    ck = os.path.join(d, "m.t7"); t7.make_synthetic_checkpoint(ck, seed=1)
+    ck = os.path.join(d, "m.t7"); t7.make_synthetic_checkpoint(ck, arch=arch, seed=1)
     net = fav_amd.Net(ck, 0)
 hp = a.face
 vr = fav_amd.VR(net, hp, hp, overlap_w=a.overlap, overlap_h=a.overlap, median=3, out_equi_w=2560, out_equi_h=1440, fill_random=True, seed=3)
@@ -42,6 +47,6 @@ for fr in range(2, 2 + a.frames):
     e, c = frame(fr)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"workload": "VR cube map, 6 x %dx%d faces/frame, overlap %d, equirect 2560x1440 + cube map, 1 GPU" % (hp, hp, a.overlap),
+print(json.dumps({"workload": "VR cube map, 6 x %dx%d faces/frame, overlap %d, equirect 2560x1440 + cube map, 1 GPU" % (hp, hp, a.overlap), "arch": arch,
                   "frames": a.frames, "frames_per_s": round(a.frames / dt, 3), "faces_per_s": round(6 * a.frames / dt, 2),
                   "ms_per_frame": round(dt / a.frames * 1e3, 2), "equi": list(e.shape), "cubemap": list(c.shape)}))

@@ -48,16 +48,18 @@ def _one(usage, *parts):
 
 
 def test_stride2_kernels_do_not_spill(usage):
-    for inst, waves in (("ILi2ELi4E", 2), ("ILi4ELi3E", 3), ("ILi4ELi2E", 2)):
+    # (Lb1E: the instantiation that computes more than 128 filters in groups of 128, round 5)
+    for inst, waves in (("ILi2ELi4ELb0E", 2), ("ILi4ELi3ELb0E", 3), ("ILi4ELi2ELb0E", 2), ("ILi4ELi3ELb1E", 3)):
         u = _one(usage, "conv3s2w_kernel", inst)
         assert u["ScratchSize"] == 0, (inst, u)
         assert u["Occupancy"] >= waves and u["VGPRs"] <= (256 if waves == 2 else 168), (inst, u)
 
 
 def test_nine_position_kernel_fits_three_waves_per_simd(usage):
-    u = _one(usage, "conv3_up2w_kernel")
-    assert u["Occupancy"] == 3 and u["VGPRs"] <= 168, u
-    assert u["ScratchSize"] <= 160, u              # epilogue (the fourth output of every pixel) + a handful of K-loop temporaries
+    for inst in ("ILb0E", "ILb1E"):                # one group of 64 filters (canonical) | any number of groups
+        u = _one(usage, "conv3_up2w_kernel", inst)
+        assert u["Occupancy"] == 3 and u["VGPRs"] <= 168, u
+        assert u["ScratchSize"] <= 160, u          # epilogue (the fourth output of every pixel) + a handful of K-loop temporaries
 
 
 def test_winograd_kernel_keeps_its_accumulators_in_registers(usage):

@@ -1022,6 +1022,101 @@ def test_stride2_layers_in_networks(favlib, oracle, cuda, tmp_path, arch, size):
     assert np.abs(ref).std() > 5
 
 
+# ---- checkpoints with more filters than the canonical one (round 5) ----------------------------------------------------------------
+# models_video.lua:55-140 builds the network from ANY architecture string and the published VR checkpoints "have more filters"
+# (README.md:141, models/download_models_vr.sh:1-5).  Their layers run on the same minimal-filtering kernels as the canonical
+# network's, in groups of output channels (F(4x4) residual 3x3: groups of 128; stride-2: 128; U2 + 3x3: 64; first layer: 32; the last
+# layer: passes of 64 input channels) -- kernel ids as fav_net::timed_conv reports them through fav_net_profile_read_host
+WIDE2 = "c9s1-64,d128,d256,R256,R256,R256,R256,R256,U2,c3s1-128,U2,c9s1-3"          # every filter count doubled
+WIDE15 = "c9s1-48,d96,d192,R192,R192,R192,R192,R192,U2,c3s1-96,U2,c9s1-3"          # x1.5: runs zero-padded to 64 / 128 / 256
+WIDE_KERNEL_IDS = [16, 700 + 128, 700 + 256] + [600 + 256] * 10 + [500 + 128, 1]
+
+
+def _wide_forward(favlib, cuda, path, x):
+    net = favlib.Net(path, 0)
+    net.profile_enable(True)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    ids = [kid for (ms, n, macs, kid) in net.profile_read()]
+    net.profile_enable(False)
+    net.check()
+    return net, got, ids
+
+
+@pytest.mark.parametrize("arch,size", [(WIDE2, (88, 120)), (WIDE2, (150, 210)), (WIDE15, (90, 122)), (WIDE2, (720, 1280)), (WIDE15, (720, 1280))],
+                         ids=["2x-88x120", "2x-150x210", "1.5x-90x122", "2x-720p", "1.5x-720p"])
+def test_networks_with_more_filters_stay_on_the_fast_kernels(favlib, oracle, cuda, tmp_path, arch, size):
+    """Doubled and x1.5 filter counts against the oracle's direct form, small ragged sizes and 1280x720; every convolution must have
+    run on the kernel the canonical network uses for that layer (no generic implicit-GEMM fallback)."""
+    p = str(tmp_path / "wide.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=91)
+    layers = _layers(p)
+    h, w = size
+    x = (np.random.default_rng(16).standard_normal((7, h, w)) * 60).astype(np.float32)
+    big = h * w > 500000
+    if big: oracle.set_threads(len(os.sched_getaffinity(0)))
+    try:
+        ref = oracle.net_forward(layers, x)
+    finally:
+        if big: oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+    net, got, ids = _wide_forward(favlib, cuda, p, x)
+    assert ids == WIDE_KERNEL_IDS, ids
+    assert net.describe() == favlib.describe_layers(layers)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    print("more filters %s at %dx%d: max-abs %.3e (150*tanh space)" % (arch.split(",")[0], h, w, err))
+    assert err <= 2e-2, err
+    assert np.abs(ref).std() > 10
+    again = net.forward(T(x, cuda)).cpu().numpy()
+    assert np.array_equal(got, again)
+
+
+def test_stream_k_shares_with_more_filters(favlib, cuda, tmp_path):
+    """The F(4x4) kernel's stream-K mode with two groups of 128 filters (group-major sequence, shares that cross from one group into the
+    next): FAV_W4_GRID forces many shares at a small size; same numbers as whole units, same bits from run to run."""
+    import subprocess, sys
+    p = str(tmp_path / "wide.t7")
+    t7.make_synthetic_checkpoint(p, arch="c3s1-128,d256,R256,R256,U2,c9s1-3", seed=92)
+    x = (np.random.default_rng(17).standard_normal((7, 118, 150)) * 60).astype(np.float32)
+    np.save(tmp_path / "x.npy", x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "x = torch.from_numpy(np.load(%r)).cuda(); net = fav_amd.Net(%r, 0)\n"
+             "a = net.forward(x).cpu().numpy(); b = net.forward(x).cpu().numpy()\n"
+             "assert np.array_equal(a, b)\n"
+             "np.save(sys.argv[1], a)\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), p))
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(os.environ, FAV_W4_NO_STREAM="1", FAV_W4_GRID="7"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(os.environ, FAV_W4_GRID="7"), timeout=300)
+    whole, stream = np.load(tmp_path / "whole.npy"), np.load(tmp_path / "stream.npy")
+    assert np.isfinite(stream).all()
+    d = np.abs(stream - whole).max()
+    print("more filters, stream-K vs whole units: max-abs %.3e" % d)
+    assert d <= 5e-3 and not np.array_equal(stream, whole), d
+
+
+@pytest.mark.parametrize("arch,size,ids", [
+    ("c9s1-64,c9s1-3", (40, 70), [16, None]),                                   # first layer alone: two groups of 32, ragged tiles
+    ("c9s1-96,d64,c9s1-3", (36, 52), [16, 764, None]),                          # 96 filters: padded to 128 = four groups
+    ("c3s1-64,d256,c9s1-3", (38, 134), [None, 956, None]),                      # stride 2 into 256: 64 input channels, ragged tiles
+    ("c3s1-128,U2,c3s1-128,c9s1-3", (29, 43), [None, 628, None]),               # U2 + 3x3 into 128: two groups of 64
+    ("c3s1-128,U2,c3s1-256,c3s1-16,c9s1-3", (24, 40), [None, 756, None, None]),   # ... into 256: four groups
+    ("c3s1-128,U2,c9s1-3", (41, 70), [None, 1]),                                # last layer on 128 channels: two passes of 64
+    ("c3s1-256,U2,c9s1-3", (26, 37), [None, 1]),                                # ... on 256: four passes
+], ids=["first64", "first96", "d256", "up2-128", "up2-256", "last128", "last256"])
+def test_layers_with_more_filters_one_at_a_time(favlib, oracle, cuda, tmp_path, arch, size, ids):
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=93)
+    layers = _layers(p)
+    h, w = size
+    x = (np.random.default_rng(18).standard_normal((7, h, w)) * 60).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    net, got, kids = _wide_forward(favlib, cuda, p, x)
+    assert len(kids) == len(ids) and all(want is None or want == k for want, k in zip(ids, kids)), kids
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 2e-2, err
+    assert np.abs(ref).std() > 5
+
+
 def _seq_sum(x):
     return np.add.accumulate(x.astype(np.float32), dtype=np.float32)[-1]     # sequential, one rounding per element
 
