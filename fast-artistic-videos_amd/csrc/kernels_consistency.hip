@@ -709,7 +709,10 @@ size_t seqsum_workspace_bytes(size_t n)
 static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st)
 {
     static const bool one_block = getenv("FAV_AVG_ONE_BLOCK") != nullptr;       // (A/B: the round-3 form)
-    if (n < 65536 || one_block || !ws) {
+    // (very long arrays too: avg_chunk_class_kernel re-adds the chunk sums before its chunk in every block -- nc^2 / 2 reads, nothing at
+    //  1280x720 (3 600 chunks) or a 1504^2 VR face (8 836), minutes of L2 traffic at the 2^31 elements fav_sequential_sum_f32 accepts;
+    //  the one-block kernel is linear.  Both produce the same bits: the sequential fp32 sum is what they compute)
+    if (n < 65536 || one_block || !ws || n > (size_t)16384 * ACH) {
         hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(nullptr));
         return;
     }

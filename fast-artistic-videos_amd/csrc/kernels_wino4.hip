@@ -9,22 +9,26 @@
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        (matrices in wino4_pack.h)
 //
-// Work unit = 4 x 4 tiles = 16 x 16 output pixels x 128 output channels, one block of FOUR waves per CU, one wave per SIMD with the
-// whole 512-register file of its SIMD:
+// Work unit = 4 x 4 tiles = 16 x 16 output pixels x 128 output channels, one block of EIGHT waves (512 threads) per CU, two waves per
+// SIMD with 256 registers each (amdgpu_waves_per_eu(2, 2)); layers with more than 128 filters run as several such units per pixel unit
+// (WIDE instantiations, one group of 128 output channels each):
 //   * v_mfma_f32_16x16x4_f32: M = the unit's 16 tiles, N = 16 output channels, K = 4 input channels.  Wave w owns output channels
-//     32 w .. 32 w + 31 for ALL 36 transform positions and all 16 tiles: 36 x 2 x 4 = 288 accumulator registers.  Every
-//     (tile, output channel) has its 36 position values in ONE lane, so the output transform A^T M A never leaves the lane -- no
-//     exchange between waves, no LDS pass (the F(2x2) kernel spends 4.9 of 39 us per unit there)
-//   * input: per 16-channel slice the 18 x 18 pixel halo is loaded once (16 bytes per thread and row), the producing layer's pending
-//     InstanceNorm / ReLU (or pending residual join) applied, and B^T d B formed in TWO passes through LDS by all four waves between
-//     their matrix instructions: rows (288 items of 6 -> 6) into L, columns (384 items) into V[position][tile][channel].  An A
-//     fragment is then ONE conflict-free ds_read_b128 per position and 16 channels (tile pitch 20 words = 5 sixteen-byte slots)
-//     -- 0.5 vector instructions per matrix instruction in all
+//     16 w .. 16 w + 15 (wave = 2 w' + nt in wino4_pack.h's (w', nt) numbering) for ALL 36 transform positions and all 16 tiles:
+//     acc[36] x 4 = 144 accumulator registers.  Every (tile, output channel) has its 36 position values in ONE lane, so the output
+//     transform A^T M A never leaves the lane -- no exchange between waves, no LDS pass (the F(2x2) kernel spends 4.9 of 39 us per unit there)
+//   * input: per 16-channel slice the 18 x 18 pixel halo arrives as raw rows by `buffer_load ... lds` (requested a slice ahead, 64 contiguous
+//     bytes per four adjacent lanes), the producing layer's pending InstanceNorm / ReLU (or pending residual join) is applied, and
+//     B^T d B is formed in TWO passes through LDS between the matrix instructions: rows (288 items of 6 -> 6: threads 0..287, i.e.
+//     waves 0-3 and half of wave 4) into L, columns (384 items: waves 2..7, one transform line each) into V[position][chunk][tile].
+//     An A fragment is then ONE conflict-free ds_read_b128 per position and 16 channels
 //   * weights: transformed in double and packed on the host in exactly the fragment order (wino4_pack.h); no two waves share a
-//     weight, so they go global -> registers directly (two contiguous 1 KiB loads per position), eight positions ahead through a
-//     ring of nine register pairs; 2.36 MB per layer, L2-resident
-//   * two barriers per slice (L complete, V complete); the slice's 288 matrix instructions per wave run between them
-// Units are independent (nothing handed over, nothing co-resident assumed): persistent blocks walk the units round-robin.
+//     weight, so they go global -> registers directly (one contiguous 1 KiB load per position), four to five positions ahead through a
+//     ring of SIX register quads (fb[6]) that lives across slices and units; 2.36 MB per layer and group, L2-resident
+//   * two barriers per slice (L complete, V complete); the slice's 144 matrix instructions per wave run between them
+//   * epilogue: since round 5 the transformed input is the M operand, so a lane holds ONE channel of the four tiles of a tile row and
+//     the 16 adjacent lanes of a group store 64 contiguous bytes of a pixel (2 048 store requests per unit instead of 8 192)
+// Units are independent (nothing handed over, nothing co-resident assumed): persistent blocks walk the units round-robin; a launch with a
+// thin last round is dealt out as one sequence of slices instead ("stream-K": a unit cut by a share boundary is computed in two parts).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -41,7 +45,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int MAX_DEVICES = 64;
-constexpr int W4_MEET_MAX = 256;             // meeting places of ks_ws / ks_cnt (conv3_wino4_ksplit_bytes): one per block of a stream-K launch
+constexpr int W4_MEET_MAX = 256;             // meeting places of ks_ws / ks_cnt (conv3_wino4_ksplit_bytes): one per share boundary of a stream-K launch
+constexpr int W4_SHARES = 252;               // shares of a stream-K launch: a constant, so that the cuts (and with them the output's bits) do not depend on the device
 inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
 
 // LDS layouts, in 16-byte SLOTS (4 words).  A ds_read_b128 is served in four NON-contiguous groups of 16 lanes -- {0-3, 12-15, 20-27},
@@ -73,8 +78,8 @@ struct Wino4Args {
     // stream != 0: the launch's units x slices are dealt out as ONE sequence of 16-channel slices, an equal share per block (launch_wino4_t);
     // a unit cut by a share boundary is computed in two parts -- the slices before the cut by one block, those behind it by the next --
     // whose partial outputs meet in ks_ws: whichever part is finished second adds the other's to its own (+ bias) and stores the unit
-    // (shares: how many -- a function of the layer and the device alone, NOT of how many blocks this launch may use: the look-ahead mode
-    //  leaves the side queues a few CUs, and both modes must produce the same bits)
+    // (shares: how many -- the constant W4_SHARES, NOT a function of the device or of how many blocks this launch may use: every device
+    //  and every side-queue setting must cut the same units at the same slices, i.e. produce the same bits)
     int stream, shares; float* ks_ws; int* ks_cnt;
     long long* dbg;
     // WIDE instantiations only (layers with more than 128 filters: the VR checkpoints "have more filters", README.md:141): the output
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define ho_(a_) (ho0 + min((a_), hrmax) * hrow)
         // the row REQUESTS use another item numbering than the row pass: request lane d asks for pixel d >> 2, chunk d & 3 -- four
         // adjacent lanes = the 64 contiguous bytes of one pixel's slice, one request instead of four 16-byte ones -- and lands it in slot d;
-        // the row pass's thread reads slot 4 pix + cq (another wave's request: a wait + barrier lie between, see the K loop)
+        // the row pass's thread reads slot 4 pix + cq (slots 64 w .. 64 w + 63 are requested AND read by wave w, but by different lanes: the
+        // request's `s_waitcnt vmcnt` precedes the read in the same wave; the barrier in between serves the readers of L)
         const int dpix = min(t >> 2, 71), dty = (dpix * 3641) >> 16, dx = dpix - dty * 18;
         const int hd0 = ((min(oy0 + 4 * dty, p.IH - 1) * p.IWp + min(ox0 + dx, p.IW - 1)) * CIN + (t & 3) * 4) * 4;
         const int hdmax = max(p.IH - 1 - (oy0 + 4 * dty), 0);
@@ -318,8 +324,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (pos + 5 < 36) { W4_LOAD_B((pos + 5) % 6, s, pos + 5); } else { W4_LOAD_B((pos + 5) % 6, sw, pos + 5 - 36); } } \
             W4_FENCE();                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[pos % 6][j], fa[pos % 4][j], acc[pos], 0, 0, 0); \
-                acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[(pos + 1) % 6][j], fa[(pos + 1) % 4][j], acc[pos + 1], 0, 0, 0); \
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[pos % 4][j], fb[pos % 6][j], acc[pos], 0, 0, 0); \
+                acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[(pos + 1) % 4][j], fb[(pos + 1) % 6][j], acc[pos + 1], 0, 0, 0); \
             }                                                                                       \
             W4_FENCE(); } }
         for (int sl = 0; sl < nsl; ++sl) {
@@ -370,21 +376,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef W4_READ_A
 #undef W4_LOAD_B
 
-        // ---- output transform, in the lane.  The matrix instructions were issued with the WEIGHTS as the M operand: acc[6 i + j][r] =
-        // M[i][j] of tile (lane & 15), output channel 16 wave + 4 (lane >> 4) + r -- a lane holds FOUR CONSECUTIVE channels of one tile,
-        // i.e. 16 contiguous bytes of every output pixel.  Y = A^T M A (4 x 4), bias, NHWC store (b128), per-unit InstanceNorm
-        // partials (mean, M2, count) like the other kernels
-        const int tl = lane & 15, g = lane >> 4;
+        // ---- output transform, in the lane.  The matrix instructions are issued with the transformed INPUT as the M operand (round 5;
+        // rounds 4's form had the weights there and a lane held four consecutive channels of one tile -- its 16-byte stores were 8 192
+        // separate requests per unit, four NON-adjacent lanes per 64 contiguous bytes): acc[6 i + j][r] = M[i][j] of tile (row g = lane >> 4,
+        // column r), output channel 16 wave + (lane & 15) -- a lane holds ONE channel of the four tiles of a tile row, and the 16 adjacent
+        // lanes of a group store 16 consecutive channels of a pixel, 64 contiguous bytes, as one request (2 048 per unit).
+        // Y = A^T M A (4 x 4), bias, NHWC store, per-unit InstanceNorm partials (mean, M2, count) like the other kernels
+        const int cn = lane & 15, g = lane >> 4;
         const int nrows = max(0, min(16, p.OH - oy0)), ncols = max(0, min(16, p.OW - ox0));
         const int nv = nrows * ncols;
         const int cpb = WIDE ? p.COUT * 4 : 512;             // bytes per output pixel
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.OH * p.OWp * cpb, 0x00020000);
         const bool inside = nv == 256;         // (wave-uniform: nine units in ten lie wholly inside the image and skip every per-pixel test)
-        const int oyb = oy0 + 4 * (tl >> 2), oxb = ox0 + 4 * (tl & 3);
-        const int cb = (WIDE ? grp * 128 : 0) + wave * 16 + 4 * g;      // first of this lane's four channels
-        float y[4][4][4];                      // [row a][column b][channel r]
+        const int oyb = oy0 + 4 * g;           // first output row of this lane's tile row
+        const int cb = (WIDE ? grp * 128 : 0) + wave * 16 + cn;      // this lane's channel
+        float y[4][4][4];                      // [row a][column b][tile column r]
         {
-            const v4f bv = whole ? *reinterpret_cast<const v4f*>(p.bias + cb) : v4f{0.f, 0.f, 0.f, 0.f};
+            const float bv = whole ? p.bias[cb] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float Q[4][6];
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int a = 0; a < 4; ++a) {
                     float o[4]; w4_at(Q[a], o);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) y[a][b][r] = o[b] + bv[r];
+                    for (int b = 0; b < 4; ++b) y[a][b][r] = o[b] + bv;
                 }
             }
         }
@@ -431,50 +439,77 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (t == 0) __hip_atomic_store(p.ks_cnt + meet, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-            const v4f bv = *reinterpret_cast<const v4f*>(p.bias + cb);
+            const float bv = p.bias[cb];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const v4f o = *reinterpret_cast<const v4f*>(other + (a * 4 + b) * 2048);
-                    y[a][b][0] = (y[a][b][0] + o.x) + bv.x; y[a][b][1] = (y[a][b][1] + o.y) + bv.y;
-                    y[a][b][2] = (y[a][b][2] + o.z) + bv.z; y[a][b][3] = (y[a][b][3] + o.w) + bv.w;
+                    y[a][b][0] = (y[a][b][0] + o.x) + bv; y[a][b][1] = (y[a][b][1] + o.y) + bv;
+                    y[a][b][2] = (y[a][b][2] + o.z) + bv; y[a][b][3] = (y[a][b][3] + o.w) + bv;
                 }
         }
-        unsigned vmask = 0;                    // bit 4 a + b: pixel (a, b) of this lane's tile lies inside the image
+        // pixel (a, 4 r + b) of the lane's tile row.  Nine units in ten lie wholly inside the image (wave-uniform) and take the first form:
+        // no per-pixel test.  In a ragged unit the COLUMNS past the image are skipped by wave-uniform branches (every lane of a wave has
+        // the same columns) and the ROWS past it -- they differ between the lane groups -- get an offset past the buffer (the hardware
+        // drops the store) and a zero weight in the statistics: four per-lane conditions, not sixty-four
+        float sm = 0.f, mu = 0.f, m2 = 0.f;
+        if (inside) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int ro = ((oyb + a) * p.OWp + oxb) * cpb + cb * 4;          // byte offset of column 0; columns follow one pixel (512 B) apart
-            const bool rv = oyb + a < p.OH;
+            for (int a = 0; a < 4; ++a) {
+                const int ro = ((oyb + a) * p.OWp + ox0) * cpb + cb * 4;      // byte offset of column 0 of the unit; columns follow one pixel (512 B) apart
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const bool v = inside || (rv && oxb + b < p.OW);               // (outside the image: an offset past the buffer, the store is dropped)
-                vmask |= (v ? 1u : 0u) << (4 * a + b);
-                const v4f w = {y[a][b][0], y[a][b][1], y[a][b][2], y[a][b][3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, w), ors, v ? ro : (int)0xFFFFF000, b * cpb, 0);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, y[a][b][r]), ors, ro + r * 4 * cpb + b * cpb, 0, 0);
+                        sm += y[a][b][r];
+                    }
+            }
+            if (p.partials != nullptr) {
+                // per channel: a lane holds 64 of the unit's 256 pixels, the lanes cn + 16, cn + 32, cn + 48 the rest
+                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                mu = sm * (1.f / 256.f);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) { const float d = y[a][b][r] - mu; m2 = fmaf(d, d, m2); }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool rv = oyb + a < p.OH;
+                const int ro = rv ? ((oyb + a) * p.OWp + ox0) * cpb + cb * 4 : (int)0xFFFF0000;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < ncols) {                                           // (wave-uniform)
+                        const float v = y[a][c & 3][c >> 2];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ors, ro + c * cpb, 0, 0);
+                        sm += rv ? v : 0.f;
+                    }
+                }
+            }
+            if (p.partials != nullptr) {
+                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+                mu = nv ? sm / (float)nv : 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bool rv = oyb + a < p.OH;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if (c < ncols) {
+                            const float d = y[a][c & 3][c >> 2] - mu;
+                            m2 = rv ? fmaf(d, d, m2) : m2;
+                        }
+                    }
+                }
             }
         }
         if (p.partials != nullptr) {
-            // per channel: the 16 lanes of a group hold its 16 tiles; sums by butterfly inside the group
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sm = 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) sm += (inside || ((vmask >> (4 * a + b)) & 1u)) ? y[a][b][r] : 0.f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
-                const float mu = nv ? sm / (float)nv : 0.f;
-                float m2 = 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) { const float d = y[a][b][r] - mu; if (inside || ((vmask >> (4 * a + b)) & 1u)) m2 = fmaf(d, d, m2); }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
-                if (tl == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb + r] = make_float2(mu, m2);
-            }
+            m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+            if (g == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb] = make_float2(mu, m2);
         }
         if (p.partials != nullptr && t == 0 && grp == 0) p.counts[u] = nv;
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
@@ -553,14 +588,14 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     // second to finish adds them (ks_ws / ks_cnt: one meeting place per boundary).  Costs a second prologue and output transform per
     // block and the hand-over, i.e. ~0.3 unit times: worth it when the last round is less than ~0.6 full
     // (FAV_W4_GRID: fewer blocks than CUs -- the tests reach the many-shares case with small images through it)
-    // The number of shares depends on the layer and the device only (CUs - 4: what the look-ahead mode leaves the network's grids,
-    // fav_net::reserve_cus) -- with all 256 CUs four blocks of such a launch stay idle (1.6 %), and both modes cut the same units at the
-    // same slices: same bits
+    // The number of shares is a CONSTANT (W4_SHARES = 252: the 256 CUs of an MI355X minus the four the look-ahead mode leaves the side
+    // queues) -- not a function of the device's CU count or of reserve_cus: which units are cut, and at which slice, decides the order
+    // the channels of a cut unit are summed in, i.e. the fp32 bits of the output.  Every device, partition mode and side-queue
+    // setting (FAV_SIDE_CUS) therefore produces the same bits; with fewer blocks than shares a block simply takes several shares
     static const bool no_stream = getenv("FAV_W4_NO_STREAM") != nullptr;
     static const int grid_cap = getenv("FAV_W4_GRID") ? atoi(getenv("FAV_W4_GRID")) : 0;
     if (grid_cap > 0) grid = std::min(grid, std::max(1, grid_cap));
-    const int free_cus = std::max(4, reserve_cus);        // (more than the default four reserved -- FAV_SIDE_CUS: that many fewer shares, other bits)
-    const int shares = std::max(1, grid_cap > 0 ? std::min(cus[dv] - free_cus, grid_cap) : cus[dv] - free_cus);
+    const int shares = grid_cap > 0 ? std::max(1, std::min(W4_SHARES, grid_cap)) : W4_SHARES;
     const int rounds = (units + shares - 1) / shares, rem = units - (rounds - 1) * shares;
     a.stream = (rounds >= 2 && rem * 5 <= shares * 3 && shares <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
     a.shares = shares;

@@ -1085,6 +1085,15 @@ static int state_for_writing(fav_stream* s, hipStream_t st)
     return FAV_OK;
 }
 
+// the forward that was to fill the buffer state_for_writing() switched to has failed: `state` names the last COMPLETE frame again
+static void state_writing_failed(fav_stream* s)
+{
+    if (!s->state_other) return;
+    std::swap(s->state, s->state_other);
+    std::swap(s->png_done, s->png_done_other);
+    std::swap(s->png_pending, s->png_pending_other);
+}
+
 static int stream_finish(fav_stream* s, float* out_rgb_f32, uint8_t* out_rgb8_hwc, hipStream_t st)
 {
     const size_t n = (size_t)s->Ho * s->Wo;
@@ -1108,7 +1117,7 @@ extern "C" int fav_stream_first_frame(fav_stream* s, const uint8_t* frame_rgb_hw
     s->last_st = st; s->ran = true;
     fav_net* fn = s->img_net ? s->img_net : s->net;      // image model: 3 content channels (the zero prior / mask planes meet zero weights)
     rc = state_for_writing(s, st); if (rc) return rc;
-    rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) return rc;
+    rc = fn->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); if (rc) { state_writing_failed(s); return rc; }
     return stream_finish(s, out_rgb_f32, out_rgb8_hwc, st);
 }
 
@@ -1145,7 +1154,7 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
     s->last_st = st; s->ran = true;
     rc = state_for_writing(s, st); if (rc) return rc;       // (the prior was read from the previous state above)
     { TraceRange tr_net("fav:network"); rc = s->net->forward_padded(s->in8, s->H, s->W, s->state, nullptr, st); }
-    if (rc) return rc;
+    if (rc) { state_writing_failed(s); return rc; }
     return stream_finish(s, out_f32, out_u8, st);
 }
 
@@ -1314,6 +1323,10 @@ extern "C" int fav_stream_encode_png_async(fav_stream* s, void* png_out, size_t 
             return hip_fail(e, "fav_stream_encode_png_async: encoder queue / second state buffer");
         }
         s->png_q = q; s->ev_png_in = e0; s->png_done = e1; s->png_done_other = e2; s->state_other = other;
+        // from now on the encoder's kernels run NEXT TO the following frame's network, like the look-ahead masks do: the network's
+        // persistent grids leave them SIDE_CUS CUs and the generic kernel's hand-off between co-resident blocks is off (timed_conv)
+        s->net->reserve_cus = std::max(s->net->reserve_cus, SIDE_CUS);
+        if (s->img_net) s->img_net->reserve_cus = std::max(s->img_net->reserve_cus, SIDE_CUS);
     }
     FAV_HIP(hipEventRecord(s->ev_png_in, st));                 // the frame is complete at this point of the caller's queue
     FAV_HIP(hipStreamWaitEvent(s->png_q, s->ev_png_in, 0));

@@ -22,8 +22,9 @@
 // Packed order = the order the kernel's waves consume it (every weight load is one contiguous 1 KiB wave access):
 //   out[(((((s * 36 + p) * NW + w) * 2 + nt) * 64 + lane) * 4 + j]
 //     s     slice of 16 input channels         p = 6 i + j'  transform position (row i, column j')
-//     w     the wave that owns output channels 32 w .. 32 w + 31 (NW = cout / 32)
-//     nt    half of those (16 channels: the N of v_mfma_f32_16x16x4_f32)
+//     w     pair of kernel waves 2 w, 2 w + 1 that owns output channels 32 w .. 32 w + 31 (NW = cout / 32)
+//     nt    half of those (16 channels: the N of v_mfma_f32_16x16x4_f32) = kernel wave 2 w + nt: the kernel (8 waves of 16 channels)
+//           addresses block (w, nt) as wave * 1 KiB
 //     lane  n = lane & 15 (output channel 32 w + 16 nt + n), kq = lane >> 4
 //     j     MFMA step inside the slice: the instruction of step j multiplies input channels 16 s + 4 kq + j, kq = 0..3
 #pragma once

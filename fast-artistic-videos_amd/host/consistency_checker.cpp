@@ -12,7 +12,29 @@
 // a single call pays for a HIP context (tens of milliseconds, more than the reference's whole CPU run of a 1280x720 pair), a list of
 // N pairs pays it once.  Each line's output path is printed as in the single-call form, one per line.  INTEGRATION.md section 1
 // shows the two-line change to makeOptFlow_deepflow.sh:45-66.
+//
+// Round 5 -- the single call without that change: a call of the four-argument form costs 0.3 s as a fresh process (HIP runtime start-up:
+// profiles/r6*_checker_breakdown.log) against 0.09 / 0.14 s for the reference's CPU binary, and makeOptFlow_deepflow.sh:59-60 makes two
+// such calls per frame.  The first call therefore leaves a RESIDENT HELPER behind: it forks, the child detaches, creates the GPU context
+// once and serves later calls over a unix-domain socket (same argv, same bytes, same exit codes; one request at a time, like a
+// sequence of processes).  A later call connects, hands over its arguments (paths made absolute against ITS working directory), waits
+// for the status and prints the output name -- no HIP in the calling process at all.  The helper exits after FAV_CC_IDLE_S seconds
+// without a request (default 120) and removes its socket.  FAV_CC_DAEMON=0 switches all of this off (every call computes in its own
+// process, as in round 4).  The socket lives in a directory only the calling user can enter (mode 0700, ownership checked):
+// $XDG_RUNTIME_DIR/fav-cc or /tmp/fav-cc-<uid>; one helper per GPU (FAV_GPU).  FAV_CC_TIMING=1 prints where a call's time goes.
 #include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <chrono>
+#include <csignal>
+#include <fcntl.h>
+#include <poll.h>
+#include <sys/file.h>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/un.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -53,10 +75,14 @@ struct Batch {
         memcpy(w, hd + 4, 4); memcpy(h, hd + 8, 4);
         return *w > 0 && *h > 0 && (long long)*w * *h < (1ll << 28);
     }
+    // one call; a failure's message goes to `err` (the helper hands it back to the caller, who prints it)
+    std::string err;
+    int failf(const char* what) { err = std::string("consistencyChecker: ") + what + ": " + fav_last_error() + "\n"; return 1; }
     int run(const std::vector<std::string>& a)
     {
+        err.clear();
         int w1, h1s;
-        if (!flo_size(a[0].c_str(), &w1, &h1s)) { fprintf(stderr, "consistencyChecker: cannot read %s\n", a[0].c_str()); return 1; }
+        if (!flo_size(a[0].c_str(), &w1, &h1s)) { err = "consistencyChecker: cannot read " + a[0] + "\n"; return 1; }
         const size_t n = (size_t)w1 * h1s;
         if (w1 != W || h1s != H) {
             release();
@@ -65,24 +91,24 @@ struct Batch {
             if (hipMalloc((void**)&d1, n * 8) || hipMalloc((void**)&d2, n * 8) || hipMalloc((void**)&dout, n) || hipMalloc((void**)&dimg, n * 3) ||
                 (wsb && hipMalloc(&ws, wsb)) || hipHostMalloc((void**)&h1, n * 8, hipHostMallocDefault) || hipHostMalloc((void**)&h2, n * 8, hipHostMallocDefault) ||
                 hipHostMalloc((void**)&himg, n * 3, hipHostMallocDefault) || hipHostMalloc((void**)&hout, n, hipHostMallocDefault)) {
-                fprintf(stderr, "consistencyChecker: out of memory\n"); release(); return 1; }
+                err = "consistencyChecker: out of memory\n"; release(); return 1; }
         }
         int w, h, ch;
-        if (fav_read_flo_into_host(a[0].c_str(), h1, n * 2, &w, &h)) return fail(a[0].c_str());
-        if (fav_read_flo_into_host(a[1].c_str(), h2, n * 2, &w, &h)) return fail(a[1].c_str());
-        if (w != W || h != H) { fprintf(stderr, "consistencyChecker: flow sizes differ\n"); return 1; }                  // :144-145
+        if (fav_read_flo_into_host(a[0].c_str(), h1, n * 2, &w, &h)) return failf(a[0].c_str());
+        if (fav_read_flo_into_host(a[1].c_str(), h2, n * 2, &w, &h)) return failf(a[1].c_str());
+        if (w != W || h != H) { err = "consistencyChecker: flow sizes differ\n"; return 1; }                  // :144-145
         const bool img = a.size() >= 4;
         if (img) {
-            if (fav_read_pnm_into_host(a[3].c_str(), himg, n * 3, &w, &h, &ch)) return fail(a[3].c_str());
-            if (w != W || h != H || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); return 1; }
+            if (fav_read_pnm_into_host(a[3].c_str(), himg, n * 3, &w, &h, &ch)) return failf(a[3].c_str());
+            if (w != W || h != H || ch != 3) { err = "consistencyChecker: image must be a P6 of the flow's size\n"; return 1; }
         }
         hipMemcpyAsync(d1, h1, n * 8, hipMemcpyHostToDevice, nullptr);
         hipMemcpyAsync(d2, h2, n * 8, hipMemcpyHostToDevice, nullptr);
         if (img) hipMemcpyAsync(dimg, himg, n * 3, hipMemcpyHostToDevice, nullptr);
-        if (fav_consistency_u8(d1, d2, img ? dimg : nullptr, dout, W, H, ws, wsb, nullptr)) return fail("fav_consistency_u8");
+        if (fav_consistency_u8(d1, d2, img ? dimg : nullptr, dout, W, H, ws, wsb, nullptr)) return failf("fav_consistency_u8");
         if (hipMemcpyAsync(hout, dout, n, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
-            fprintf(stderr, "consistencyChecker: device error\n"); return 1; }
-        if (fav_write_pgm_host(a[2].c_str(), hout, W, H)) return fail(a[2].c_str());
+            err = "consistencyChecker: device error\n"; return 1; }
+        if (fav_write_pgm_host(a[2].c_str(), hout, W, H)) return failf(a[2].c_str());
         return 0;
     }
 };
@@ -104,23 +130,206 @@ int batch_main(const char* list)
         while (is >> tok) a.push_back(tok);
         if (a.empty() || a[0][0] == '#') continue;
         if (a.size() < 3 || a.size() > 4) { fprintf(stderr, "consistencyChecker: %s:%d: expected <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n", list, lineno); rc = 2; break; }
-        if ((rc = b.run(a)) != 0) break;                          // as a sequence of single calls under `set -e`: stop at the first failure
+        if ((rc = b.run(a)) != 0) { fputs(b.err.c_str(), stderr); break; }      // as a sequence of single calls under `set -e`: stop at the first failure
         printf("%s\n", a[2].c_str()); fflush(stdout);
     }
     if (f != stdin) fclose(f);
     b.release();
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// resident helper (see the header): socket, protocol, client and server sides
+// ------------------------------------------------------------------------------------------------------------------------------
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int gpu_index() { const char* g = getenv("FAV_GPU"); return g ? atoi(g) : 0; }
+
+// the socket's directory: created 0700, and only trusted when it is a directory of ours that nobody else can enter
+bool socket_paths(std::string& dir, std::string& sock, std::string& lock)
+{
+    const char* x = getenv("XDG_RUNTIME_DIR");
+    char buf[256];
+    if (x && *x) snprintf(buf, sizeof buf, "%s/fav-cc", x);
+    else snprintf(buf, sizeof buf, "/tmp/fav-cc-%u", (unsigned)getuid());
+    dir = buf;
+    if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return false;
+    snprintf(buf, sizeof buf, "/gpu%d.sock", gpu_index()); sock = dir + buf;
+    snprintf(buf, sizeof buf, "/gpu%d.lock", gpu_index()); lock = dir + buf;
+    return sock.size() < sizeof(((sockaddr_un*)nullptr)->sun_path);
+}
+
+bool write_all(int fd, const void* p, size_t n)
+{
+    const char* c = static_cast<const char*>(p);
+    while (n) { const ssize_t k = send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
+    return true;
+}
+bool read_all(int fd, void* p, size_t n)
+{
+    char* c = static_cast<char*>(p);
+    while (n) { const ssize_t k = recv(fd, c, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
+    return true;
+}
+constexpr uint32_t CC_MAGIC = 0x31434346u;      // "FCC1"
+
+int connect_helper(const std::string& sock)
+{
+    const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    if (fd < 0) return -1;
+    sockaddr_un sa{}; sa.sun_family = AF_UNIX; strncpy(sa.sun_path, sock.c_str(), sizeof(sa.sun_path) - 1);
+    if (connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof sa) != 0) { close(fd); return -1; }
+    return fd;
+}
+
+// client: 0 = served (status in *rc), -1 = no answer (the caller computes in-process)
+int ask_helper(int fd, const std::vector<std::string>& a, int* rc)
+{
+    uint32_t hd[2] = {CC_MAGIC, (uint32_t)a.size()};
+    if (!write_all(fd, hd, sizeof hd)) return -1;
+    for (const std::string& s : a) { const uint32_t n = (uint32_t)s.size(); if (!write_all(fd, &n, 4) || !write_all(fd, s.data(), n)) return -1; }
+    int32_t status; uint32_t mlen;
+    if (!read_all(fd, &status, 4) || !read_all(fd, &mlen, 4) || mlen > (1u << 20)) return -1;
+    std::string msg(mlen, '\0');
+    if (mlen && !read_all(fd, &msg[0], mlen)) return -1;
+    if (!msg.empty()) fputs(msg.c_str(), stderr);
+    *rc = status;
+    return 0;
+}
+
+volatile sig_atomic_t g_stop = 0;
+void on_term(int) { g_stop = 1; }
+
+// server: never returns.  Detached from the caller (own session, no inherited descriptors, cwd /); one request at a time
+// `ready_fd`: the write end of a pipe the starting call waits on -- one byte when the helper listens, end-of-file when it gave up
+[[noreturn]] void serve(const std::string& sock, const std::string& lock, int ready_fd)
+{
+    if (setsid() < 0) _exit(0);
+    const int nul = open("/dev/null", O_RDWR);
+    if (nul >= 0) { dup2(nul, 0); dup2(nul, 1); dup2(nul, 2); if (nul > 2 && nul != ready_fd) close(nul); }
+    (void)chdir("/");
+    for (int fd = 3; fd < 256; ++fd) if (fd != ready_fd) close(fd);
+    // one helper per GPU: the lock is held for the helper's lifetime (a second one, started by a concurrent first call, leaves at once)
+    const int lfd = open(lock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    if (lfd < 0 || flock(lfd, LOCK_EX | LOCK_NB) != 0) { const char r = 'L'; (void)write(ready_fd, &r, 1); _exit(0); }      // 'L': somebody else is (becoming) the helper
+    { char pidbuf[32]; const int n = snprintf(pidbuf, sizeof pidbuf, "%d\n", (int)getpid()); (void)ftruncate(lfd, 0); (void)pwrite(lfd, pidbuf, (size_t)n, 0); }      // (for `kill $(cat gpu0.lock)`)
+    unlink(sock.c_str());                                          // (a dead helper's socket: nobody listens, the lock was free)
+    const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    sockaddr_un sa{}; sa.sun_family = AF_UNIX; strncpy(sa.sun_path, sock.c_str(), sizeof(sa.sun_path) - 1);
+    // the GPU context first, the socket after it: a caller that can connect finds a helper that can compute
+    if (ls < 0 || fav_device_count() <= 0 || hipSetDevice(gpu_index()) != hipSuccess || hipFree(nullptr) != hipSuccess) _exit(0);
+    const mode_t um = umask(0177);
+    const bool bound = bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof sa) == 0 && listen(ls, 16) == 0;
+    umask(um);
+    if (!bound) _exit(0);
+    { const char r = 'R'; (void)write(ready_fd, &r, 1); close(ready_fd); }
+    struct sigaction act{}; act.sa_handler = on_term; sigaction(SIGTERM, &act, nullptr); sigaction(SIGINT, &act, nullptr); sigaction(SIGHUP, &act, nullptr);
+    signal(SIGPIPE, SIG_IGN);
+    const char* idle_s = getenv("FAV_CC_IDLE_S");
+    const int idle_ms = (idle_s && atoi(idle_s) > 0 ? atoi(idle_s) : 120) * 1000;
+    Batch b;
+    while (!g_stop) {
+        pollfd pf{ls, POLLIN, 0};
+        const int pr = poll(&pf, 1, idle_ms);
+        if (pr == 0) break;                                        // idle: leave
+        if (pr < 0) { if (errno == EINTR) continue; break; }
+        const int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+        if (c < 0) continue;
+        timeval tv{10, 0}; setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);       // (a caller that dies mid-request does not hang the helper)
+        uint32_t hd[2];
+        std::vector<std::string> a;
+        bool ok = read_all(c, hd, sizeof hd) && hd[0] == CC_MAGIC && hd[1] >= 3 && hd[1] <= 4;
+        for (uint32_t i = 0; ok && i < hd[1]; ++i) {
+            uint32_t n;
+            ok = read_all(c, &n, 4) && n > 0 && n < 65536;
+            if (ok) { std::string s(n, '\0'); ok = read_all(c, &s[0], n) && s[0] == '/'; a.push_back(s); }
+        }
+        int32_t status = 2; std::string msg = "consistencyChecker: malformed request to the resident helper\n";
+        if (ok) { status = b.run(a); msg = b.err; }
+        const uint32_t mlen = (uint32_t)msg.size();
+        (void)(write_all(c, &status, 4) && write_all(c, &mlen, 4) && (mlen == 0 || write_all(c, msg.data(), mlen)));
+        close(c);
+    }
+    unlink(sock.c_str());
+    b.release();
+    _exit(0);
+}
+
+std::string absolute(const char* path)
+{
+    if (path[0] == '/') return path;
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof cwd)) return path;
+    return std::string(cwd) + "/" + path;
+}
+
+// the single call through the helper: 0 = done (exit status in *rc), -1 = not available (compute here)
+int via_helper(int argc, char** argv, int* rc)
+{
+    const char* off = getenv("FAV_CC_DAEMON");
+    if (off && strcmp(off, "0") == 0) return -1;
+    std::string dir, sock, lock;
+    if (!socket_paths(dir, sock, lock)) return -1;
+    std::vector<std::string> a;
+    for (int i = 1; i < argc && i <= 4; ++i) a.push_back(absolute(argv[i]));
+    int fd = connect_helper(sock);
+    if (fd < 0) {
+        // nobody there: start one and wait until it listens (its GPU context is what a call in this process would have paid for anyway)
+        fflush(stdout); fflush(stderr);
+        int pp[2];
+        if (pipe(pp) != 0) return -1;
+        const pid_t pid = fork();
+        if (pid < 0) { close(pp[0]); close(pp[1]); return -1; }
+        if (pid == 0) {
+            close(pp[0]);
+            const pid_t p2 = fork();                                // (double fork: the helper is nobody's zombie)
+            if (p2 != 0) _exit(0);
+            serve(sock, lock, pp[1]);
+        }
+        close(pp[1]);
+        int st; (void)waitpid(pid, &st, 0);
+        // 'R': it listens; 'L': another helper holds the lock (it listens already, or will in a moment); end-of-file: it gave up (no GPU)
+        pollfd pf{pp[0], POLLIN, 0};
+        char r = 0;
+        if (!(poll(&pf, 1, 15000) > 0 && read(pp[0], &r, 1) == 1)) r = 0;
+        close(pp[0]);
+        if (r == 0) return -1;
+        fd = connect_helper(sock);
+        if (fd < 0 && r == 'L') {      // the lock holder may still be creating its context
+            const double t0 = now_s();
+            while (fd < 0 && now_s() - t0 < 3.0) { usleep(5000); fd = connect_helper(sock); }
+        }
+        if (fd < 0) return -1;
+    }
+    const int r = ask_helper(fd, a, rc);
+    close(fd);
+    return r;
+}
 }  // namespace
 
 int main(int argc, char** argv)
 {
     if (argc == 3 && strcmp(argv[1], "-batch") == 0) return batch_main(argv[2]);
+    if (argc >= 4) {
+        int rc = 0;
+        const double t0 = now_s();
+        if (via_helper(argc, argv, &rc) == 0) {
+            if (rc == 0) printf("%s", argv[3]);      // :166
+            if (getenv("FAV_CC_TIMING")) fprintf(stderr, "consistencyChecker timing: through the resident helper %.1f ms\n", (now_s() - t0) * 1e3);
+            return rc;
+        }
+    }
     if (argc < 4) {
         fprintf(stderr, "usage: consistencyChecker <flow1.flo> <flow2.flo> <out.pgm> [<image.ppm>]\n"
                         "       consistencyChecker -batch <list.txt|->      (one such argument line per pair, one GPU context for all)\n");
         return 2;
     }
+    // (computing in this process: FAV_CC_DAEMON=0, or no helper could be reached)
+    const bool timing = getenv("FAV_CC_TIMING") != nullptr;
+    double tq = now_s();
+    auto lap = [&](const char* what) { if (timing) { const double t = now_s(); fprintf(stderr, "consistencyChecker timing: %-34s %8.2f ms\n", what, (t - tq) * 1e3); tq = t; } };
     float *f1 = nullptr, *f2 = nullptr;
     int w1, h1, w2, h2;
     if (fav_read_flo_host(argv[1], &f1, &w1, &h1)) return fail(argv[1]);
@@ -132,7 +341,9 @@ int main(int argc, char** argv)
         if (fav_read_pnm_host(argv[4], &img, &wi, &hi, &ch)) return fail(argv[4]);
         if (wi != w1 || hi != h1 || ch != 3) { fprintf(stderr, "consistencyChecker: image must be a P6 of the flow's size\n"); return 1; }
     }
+    lap("read the input files");
     if (fav_device_count() <= 0) return fail("device");
+    lap("hipInit + device enumeration");
     const char* g = getenv("FAV_GPU");
     if (hipSetDevice(g ? atoi(g) : 0) != hipSuccess) { fprintf(stderr, "consistencyChecker: cannot select GPU\n"); return 1; }
     const size_t n = (size_t)w1 * h1;
@@ -140,13 +351,19 @@ int main(int argc, char** argv)
     const size_t wsb = fav_consistency_workspace_bytes(w1, h1, img != nullptr);
     if (hipMalloc((void**)&d1, n * 8) || hipMalloc((void**)&d2, n * 8) || hipMalloc((void**)&dout, n) ||
         (img && hipMalloc((void**)&dimg, n * 3)) || (wsb && hipMalloc(&ws, wsb))) { fprintf(stderr, "consistencyChecker: hipMalloc failed\n"); return 1; }
+    lap("context + device buffers");
     hipMemcpy(d1, f1, n * 8, hipMemcpyHostToDevice);
     hipMemcpy(d2, f2, n * 8, hipMemcpyHostToDevice);
     if (img) hipMemcpy(dimg, img, n * 3, hipMemcpyHostToDevice);
+    lap("host -> device copies (pageable)");
     if (fav_consistency_u8(d1, d2, dimg, dout, w1, h1, ws, wsb, nullptr)) return fail("fav_consistency_u8");
+    if (timing) hipDeviceSynchronize();
+    lap("code object load + the mask's kernels");
     std::vector<uint8_t> out(n);
     if (hipMemcpy(out.data(), dout, n, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "consistencyChecker: device error\n"); return 1; }
+    lap("device -> host copy");
     if (fav_write_pgm_host(argv[3], out.data(), w1, h1)) return fail(argv[3]);
+    lap("write the .pgm");
     printf("%s", argv[3]);   // :166
     fav_free_host(f1); fav_free_host(f2); fav_free_host(img);
     hipFree(d1); hipFree(d2); hipFree(dimg); hipFree(dout); hipFree(ws);

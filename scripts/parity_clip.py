@@ -26,6 +26,7 @@ functions of the seeded clip:
                (the oracle's own free-running chain on the same clip, compared at those positions / frames)
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -173,6 +174,7 @@ def gpu_dump(fav, model_path, h, w, n_frames, path, seed=1000, pool=8, log=print
     st = fav.Stream(net, h, w)
     samples = np.zeros((n_frames, 3, SAMPLES), np.float32)
     mask_sums = np.zeros(n_frames, np.int64)
+    mask_sha = [""] * n_frames         # SHA-256 of every mask's H*W bytes: 300 whole masks (276 MB) do not fit gpurun_out, their digests do
     full = {}
     cps = {c if c > 0 else n_frames for c in CHECKPOINTS if c <= n_frames}
     for i in range(n_frames):
@@ -181,12 +183,14 @@ def gpu_dump(fav, model_path, h, w, n_frames, path, seed=1000, pool=8, log=print
             o, _ = st.first_frame(dfr[fi])
         else:
             o, _ = st.next_frame_flow(dfr[fi], dbw[bi], dfw[wi])
-            mask_sums[i] = int(st.last_mask().to(torch.int64).sum().item())
+            mk = st.last_mask().cpu().numpy()
+            mask_sums[i] = int(mk.astype(np.int64).sum())
+            mask_sha[i] = hashlib.sha256(np.ascontiguousarray(mk).tobytes()).hexdigest()
         samples[i] = o[:, tys, txs].cpu().numpy()
         if i + 1 in cps:
             full[f"full_{i + 1}"] = o.cpu().numpy()
     net.check()
-    np.savez(path, samples=samples, mask_sums=mask_sums, h=h, w=w, seed=seed, pool=pool, frames=n_frames, **full)
+    np.savez(path, samples=samples, mask_sums=mask_sums, mask_sha256=np.array(mask_sha), h=h, w=w, seed=seed, pool=pool, frames=n_frames, **full)
     log(f"wrote {path}: {n_frames} frames, {len(full)} whole frames")
 
 
@@ -211,6 +215,8 @@ def compare_dump(O, model_path, path, threads=None, log=print):
         else:
             mask = O.consistency(bw, fw)
             row["mask_byte_sum_equal"] = bool(int(mask.astype(np.int64).sum()) == int(d["mask_sums"][i]))
+            if "mask_sha256" in d.files:      # every byte of the mask, through its digest (dumps older than round 5 carry the byte sums only)
+                row["mask_bytes_equal"] = bool(hashlib.sha256(np.ascontiguousarray(mask).tobytes()).hexdigest() == str(d["mask_sha256"][i]))
             r = ref.next(_f01(frame), bw, mask.astype(np.float32) / np.float32(255))
         g = d["samples"][i]
         diff = np.abs(g - r[:, ys, xs])
@@ -227,9 +233,11 @@ def compare_dump(O, model_path, path, threads=None, log=print):
            "sampled_max_abs_worst": max(r["sampled_max_abs"] for r in rows), "sampled_max_abs_last": rows[-1]["sampled_max_abs"],
            "full_frames": {str(r["frame"]): {"max_abs": r["full_max_abs"], "psnr8_db": r["full_psnr8_db"]} for r in rows if "full_max_abs" in r},
            "mask_byte_sums_equal_on_all_frames": all(r.get("mask_byte_sum_equal", True) for r in rows),
+           "mask_bytes_equal_on_all_frames": (all(r["mask_bytes_equal"] for r in rows if "mask_bytes_equal" in r) if any("mask_bytes_equal" in r for r in rows) else None),
+           "mask_comparison": "SHA-256 of the H*W mask bytes of every frame (GPU side computed on the box, oracle side here): equal digests = byte-for-byte equal masks",
            "gate": "2e-4 de-processed / 50 dB (BASELINE.md section 4)"}
     out["within_gate"] = bool(out["sampled_max_abs_worst"] <= 2e-4 and all(v["max_abs"] <= 2e-4 and v["psnr8_db"] >= 50 for v in out["full_frames"].values())
-                              and out["mask_byte_sums_equal_on_all_frames"])
+                              and out["mask_byte_sums_equal_on_all_frames"] and out["mask_bytes_equal_on_all_frames"] is not False)
     return out
 
 

@@ -134,8 +134,8 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
                 dst = (6 * i + j) * VPOS + (kq * 16 + m2) * 4
                 V[dst: dst + 4] = o.astype(f)
         # matrix instructions: v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]
-        # and, in register r, D[4 (l >> 4) + r][l & 15].  The kernel passes the WEIGHTS as A (i = channel inside the 16-group) and the
-        # transformed input as B (j = tile): register r of lane l = tile l & 15, channel 4 (l >> 4) + r
+        # and, in register r, D[4 (l >> 4) + r][l & 15].  The kernel passes the TRANSFORMED INPUT as A (i = tile) and the weights as B
+        # (j = channel inside the 16-group; round 5 -- the other way round before): register r of lane l = tile 4 (l >> 4) + r, channel l & 15
         aA = lanes * 4                                                       # V[p][kq = lane >> 4][m = lane & 15]
         for w in range(4):
             for p in range(36):
@@ -146,19 +146,20 @@ def emulate_unit(x, wpk, bias, scale, shift, relu, oy0, ox0, f=np.float32):
                     for j in range(4):
                         a2 = Wf[:, j].reshape(4, 16)         # [k][channel i]   (lane = k * 16 + i)
                         b2 = Vf[:, j].reshape(4, 16)         # [k][tile j]
-                        D = (a2.T.astype(np.float64) @ b2.astype(np.float64)).astype(f)      # [channel][tile]
+                        D = (b2.T.astype(np.float64) @ a2.astype(np.float64)).astype(f)      # [tile][channel]
                         for r in range(4):
                             acc[w, p, nt, :, r] += D[4 * (lanes >> 4) + r, lanes & 15]
-    # output transform in the lane: register r of lane l = tile l & 15, channel 32 w + 16 nt + 4 (l >> 4) + r
+    # output transform in the lane: register r of lane l = tile (row g = l >> 4, column r), channel 32 w + 16 nt + (l & 15): the 16
+    # adjacent lanes of a group hold 16 consecutive channels of the same pixels -- 64 contiguous bytes per store request
     Y = np.zeros((16, 16, 128), f)
     for w in range(4):
         for nt in range(2):
             for lane in range(64):
-                tile, g = lane & 15, lane >> 4
+                cn, g = lane & 15, lane >> 4
                 for r in range(4):
                     M = acc[w, :, nt, lane, r].reshape(6, 6).astype(np.float64)
-                    co = 32 * w + 16 * nt + 4 * g + r
-                    Y[4 * (tile >> 2): 4 * (tile >> 2) + 4, 4 * (tile & 3): 4 * (tile & 3) + 4, co] = (AT @ M @ AT.T + bias[co]).astype(f)
+                    co = 32 * w + 16 * nt + cn
+                    Y[4 * g: 4 * g + 4, 4 * r: 4 * r + 4, co] = (AT @ M @ AT.T + bias[co]).astype(f)
     return Y
 
 

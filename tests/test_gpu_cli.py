@@ -28,7 +28,74 @@ def _write_clip(oracle, d, h, w, n, seed):
     return frames, bws, fws
 
 
-def test_consistency_checker_binary(oracle, favlib, tmp_path):
+def _stop_helper(run_dir):
+    """terminate the checker's resident helper whose socket lives under run_dir/fav-cc (its pid is in the lock file)"""
+    import signal, time
+    lock = os.path.join(run_dir, "fav-cc", "gpu0.lock")
+    if not os.path.exists(lock):
+        return None
+    try:
+        pid = int(open(lock).read().split()[0])
+    except (ValueError, IndexError):
+        return None
+    try:
+        os.kill(pid, signal.SIGTERM)
+    except ProcessLookupError:
+        return pid
+    for _ in range(200):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.02)
+    return pid
+
+
+def test_consistency_checker_resident_helper(oracle, favlib, tmp_path):
+    """A single call of the four-argument form costs a HIP start-up per process; makeOptFlow_deepflow.sh:59-60 makes two per frame.  The
+    first call leaves a resident helper behind (own session, socket in a 0700 directory), later calls hand it their argv: same bytes,
+    same exit codes, relative paths resolved against the CALLER's directory, sizes may change between calls; FAV_CC_DAEMON=0 computes
+    in the calling process as before; SIGTERM (or FAV_CC_IDLE_S seconds without a request) ends it and removes the socket."""
+    import time
+    run = tmp_path / "run"; run.mkdir(mode=0o700)
+    env = dict(os.environ, XDG_RUNTIME_DIR=str(run), FAV_CC_IDLE_S="60")
+    exe = os.path.join(BIN, "consistencyChecker")
+    cases = []
+    for k, (h, w) in enumerate([(90, 130), (90, 130), (72, 100)]):
+        bw = synth.backward_flow(h, w, 10 + k); fw = synth.forward_flow_from_backward(bw, 20 + k); img = synth.smooth_frame(h, w, 30 + k)
+        d = tmp_path / ("c%d" % k); d.mkdir()
+        oracle.write_flo(str(d / "a.flo"), bw); oracle.write_flo(str(d / "b.flo"), fw); oracle.write_pnm(str(d / "i.ppm"), img)
+        cases.append((d, h, w, bw, fw, img))
+    try:
+        times = []
+        for k, (d, h, w, bw, fw, img) in enumerate(cases):
+            for four in (False, True):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "a.flo", "b.flo", "o.pgm"] + (["i.ppm"] if four else []), capture_output=True, text=True, cwd=str(d), env=env)   # relative paths
+                times.append(time.perf_counter() - t0)
+                assert r.returncode == 0 and r.stdout == "o.pgm", (r.returncode, r.stdout, r.stderr)
+                want = oracle.consistency(bw, fw, img if four else None)
+                assert open(d / "o.pgm", "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + want.tobytes(), (k, four)
+        print("consistencyChecker wall time per call: first (starts the helper) %.3f s, then %s" % (times[0], " ".join("%.3f" % t for t in times[1:])))
+        assert os.path.exists(run / "fav-cc" / "gpu0.sock")
+        assert min(times[1:]) < times[0]                                 # later calls do not pay for a GPU context
+        # failures come back as the exit code and the message
+        r = subprocess.run([exe, "a.flo", "missing.flo", "o.pgm"], capture_output=True, text=True, cwd=str(cases[0][0]), env=env)
+        assert r.returncode != 0 and "missing.flo" in r.stderr and r.stdout == ""
+        # ... and the helper is still there afterwards; the in-process form gives the same bytes
+        d, h, w, bw, fw, img = cases[0]
+        r = subprocess.run([exe, "a.flo", "b.flo", "o2.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=dict(env, FAV_CC_DAEMON="0"))
+        assert r.returncode == 0 and open(d / "o2.pgm", "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw, img).tobytes()
+        r = subprocess.run([exe, "a.flo", "b.flo", "o3.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=env)
+        assert r.returncode == 0 and open(d / "o3.pgm", "rb").read() == open(d / "o2.pgm", "rb").read()
+    finally:
+        pid = _stop_helper(str(run))
+    assert pid is not None
+    assert not os.path.exists(run / "fav-cc" / "gpu0.sock")             # SIGTERM: the helper removes its socket
+
+
+def test_consistency_checker_binary(oracle, favlib, tmp_path, monkeypatch):
+    monkeypatch.setenv("FAV_CC_DAEMON", "0")                            # (the process-per-call form; the resident helper has its own test)
     h, w = 90, 130
     bw = synth.backward_flow(h, w, 1); fw = synth.forward_flow_from_backward(bw, 2); img = synth.smooth_frame(h, w, 3)
     a, b, i, o = (str(tmp_path / n) for n in ("a.flo", "b.flo", "i.ppm", "o.pgm"))
@@ -64,7 +131,8 @@ def test_fav_stylize_matches_oracle_loop(oracle, favlib, tmp_path, golden_dir, f
     for i in range(2, n + 1):     # makeOptFlow_deepflow.sh:59
         if not fused:
             subprocess.check_call([checker, str(tmp_path / "flow" / f"backward_{i}_{i-1}.flo"), str(tmp_path / "flow" / f"forward_{i-1}_{i}.flo"),
-                                   str(tmp_path / "flow" / f"reliable_{i}_{i-1}.pgm"), str(tmp_path / f"frame_{i:05d}.ppm")], stdout=subprocess.DEVNULL)
+                                   str(tmp_path / "flow" / f"reliable_{i}_{i-1}.pgm"), str(tmp_path / f"frame_{i:05d}.ppm")], stdout=subprocess.DEVNULL,
+                                  env=dict(os.environ, FAV_CC_DAEMON="0"))      # (no resident helper left behind by this test)
         masks.append(oracle.consistency(bws[i - 1], fws[i - 1], frames[i - 1]))
     cmd = [os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"),
            "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),

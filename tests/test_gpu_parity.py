@@ -267,7 +267,7 @@ def test_canonical_network_vs_oracle(favlib, oracle, cuda, canonical):
     ref = oracle.net_forward(_layers(canonical), x)
     got = net.forward(T(x, cuda)).cpu().numpy()
     err = np.abs(got - ref).max()
-    assert err <= 5e-2, err
+    assert err <= 1e-2, err                                       # (measured 2-3e-3 with F(4x4); BASELINE.md section 4 allows 5e-2)
     assert np.abs(ref).max() > 100 and np.abs(ref).std() > 20     # not saturated / not trivial
 
 
@@ -708,10 +708,47 @@ def test_config2_free_running_whole_clip_contractive_weights(favlib, oracle, cud
             json.dump(res, f, indent=1)
     print({k: v for k, v in res.items() if k != "per_frame"})
     assert res["frames_compared"] == 32
-    assert res["free_max_abs_worst"] <= 2e-4, [r["free_max_abs"] for r in res["per_frame"]]
-    assert res["free_psnr8_db_min"] >= 50.0, res["free_psnr8_db_min"]
+    # gates at what DESIGN.md states for the F(4x4) build (measured 7.2e-6 / 86.6 dB), not at BASELINE.md's 2e-4 / 50 dB ceiling
+    assert res["free_max_abs_worst"] <= 5e-5, [r["free_max_abs"] for r in res["per_frame"]]
+    assert res["free_psnr8_db_min"] >= 75.0, res["free_psnr8_db_min"]
     # the recurrent path is live: the prior moves the output by far more than the gate (a dead prior would make the gate vacuous)
     assert res["prior_influence_max_abs"] > 50 * 2e-4, res["prior_influence_max_abs"]
+
+
+def test_unit_gain_free_run_divergence_against_a_perturbed_oracle_control(favlib, oracle, cuda, canonical):
+    """The whole-clip free-running gate above runs on a contractive checkpoint (recurrent gain 0.05): errors in the recurrent path --
+    warp, prior, mask, the F(4x4) error fed back through the prior -- are damped 20x there.  On the UNIT-gain random-init checkpoint
+    frame -> frame is an expanding map (any perturbation grows ~3x per frame), so an absolute gate is meaningless -- but a RELATIVE one is
+    not: the oracle chain is run twice, clean and with its first output perturbed by Gaussian noise of the GPU's own first-frame rms
+    error; the GPU chain must not diverge from the clean oracle chain faster than that control does (factor 10: the control's noise
+    is white, the GPU's error is not).  A regression in the recurrent path (a wrong prior, a mask off by a pixel) shows as a
+    divergence orders of magnitude above the control from the first recurrent frame on."""
+    h, w, n = 256, 256, 6
+    layers = _layers(canonical)
+    frames, bws, fws = _clip(h, w, n, 95)
+    masks = [None] + [oracle.consistency(bws[i], fws[i]) for i in range(1, n)]
+    net = favlib.Net(canonical, 0)
+    st = favlib.Stream(net, h, w)
+    gpu = [st.first_frame(T(frames[0], cuda))[0].cpu().numpy()]
+    for i in range(1, n):
+        gpu.append(st.next_frame_cert(T(frames[i], cuda), T(bws[i], cuda), T(masks[i], cuda))[0].cpu().numpy())
+    net.check()
+    clean, ctrl = oracle.Stylizer(layers), oracle.Stylizer(layers)
+    a0 = clean.first(_f01(frames[0])); ctrl.first(_f01(frames[0]))
+    rms0 = float(np.sqrt(np.mean((gpu[0] - a0).astype(np.float64) ** 2)))
+    assert 0 < rms0 < 1e-5, rms0
+    ctrl.last = (a0 + np.random.default_rng(7).standard_normal(a0.shape).astype(np.float32) * np.float32(rms0)).astype(np.float32)
+    rows = []
+    for i in range(1, n):
+        c01 = masks[i].astype(np.float32) / np.float32(255)
+        a = clean.next(_f01(frames[i]), bws[i], c01); b = ctrl.next(_f01(frames[i]), bws[i], c01)
+        dg = float(np.sqrt(np.mean((gpu[i] - a).astype(np.float64) ** 2))); dc = float(np.sqrt(np.mean((b - a).astype(np.float64) ** 2)))
+        rows.append((i + 1, dg, dc))
+    print("unit-gain free run, rms divergence from the clean oracle chain (frame, GPU, perturbed-oracle control): " +
+          "  ".join("%d: %.2e / %.2e" % r for r in rows))
+    for (fr, dg, dc) in rows:
+        assert dg <= 10.0 * dc + 1e-6, (fr, dg, dc)
+    assert rows[-1][2] > rows[0][2]                 # the map really expands: the control's divergence grows over the clip
 
 
 def test_canonical_1280x720_recurrent_step_vs_oracle(favlib, oracle, cuda, canonical, poison):
@@ -738,8 +775,10 @@ def test_canonical_1280x720_recurrent_step_vs_oracle(favlib, oracle, cuda, canon
         ref.last = o0.cpu().numpy()                 # teacher-forced: the step under test is the recurrent one
         r1 = ref.next(_f01(frames[1]), bws[1], mask.astype(np.float32) / np.float32(255))
         err = float(np.abs(o1.cpu().numpy() - r1).max())
-        assert err <= 2e-4, err
-        assert psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1)) >= 50.0
+        ps = psnr8(u1.cpu().numpy(), oracle.to_u8_hwc(r1))
+        print("1280x720 recurrent step: max-abs %.3e (de-processed), 8-bit PSNR %.1f dB" % (err, ps))
+        assert err <= 5e-5, err                     # (measured 9.0e-6 / 85.2 dB with F(4x4), 4.6e-6 / 87.8 dB with F(2x2); BASELINE.md's ceiling: 2e-4 / 50 dB)
+        assert ps >= 75.0, ps
         assert np.abs(r1).std() > 0.05              # not a saturated / trivial frame
     finally:
         oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
@@ -1115,6 +1154,36 @@ def test_layers_with_more_filters_one_at_a_time(favlib, oracle, cuda, tmp_path, 
     err = np.abs(got - ref).max()
     assert err <= 2e-2, err
     assert np.abs(ref).std() > 5
+
+
+def _stress_cases():
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import wino4_stress
+    return [c[0] for c in wino4_stress.CASES]
+
+
+@pytest.mark.parametrize("case", _stress_cases())
+def test_f4x4_under_stress(favlib, oracle, cuda, tmp_path, case):
+    """The F(4x4,3x3) layers outside the comfort zone of rounds 2-4 (N(0, sqrt(2 / fan-in)) weights, 128 input channels, N(0, 60)
+    inputs): 1 % weight outliers at 20 sigma, InstanceNorm gammas up to 8, inputs at std 600, 64 and 256 input channels
+    (scripts/wino4_stress.py builds the checkpoints; run as a script it reports F(4x4) / F(2x2) / direct side by side ->
+    profiles/*wino4_stress*).  Every case stays inside BASELINE.md's 5e-2 (150*tanh space) with a margin of 5."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import wino4_stress
+    p = str(tmp_path / "stress.t7")
+    x = wino4_stress.write_case(p, case)
+    layers = _layers(p)
+    ref = oracle.net_forward(layers, x)
+    net = favlib.Net(p, 0)
+    net.profile_enable(True)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    ids = [kid for (ms, n, macs, kid) in net.profile_read()]
+    net.check()
+    assert any(k in (728, 729, 856) for k in ids), ids          # at least one layer ran on the F(4x4) kernel
+    err = np.abs(got - ref).max()
+    print("F(4x4) stress %-32s max-abs %.3e (150*tanh space)" % (case, err))
+    assert err <= 1e-2, err
+    assert np.abs(ref).std() > 20 and (np.abs(ref) > 149.0).mean() < 0.01
 
 
 def _seq_sum(x):
