@@ -375,15 +375,19 @@ def hbm_kernel_block(dev):
     # this same command (kernel-trace durations + FETCH_SIZE / WRITE_SIZE of separate --pmc passes)
     try:
         import csv
-        ks = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03n_kernel_stats.csv")))}
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03n_pmc_hbm.json")))
+        # which committed summaries: profiles/CURRENT_PROFILE.json names the round's rocprofv3 kernel statistics and PMC summary of this
+        # command (written by hand next to the files it names when a round's final profile is committed)
+        cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT_PROFILE.json")))
+        ks = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", cur["kernel_stats"])))}
+        pm = json.load(open(os.path.join(ROOT, "profiles", cur["pmc_summary"])))
         for name, alg in (("prep_input_kernel", (3 + 8 + 4 + 12) * px + (H + 80) * (W + 80) * 32), ("min_filter_kernel<2>", 16 * px + 5 * px)):
             us = [v for k, v in ks.items() if name in k][0]
             c = [v for k, v in pm.items() if name in k][0]
-            res[name + " (from profiles/r03n_*)"] = {"algorithmic_bytes": int(alg), "counter_bytes": int((c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024),
-                                                     "us_per_launch": round(us, 2), "gb_per_s": round(alg / us / 1e3, 1), "frac_of_8tb_s": round(alg / us / 1e3 / 8000.0, 4)}
-    except Exception:
-        pass
+            res[name + " (from profiles/%s, %s)" % (cur["kernel_stats"], cur["pmc_summary"])] = {
+                "algorithmic_bytes": int(alg), "counter_bytes": int((c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024),
+                "us_per_launch": round(us, 2), "gb_per_s": round(alg / us / 1e3, 1), "frac_of_8tb_s": round(alg / us / 1e3 / 8000.0, 4)}
+    except Exception as e:
+        res["fused_kernels_from_profiles"] = {"error": repr(e)[:200]}
     res["note"] = ("back-to-back launches timed with events on the launching stream (kernel boundaries included); these kernels move 16-60 MB, i.e. 2-8 us at "
                    "8 TB/s: they run in the launch-latency regime.  prep_input_kernel (A2+A6+A7+pad fused, ~60 MB algorithmic): profiles/*_kernel_stats.csv")
     return res
