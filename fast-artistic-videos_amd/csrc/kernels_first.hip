@@ -15,6 +15,7 @@
 // halo travels through registers while this one is computed.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "fav_internal.h"
 #include "first_pack.h"
@@ -46,6 +47,7 @@ struct FirstArgs {
     // keeps ONE group's transformed weights in LDS and walks the tiles (gridDim.x % groups == 0); COUTP = the channel pitch of partials;
     // wpk holds one packed block (conv_first2d_pack) per group
     int COUTP, groups;
+    long long* dbg = nullptr;       // make DIAG=1 + FAV_FIRST_DBG=n: in-kernel timeline of the n-th launch (accumulated wall-clock ticks per phase and block)
 };
 
 __device__ __forceinline__ float2 merge_rows(const float2* st, const int* wn, int c, int* n_out)
@@ -338,9 +340,17 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
     const float* const b_hi = b_lo + hi_words;                               // positions 8..15 (their offsets would not fit a DS immediate)
     __syncthreads();
 
+#ifdef FAV_DIAG
+    long long dt_[5] = {0, 0, 0, 0, 0}, tq_ = 0; int ntl_ = 0;
+#define G_DBG(i_) { if (p.dbg && t == 0) { const long long n_ = wall_clock64(); dt_[i_] += n_ - tq_; tq_ = n_; } }
+    if (p.dbg && t == 0) tq_ = wall_clock64();
+#else
+#define G_DBG(i_)
+#endif
     for (; tile < ntiles; tile += tstep) {
         const int nxt = tile + tstep;
         if (nxt < ntiles) G_LOAD_HALO(nxt);
+        G_DBG(0);      /* issue of the next halo's loads (+ the previous tile's last barrier) */
         v4f acc[16][2];
 #pragma unroll
         for (int ps = 0; ps < 16; ++ps)
@@ -386,8 +396,10 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
 #undef G_READ_R
 #undef G_READ_B
 #undef G_FENCE
+        G_DBG(1);      /* the quads: matrix instructions + patch transforms */
         __syncthreads();                    // every wave is done with the halo
         if (nxt < ntiles) G_STORE_HALO();
+        G_DBG(2);      /* barrier + next halo into LDS */
 
         // ---- output transform (A^T M A, in registers) + epilogue.  Register r of an accumulator = tile column 4 g + r, lane & 15 =
         // output channel inside the half nt
@@ -424,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
                     }
             }
         }
+        G_DBG(3);      /* output transform + stores */
         if (p.partials != nullptr) {
             float2* st = reinterpret_cast<float2*>(red);          // [8 waves][32]
             int* wn = reinterpret_cast<int*>(red + 8 * 64);         // [8]
@@ -457,7 +470,15 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
             }
         }
         __syncthreads();            // the halo of the next tile is complete; red scratch free again
+        G_DBG(4);      /* statistics + their two barriers */
+#ifdef FAV_DIAG
+        ++ntl_;
+#endif
     }
+#ifdef FAV_DIAG
+    if (p.dbg && t == 0) { for (int i = 0; i < 5; ++i) p.dbg[blockIdx.x * 8 + i] = dt_[i]; p.dbg[blockIdx.x * 8 + 5] = ntl_; }
+#endif
+#undef G_DBG
 #undef G_LOAD_HALO
 #undef G_STORE_HALO
 }
@@ -479,9 +500,28 @@ int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
     int grid = std::max(1, nblocks[dv] - reserve_cus);
     grid = std::min(grid, tiles * ngrp);
     if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block keeps one group's weights
+#ifdef FAV_DIAG
+    static int dbg_n = getenv("FAV_FIRST_DBG") ? atoi(getenv("FAV_FIRST_DBG")) : 0;
+    static long long* dbuf = nullptr;
+    const bool dbg = dbg_n > 0 && --dbg_n == 0;
+    FirstArgs ad = a;
+    if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 1024 * 8 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 1024 * 8 * 8, st)); ad.dbg = dbuf; }
+    hipLaunchKernelGGL((conv_first2d_kernel<CR, WIDE>), dim3(grid), dim3(512), lds, st, ad);
+    FAV_LAUNCH_CHECK("conv_first2d_kernel");
+    if (dbg) {
+        std::vector<long long> hb((size_t)1024 * 8);
+        FAV_HIP(hipStreamSynchronize(st)); FAV_HIP(hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost));
+        double sum[5] = {0, 0, 0, 0, 0}, nt = 0;
+        for (int b = 0; b < grid; ++b) { for (int i = 0; i < 5; ++i) sum[i] += hb[b * 8 + i] * 0.01; nt += hb[b * 8 + 5]; }
+        fprintf(stderr, "FIRSTDBG grid=%d tiles=%.0f  per tile (us): halo request %.2f  quads %.2f  barrier + halo to LDS %.2f  transform + stores %.2f  statistics %.2f\n",
+                grid, nt, sum[0] / nt, sum[1] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt);
+    }
+    return FAV_OK;
+#else
     hipLaunchKernelGGL((conv_first2d_kernel<CR, WIDE>), dim3(grid), dim3(512), lds, st, a);
     FAV_LAUNCH_CHECK("conv_first2d_kernel");
     return FAV_OK;
+#endif
 }
 
 }  // namespace
@@ -518,7 +558,7 @@ int launch_conv_first2d(const ConvLaunch& c, int cin_real, const float* wpk, int
     a.in = c.in; a.wpk = wpk; a.bias = c.bias; a.out = c.out; a.partials = reinterpret_cast<float2*>(c.partials); a.counts = counts;
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.COUT = c.COUT; a.pad = c.pad; a.OH = c.OH; a.OW = c.OW;
     a.tiles_x = (c.OW + G_TW - 1) / G_TW; a.tiles_y = (c.OH + G_TH - 1) / G_TH;
-    a.COUTP = c.COUTp; a.groups = c.COUTp / 32;
+    a.COUTP = c.COUTp; a.groups = c.COUTp / 32; a.dbg = nullptr;
     if (a.groups > 1) return cin_real == 7 ? launch_first2d_t<7, true>(a, c.reserve_cus, st) : launch_first2d_t<3, true>(a, c.reserve_cus, st);
     return cin_real == 7 ? launch_first2d_t<7>(a, c.reserve_cus, st) : launch_first2d_t<3>(a, c.reserve_cus, st);
 }
