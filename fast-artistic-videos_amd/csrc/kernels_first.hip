@@ -483,6 +483,12 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
 #undef G_STORE_HALO
 }
 
+// (Measured and removed in round 5, profiles/r6p_first_layer_subblocks_ab.log, r6q_*: the block's eight waves as two independent halves
+//  of four -- own 8 x 32 tiles, own halo buffers, a counter in LDS as their barrier, position 15's weights from global memory to make
+//  room for the second halo -- so that one half's halo load, epilogue and statistics run under the other's matrix instructions.  Correct
+//  (48 network tests), and 198-200 us against 190-192 for this kernel, whatever the start offset between the halves: the quads need BOTH
+//  waves of a SIMD to keep the matrix pipe busy (a wave's operands come out of an LDS read -> row / column combination -> MFMA chain), so
+//  a half that is alone in its quads runs at little more than half rate and the overlap buys nothing; the halo load it exposes costs 8 us.)
 template <int CR, bool WIDE = false>
 int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
 {
