@@ -91,7 +91,15 @@ struct Affine {            // pending per-channel transform t(x) = relu?(x*scale
     const float* scale1 = nullptr; const float* shift1 = nullptr; int relu1 = 0;
     const float* scale2 = nullptr; const float* shift2 = nullptr; int relu2 = 0;
     int stages = 0;
+    // Round 5: stage 1 as an InstanceNorm whose statistics are still ACCUMULATORS (stat_acc.h): the producing convolution added every
+    // work unit's exact fixed-point (sum, sum of squares) to them with integer atomics, the CONSUMER forms scale / shift in its
+    // prologue (no in_finalize launch in between).  acc1 != null => scale1 / shift1 are null; only conv3_wino4_kernel<1> takes it
+    const long long* acc1 = nullptr; long long* acc1_zero = nullptr;      // this frame's accumulators | the other parity's (zeroed by the consumer for the next frame)
+    const float* gamma1 = nullptr; const float* beta1 = nullptr; float eps1 = 0.f; int count1 = 0;
 };
+// accumulator layout of one InstanceNorm: [parity 2][copy STAT_COPIES][channel C][4 words: sum lo, sum hi, squares lo, squares hi]
+constexpr int STAT_COPIES = 8;       // one copy per XCD (blockIdx & 7): 8x shallower chains of atomics on one address
+inline size_t stat_acc_words(int C) { return (size_t)STAT_COPIES * C * 4; }      // per parity
 
 struct ConvLaunch {
     const float* in = nullptr;      // NHWC physical [IHp][IWp][CIN]
@@ -125,6 +133,8 @@ struct ConvLaunch {
     // join_skip = the skip tensor's pixel under y's pixel (0, 0) at the SAME row pitch IWp, join_out = where the joined tensor is
     // written (pitch IWp as well).  OWp > 0: row pitch of `out` in pixels (the output is laid out under a later join's skip tensor).
     const float* join_skip = nullptr; float* join_out = nullptr; int OWp = 0;
+    // F(4x4) Winograd kernel only: accumulators of the InstanceNorm that follows (this frame's parity) instead of `partials`, or null
+    long long* stat_acc = nullptr;
     // F(4x4) Winograd kernel only: meeting places of the two parts of a unit that a stream-K share boundary cuts (conv3_wino4_ksplit_bytes()
     // bytes: 256 boundaries x 2 parts x 16 x 16 pixels x 128 channels) and their arrival counters (256 ints, zero between launches);
     // null => whole units only
@@ -199,7 +209,8 @@ int launch_stats(const float* x, int M, int C, const Affine& t, float* partials,
 // (mean, M2, count) statistics of z ([res_add_stat_blocks(OH, OW)][C] float2 + counts) for an InstanceNorm that follows the join
 int launch_res_add(const float* y, const float* scale, const float* shift,
                    const float* skip, int SH, int SW, int shave, const Affine& skip_t,
-                   int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch = 0);
+                   int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch = 0, const Affine* branch_acc = nullptr);
+// (branch_acc: the branch's InstanceNorm as accumulators -- Affine::acc1 -- instead of scale / shift; plain joins only)
 inline int res_add_stat_blocks(int OH, int OW) { return OH * ((OW + 127) / 128); }
 // NCHW [C][H][W] -> NHWC [H+2p][W+2p][Cp] with reflection padding p and zero channels >= C
 int launch_nchw_to_nhwc_pad(const float* in, int C, int H, int W, int pad, int Cp, float* out, hipStream_t st);

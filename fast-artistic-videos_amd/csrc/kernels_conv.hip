@@ -2654,10 +2654,42 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* x, int M, int C
 // res_add_stats_kernel: the join feeds an InstanceNorm (directly or through a nearest upsample, which leaves mean and biased
 // variance unchanged: the R128 -> U2 -> IN tail of models_video.lua:94-98): one block = one row segment of up to 128 pixels, and
 // the same pass yields that norm's per-segment (mean, M2, count) partials instead of a second read-only pass over the joined tensor.
+// ACC (round 5): the branch's InstanceNorm arrives as accumulators (Affine::acc1, fav_internal.h) -- every block forms scale / shift
+// for all C channels in its prologue (the arithmetic of in_finalize_kernel on exact integer sums) and keeps them in LDS; the launch
+// uses at most 1024 blocks then (32 KB of accumulator words per block)
+template <bool ACC>
 __global__ __launch_bounds__(256) void res_add_kernel(const float* y, const float* scale, const float* shift,
                                                       const float* skip, int SW, int shave, const Affine sa,
-                                                      int OH, int OW, int C, float* z)
+                                                      int OH, int OW, int C, float* z, const Affine br)
 {
+    __shared__ float ss[ACC ? 2048 : 4];       // [scale C | shift C], C <= 1024
+    if (ACC) {
+        for (int i = threadIdx.x; i < C; i += 256) {
+            long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+            for (int cp = 0; cp < STAT_COPIES; ++cp) {
+                const longlong2* a = reinterpret_cast<const longlong2*>(br.acc1 + ((size_t)cp * C + i) * 4);
+                const longlong2 lo = a[0], hi = a[1];
+                w0 += lo.x; w1 += lo.y; w2 += hi.x; w3 += hi.y;
+            }
+            const double s1 = ((double)w1 * 4294967296.0 + (double)w0) * (1.0 / 1099511627776.0);
+            const double s2 = ((double)w3 * 4294967296.0 + (double)w2) * (1.0 / 1099511627776.0);
+            const double mean = s1 / (double)br.count1;
+            double var = s2 / (double)br.count1 - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double sc = (double)br.gamma1[i] / sqrt(var + (double)br.eps1);
+            ss[i] = (float)sc; ss[C + i] = (float)((double)br.beta1[i] - mean * sc);
+            if (blockIdx.x == 0) {      // the other parity's accumulators: zero for the next frame
+#pragma unroll
+                for (int cp = 0; cp < STAT_COPIES; ++cp) {
+                    longlong2* zz = reinterpret_cast<longlong2*>(br.acc1_zero + ((size_t)cp * C + i) * 4);
+                    zz[0] = longlong2{0, 0}; zz[1] = longlong2{0, 0};
+                }
+            }
+        }
+        __syncthreads();
+        scale = ss; shift = ss + C;
+    }
     const int groups = C >> 2;
     const size_t total = (size_t)OH * OW * groups;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -2818,11 +2850,12 @@ int launch_stats(const float* x, int M, int C, const Affine& t, float* partials,
 }
 
 int launch_res_add(const float* y, const float* scale, const float* shift, const float* skip, int SH, int SW,
-                   int shave, const Affine& skip_t, int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch)
+                   int shave, const Affine& skip_t, int C, float* z, float* partials, int* counts, hipStream_t st, int skip_pitch, const Affine* branch_acc)
 {
     const int OH = SH - 2 * shave, OW = SW - 2 * shave;
     if (skip_pitch > 0) SW = skip_pitch;              // the kernels use SW as the skip's row pitch only
     FAV_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && OH > 0 && OW > 0, "res_add: bad shape (C=%d)", C);
+    FAV_REQUIRE(!(partials && branch_acc && branch_acc->acc1), "res_add: the statistics-taking join does not take an accumulator-form InstanceNorm");
     if (partials) {
         const dim3 grid(res_add_stat_blocks(OH, OW));
         float2* pp = reinterpret_cast<float2*>(partials);
@@ -2830,9 +2863,12 @@ int launch_res_add(const float* y, const float* scale, const float* shift, const
         else if (C == 64) hipLaunchKernelGGL(res_add_stats_kernel<8>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z, pp, counts);
         else hipLaunchKernelGGL(res_add_stats_kernel<0>, grid, dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t, OW, C, z, pp, counts);
     }
+    else if (branch_acc != nullptr && branch_acc->acc1 != nullptr)
+        hipLaunchKernelGGL(res_add_kernel<true>, dim3(std::min(1024, grid_for((size_t)OH * OW * (C / 4)))), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t,
+                           OH, OW, C, z, *branch_acc);
     else
-        hipLaunchKernelGGL(res_add_kernel, dim3(grid_for((size_t)OH * OW * (C / 4))), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t,
-                           OH, OW, C, z);
+        hipLaunchKernelGGL(res_add_kernel<false>, dim3(grid_for((size_t)OH * OW * (C / 4))), dim3(256), 0, st, y, scale, shift, skip, SW, shave, skip_t,
+                           OH, OW, C, z, Affine());
     FAV_LAUNCH_CHECK("res_add_kernel");
     return FAV_OK;
 }

@@ -82,6 +82,9 @@ struct Wino4Args {
     //  and every side-queue setting must cut the same units at the same slices, i.e. produce the same bits)
     int stream, shares; float* ks_ws; int* ks_cnt;
     long long* dbg;
+    // InstanceNorm statistics as accumulators (fav_internal.h, Affine::acc1): stat_acc = where THIS launch adds its units' (sum, sum of
+    // squares) -- instead of partials --; acc1 ... count1 = the pending InstanceNorm of the INPUT, formed in the prologue (MODE 1)
+    long long* stat_acc; const long long* acc1; long long* acc1_zero; const float* gamma1; const float* beta1; float eps1; int count1;
     // WIDE instantiations only (layers with more than 128 filters: the VR checkpoints "have more filters", README.md:141): the output
     // channels are computed in `groups` groups of 128, a work unit = (pixel unit, group); COUT = 128 * groups is the channel pitch of
     // out / partials, wpk holds one packed block (conv_wino4_pack of 128 filters) per group
@@ -152,7 +155,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
+    if (MODE == 1 && p.acc1 != nullptr) {
+        // the input's InstanceNorm from its accumulators (what in_finalize_kernel computes from partials: mean = S1 / M, biased variance =
+        // S2 / M - mean^2 in double): channel i sums the copies' words as integers -- exact, whatever order the atomics arrived in
+        for (int i = t; i < CIN; i += NT) {
+            long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+            for (int cp = 0; cp < STAT_COPIES; ++cp) {
+                const longlong2* a = reinterpret_cast<const longlong2*>(p.acc1 + ((size_t)cp * CIN + i) * 4);
+                const longlong2 lo = a[0], hi = a[1];
+                w0 += lo.x; w1 += lo.y; w2 += hi.x; w3 += hi.y;
+            }
+            const double s1 = ((double)w1 * 4294967296.0 + (double)w0) * (1.0 / 1099511627776.0);
+            const double s2 = ((double)w3 * 4294967296.0 + (double)w2) * (1.0 / 1099511627776.0);
+            const double mean = s1 / (double)p.count1;
+            double var = s2 / (double)p.count1 - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double sc = (double)p.gamma1[i] / sqrt(var + (double)p.eps1);
+            aff[i] = (float)sc; aff[CIN + i] = (float)((double)p.beta1[i] - mean * sc);
+            if (blockIdx.x == 0) {      // the other parity's accumulators were last read a frame ago: zero for the next frame
+#pragma unroll
+                for (int cp = 0; cp < STAT_COPIES; ++cp) {
+                    longlong2* z = reinterpret_cast<longlong2*>(p.acc1_zero + ((size_t)cp * CIN + i) * 4);
+                    z[0] = longlong2{0, 0}; z[1] = longlong2{0, 0};
+                }
+            }
+        }
+    } else if (AFF) for (int i = t; i < CIN; i += NT) { aff[i] = p.scale1[i]; aff[CIN + i] = p.shift1[i]; }
     const float lo1 = (MODE == 1 && p.relu1) ? 0.f : -INFINITY;
 
     // stage 1 (rows): item = (pixel pix = 18 ty + x of the 4 x 18 (tile row, raw column) grid, 16-byte channel chunk cq) -> raw rows
@@ -509,9 +538,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (p.partials != nullptr) {
             m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
-            if (g == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb] = make_float2(mu, m2);
+            if (p.stat_acc != nullptr) {
+                // the unit's (n mean, M2 + n mean^2) -- the terms in_finalize_kernel sums in double -- as 2^-40 fixed point in two words each
+                // (value * 2^40 = hi * 2^32 + lo, 0 <= lo < 2^32), added with integer atomics: the sum does not depend on the order.
+                // All four lanes of a channel hold (mu, m2): lane group g adds word g (0: sum lo, 1: sum hi, 2: squares lo, 3: squares hi)
+                const double nd = (double)nv, mud = (double)mu;
+                const double v = (g & 2) ? (double)m2 + nd * mud * mud : nd * mud;
+                const double tt = v * 1099511627776.0;
+                const double hi = floor(tt * (1.0 / 4294967296.0));
+                const long long word = (g & 1) ? (long long)hi : (long long)(tt - hi * 4294967296.0);
+                long long* const dst = p.stat_acc + ((size_t)(blockIdx.x & (STAT_COPIES - 1)) * (WIDE ? p.COUT : 128) + cb) * 4 + g;
+                __hip_atomic_fetch_add(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (g == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb] = make_float2(mu, m2);
         }
-        if (p.partials != nullptr && t == 0 && grp == 0) p.counts[u] = nv;
+        if (p.partials != nullptr && p.stat_acc == nullptr && t == 0 && grp == 0) p.counts[u] = nv;
         // (no barrier here: the last slice ended with one, the epilogue touches no LDS, the next prologue has its own)
         DBG_T();   /* epilogue end */
     };
@@ -640,6 +680,10 @@ int launch_conv3_wino4(const ConvLaunch& c, const float* wpk, int* counts, hipSt
     a.skip = c.join_skip; a.zout = c.join_out; a.OWp = c.OWp > 0 ? c.OWp : c.OW;
     a.ks_ws = c.ks_ws; a.ks_cnt = c.ks_cnt; a.stream = 0; a.shares = 1;
     a.COUT = c.COUT; a.groups = c.COUT / 128;
+    a.stat_acc = c.stat_acc; a.acc1 = c.pre.acc1; a.acc1_zero = c.pre.acc1_zero; a.gamma1 = c.pre.gamma1; a.beta1 = c.pre.beta1; a.eps1 = c.pre.eps1; a.count1 = c.pre.count1;
+    // (accumulator mode reuses the `partials != null` test of the epilogue: any non-null value selects the statistics, stat_acc the form)
+    if (c.stat_acc != nullptr && a.partials == nullptr) a.partials = reinterpret_cast<float2*>(c.stat_acc);
+    FAV_REQUIRE(c.pre.acc1 == nullptr || (c.join_skip == nullptr && c.pre.stages == 1 && c.pre.count1 > 0), "winograd F(4x4) conv: accumulator-form InstanceNorm on an unsupported input");
     if (c.join_skip != nullptr) {
         FAV_REQUIRE(c.join_out != nullptr && c.pre.stages == 1 && c.pre.relu1 == 0, "winograd F(4x4) conv: a pending residual join needs its output tensor and exactly one pending normalisation");
         FAV_REQUIRE(a.groups == 1, "winograd F(4x4) conv: a pending residual join is formed by 128-filter layers only");

@@ -36,7 +36,8 @@ namespace {
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wwino4 = nullptr; float* wup2 = nullptr; float* ws2w = nullptr; float* wfirst = nullptr; float* wfirst2d = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
-struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr; };
+struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr;
+               long long* acc = nullptr; };      // accumulator form of the statistics (fav_internal.h, Affine::acc1): [2 parities][stat_acc_words(C)], zero between frames
 
 struct Act {
     float* data = nullptr;
@@ -51,6 +52,7 @@ struct Act {
     // pending residual join (conv3_wino_kernel MODE 2): data = the branch's raw output, pre = its InstanceNorm, join_skip = the skip
     // tensor's pixel under data's pixel (0, 0) at the same pitch; join_out = where the consuming convolution writes the joined tensor
     const float* join_skip = nullptr; float* join_out = nullptr;
+    long long* acc = nullptr; long long* acc_other = nullptr;      // the producing convolution added its statistics to accumulators (this frame's parity | the other one)
     int H() const { return Hp << ups; }
     int W() const { return Wp << ups; }
     int P() const { return pitch ? pitch : Wp; }
@@ -88,11 +90,12 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 }
 
 // Tuning / ablation switches (not part of the product contract): read ONCE per process, never on the launch path.
-struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w, wino_f2; };
+struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w, wino_f2, no_acc_stats; };
 const Tuning& tuning()
 {
     static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr, getenv("FAV_NO_S2W") != nullptr,
-                             getenv("FAV_WINO_F2") != nullptr};      // FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (rounds 2-3) instead of F(4x4,3x3)
+                             getenv("FAV_WINO_F2") != nullptr,       // FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (rounds 2-3) instead of F(4x4,3x3)
+                             getenv("FAV_NO_ACC_STATS") != nullptr}; // FAV_NO_ACC_STATS: every InstanceNorm through partials + an in_finalize launch (rounds 1-4)
     return t;
 }
 
@@ -192,6 +195,8 @@ struct fav_net {
     unsigned* sk_err_host = nullptr; unsigned* sk_err_dev = nullptr;               // host-mapped: a hand-off wait timed out
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
+    int acc_parity = 0;             // which half of the InstanceNorm accumulators this forward adds to (the consumers zero the other half)
+    bool branch_tail_acc_ok = false; // set by L_RES around its branch: the join is a plain res_add launch, which takes the last InstanceNorm as accumulators
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_wino4 = false, use_up2 = false, use_first = false, use_first2d = false, use_s2w = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
     // activation arena: buffers are created on the first forward for a given (H, W) and reused after
@@ -213,7 +218,7 @@ struct fav_net {
         (void)hipSetDevice(device);
         (void)hipFree(stage);
         for (auto& c : convs) { (void)hipFree(c.wgt); (void)hipFree(c.bias); (void)hipFree(c.wfold); (void)hipFree(c.wc8d); (void)hipFree(c.wwino); (void)hipFree(c.wwino4); (void)hipFree(c.wup2); (void)hipFree(c.ws2w); (void)hipFree(c.wfirst); (void)hipFree(c.wfirst2d); (void)hipFree(c.wgt16); }
-        for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); }
+        for (auto& i : ins) { (void)hipFree(i.gamma); (void)hipFree(i.beta); (void)hipFree(i.scale); (void)hipFree(i.shift); (void)hipFree(i.acc); }
         for (void* sp : slabs) (void)hipFree(sp);
         (void)hipFree(ones); (void)hipFree(zeros); (void)hipFree(sk_ws); (void)hipFree(sk_flags); (void)hipFree(ks_ws); (void)hipFree(ks_cnt); if (sk_err_host) (void)hipHostFree(sk_err_host);
     }
@@ -223,6 +228,7 @@ struct fav_net {
     int timed_conv(const ConvLaunch& c, int conv_index, const Layer& L);
     int run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, float* out_raw);
     bool res_block_is_winograd(const Layer& R, size_t first_conv) const;
+    bool acc_stats_ok(const std::vector<Layer>& ls, size_t li) const;
     int forward_padded(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     int forward_padded_unordered(const float* in8, int H, int W, float* out_planar, float* out_raw, hipStream_t stream);
     void out_size(int H, int W, int* Ho, int* Wo) const;
@@ -328,6 +334,8 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             rc = dev_upload(L.beta, 0, &d.beta); if (rc) return rc;
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.scale), L.gamma.size() * sizeof(float)));
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
+            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.acc), 2 * stat_acc_words((int)L.gamma.size()) * sizeof(long long)));
+            FAV_HIP(hipMemset(d.acc, 0, 2 * stat_acc_words((int)L.gamma.size()) * sizeof(long long)));
         } else if (L.type == L_BN) {
             if ((int)L.mean.size() != chan_pitch) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan_pitch); return FAV_EFORMAT; }
             // evaluate mode: a fixed per-channel affine, folded into the consumer's load like InstanceNorm's
@@ -413,6 +421,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
 {
     const float* wfold = (c.final_mode && !tuning().no_fold && conv_fold_launchable(c.CIN, c.KH, c.pad, c.ups, c.IH, c.IW)) ? convs[conv_index].wfold : nullptr;
     const float* c8d_w = (use_c8 && !tuning().no_c8d && conv_c8d_eligible(c.CIN, L.cin, c.COUTp, L.k, c.stride, c.pre.stages, c.ups)) ? convs[conv_index].wc8d : nullptr;
+    if (c.pre.acc1 != nullptr && !(use_wino && use_wino4)) { set_error("internal: accumulator-form InstanceNorm in front of a kernel that cannot take it"); return FAV_EINVAL; }
     ConvLaunch cs = c;
     cs.reserve_cus = reserve_cus;
     cs.no_sk = shared_device ? 1 : 0;
@@ -452,6 +461,19 @@ static int count_convs(const std::vector<Layer>& ls)
     int n = 0;
     for (const Layer& l : ls) { if (l.type == L_CONV) ++n; else if (l.type == L_RES) n += count_convs(l.block); }
     return n;
+}
+
+// conv - InstanceNorm - ReLU - conv with both convolutions on the F(4x4) kernel (the first half of a residual branch,
+// models_video.lua:10-39): the first convolution adds its units' statistics to the InstanceNorm's accumulators and the second forms
+// scale / shift from them in its prologue -- no in_finalize launch between the two (round 5).  ls[li] = the first convolution;
+// conv_cursor already points at the second one's weights
+bool fav_net::acc_stats_ok(const std::vector<Layer>& ls, size_t li) const
+{
+    if (tuning().no_acc_stats || tuning().no_wino || precision != 0) return false;
+    if (li + 3 >= ls.size() || ls[li + 1].type != L_IN || ls[li + 2].type != L_RELU || ls[li + 3].type != L_CONV) return false;
+    if (conv_cursor >= convs.size()) return false;
+    const Layer& c2 = ls[li + 3]; const DevConvW& d2 = convs[conv_cursor];
+    return !c2.transposed && d2.wwino4 != nullptr && conv3_wino4_eligible(d2.cinp, c2.cout, d2.coutp, c2.k, c2.stride, c2.pad, 1, 0);
 }
 
 // conv - InstanceNorm - ReLU - conv - InstanceNorm (models_video.lua:10-39) with both convolutions on the Winograd kernel
@@ -531,8 +553,15 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             static const bool first_1d = getenv("FAV_FIRST_1D") != nullptr;      // (tuning: read once) the 1-D form of the first layer
             const bool first2d = first_wide || (first && d.wfirst2d != nullptr && !first_1d);
             nxt.mblocks = first ? (first2d ? conv_first2d_tiles(c.OH, c.OW) : conv_first_tiles(c.OH, c.OW)) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? (wino4 ? conv3_wino4_tiles(c.OH, c.OW) : conv3_wino_tiles(c.OH, c.OW)) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
-            if (want_stats) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
-            if (want_stats && (c8 || first || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
+            const bool acc = wino4 && want_stats && !pitched_out && cur.join_skip == nullptr &&
+                             (acc_stats_ok(ls, li) || (branch_tail_acc_ok && !top && li + 2 == ls.size() && !tuning().no_acc_stats && precision == 0));
+            if (acc) {
+                DevIN& din = ins[in_cursor];                   // the InstanceNorm that follows
+                nxt.acc = din.acc + (size_t)acc_parity * stat_acc_words(L.cout); nxt.acc_other = din.acc + (size_t)(acc_parity ^ 1) * stat_acc_words(L.cout);
+                c.stat_acc = nxt.acc;
+            }
+            if (want_stats && !acc) { rc = alloc((size_t)nxt.mblocks * d.coutp * 2 * sizeof(float), &nxt.partials); if (rc) return rc; }
+            if (want_stats && !acc && (c8 || first || h3 || s2 || wino || up2 || s2w)) { float* cp = nullptr; rc = alloc((size_t)nxt.mblocks * sizeof(int), &cp); if (rc) return rc; nxt.counts = reinterpret_cast<int*>(cp); }
             c.out = nxt.data; c.partials = nxt.partials;
             if (cur.join_skip != nullptr || pitched_out) {
                 if (!wino) { set_error("internal: a pending residual join next to a convolution that is not the Winograd kernel's"); return FAV_EINVAL; }
@@ -550,7 +579,12 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const int C = (int)L.gamma.size();
             const int M = cur.Hp * cur.Wp;
             if (cur.data == nullptr || C != cur.C) { set_error("network: misplaced InstanceNormalization"); return FAV_EUNSUPPORTED; }
-            if (cur.partials != nullptr && cur.pre.stages == 0) {
+            if (cur.acc != nullptr && cur.pre.stages == 0) {
+                // nothing is launched: the consuming convolution forms scale / shift from the accumulators (acc_stats_ok)
+                cur.pre = Affine();
+                cur.pre.acc1 = cur.acc; cur.pre.acc1_zero = cur.acc_other; cur.pre.gamma1 = d.gamma; cur.pre.beta1 = d.beta; cur.pre.eps1 = L.eps; cur.pre.count1 = M;
+                cur.pre.relu1 = 0; cur.pre.stages = 1;
+            } else if (cur.partials != nullptr && cur.pre.stages == 0) {
                 int rc = launch_in_finalize(cur.partials, cur.counts, cur.mblocks, M, CONV_BM, C, cur.ppitch, d.gamma, d.beta, L.eps,
                                             d.scale, d.shift, st);
                 if (rc) return rc;
@@ -567,7 +601,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 if (cur.pre.stages == 0) { cur.pre.scale1 = d.scale; cur.pre.shift1 = d.shift; cur.pre.relu1 = 0; cur.pre.stages = 1; }
                 else { cur.pre.scale2 = d.scale; cur.pre.shift2 = d.shift; cur.pre.relu2 = 0; cur.pre.stages = 2; }
             }
-            cur.partials = nullptr; cur.counts = nullptr;
+            cur.partials = nullptr; cur.counts = nullptr; cur.acc = nullptr; cur.acc_other = nullptr;
             break;
         }
         case L_BN: {
@@ -618,8 +652,16 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             const bool lazy_out = !no_lazy && (tuning().wino_f2 || want_lazy) && precision == 0 && li + 1 < ls.size() && ls[li + 1].type == L_RES && skip.pre.stages == 0 && skip.ups == 0 &&
                                   res_block_is_winograd(L, conv_cursor) && res_block_is_winograd(ls[li + 1], conv_cursor + (size_t)nconv);
             if (lazy_out) { lazy.active = true; lazy.pitch = skip.P(); lazy.rows = skip.Hp; lazy.shave = L.shave; lazy.conv_index = (int)conv_cursor + nconv - 1; }
+            // the join below is a plain res_add launch (no statistics of its own, not left pending): it can take the branch's last
+            // InstanceNorm as accumulators (round 5) -- no in_finalize launch between the branch's last convolution and the join
+            {
+                size_t nx0 = li + 1;
+                if (nx0 < ls.size() && ls[nx0].type == L_UP && ls[nx0].scale == 2) ++nx0;
+                const bool join_stats = nx0 < ls.size() && ls[nx0].type == L_IN;
+                branch_tail_acc_ok = !lazy_out && !join_stats;
+            }
             rc = run(L.block, br, false, nullptr, nullptr);
-            lazy.active = false;
+            lazy.active = false; branch_tail_acc_ok = false;
             if (rc) return rc;
             if (br.pre.stages != 1 || br.pre.relu1 || br.ups != 0) { set_error("network: residual branch must end in conv + InstanceNormalization"); return FAV_EUNSUPPORTED; }
             if (br.Hp != skip.Hp - 2 * L.shave || br.Wp != skip.Wp - 2 * L.shave || br.C != skip.C) {
@@ -645,7 +687,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                 float* cp = nullptr; rc = alloc((size_t)z.mblocks * sizeof(int), &cp); if (rc) return rc; z.counts = reinterpret_cast<int*>(cp);
             }
             rc = launch_res_add(br.data, br.pre.scale1, br.pre.shift1, skip.data, skip.Hp, skip.Wp, L.shave, skip.pre, z.C,
-                                z.data, z.partials, z.counts, st, skip.P());
+                                z.data, z.partials, z.counts, st, skip.P(), &br.pre);
             if (rc) return rc;
             cur = z;
             break;
@@ -738,6 +780,7 @@ int fav_net::forward_padded_unordered(const float* in8, int H, int W, float* out
         curH = H; curW = W;
     }
     st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0;
+    acc_parity ^= 1;
     Act cur;
     cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.C = 8;
     return run(exec, cur, true, out_planar, out_raw);

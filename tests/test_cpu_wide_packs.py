@@ -87,3 +87,32 @@ def test_first_layer_groups_of_32(packs, cin, cout, coutp):
         else:
             assert np.array_equal(blk, packs("f2", sub))
     assert whole.any()
+
+
+def test_fixed_point_words_of_the_accumulator_statistics():
+    """kernels_wino4.hip / res_add_kernel<true> (round 5): a unit's statistics term v (a double) is added to an InstanceNorm's accumulators as
+    2^-40 fixed point in TWO 64-bit words -- t = v * 2^40, hi = floor(t / 2^32), lo = trunc(t - hi * 2^32) in [0, 2^32) -- with integer atomics, and the
+    consumer reassembles (sum hi * 2^32 + sum lo) * 2^-40 in double.  Restated with Python integers: the split is exact up to the truncation
+    below 2^-40, the sums of the words do not depend on the order, negative terms work, and 4 000 terms of magnitude 1e10 stay far inside
+    64 bits per word."""
+    import math, random
+    rnd = random.Random(5)
+    def split(v):
+        t = v * 1099511627776.0                       # exact: a power of two
+        hi = math.floor(t * (1.0 / 4294967296.0))
+        lo = int(t - hi * 4294967296.0)               # the subtraction is exact (both multiples of t's ulp); the conversion truncates
+        return int(hi), lo
+    terms = [rnd.uniform(-1e10, 1e10) for _ in range(2000)] + [rnd.uniform(-1e-3, 1e-3) for _ in range(2000)] + [0.0, -0.0, 1e-13, -1e-13, 256.0 * 300.0]
+    his, los = zip(*(split(v) for v in terms))
+    for v, h, l in zip(terms, his, los):
+        assert 0 <= l < 2 ** 32
+        exact = int(math.floor(v * 2 ** 40)) if (v * 2 ** 40) == math.floor(v * 2 ** 40) else None
+        assert abs((h * 2 ** 32 + l) - v * 2 ** 40) < 1.0                 # truncation below one unit of 2^-40
+        if exact is not None:
+            assert h * 2 ** 32 + l == exact
+    H, L = sum(his), sum(los)
+    assert abs(H) < 2 ** 62 and 0 <= L < 2 ** 62
+    order = list(range(len(terms))); rnd.shuffle(order)
+    assert sum(his[i] for i in order) == H and sum(los[i] for i in order) == L      # integer sums: any order
+    total = (float(H) * 4294967296.0 + float(L)) * (1.0 / 1099511627776.0)
+    assert abs(total - math.fsum(terms)) <= len(terms) * 2.0 ** -40 + abs(math.fsum(terms)) * 2.0 ** -52

@@ -304,6 +304,44 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     assert e2 <= 5e-2 and np.abs(got - f2).max() <= 2e-2 and not np.array_equal(got, f2)
 
 
+def test_accumulator_statistics_match_the_partials_form(favlib, oracle, cuda, canonical, tmp_path):
+    """Round 5: nine of the sixteen InstanceNorms of the canonical network (conv -> IN -> ReLU -> conv inside the residual branches, and the
+    branch's last IN in front of a plain join) take their statistics through ACCUMULATORS -- every work unit of the producing F(4x4)
+    launch adds its exact 2^-40 fixed-point (sum, sum of squares) with 64-bit integer atomics, the consumer forms scale / shift in its
+    prologue, no in_finalize launch in between (kernels_wino4.hip, Affine::acc1).  Integer addition commutes: the result must not depend
+    on the order the atomics arrive in -- the same bits from run to run -- and must agree with the partials + in_finalize form
+    (FAV_NO_ACC_STATS=1, a child process: the switch is read once) to rounding.  Two frame sizes, so that the accumulators' zeroing
+    between frames (the consumer zeroes the other parity) is exercised across a re-allocation of the activation arena as well."""
+    import subprocess, sys
+    rng = np.random.default_rng(21)
+    xs = [(rng.standard_normal((7, 88, 120)) * 60).astype(np.float32), (rng.standard_normal((7, 150, 210)) * 60).astype(np.float32)]
+    for k, x in enumerate(xs):
+        np.save(tmp_path / ("x%d.npy" % k), x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "net = fav_amd.Net(%r, 0)\n"
+             "for k in (0, 1, 0):\n"
+             "    x = torch.from_numpy(np.load(%r %% k)).cuda()\n"
+             "    np.save(%r %% k, net.forward(x).cpu().numpy())\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), canonical, str(tmp_path / "x%d.npy"), str(tmp_path / "p%d.npy")))
+    subprocess.check_call([sys.executable, "-c", child], env=dict(os.environ, FAV_NO_ACC_STATS="1"), timeout=300)
+    net = favlib.Net(canonical, 0)
+    first = {}
+    for rep in range(3):                                  # frames alternate sizes: parity flips every forward
+        for k in (0, 1):
+            got = net.forward(T(xs[k], cuda)).cpu().numpy()
+            if rep == 0:
+                first[k] = got
+                ref = oracle.net_forward(_layers(canonical), xs[k])
+                part = np.load(tmp_path / ("p%d.npy" % k))
+                d = np.abs(got - part).max()
+                print("accumulator vs partials statistics at %dx%d: max-abs %.3e (150*tanh space)" % (xs[k].shape[2], xs[k].shape[1], d))
+                assert np.abs(got - ref).max() <= 1e-2 and np.abs(part - ref).max() <= 1e-2
+                assert d <= 2e-3, d
+            else:
+                assert np.array_equal(got, first[k]), (rep, k)      # bit-deterministic, whatever order the atomics arrive in
+    net.check()
+
+
 @pytest.mark.parametrize("size,grid,lazy", [((88, 120), 4, 0), ((88, 120), 7, 1), ((90, 122), 5, 0), ((360, 640), 37, 1), ((720, 1280), 0, 0)])
 def test_stream_k_shares_of_the_winograd_layers(favlib, cuda, canonical, tmp_path, size, grid, lazy):
     """conv3_wino4_kernel deals a launch with a thin last round out as one sequence of 16-channel slices, an equal share per block; a unit
