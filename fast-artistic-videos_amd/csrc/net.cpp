@@ -37,7 +37,7 @@ namespace {
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 struct DevConvW { float* wgt = nullptr; float* bias = nullptr; float* wfold = nullptr; float* wc8d = nullptr; float* wwino = nullptr; float* wwino4 = nullptr; float* wup2 = nullptr; float* ws2w = nullptr; float* wfirst = nullptr; float* wfirst2d = nullptr; unsigned short* wgt16 = nullptr; int cinp = 0, coutp = 0, kpad = 0; };
 struct DevIN { float* gamma = nullptr; float* beta = nullptr; float* scale = nullptr; float* shift = nullptr;
-               long long* acc = nullptr; };      // accumulator form of the statistics (fav_internal.h, Affine::acc1): [2 parities][stat_acc_words(C)], zero between frames
+               long long* acc = nullptr; size_t acc_bytes = 0; };      // accumulator form of the statistics (fav_internal.h, Affine::acc1): [2 parities][stat_acc_words(C)], zero between frames
 
 struct Act {
     float* data = nullptr;
@@ -196,6 +196,7 @@ struct fav_net {
     bool shared_device = false;     // data-parallel grids only: set by the caller (fav_net_set_shared_device) or by a timed-out hand-off
     int precision = 0;              // 0 = fp32 (parity mode), 1 = bf16 operands in the halo-resident 3x3 convolutions (fast mode)
     int acc_parity = 0;             // which half of the InstanceNorm accumulators this forward adds to (the consumers zero the other half)
+    bool acc_dirty = false;         // a forward failed half-way (or the precision changed): every accumulator is zeroed before the next forward
     bool branch_tail_acc_ok = false; // set by L_RES around its branch: the join is a plain res_add launch, which takes the last InstanceNorm as accumulators
     int reserve_cus = 0;            // set when a stream uses the look-ahead side queues (they are CU-masked to this many CUs)
     bool use_c8 = false, use_h3 = false, use_s2 = false, use_wino = false, use_wino4 = false, use_up2 = false, use_first = false, use_first2d = false, use_s2w = false; int* c8_counts = nullptr;                                    // first-layer kernel selection for the next launch
@@ -334,8 +335,9 @@ int fav_net::upload_layers(std::vector<Layer>& ls, int& chan_pitch, int& maxc)
             rc = dev_upload(L.beta, 0, &d.beta); if (rc) return rc;
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.scale), L.gamma.size() * sizeof(float)));
             FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.shift), L.gamma.size() * sizeof(float)));
-            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.acc), 2 * stat_acc_words((int)L.gamma.size()) * sizeof(long long)));
-            FAV_HIP(hipMemset(d.acc, 0, 2 * stat_acc_words((int)L.gamma.size()) * sizeof(long long)));
+            d.acc_bytes = 2 * stat_acc_words((int)L.gamma.size()) * sizeof(long long);
+            FAV_HIP(hipMalloc(reinterpret_cast<void**>(&d.acc), d.acc_bytes));
+            FAV_HIP(hipMemset(d.acc, 0, d.acc_bytes));
         } else if (L.type == L_BN) {
             if ((int)L.mean.size() != chan_pitch) { set_error("network: SpatialBatchNormalization(%zu) after %d channels", L.mean.size(), chan_pitch); return FAV_EFORMAT; }
             // evaluate mode: a fixed per-channel affine, folded into the consumer's load like InstanceNorm's
@@ -780,10 +782,19 @@ int fav_net::forward_padded_unordered(const float* in8, int H, int W, float* out
         curH = H; curW = W;
     }
     st = stream; cursor = 0; conv_cursor = 0; in_cursor = 0;
-    acc_parity ^= 1;
+    // InstanceNorm accumulators (Affine::acc1): a forward adds to one half and its consumers zero the other for the next one.  The halves
+    // alternate over the forwards that USE them (fp32 mode; which layers do depends on the network and the process-wide switches only), so a
+    // half is zero whenever it is added to -- unless a forward stopped between a producer and its consumer: then everything is zeroed here
+    if (acc_dirty) {
+        for (DevIN& i : ins) if (i.acc) FAV_HIP(hipMemsetAsync(i.acc, 0, i.acc_bytes, stream));
+        acc_dirty = false;
+    }
+    if (precision == 0 && !tuning().no_acc_stats && !tuning().no_wino) acc_parity ^= 1;
     Act cur;
     cur.data = const_cast<float*>(in8); cur.Hp = H + 2 * pad; cur.Wp = W + 2 * pad; cur.C = 8;
-    return run(exec, cur, true, out_planar, out_raw);
+    const int rc = run(exec, cur, true, out_planar, out_raw);
+    if (rc) acc_dirty = true;
+    return rc;
 }
 
 // ================================================================================================
@@ -1054,7 +1065,7 @@ struct fav_stream {
 extern "C" int fav_net_set_precision(fav_net* net, int mode)
 {
     FAV_REQUIRE(net && (mode == 0 || mode == 1), "fav_net_set_precision: mode must be FAV_PRECISION_FP32 or FAV_PRECISION_BF16_OPERANDS");
-    if (net->precision != mode) net->curH = -1;      // the two modes tile (and size the statistics buffers) differently: rebuild the arena
+    if (net->precision != mode) { net->curH = -1; net->acc_dirty = true; }      // the two modes tile (and size the statistics buffers) differently: rebuild the arena
     net->precision = mode;
     return FAV_OK;
 }

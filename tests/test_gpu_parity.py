@@ -339,6 +339,14 @@ def test_accumulator_statistics_match_the_partials_form(favlib, oracle, cuda, ca
                 assert d <= 2e-3, d
             else:
                 assert np.array_equal(got, first[k]), (rep, k)      # bit-deterministic, whatever order the atomics arrive in
+    # forwards that do NOT use the accumulators in between (the bf16-operand mode has other kernels in the residual stage): one, then two
+    for nb in (1, 2):
+        net.set_precision(True)
+        for _ in range(nb):
+            net.forward(T(xs[0], cuda))
+        net.set_precision(False)
+        assert np.array_equal(net.forward(T(xs[0], cuda)).cpu().numpy(), first[0]), nb
+        assert np.array_equal(net.forward(T(xs[1], cuda)).cpu().numpy(), first[1]), nb
     net.check()
 
 
