@@ -330,7 +330,10 @@ int fav_stream_encode_png(fav_stream* s, void* png_out, size_t capacity, uint32_
  * next to the one being encoded, and the frame after it waits (on the device) for the encoder of the buffer it returns to -- so the
  * fav_stream_* calls may follow immediately.  png_out / png_bytes_out are complete when *png_bytes_out (set it to 0 first; e.g.
  * host-mapped memory) becomes the file's size, or behind fav_stream_wait_png on a queue of the caller's.  One encode per frame;
- * successive encodes run in order.  Same bytes as fav_stream_encode_png. */
+ * successive encodes run in order.  Same bytes as fav_stream_encode_png.  From the first call on the stream's network(s) run the way they
+ * do next to the look-ahead masks (a few CUs left to the side queue, no hand-off between co-resident blocks of the generic kernel): the
+ * encoder shares the device with the following forward.  A forward that fails leaves the state at the last complete frame.
+ * User: `fav_stylize -png_overlap 1` (measured: no gain over the default). */
 int fav_stream_encode_png_async(fav_stream* s, void* png_out, size_t capacity, uint32_t* png_bytes_out, fav_hipstream_t stream);
 /* makes `stream` wait (on the device) for the asynchronous encodes issued so far */
 int fav_stream_wait_png(fav_stream* s, fav_hipstream_t stream);

@@ -1,0 +1,54 @@
+"""bin/consistencyChecker on a host WITHOUT a GPU (the CPU suite's machine): the resident helper the first call tries to start gives up at once
+(no HIP device), says so through its start-up pipe, and the call falls back to computing in its own process -- which fails loudly (there is no
+CPU fallback) instead of waiting for a helper that will never listen.  With a GPU present the same command simply succeeds; the test accepts both."""
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fast-artistic-videos_amd", "bin", "consistencyChecker")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EXE), reason="bin/consistencyChecker not built")
+
+
+def _flo(path, h, w):
+    with open(path, "wb") as f:
+        f.write(np.float32(202021.25).tobytes()); f.write(np.array([w, h], "<i4").tobytes()); f.write(np.zeros((h, w, 2), "<f4").tobytes())
+
+
+def test_checker_without_a_gpu_fails_fast_and_leaves_no_helper(tmp_path):
+    run = tmp_path / "run"; run.mkdir(mode=0o700)
+    _flo(tmp_path / "a.flo", 24, 32); _flo(tmp_path / "b.flo", 24, 32)
+    env = dict(os.environ, XDG_RUNTIME_DIR=str(run), FAV_CC_IDLE_S="5")
+    t0 = time.time()
+    r = subprocess.run([EXE, "a.flo", "b.flo", "o.pgm"], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=120)
+    dt = time.time() - t0
+    if r.returncode == 0:                       # a GPU is present: the call was served
+        assert r.stdout == "o.pgm" and (tmp_path / "o.pgm").read_bytes().startswith(b"P5\n32 24\n255\n")
+        lock = run / "fav-cc" / "gpu0.lock"
+        if lock.exists():                       # end the helper it started
+            import signal
+            try:
+                os.kill(int(lock.read_text().split()[0]), signal.SIGTERM)
+            except (ProcessLookupError, ValueError, IndexError):
+                pass
+        return
+    assert "device" in r.stderr and r.stdout == ""
+    assert dt < 10.0, dt                        # no waiting for a helper that cannot exist
+    assert not (run / "fav-cc" / "gpu0.sock").exists()
+    # the socket directory is only trusted when nobody else can enter it
+    assert (os.stat(run / "fav-cc").st_mode & 0o077) == 0
+    # FAV_CC_DAEMON=0: the same failure without the attempt
+    r = subprocess.run([EXE, "a.flo", "b.flo", "o.pgm"], capture_output=True, text=True, cwd=str(tmp_path), env=dict(env, FAV_CC_DAEMON="0"), timeout=120)
+    assert r.returncode != 0 and "device" in r.stderr
+
+
+def test_checker_usage_and_bad_arguments(tmp_path):
+    r = subprocess.run([EXE], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([EXE, str(tmp_path / "missing.flo"), str(tmp_path / "missing2.flo"), str(tmp_path / "o.pgm")], capture_output=True, text=True,
+                       env=dict(os.environ, FAV_CC_DAEMON="0"))
+    assert r.returncode != 0 and "missing.flo" in r.stderr
