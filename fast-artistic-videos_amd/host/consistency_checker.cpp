@@ -303,6 +303,11 @@ int via_helper(int argc, char** argv, int* rc)
         }
         if (fd < 0) return -1;
     }
+    // (a helper that stops answering -- a hung device -- must not hang its callers: after FAV_CC_REPLY_S seconds, default 300, the call
+    //  gives up on it and computes in its own process, which then reports what is wrong with the device)
+    const char* rs = getenv("FAV_CC_REPLY_S");
+    timeval tv{rs && atoi(rs) > 0 ? atoi(rs) : 300, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
     const int r = ask_helper(fd, a, rc);
     close(fd);
     return r;
