@@ -261,6 +261,10 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
                       void* workspace, size_t ws_bytes, hipStream_t st);
 int launch_check_cert(const float* backward_flo, const float* forward_flo, const float* structure, const float* avg, uint8_t* mask_out,
                       int invert, int fix_occ, int border, int r, float* cert, int H, int W, hipStream_t st);
+// ... and the input assembly on top of it (launch_check_cert + launch_prep_input in one launch; round 5)
+int launch_check_prep(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo, const float* forward_flo,
+                      const float* structure, const float* avg, uint8_t* mask_out, float* cert, int invert, int fix_occ, int border, int r,
+                      int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index);
 int launch_store_flag(uint32_t* flag_host, uint32_t value, hipStream_t st);
 int launch_unpad_input(const float* in8, int H, int W, int pad, float* in7, hipStream_t st);
 int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const float* backward_flo, const uint8_t* cert_u8, int border,

@@ -209,28 +209,21 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* frame, const
 //   ch 0..2 content (BGR, mean-subtracted), ch 3..5 masked warped prior, ch 6 certainty, ch 7 zero
 // prev_rgb: [3][Hs][Ws] -- the previous OUTPUT, which is larger than the frame when H or W is not a multiple of 4; the warp samples it
 // on the flow's H x W grid (BilinearSamplerBDHW.lua:71), bounds and pitch are the source's
-__global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws,
-                                                         const float2* bw_flo, const float* cert, int border, int H,
-                                                         int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
+// the eight floats of network-input pixel (y, x) of the UNPADDED frame (shared by prep_input_kernel and check_prep_kernel: one body,
+// one rounding).  cv: the pixel's eroded certainty (ignored without a previous frame); byte01: the block's table of byte / 255
+__device__ __forceinline__ void prep_pixel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float2* bw_flo, float cv_in,
+                                           int border, int H, int W, int y, int x, const float* byte01, int fill_random, unsigned seed, unsigned index,
+                                           float4& lo, float4& hi)
 {
-    // image.load: byte / 255 -- a correctly rounded division (a dozen instructions); the 256 possible quotients are formed once per block
-    __shared__ float byte01[256];
-    byte01[threadIdx.x] = (float)threadIdx.x / 255.f;
-    __syncthreads();
-    const int Wp = W + 2 * pad;
-    const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
-    if (xp >= Wp) return;
-    const int y = reflect(yp - pad, H), x = reflect(xp - pad, W);
     const size_t i = (size_t)y * W + x;
     const uint8_t* px = frame_hwc + i * 3;
     const float rgb[3] = {byte01[px[0]], byte01[px[1]], byte01[px[2]]};
-    float4 lo, hi;
     lo.x = rgb[2] * 255.f - 103.939f;
     lo.y = rgb[1] * 255.f - 116.779f;
     lo.z = rgb[0] * 255.f - 123.68f;
     // generate_fill (core.lua:108-117): 0 (vgg-mean) or pre(u) * (1 - cert) with u the documented counter RNG
     float fb = 0.f, fg = 0.f, fr = 0.f;
-    const float cv = prev_rgb != nullptr ? cert[i] : 0.f;
+    const float cv = prev_rgb != nullptr ? cv_in : 0.f;
     if (fill_random) {
         const float cinv = (cv + -1.f) * -1.f;
         fb = (fill_uniform(seed, index, 2, y, x) * 255.f - 103.939f) * cinv;
@@ -250,8 +243,85 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hw
         lo.w = fb; hi.x = fg; hi.y = fr; hi.z = 0.f;                    // core:133-138: fill only, zero mask
     }
     hi.w = 0.f;
+}
+
+__global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws,
+                                                         const float2* bw_flo, const float* cert, int border, int H,
+                                                         int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
+{
+    // image.load: byte / 255 -- a correctly rounded division (a dozen instructions); the 256 possible quotients are formed once per block
+    __shared__ float byte01[256];
+    byte01[threadIdx.x] = (float)threadIdx.x / 255.f;
+    __syncthreads();
+    const int Wp = W + 2 * pad;
+    const int yp = blockIdx.y, xp = blockIdx.x * 256 + threadIdx.x;
+    if (xp >= Wp) return;
+    const int y = reflect(yp - pad, H), x = reflect(xp - pad, W);
+    float4 lo, hi;
+    prep_pixel(frame_hwc, prev_rgb, Hs, Ws, bw_flo, prev_rgb != nullptr ? cert[(size_t)y * W + x] : 0.f, border, H, W, y, x, byte01, fill_random, seed, index, lo, hi);
     float4* o = reinterpret_cast<float4*>(in8 + ((size_t)yp * Wp + xp) * 8);
     o[0] = lo; o[1] = hi;
+}
+
+// Round 5: forward-backward check + certainty options + erosion (min_filter_kernel<2>) AND the input assembly (prep_input_kernel) of a
+// frame in ONE launch: a tile of 64 x 16 frame pixels (+ the erosion's halo) runs the check into LDS, erodes it there, and every own
+// pixel -- its eroded certainty in a register -- is assembled and written to its place in the padded network input and to the places
+// the reflection padding copies it to (nn.SpatialReflectionPadding: a pixel within `pad` of an edge appears up to three times per axis).
+// One launch and one certainty round trip less per frame; the same bytes: the check is consistency_pixel, the assembly prep_pixel.
+__global__ __launch_bounds__(256) void check_prep_kernel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float2* bw_flo,
+                                                         const float2* fw_flo, const float* structure, const float* avg_ptr, uint8_t* mask_out,
+                                                         float* cert_out, int invert, int fix_occ, int border, int r, int H, int W, int pad,
+                                                         float* in8, int fill_random, unsigned seed, unsigned index)
+{
+    __shared__ float a[MF_TY + MF_RMAX - 1][MF_TX + MF_RMAX];        // 1 - cert, -inf outside the image
+    __shared__ float b[MF_TY + MF_RMAX - 1][MF_TX + 1];              // row maxima
+    __shared__ float byte01[256];
+    const int t = threadIdx.x, p = r / 2;
+    byte01[t] = (float)t / 255.f;
+    const int x0 = blockIdx.x * MF_TX, y0 = blockIdx.y * MF_TY;
+    const int TW = MF_TX + r - 1, THh = MF_TY + r - 1;
+    for (int e = t; e < TW * THh; e += 256) {
+        const int ly = e / TW, lx = e - ly * TW;
+        const int yy = y0 + ly - p, xx = x0 + lx - p;
+        float v = -INFINITY;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const uint8_t mb = consistency_pixel(bw_flo, fw_flo, structure, avg_ptr, xx, yy, W, H);
+            if (ly >= p && ly < p + MF_TY && lx >= p && lx < p + MF_TX) mask_out[(size_t)yy * W + xx] = mb;      // the tile's own pixels
+            const float c = cert_from_byte(mb, bw_flo, invert, fix_occ, border, yy, xx, H, W);
+            v = c * -1.f + 1.f;                                      // MulConstant(-1), AddConstant(1)
+        }
+        a[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < MF_TX * THh; e += 256) {
+        const int ly = e / MF_TX, lx = e - ly * MF_TX;
+        float m = -INFINITY;
+        for (int d = 0; d < r; ++d) m = fmaxf(m, a[ly][lx + d]);
+        b[ly][lx] = m;
+    }
+    __syncthreads();
+    const int Wp = W + 2 * pad;
+    for (int e = t; e < MF_TX * MF_TY; e += 256) {
+        const int ly = e / MF_TX, lx = e - ly * MF_TX;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        float m = -INFINITY;
+        for (int d = 0; d < r; ++d) m = fmaxf(m, b[ly + d][lx]);
+        const float cv = m * -1.f + 1.f;
+        cert_out[(size_t)y * W + x] = cv;
+        float4 lo, hi;
+        prep_pixel(frame_hwc, prev_rgb, Hs, Ws, bw_flo, cv, border, H, W, y, x, byte01, fill_random, seed, index, lo, hi);
+        // the pixel's places in the padded input: row y + pad, and -- reflect(yp - pad, H) == y -- pad - y above the image (1 <= y <= pad),
+        // pad + 2 (H - 1) - y below it (H - 1 - pad <= y <= H - 2); columns likewise
+        int yt[3], xt[3], ny = 0, nx = 0;
+        yt[ny++] = y + pad; if (y >= 1 && y <= pad) yt[ny++] = pad - y; if (y <= H - 2 && y >= H - 1 - pad) yt[ny++] = pad + 2 * (H - 1) - y;
+        xt[nx++] = x + pad; if (x >= 1 && x <= pad) xt[nx++] = pad - x; if (x <= W - 2 && x >= W - 1 - pad) xt[nx++] = pad + 2 * (W - 1) - x;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) {
+                float4* o = reinterpret_cast<float4*>(in8 + ((size_t)yt[i] * Wp + xt[j]) * 8);
+                o[0] = lo; o[1] = hi;
+            }
+    }
 }
 
 // test view of the fused input: interior of the padded NHWC8 buffer -> planar [7][H][W] (fav_stream_get_input_f32)
@@ -364,6 +434,20 @@ int launch_check_cert(const float* backward_flo, const float* forward_flo, const
                        reinterpret_cast<const float2*>(backward_flo), invert, fix_occ, border, cert, H, W, r,
                        reinterpret_cast<const float2*>(forward_flo), structure, avg, mask_out);
     FAV_LAUNCH_CHECK("min_filter_kernel<check>");
+    return FAV_OK;
+}
+
+// check + certainty options + erosion + input assembly of one frame in one launch (check_prep_kernel); needs a previous frame
+int launch_check_prep(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo, const float* forward_flo,
+                      const float* structure, const float* avg, uint8_t* mask_out, float* cert, int invert, int fix_occ, int border, int r,
+                      int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index)
+{
+    FAV_REQUIRE(r >= 1 && r <= MF_RMAX, "min filter: window %d unsupported (1..%d)", r, MF_RMAX);
+    FAV_REQUIRE(prev_rgb != nullptr && pad < H && pad < W, "fused check + input assembly: needs a previous frame and pad < H, W");
+    hipLaunchKernelGGL(check_prep_kernel, dim3((W + MF_TX - 1) / MF_TX, (H + MF_TY - 1) / MF_TY), dim3(256), 0, st, frame_hwc, prev_rgb, Hs, Ws,
+                       reinterpret_cast<const float2*>(backward_flo), reinterpret_cast<const float2*>(forward_flo), structure, avg, mask_out, cert,
+                       invert, fix_occ, border, r, H, W, pad, in8, fill_random, seed, index);
+    FAV_LAUNCH_CHECK("check_prep_kernel");
     return FAV_OK;
 }
 

@@ -1189,12 +1189,13 @@ extern "C" int fav_stream_set_image_net(fav_stream* s, fav_net* image_net)
 }
 
 // cert_ready: the certainty (mask options + erosion applied) is already in s->cert (computed ahead on a side queue)
+// input_ready: ... and the network input in s->in8 as well (fav_stream_next_frame_flow's fused check + assembly; frame_counter advanced)
 static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, const uint8_t* mask, float* out_f32, uint8_t* out_u8,
-                       hipStream_t st, bool cert_ready = false)
+                       hipStream_t st, bool cert_ready = false, bool input_ready = false)
 {
     FAV_REQUIRE(s->has_state, "fav_stream_next_frame: no previous stylised frame (call fav_stream_first_frame or fav_stream_set_state first)");
     int rc = FAV_OK;
-    {
+    if (!input_ready) {
         TraceRange tr_pre("fav:certainty+warp+assemble");
         if (!cert_ready)
             rc = launch_cert_prepare(mask, bw, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
@@ -1258,7 +1259,17 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
     if (use_structure) {
         int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->ws, s->ws_bytes, &structure, &avg, st); if (rc) return rc;
     }
-    // check + certainty options + erosion in one tile kernel (the mask byte of every pixel is still written: fav_stream_last_mask)
+    // check + certainty options + erosion + input assembly in ONE tile kernel (round 5; the mask byte and the eroded certainty of every pixel
+    // are still written: fav_stream_last_mask); FAV_NO_CHECK_PREP: the check and the assembly as two launches (rounds 3-4)
+    static const bool fused_prep = getenv("FAV_NO_CHECK_PREP") == nullptr;      // (tuning: read once)
+    if (fused_prep && s->has_state) {
+        ++s->frame_counter;
+        int rcp = launch_check_prep(frame_rgb_hwc, s->state, s->Ho, s->Wo, backward_flo, forward_flo, structure, avg, s->mask, s->cert,
+                                    s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode, s->opts.occlusions_min_filter,
+                                    s->H, s->W, s->net->pad, s->in8, st, s->opts.fill_random, s->opts.seed, s->frame_counter);
+        if (rcp) return rcp;
+        return stream_next(s, frame_rgb_hwc, backward_flo, s->mask, out_rgb_f32, out_rgb8_hwc, st, true, true);
+    }
     int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, s->mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
                                s->opts.occlusions_min_filter, s->cert, s->H, s->W, st);
     if (rc) return rc;

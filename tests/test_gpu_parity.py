@@ -624,6 +624,34 @@ def test_stream_options(favlib, oracle, cuda, golden_dir):
 
 
 # ---------------------------------------------------------------------------------------------- full size
+@pytest.mark.parametrize("size,opts", [((60, 76), dict()), ((53, 71), dict(invert_occlusion=True, fix_occlusions=True)), ((96, 160), dict(fill_random=True, seed=5, min_filter_r=5))],
+                         ids=["pad-overlap", "options-odd-size", "random-fill-r5"])
+def test_fused_check_and_input_assembly_gives_the_bytes_of_the_two_launches(favlib, cuda, canonical, tmp_path, size, opts):
+    """Round 5: fav_stream_next_frame_flow runs the forward-backward check, the certainty options, the erosion AND the input assembly
+    (warp of the previous output, pre-processing, masking, fill, reflection padding) of a frame in ONE tile kernel (check_prep_kernel);
+    FAV_NO_CHECK_PREP=1 (read once per process: a child runs it) keeps them as two launches (min_filter_kernel<2> + prep_input_kernel).
+    Same mask bytes, same network input, same stylised frames bit for bit -- the stylised frame depends on every padded input pixel, so
+    the reflections the tile kernel writes itself are covered; 60 rows with 40 of padding make a pixel appear three times per axis."""
+    import subprocess, sys
+    h, w = size
+    frames, bws, fws = _clip(h, w, 3, 300 + h)
+    np.savez(tmp_path / "clip.npz", f0=frames[0], f1=frames[1], f2=frames[2], b1=bws[1], b2=bws[2], w1=fws[1], w2=fws[2])
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "d = np.load(%r); T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+             "net = fav_amd.Net(%r, 0); st = fav_amd.Stream(net, %d, %d, **%r)\n"
+             "st.first_frame(T(d['f0']))\n"
+             "o1, _ = st.next_frame_flow(T(d['f1']), T(d['b1']), T(d['w1'])); i1 = st.last_input().cpu().numpy(); m1 = st.last_mask().cpu().numpy()\n"
+             "o2, _ = st.next_frame_flow(T(d['f2']), T(d['b2']), T(d['w2'])); m2 = st.last_mask().cpu().numpy()\n"
+             "np.savez(sys.argv[1], o1=o1.cpu().numpy(), o2=o2.cpu().numpy(), i1=i1, m1=m1, m2=m2)\n"
+             % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "clip.npz"), canonical, h, w, opts))
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "two.npz")], env=dict(os.environ, FAV_NO_CHECK_PREP="1"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "one.npz")], env=os.environ.copy(), timeout=300)
+    a, b = np.load(tmp_path / "two.npz"), np.load(tmp_path / "one.npz")
+    for k in ("m1", "m2", "i1", "o1", "o2"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["m1"].min() == 0 and a["m1"].max() == 255 and np.abs(a["o2"]).std() > 0.01
+
+
 def test_full_size_properties_1280x720(favlib, oracle, cuda, canonical):
     """BASELINE config 3 geometry: size-independent properties (the oracle needs ~20 s per frame here)."""
     import torch
