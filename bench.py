@@ -135,7 +135,9 @@ def reference_checker_baseline(bw, fw, frame):
                 drop[name + "_fresh_process_bytes_equal_reference"] = open(o2, "rb").read() == want[name]
             try:      # end the helper (its pid is in the lock file; it would leave by itself after FAV_CC_IDLE_S)
                 import signal
-                os.kill(int(open(os.path.join(run, "fav-cc", "gpu0.lock")).read().split()[0]), signal.SIGTERM)
+                import glob
+                for lk in glob.glob(os.path.join(run, "fav-cc", "gpu0*.lock")):
+                    os.kill(int(open(lk).read().split()[0]), signal.SIGTERM)
             except Exception:
                 pass
             drop["reference_s_per_call"] = {"3arg": round(res["3arg"], 4), "4arg": round(res["4arg"], 4)}

@@ -156,8 +156,21 @@ bool socket_paths(std::string& dir, std::string& sock, std::string& lock)
     if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
     struct stat st;
     if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return false;
-    snprintf(buf, sizeof buf, "/gpu%d.sock", gpu_index()); sock = dir + buf;
-    snprintf(buf, sizeof buf, "/gpu%d.lock", gpu_index()); lock = dir + buf;
+    // one helper per device AS THE CALLER SEES IT: FAV_GPU indexes the devices the runtime's visibility variables leave, so their values are
+    // part of the name (a call with another HIP_VISIBLE_DEVICES must not reach a helper that sits on another device)
+    char tag[24] = "";
+    {
+        uint32_t hsh = 2166136261u; bool any = false;
+        for (const char* v : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "CUDA_VISIBLE_DEVICES"}) {
+            const char* e = getenv(v);
+            if (e && *e) any = true;
+            for (const char* c = e ? e : ""; *c; ++c) { hsh ^= (unsigned char)*c; hsh *= 16777619u; }
+            hsh ^= ';'; hsh *= 16777619u;
+        }
+        if (any) snprintf(tag, sizeof tag, "-%08x", hsh);
+    }
+    snprintf(buf, sizeof buf, "/gpu%d%s.sock", gpu_index(), tag); sock = dir + buf;
+    snprintf(buf, sizeof buf, "/gpu%d%s.lock", gpu_index(), tag); lock = dir + buf;
     return sock.size() < sizeof(((sockaddr_un*)nullptr)->sun_path);
 }
 

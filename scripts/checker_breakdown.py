@@ -47,7 +47,9 @@ try:
         print("-- through the resident helper: first call (starts it) %.1f ms, then %s ms%s" %
               (ts[0] * 1e3, " ".join("%.1f" % (t * 1e3) for t in ts[1:]), "" if want is None else "   bytes equal: %s" % (open(o, "rb").read() == want)))
         try:
-            os.kill(int(open(os.path.join(run, "fav-cc", "gpu0.lock")).read().split()[0]), signal.SIGTERM)
+            import glob
+            for lk in glob.glob(os.path.join(run, "fav-cc", "gpu0*.lock")):
+                os.kill(int(open(lk).read().split()[0]), signal.SIGTERM)
         except Exception as e:
             print("   (could not stop the helper: %r)" % (e,))
 finally:
