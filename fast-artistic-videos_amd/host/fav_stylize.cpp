@@ -10,7 +10,8 @@
 //
 // Additive flags (not in the reference): -forward_flow_pattern <pat> (run the consistency check on the
 // GPU instead of reading .pgm files), -structure <0|1> (4-argument checker mode, default 1 as in
-// makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>,
+// makeOptFlow_deepflow.sh:59), -warp_border <stn|cpu>, -poll_timeout <sec>, -poll_settle <sec> (1.0: a file younger than this is
+//   taken only once it has not been modified for that long -- what utils.lua:79's `sleep 1` buys; host/fav_poll.h),
 // -png_overlap <0|1> (0, default; 1: with -png_encoder gpu the encoder's kernels run on a queue of their own next to the following frame's
 //   network -- fav_stream_encode_png_async -- instead of in front of it: +0.5 % in HBM, but the events between the queues cost this
 //   process 1.6 ms of CPU per frame and the file -> PNG rate does not move, profiles/bench_r5e.log against bench_r5f.log)
@@ -59,6 +60,7 @@
 
 #include "../../include/fav.h"
 #include "fav_launcher.h"
+#include "fav_poll.h"
 
 namespace {
 
@@ -107,30 +109,20 @@ std::string flow_name(const std::string& pattern, int from, int to)
     return out;
 }
 
-// utils.wait_for_file (fast_artistic_video/utils.lua:74-80), bounded: poll until the file exists and its
-// size is stable (the reference sleeps one extra second instead)
-void wait_for_file(const std::string& path, double timeout_s)
+// utils.wait_for_file (fast_artistic_video/utils.lua:74-80), bounded, with the settle rule of fav_poll.h
+void wait_for_file(const std::string& path, const favp::Poll& p)
 {
-    using clk = std::chrono::steady_clock;
-    const auto t0 = clk::now();
-    bool announced = false;
-    long long last = -1;
-    for (;;) {
-        struct stat st;
-        if (stat(path.c_str(), &st) == 0 && st.st_size > 0) {
-            if ((long long)st.st_size == last) return;
-            // a file nobody has touched for a second is not being written any more: no second look (the two looks 2 ms apart are
-            // for files that appear while we wait; on finished inputs they were 4 ms of sleep per frame in every loader)
-            struct timespec now; clock_gettime(CLOCK_REALTIME, &now);
-            if ((now.tv_sec - st.st_mtim.tv_sec) + 1e-9 * (now.tv_nsec - st.st_mtim.tv_nsec) > 1.0) return;
-            last = (long long)st.st_size;
-        } else if (!announced) {
-            printf("Waiting for file \"%s\"\n", path.c_str()); fflush(stdout); announced = true;
-        }
-        if (std::chrono::duration<double>(clk::now() - t0).count() > timeout_s)
-            die("timed out waiting for " + path);
-        usleep(last >= 0 && !announced ? 2000 : 50000);
-    }
+    if (favp::wait_for_file(path, p) != favp::WAIT_OK) die("timed out waiting for " + path);
+}
+
+// wait, read, and poll again while the file reads short under a producer that is still writing it (fav_poll.h)
+template <class Reader>
+void read_polled(const std::string& path, const favp::Poll& p, Reader&& reader)
+{
+    bool timed_out = false;
+    const int rc = favp::read_when_complete(path, p, reader, &timed_out);
+    if (timed_out) die("timed out waiting for " + path);
+    check(rc, path.c_str());
 }
 
 void mkdirs_for(const std::string& path)
@@ -285,6 +277,45 @@ double process_cpu_seconds()
     return ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
 }
 
+struct Pinned { uint8_t* frame = nullptr; float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr; };
+
+// Everything frame i needs from disk (fast_artistic_video.lua:93-110,153-158): the frame, and for a frame with a predecessor the backward
+// flow plus either the certainty file (the reference's path: polled, fav.lua:102) or the forward flow (fused check).
+// pd != null: decode straight into that pinned staging set of pin_px pixels (no allocation, no second copy)
+FrameIn load_frame_inputs(const Opt& o, const favp::Poll& poll, int i, bool first_of_run, const Pinned* pd, size_t pin_px)
+{
+    const bool fused_check = !o.s("forward_flow_pattern").empty();
+    FrameIn in; in.index = pd ? -i - 1 : i;              // negative index marks "pinned, do not free"
+    const std::string fp = fmt_int(o.s("input_pattern"), i);
+    if (!file_exists(fp)) return in;                                                                     // fav.lua:93-97 -> nil -> break
+    int ch;
+    if (pd) { check(fav_read_pnm_into_host(fp.c_str(), pd->frame, pin_px * 3, &in.W, &in.H, &ch), fp.c_str()); in.frame = pd->frame; }
+    else check(fav_read_pnm_host(fp.c_str(), &in.frame, &in.W, &in.H, &ch), fp.c_str());
+    if (ch != 3) die(fp + ": expected a colour (P6) frame");
+    in.single = (i == 1) || o.f("create_inconsistent") || first_of_run;                                 // fav.lua:172
+    if (!in.single) {
+        const std::string fl = flow_name(o.s("flow_pattern"), i - 1, i);                               // fav.lua:100,154
+        int w, h;
+        if (fused_check) {
+            const std::string ff = flow_name(o.s("forward_flow_pattern"), i - 1, i);
+            read_polled(ff, poll, [&] { if (pd) { in.fw = pd->fw; return fav_read_flo_into_host(ff.c_str(), pd->fw, pin_px * 2, &w, &h); }
+                                        return fav_read_flo_host(ff.c_str(), &in.fw, &w, &h); });
+            if (w != in.W || h != in.H) die(ff + ": size differs from the frame");
+        } else {
+            const std::string cp = flow_name(o.s("occlusions_pattern"), i - 1, i);
+            int cch = 0;
+            read_polled(cp, poll, [&] { if (pd) { in.cert = pd->cert; return fav_read_pnm_into_host(cp.c_str(), pd->cert, pin_px, &w, &h, &cch); }   // fav.lua:102
+                                        return fav_read_pnm_host(cp.c_str(), &in.cert, &w, &h, &cch); });
+            if (cch != 1 || w != in.W || h != in.H) die(cp + ": expected a P5 mask of the frame's size");
+        }
+        read_polled(fl, poll, [&] { if (pd) { in.bw = pd->bw; return fav_read_flo_into_host(fl.c_str(), pd->bw, pin_px * 2, &w, &h); }
+                                    return fav_read_flo_host(fl.c_str(), &in.bw, &w, &h); });
+        if (w != in.W || h != in.H) die(fl + ": size differs from the frame");
+    }
+    in.ok = true;
+    return in;
+}
+
 // One video: the loop of run_fast_neural_video (core.lua:189-229) with the video CLI's callbacks (fav.lua:93-172).
 // `net` / `net_img` live on the current device; `nwriters` PNG threads.
 void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, StreamResult* res)   // nwriters: the budget; adjusted below
@@ -294,45 +325,10 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
     const int num_frames = o.i("num_frames");
     const bool backward = o.f("backward");
     const int start = backward ? num_frames - 1 : o.i("continue_with"), end = backward ? 1 : num_frames, inc = backward ? -1 : 1;   // core:189-191
-    const double poll = o.d("poll_timeout");
+    favp::Poll poll; poll.timeout_s = o.d("poll_timeout"); poll.settle_s = std::max(0.0, o.d("poll_settle"));
 
-    struct Pinned { uint8_t* frame = nullptr; float* bw = nullptr; float* fw = nullptr; uint8_t* cert = nullptr; };
     size_t pin_px = 0;                       // capacity of a pinned staging set in pixels (0: none yet)
-    // pd != null: decode straight into that pinned staging set (no allocation, no second copy)
-    auto load = [&](int i, bool first_of_run, const Pinned* pd) {
-        FrameIn in; in.index = pd ? -i - 1 : i;              // negative index marks "pinned, do not free"
-        const std::string fp = fmt_int(o.s("input_pattern"), i);
-        if (!file_exists(fp)) return in;                                                                     // fav.lua:93-97 -> nil -> break
-        int ch;
-        if (pd) { check(fav_read_pnm_into_host(fp.c_str(), pd->frame, pin_px * 3, &in.W, &in.H, &ch), fp.c_str()); in.frame = pd->frame; }
-        else check(fav_read_pnm_host(fp.c_str(), &in.frame, &in.W, &in.H, &ch), fp.c_str());
-        if (ch != 3) die(fp + ": expected a colour (P6) frame");
-        in.single = (i == 1) || o.f("create_inconsistent") || first_of_run;                                 // fav.lua:172
-        if (!in.single) {
-            const std::string fl = flow_name(o.s("flow_pattern"), i - 1, i);                               // fav.lua:100,154
-            int w, h;
-            if (fused_check) {
-                const std::string ff = flow_name(o.s("forward_flow_pattern"), i - 1, i);
-                wait_for_file(fl, poll); wait_for_file(ff, poll);
-                if (pd) { check(fav_read_flo_into_host(ff.c_str(), pd->fw, pin_px * 2, &w, &h), ff.c_str()); in.fw = pd->fw; }
-                else check(fav_read_flo_host(ff.c_str(), &in.fw, &w, &h), ff.c_str());
-                if (w != in.W || h != in.H) die(ff + ": size differs from the frame");
-            } else {
-                const std::string cp = flow_name(o.s("occlusions_pattern"), i - 1, i);
-                wait_for_file(cp, poll);                                                                     // fav.lua:102
-                int cch;
-                if (pd) { check(fav_read_pnm_into_host(cp.c_str(), pd->cert, pin_px, &w, &h, &cch), cp.c_str()); in.cert = pd->cert; }
-                else check(fav_read_pnm_host(cp.c_str(), &in.cert, &w, &h, &cch), cp.c_str());
-                if (cch != 1 || w != in.W || h != in.H) die(cp + ": expected a P5 mask of the frame's size");
-                wait_for_file(fl, poll);
-            }
-            if (pd) { check(fav_read_flo_into_host(fl.c_str(), pd->bw, pin_px * 2, &w, &h), fl.c_str()); in.bw = pd->bw; }
-            else check(fav_read_flo_host(fl.c_str(), &in.bw, &w, &h), fl.c_str());
-            if (w != in.W || h != in.H) die(fl + ": size differs from the frame");
-        }
-        in.ok = true;
-        return in;
-    };
+    auto load = [&](int i, bool first_of_run, const Pinned* pd) { return load_frame_inputs(o, poll, i, first_of_run, pd, pin_px); };
 
     // -png_encoder gpu (default): the PNG file's bytes are produced on the device (fav_stream_encode_png: Sub filter + fixed-Huffman /
     // run-length deflate per row + Adler-32 / CRC-32 combine), leave as ONE exact-size DMA and the writer thread only write()s them;
@@ -721,11 +717,14 @@ int main(int argc, char** argv)
            {"style_image", "images/styles/candy.jpg"}, {"style_image_size", "256"}, {"style_weights", "1.0"},
            {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
            // additive
-           {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"},
+           {"forward_flow_pattern", ""}, {"structure", "1"}, {"warp_border", "stn"}, {"poll_timeout", "3600"}, {"poll_settle", "1.0"},
            {"png_level", "1"}, {"png_encoder", "gpu"}, {"png_overlap", "0"}, {"writers", "0"}, {"timing", "0"}, {"temporal_eval_file", ""}, {"seed", "1"}, {"precision", "fp32"},
            {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"shared_gpu", "0"}, {"pin_workers", "1"},
            // internal (set by the launcher for its workers)
-           {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
+           {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""},
+           // test hook: -load_probe <i> loads frame i's inputs exactly as the frame loop's loader threads do (polling included), prints one
+           // JSON line with a hash of each and exits -- no device is touched (tests/test_cpu_poll.py)
+           {"load_probe", "0"}};
     o.b = {{"invert_occlusion", false}, {"fix_occlusions", false}, {"backward", false}, {"create_inconsistent", false},
            {"evaluate", false}, {"invert_occlusion_eval", false}, {"fix_occlusions_eval", false}, {"backward_eval", false}};
     for (int a = 1; a < argc; ++a) {
@@ -746,6 +745,19 @@ int main(int argc, char** argv)
     if (o.s("fill_occlusions") != "vgg-mean" && o.s("fill_occlusions") != "uniform-random") die("-fill_occlusions must be vgg-mean or uniform-random");
     if (o.s("png_encoder") != "gpu" && o.s("png_encoder") != "host") die("-png_encoder must be gpu (the file's bytes are produced on the device) or host (zlib, -png_level)");
     if (o.s("precision") != "fp32" && o.s("precision") != "bf16") die("-precision must be fp32 (parity mode) or bf16 (bf16 operands in the 3x3 residual convolutions)");
+    if (o.i("load_probe") > 0) {
+        favp::Poll poll; poll.timeout_s = o.d("poll_timeout"); poll.settle_s = std::max(0.0, o.d("poll_settle"));
+        const auto t0 = std::chrono::steady_clock::now();
+        FrameIn in = load_frame_inputs(o, poll, o.i("load_probe"), false, nullptr, 0);
+        auto fnv = [](const void* p, size_t n) { unsigned long long h = 1469598103934665603ull; const uint8_t* b = (const uint8_t*)p;
+                                                 if (!p) return 0ull; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; };
+        const size_t n = (size_t)in.W * in.H;
+        size_t cert255 = 0; if (in.cert) for (size_t i = 0; i < n; ++i) cert255 += in.cert[i] == 255;
+        printf("{\"ok\": %s, \"W\": %d, \"H\": %d, \"seconds\": %.3f, \"frame\": \"%016llx\", \"cert\": \"%016llx\", \"cert_255\": %zu, \"bw\": \"%016llx\", \"fw\": \"%016llx\"}\n",
+               in.ok ? "true" : "false", in.W, in.H, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+               fnv(in.frame, n * 3), fnv(in.cert, n), cert255, fnv(in.bw, n * 8), fnv(in.fw, n * 8));
+        return in.ok ? 0 : 1;
+    }
     const bool dry = o.i("dry_run") != 0;
     std::vector<std::string> streams = favl::split_list(o.s("streams"));
     const bool named = !streams.empty();

@@ -5,7 +5,7 @@
 // "<prefix>-%05d_equi.png" / "<prefix>-%05d_cubemap.png" (:541,552).  All compute goes through libfav's C ABI (fav_vr_*);
 // there is no CPU backend.  Not provided (rejected with a message): -evaluate, -backward, -smooth_certainty and
 // -continue_with > 1 (in the reference that option reloads per-face PNGs which func_save_image no longer writes, :521-523).
-// Additive flags: -precision <fp32|bf16>, -warp_border <stn|cpu>, -poll_timeout <sec>, -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>,
+// Additive flags: -precision <fp32|bf16>, -warp_border <stn|cpu>, -poll_timeout <sec>, -poll_settle <sec> (host/fav_poll.h), -png_level <0..9>, -seed <n> (uniform-random fill), -timing <0|1>,
 // and -- several 360-degree videos on several GPUs (BASELINE config 5; the faces of one frame depend on each other through the
 // border priors, so the unit of sharding is the video) -- -streams <a,b,...> / -gpus <n> / -force_dist / -dry_run exactly as in
 // fav_stylize (host/fav_launcher.h): %S in -input_pattern, -flow_pattern, -occlusions_pattern and -output_prefix is the stream's
@@ -25,6 +25,7 @@
 
 #include "../../include/fav.h"
 #include "fav_launcher.h"
+#include "fav_poll.h"
 
 namespace {
 
@@ -51,18 +52,14 @@ std::string flow_name(const std::string& pattern, int from, int to, int face)
     return fmt1(out, face);
 }
 
-void wait_for_file(const std::string& path, double timeout_s)      // utils.lua:74-80, bounded
+// utils.lua:74-80 with the settle rule of fav_poll.h: wait, read, poll again while the file reads short under its producer
+template <class Reader>
+void read_polled(const std::string& path, const favp::Poll& p, const char* what, Reader&& reader)
 {
-    using clk = std::chrono::steady_clock;
-    const auto t0 = clk::now();
-    bool announced = false; long long last = -1;
-    for (;;) {
-        struct stat st;
-        if (stat(path.c_str(), &st) == 0 && st.st_size > 0) { if ((long long)st.st_size == last) return; last = (long long)st.st_size; }
-        else if (!announced) { printf("Waiting for file \"%s\"\n", path.c_str()); fflush(stdout); announced = true; }
-        if (std::chrono::duration<double>(clk::now() - t0).count() > timeout_s) die("timed out waiting for " + path);
-        usleep(last >= 0 && !announced ? 2000 : 50000);
-    }
+    bool timed_out = false;
+    const int rc = favp::read_when_complete(path, p, reader, &timed_out);
+    if (timed_out) die("timed out waiting for " + path);
+    check(rc, what);
 }
 
 void mkdirs_for(const std::string& path)
@@ -125,10 +122,10 @@ int run_video(std::map<std::string, std::string>& v, std::map<std::string, bool>
         if (temporal) {                                                                                             // :225-229, :274-278
             const std::string cp = flow_name(v["occlusions_pattern"], file_idx - 1, file_idx, face);
             const std::string fp = flow_name(v["flow_pattern"], file_idx - 1, file_idx, face);
-            wait_for_file(cp, atof(v["poll_timeout"].c_str())); wait_for_file(fp, atof(v["poll_timeout"].c_str()));
+            favp::Poll poll; poll.timeout_s = atof(v["poll_timeout"].c_str()); poll.settle_s = std::max(0.0, atof(v["poll_settle"].c_str()));
             int cw_ = 0, ch_ = 0, cc = 0, fw = 0, fh = 0;
-            check(fav_read_pnm_host(cp.c_str(), &cert, &cw_, &ch_, &cc), "reading the certainty");
-            check(fav_read_flo_host(fp.c_str(), &flo, &fw, &fh), "reading the flow");
+            read_polled(cp, poll, "reading the certainty", [&] { return fav_read_pnm_host(cp.c_str(), &cert, &cw_, &ch_, &cc); });
+            read_polled(fp, poll, "reading the flow", [&] { return fav_read_flo_host(fp.c_str(), &flo, &fw, &fh); });
             if (cc != 1 || cw_ != W || ch_ != H || fw != W || fh != H) die("flow / certainty size does not match the face: " + fp);
             hipc(hipMemcpyAsync(d_cert, cert, (size_t)W * H, hipMemcpyHostToDevice, st), "H2D cert");
             hipc(hipMemcpyAsync(d_flow, flo, (size_t)W * H * 8, hipMemcpyHostToDevice, st), "H2D flow");
@@ -212,7 +209,7 @@ int main(int argc, char** argv)
         {"cudnn_benchmark", "0"}, {"evaluation_file", "evaluation.txt"}, {"flow_pattern_eval", ""}, {"occlusions_pattern_eval", ""},
         {"content_weights", "1.0"}, {"content_layers", "16"}, {"loss_network", "models/vgg16.t7"}, {"style_image", ""},
         {"style_image_size", "256"}, {"style_weights", "5.0"}, {"style_layers", "4,9,16,23"}, {"style_target_type", "gram"},
-        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"png_level", "1"}, {"png_encoder", "gpu"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
+        {"warp_border", "stn"}, {"poll_timeout", "600"}, {"poll_settle", "1.0"}, {"png_level", "1"}, {"png_encoder", "gpu"}, {"seed", "1"}, {"timing", "0"}, {"precision", "fp32"},
         {"streams", ""}, {"gpus", "1"}, {"force_dist", "0"}, {"dry_run", "0"}, {"pin_workers", "1"}, {"worker_rank", "-1"}, {"worker_world", "0"}, {"rccl_id_file", ""}};
     std::map<std::string, bool> b = {
         {"invert_occlusions", false}, {"fix_occlusions", false}, {"smooth_certainty", false}, {"create_inconsistent", false},

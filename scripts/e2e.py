@@ -14,6 +14,8 @@ model = d + "/canonical.t7"; t7.make_synthetic_checkpoint(model, seed=1234)
 for k in range(4):
     O.write_pnm(f"{d}/src/f{k}.ppm", synth.random_frame(H, W, k))
     bw = synth.backward_flow(H, W, 10 + k); O.write_flo(f"{d}/src/b{k}.flo", bw); O.write_flo(f"{d}/src/w{k}.flo", synth.forward_flow_from_backward(bw, 20 + k))
+t_old = time.time() - 30.0            # finished inputs (host/fav_poll.h: anything younger than -poll_settle is watched first)
+for f in os.listdir(d + "/src"): os.utime(f"{d}/src/{f}", (t_old, t_old))
 for i in range(1, N + 1):
     os.symlink(f"{d}/src/f{i % 4}.ppm", f"{d}/frame_{i:05d}.ppm")
     if i > 1:

@@ -27,6 +27,19 @@ except Exception:      # pragma: no cover
         return hashlib.blake2b(b, digest_size=16).digest()
 
 
+def age_files(d, seconds=30.0):
+    """mark every regular file under d as finished `seconds` ago: fav_stylize takes a file younger than -poll_settle (1 s, what
+    fast_artistic_video/utils.lua:79's `sleep 1` buys) only once it has stopped changing for that long (host/fav_poll.h) -- inputs a
+    test or a bench has just written are FINISHED inputs and say so through their modification time"""
+    import time
+    t = time.time() - seconds
+    for base, _, files in os.walk(d):
+        for f in files:
+            p = os.path.join(base, f)
+            if not os.path.islink(p):
+                os.utime(p, (t, t))
+
+
 def make_clip_dir(d, name, frames_h, bw_h, fw_h, nframes, O, cert=False):
     """RAM-backed clip: `ring` distinct frames / flow pairs under d/src, the clip's files are symlinks onto them (frame i -> source
     i % ring).  cert: also reliable_<i>_<i-1>.pgm, written by the REFERENCE's checker in the 4-argument form of
@@ -41,6 +54,7 @@ def make_clip_dir(d, name, frames_h, bw_h, fw_h, nframes, O, cert=False):
         for k in range(ring):
             subprocess.check_call([REF_CHECKER, f"{d}/src/b{k}.flo", f"{d}/src/w{k}.flo", f"{d}/src/r{k}.pgm", f"{d}/src/f{k}.ppm"],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    age_files(d + "/src")
     for i in range(1, nframes + 1):
         os.symlink(f"{d}/src/f{i % ring}.ppm", f"{d}/{name}/frame_{i:05d}.ppm")
         if i > 1:

@@ -25,7 +25,17 @@ def _write_clip(oracle, d, h, w, n, seed):
             bws.append(bw); fws.append(fw)
             oracle.write_flo(str(d / "flow" / f"backward_{i}_{i-1}.flo"), bw)
             oracle.write_flo(str(d / "flow" / f"forward_{i-1}_{i}.flo"), fw)
+    _age(d)
     return frames, bws, fws
+
+
+def _age(d):
+    """finished inputs say so through their modification time (host/fav_poll.h: anything younger than -poll_settle is watched until it
+    has stopped changing for that long, like the reference's `sleep 1`, utils.lua:79)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import e2e_content
+    e2e_content.age_files(str(d))
 
 
 def _stop_helper(run_dir):
@@ -136,6 +146,7 @@ def test_fav_stylize_matches_oracle_loop(oracle, favlib, tmp_path, golden_dir, f
                                    str(tmp_path / "flow" / f"reliable_{i}_{i-1}.pgm"), str(tmp_path / f"frame_{i:05d}.ppm")], stdout=subprocess.DEVNULL,
                                   env=dict(os.environ, FAV_CC_DAEMON="0"))      # (no resident helper left behind by this test)
         masks.append(oracle.consistency(bws[i - 1], fws[i - 1], frames[i - 1]))
+    _age(tmp_path)
     cmd = [os.path.join(BIN, "fav_stylize"), "-input_pattern", str(tmp_path / "frame_%05d.ppm"),
            "-flow_pattern", str(tmp_path / "flow" / "backward_[%d]_{%d}.flo"),
            "-occlusions_pattern", str(tmp_path / "flow" / "reliable_[%d]_{%d}.pgm"),
@@ -432,6 +443,7 @@ def test_fav_stylize_vr_matches_oracle(oracle, favlib, tmp_path, golden_dir):
             ref.face(i, np.transpose(f, (2, 0, 1)).astype(np.float32) / np.float32(255), bw,
                      ce.astype(np.float32) / np.float32(255) if ce is not None else None)
         want.append((oracle.to_u8_hwc(ref.equi), oracle.to_u8_hwc(ref.cubemap)))
+    _age(tmp_path)
     cmd = [os.path.join(ROOT, "fast-artistic-videos_amd", "host", "th"), "fast_artistic_video_vr.lua",
            "-input_pattern", str(tmp_path / "frame_%05d-%d.ppm"),
            "-flow_pattern", str(tmp_path / "flow_768-%d" / "backward_[%d]_{%d}.flo"),
@@ -502,6 +514,7 @@ def test_fav_stylize_vr_multi_stream_launcher_rccl(oracle, favlib, tmp_path, gol
                     os.makedirs(d / f"flow-{face}", exist_ok=True)
                     oracle.write_flo(str(d / f"flow-{face}" / f"backward_{fr}_{fr-1}.flo"), synth.backward_flow(hp, wp, 950 + 100 * k + face))
                     oracle.write_pnm(str(d / f"flow-{face}" / f"reliable_{fr}_{fr-1}.pgm"), ((rng.random((hp, wp)) > 0.2) * 255).astype(np.uint8))
+    _age(tmp_path)
     common = ["-flow_pattern", str(tmp_path / "%S" / "flow-%d" / "backward_[%d]_{%d}.flo"), "-occlusions_pattern", str(tmp_path / "%S" / "flow-%d" / "reliable_[%d]_{%d}.pgm"),
               "-gpu", "0", "-model_vid", model, "-model_img", "self", "-overlap_pixel_h", "24", "-overlap_pixel_w", "24",
               "-out_equi", "-out_equi_w", "96", "-out_equi_h", "48", "-fill_occlusions", "uniform-random", "-seed", "4", "-timing", "1"]
