@@ -116,7 +116,8 @@ def test_unmodified_reference_pipeline(oracle, favlib, cuda, tmp_path, checker):
     (stubs / "ffmpeg").write_text(FFMPEG_STUB); os.chmod(stubs / "ffmpeg", 0o755)
     run = tmp_path / "run"; run.mkdir(mode=0o700)
     env = dict(os.environ, PATH=f"{stubs}:{os.path.join(PKG, 'host')}:{os.environ['PATH']}", FAV_TEST_SRC=str(src),
-               XDG_RUNTIME_DIR=str(run), FAV_CC_IDLE_S="30")
+               XDG_RUNTIME_DIR=str(run), FAV_CC_IDLE_S="30",
+               FAV_TEST_FLOW_DELAY="0.6" if checker == "drop-in" else "0.15")   # (drop-in: keep the stylizer ahead of its producer)
     env.pop("FAV_CC_DAEMON", None)
 
     # ---- the reference's driver, prompts answered with their defaults: GPU 0, cudnn, original resolution, opt_res 2
