@@ -1,5 +1,6 @@
 // api.cpp -- C ABI glue: error reporting, device check, operator-level entry points (A2, A3/A4, A5, A6/A7)
 // and the host-side file formats (A1, A9).  See include/fav.h for the reference interfaces replaced.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cctype>
@@ -275,12 +276,14 @@ extern "C" int fav_read_pnm_into_host(const char* path, uint8_t* buf, size_t cap
 extern "C" int fav_write_pgm_host(const char* path, const uint8_t* data, int W, int H)
 {
     FAV_REQUIRE(path && data && W > 0 && H > 0, "fav_write_pgm_host: bad argument");
-    std::string tmp = std::string(path) + ".tmp";
+    // (the temporary name is per process: two writers of one output -- a caller that gave up on the checker's resident helper next to
+    //  the helper itself -- never share a half-written file; whoever renames last wins with complete bytes)
+    std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) { set_error("Could not open %s for writing", tmp.c_str()); return FAV_EIO; }
     fprintf(f, "P5\n%d %d\n255\n", W, H);
     const bool ok = fwrite(data, 1, (size_t)W * H, f) == (size_t)W * H;
-    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path) != 0) { set_error("write to %s failed", path); return FAV_EIO; }
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path) != 0) { unlink(tmp.c_str()); set_error("write to %s failed", path); return FAV_EIO; }
     return FAV_OK;
 }
 

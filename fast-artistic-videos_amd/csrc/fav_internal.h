@@ -63,8 +63,8 @@ enum LayerType { L_PAD, L_CONV, L_IN, L_RELU, L_RES, L_UP, L_TANH, L_MUL, L_IDEN
 
 struct Layer {
     LayerType type = L_IDENTITY;
-    // pad
-    int pl = 0, pr = 0, pt = 0, pb = 0;
+    // pad: nn.SpatialReflectionPadding (pad_mode 0) / nn.SpatialReplicationPadding (pad_mode 1), models_video.lua:12-16,27-31,70-77
+    int pl = 0, pr = 0, pt = 0, pb = 0, pad_mode = 0;
     // conv
     int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
     int transposed = 0, adj = 0;    // nn.SpatialFullConvolution: w is [cin][cout][k][k]
@@ -205,6 +205,9 @@ int launch_in_finalize(const float* partials, const int* counts, int mblocks, in
                        float* scale, float* shift, hipStream_t st);
 // statistics of t(x) over an NHWC tensor [M][C] -> partials [ceil(M/128)][C] float2
 int launch_stats(const float* x, int M, int C, const Affine& t, float* partials, hipStream_t st);
+// a padding layer INSIDE the network (padding_type reflect / replicate): out[y][x][:] = in[map(y - pt)][map(x - pl)][:] of the (optionally
+// x2 nearest-upsampled) NHWC tensor `in` with row pitch `in_pitch` pixels; mode 0 mirrors without repeating the edge, 1 repeats the edge
+int launch_pad_nhwc(const float* in, int Hp, int Wp, int in_pitch, int C, int ups, float* out, int pl, int pr, int pt, int pb, int mode, hipStream_t st);
 // z[oy][ox][c] = y[oy][ox][c]*scale[c]+shift[c] + t(skip[oy+s][ox+s][c]).  partials != null: also the per-row-segment
 // (mean, M2, count) statistics of z ([res_add_stat_blocks(OH, OW)][C] float2 + counts) for an InstanceNorm that follows the join
 int launch_res_add(const float* y, const float* scale, const float* shift,
@@ -272,7 +275,7 @@ int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const floa
 
 size_t structure_workspace_bytes(int W, int H);
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes,
-                     const float** structure_out, const float** avg_out, hipStream_t st);
+                     const float** structure_out, const float** avg_out, hipStream_t st, int max_blocks = 0);
 int launch_sequential_sum(const float* x, size_t n, float* sum_out, hipStream_t st);
 int launch_consistency(const float* f1_flo, const float* f2_flo, const float* structure, const float* avg,
                        uint8_t* out, int W, int H, hipStream_t st);

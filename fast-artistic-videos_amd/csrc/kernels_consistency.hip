@@ -39,23 +39,29 @@ struct IIR { float k, pm, pp, e2, a2; };
 // gradient [-0.5,0,0.5] with edge-repeating mirror (CFilter.h:600-611,1499-1578), second-moment sums
 // over the 3 colour planes in plane order (consistencyChecker.cpp:54-60)
 // (the three planes are written with a row pitch `pw` that is a multiple of 4 floats: the smoothing passes read 16 bytes per lane)
+// Every wide kernel of the structure map walks its work items with a grid stride: launched with one block per item it is the plain
+// data-parallel form; launched with a CAPPED grid (the look-ahead path: launch_structure's max_blocks) a mask occupies a few CUs' worth
+// of waves for longer instead of flooding the chip next to the network's persistent grids.  Same items, same arithmetic, same bits.
 __global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, float* dxx, float* dyy, float* dxy, int W, int H, int pw)
 {
-    const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const int xm = x - 1 < 0 ? 0 : x - 1, xp = x + 1 >= W ? W - 1 : x + 1;
-    const int ym = y - 1 < 0 ? 0 : y - 1, yp = y + 1 >= H ? H - 1 : y + 1;
-    float sxx = 0.f, syy = 0.f, sxy = 0.f;
-    for (int c = 0; c < 3; ++c) {
-        const float l = (float)rgb_hwc[((size_t)y * W + xm) * 3 + c], r = (float)rgb_hwc[((size_t)y * W + xp) * 3 + c];
-        const float up = (float)rgb_hwc[((size_t)ym * W + x) * 3 + c], dn = (float)rgb_hwc[((size_t)yp * W + x) * 3 + c];
-        const float mid = (float)rgb_hwc[((size_t)y * W + x) * 3 + c];
-        float dx = 0.f; dx += -0.5f * l; dx += 0.0f * mid; dx += 0.5f * r;
-        float dy = 0.f; dy += -0.5f * up; dy += 0.0f * mid; dy += 0.5f * dn;
-        sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+    const int xb = (W + 255) / 256;
+    for (int it = blockIdx.x; it < H * xb; it += gridDim.x) {
+        const int y = it / xb, x = (it - y * xb) * 256 + threadIdx.x;
+        if (x >= W) continue;
+        const int xm = x - 1 < 0 ? 0 : x - 1, xp = x + 1 >= W ? W - 1 : x + 1;
+        const int ym = y - 1 < 0 ? 0 : y - 1, yp = y + 1 >= H ? H - 1 : y + 1;
+        float sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float l = (float)rgb_hwc[((size_t)y * W + xm) * 3 + c], r = (float)rgb_hwc[((size_t)y * W + xp) * 3 + c];
+            const float up = (float)rgb_hwc[((size_t)ym * W + x) * 3 + c], dn = (float)rgb_hwc[((size_t)yp * W + x) * 3 + c];
+            const float mid = (float)rgb_hwc[((size_t)y * W + x) * 3 + c];
+            float dx = 0.f; dx += -0.5f * l; dx += 0.0f * mid; dx += 0.5f * r;
+            float dy = 0.f; dy += -0.5f * up; dy += 0.0f * mid; dy += 0.5f * dn;
+            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+        }
+        const size_t i = (size_t)y * pw + x;
+        dxx[i] = sxx; dyy[i] = syy; dxy[i] = sxy;
     }
-    const size_t i = (size_t)y * pw + x;
-    dxx[i] = sxx; dyy[i] = syy; dxy[i] = sxy;
 }
 
 // recursiveSmoothX / recursiveSmoothY (CFilter.h:1416-1464): one LANE per line, the recurrences of :1426-1437 / :1451-1462 in their
@@ -67,13 +73,18 @@ __global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, fl
 // plane) that budget covers 63 steps; the compiler additionally consumed every group right behind its own loads (s_waitcnt
 // vmcnt(31), (30), ... in the ISA), so each group of 32 steps paid a full round trip: 130-240 us per pass where the arithmetic
 // needs ~40.  With four samples per operation the same budget reaches 250 steps ahead.  v1 (the causal half) goes to `scratch`.
+// Round 6: the smoothed line leaves TRANSPOSED -- sample x of line l goes to out[x * opitch + l]: the 64 lanes of a wave are 64 neighbouring
+// lines, so one store instruction writes 256 contiguous bytes of the transposed plane.  The X pass (lines = image rows) thereby hands the
+// Y pass its lines (image columns) contiguous, and the Y pass hands the eigenvalue kernel row-major planes back: the two tile-transpose
+// launches of rounds 4-5 (22 MB + 15 MB of wide-kernel traffic next to the network) are gone; `m` is only read.
 template <int NGF, int NGB>
-__global__ __launch_bounds__(64) void iir_rows_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n, int pitch, IIR c)
+__global__ __launch_bounds__(64) void iir_rows_kernel(const float* plane0, size_t plane_stride, float* scratch0, float* out0, int opitch, int nlines, int n, int pitch, IIR c)
 {
     const int line = blockIdx.x * 64 + threadIdx.x;
     if (line >= nlines || n < 2) return;
-    float* __restrict__ m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
+    const float* __restrict__ m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
     float* __restrict__ v1 = scratch0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
+    float* __restrict__ outT = out0 + (size_t)blockIdx.y * plane_stride + line;
     constexpr int G = 16;
     const float c0f = 0.5f - c.k * c.pm, cd = c.a2 - c.e2;
     // ---------------------------------------------------------------- causal sweep, x = 0 .. n-1
@@ -166,21 +177,18 @@ __global__ __launch_bounds__(64) void iir_rows_kernel(float* plane0, size_t plan
                 float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
                 if (j == 0) bv = c1f * hm[0];
                 if (j == 1) bv = c.k * (cpe * mo1) + cd * b0;
-                m[x] = hv[j] + bv;
+                outT[(size_t)x * opitch] = hv[j] + bv;
                 b1 = b0; b0 = bv; mo2 = mo1; mo1 = hm[j];
             }
         }
         auto chain = [&](const float (&rm)[G], const float (&rv)[G], int g) {
-            float4* o = reinterpret_cast<float4*>(m + (size_t)g * G);
-            float out[G];
+            float* o = outT + (size_t)g * G * opitch;
 #pragma unroll
             for (int q = G - 1; q >= 0; --q) {
                 const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-                out[q] = rv[q] + bv;
+                o[(size_t)q * opitch] = rv[q] + bv;
                 b1 = b0; b0 = bv; mo2 = mo1; mo1 = rm[q];
             }
-#pragma unroll
-            for (int j = 3; j >= 0; --j) o[j] = make_float4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
             asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mo1), "=&v"(mo2) : "v"(rm[0]), "v"(rm[1]));      // (as above)
         };
         int gb = 0;
@@ -199,25 +207,49 @@ __global__ __launch_bounds__(64) void iir_rows_kernel(float* plane0, size_t plan
     }
 }
 
-// eigenvalue (consistencyChecker.cpp:69-77) read from the TRANSPOSED smoothed planes [W][ph] (the Y pass runs on them) and written
-// in image order [H][W] -- the order CMatrix::normalize's scan and CMatrix::avg depend on: a 32x32 tile of the three planes through LDS
-__global__ __launch_bounds__(256) void eigen_t_kernel(const float* t3, size_t ps, float* corners, int H, int W, int ph)
+// eigenvalue (consistencyChecker.cpp:69-77) from the three smoothed planes (row-major again, row pitch pw), written in image order
+// [H][W] -- the order CMatrix::normalize's scan and CMatrix::avg depend on -- together with the maximum of every NB consecutive elements
+// (pass 1 of the normalize scan below: one launch and one read of the map less)
+constexpr int NB = 1024;   // elements per block in the normalize scans
+
+__device__ __forceinline__ float eigen_min(float a, float c, float b)
 {
-    __shared__ float tl[3][32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;      // x (column) and y (row) origin of the tile
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int p = 0; p < 3; ++p)
-        for (int j = ty; j < 32; j += 8)
-            if (c0 + j < W && r0 + tx < H) tl[p][j][tx] = t3[(size_t)p * ps + (size_t)(c0 + j) * ph + r0 + tx];
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int y = r0 + j, x = c0 + tx;
-        if (y < H && x < W) {
-            const float a = tl[0][tx][j], c = tl[1][tx][j], b = tl[2][tx][j];        // dxx, dyy, dxy
-            const float temp = (float)(0.5 * (double)(a + c));                      // consistencyChecker.cpp:73
-            const float temp2 = temp * temp + b * b - a * c;
-            corners[(size_t)y * W + x] = temp2 < 0.0f ? 0.0f : temp - sqrtf(temp2);
+    const float temp = (float)(0.5 * (double)(a + c));                      // consistencyChecker.cpp:73
+    const float temp2 = temp * temp + b * b - a * c;
+    return temp2 < 0.0f ? 0.0f : temp - sqrtf(temp2);
+}
+
+__global__ __launch_bounds__(256) void eigen_blockmax_kernel(const float* p3, size_t ps, int pw, float* corners, int H, int W, float* bmax, int nb)
+{
+    __shared__ float sh[4];
+    const size_t n = (size_t)H * W;
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const size_t i0 = (size_t)b * NB + (size_t)threadIdx.x * 4;
+        float mx = -INFINITY;
+        if (i0 < n) {
+            const int y = (int)(i0 / W), x = (int)(i0 - (size_t)y * W);
+            if ((W & 3) == 0) {                          // (then i0 .. i0 + 3 lie in one row and every address is 16-byte aligned)
+                const size_t o = (size_t)y * pw + x;
+                const float4 a = *reinterpret_cast<const float4*>(p3 + o), c = *reinterpret_cast<const float4*>(p3 + ps + o), bb = *reinterpret_cast<const float4*>(p3 + 2 * ps + o);
+                float4 r;
+                r.x = eigen_min(a.x, c.x, bb.x); r.y = eigen_min(a.y, c.y, bb.y); r.z = eigen_min(a.z, c.z, bb.z); r.w = eigen_min(a.w, c.w, bb.w);
+                *reinterpret_cast<float4*>(corners + i0) = r;
+                mx = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
+            } else {
+                int yy = y, xx = x;
+                for (int j = 0; j < 4 && i0 + j < n; ++j) {
+                    const size_t o = (size_t)yy * pw + xx;
+                    const float r = eigen_min(p3[o], p3[ps + o], p3[2 * ps + o]);
+                    corners[i0 + j] = r; mx = fmaxf(mx, r);
+                    if (++xx == W) { xx = 0; ++yy; }
+                }
+            }
         }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) bmax[b] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        __syncthreads();
     }
 }
 
@@ -225,23 +257,8 @@ __global__ __launch_bounds__(256) void eigen_t_kernel(const float* t3, size_t ps
 //     if (v > cmax) cmax = v; else if (v < cmin) cmin = v;        cmax0 = -30000, cmin0 = +30000
 // cmax = max(-30000, max_i v_i).  An element updates cmin only when it is NOT a strict running
 // maximum, i.e. v_i <= max(-30000, v_0..v_{i-1}).  Both are computed exactly in parallel:
-// pass 1: per-block maxima; pass 2: exclusive prefix max over blocks (single block) then, per block,
+// pass 1: per-block maxima (eigen_blockmax_kernel above); pass 2: exclusive prefix max over blocks (single block) then, per block,
 // an in-block exclusive running max and the min over non-record elements.
-constexpr int NB = 1024;   // elements per block in the normalize scans
-
-__global__ __launch_bounds__(256) void blockmax_kernel(const float* v, size_t n, float* bmax)
-{
-    __shared__ float sh[4];
-    const size_t base = (size_t)blockIdx.x * NB;
-    float m = -INFINITY;
-    for (int j = threadIdx.x; j < NB; j += 256)
-        if (base + j < n) m = fmaxf(m, v[base + j]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) bmax[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-}
-
 // single block: exclusive prefix max of bmax (seeded with -30000) -> bpre; total max -> mm[0]
 __global__ __launch_bounds__(1024) void prefixmax_kernel(const float* bmax, int nb, float* bpre, float* mm)
 {
@@ -267,39 +284,42 @@ __global__ __launch_bounds__(1024) void prefixmax_kernel(const float* bmax, int 
     if (threadIdx.x == 0) mm[0] = carry;              // cmax
 }
 
-__global__ __launch_bounds__(256) void quirkmin_kernel(const float* v, size_t n, const float* bpre, float* bmin)
+__global__ __launch_bounds__(256) void quirkmin_kernel(const float* v, size_t n, const float* bpre, float* bmin, int nb)
 {
     __shared__ float sh[NB];
     __shared__ float red[4];
-    const size_t base = (size_t)blockIdx.x * NB;
-    for (int j = threadIdx.x; j < NB; j += 256) sh[j] = base + j < n ? v[base + j] : -INFINITY;
-    __syncthreads();
-    // each thread owns 4 consecutive elements; running max of everything before them: exclusive prefix max over the 256 threads'
-    // own maxima (max is exact and associative: wave scan by shuffles, then the waves before this one) -- the first version re-read
-    // up to 1020 LDS words per thread (0.15 ms per mask)
-    const int j0 = threadIdx.x * 4;
     __shared__ float wmax[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float inc = fmaxf(fmaxf(sh[j0], sh[j0 + 1]), fmaxf(sh[j0 + 2], sh[j0 + 3]));
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const size_t base = (size_t)b * NB;
+        for (int j = threadIdx.x; j < NB; j += 256) sh[j] = base + j < n ? v[base + j] : -INFINITY;
+        __syncthreads();
+        // each thread owns 4 consecutive elements; running max of everything before them: exclusive prefix max over the 256 threads'
+        // own maxima (max is exact and associative: wave scan by shuffles, then the waves before this one) -- the first version re-read
+        // up to 1020 LDS words per thread (0.15 ms per mask)
+        const int j0 = threadIdx.x * 4;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float inc = fmaxf(fmaxf(sh[j0], sh[j0 + 1]), fmaxf(sh[j0 + 2], sh[j0 + 3]));
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(inc, o); if (lane >= o) inc = fmaxf(inc, up); }
-    if (lane == 63) wmax[wv] = inc;
-    __syncthreads();
-    float pre = __shfl_up(inc, 1);
-    if (lane == 0) pre = -INFINITY;
-    for (int k = 0; k < wv; ++k) pre = fmaxf(pre, wmax[k]);
-    pre = fmaxf(pre, bpre[blockIdx.x]);
-    float mn = 30000.0f;
-    for (int j = j0; j < j0 + 4; ++j) {
-        if (base + j < n) {
-            const float x = sh[j];
-            if (x > pre) pre = x; else if (x < mn) mn = x;
+        for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(inc, o); if (lane >= o) inc = fmaxf(inc, up); }
+        if (lane == 63) wmax[wv] = inc;
+        __syncthreads();
+        float pre = __shfl_up(inc, 1);
+        if (lane == 0) pre = -INFINITY;
+        for (int k = 0; k < wv; ++k) pre = fmaxf(pre, wmax[k]);
+        pre = fmaxf(pre, bpre[b]);
+        float mn = 30000.0f;
+        for (int j = j0; j < j0 + 4; ++j) {
+            if (base + j < n) {
+                const float x = sh[j];
+                if (x > pre) pre = x; else if (x < mn) mn = x;
+            }
         }
+        for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+        __syncthreads();
+        if (threadIdx.x == 0) bmin[b] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
-    __syncthreads();
-    if (threadIdx.x == 0) bmin[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
 }
 
 __global__ __launch_bounds__(256) void minreduce_kernel(const float* bmin, int nb, float* mm)
@@ -313,16 +333,37 @@ __global__ __launch_bounds__(256) void minreduce_kernel(const float* bmin, int n
     if (threadIdx.x == 0) mm[1] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));   // cmin
 }
 
-__global__ __launch_bounds__(256) void normalize_kernel(float* v, size_t n, const float* mm)
+// normalize(0, 1) (CMatrix.h:731-736) fused with step 1 of the parallel CMatrix::avg below (the fp64 sum and the "has an element the
+// transducer cannot take" flag of every chunk of 256 NORMALISED elements -- same lanes, same reduction order as avg_chunk_sum_kernel):
+// one read and one launch less per mask.  csum == nullptr: normalisation only.
+__device__ __forceinline__ float normalize_one(float x, float cmin, float t) { x -= cmin; x *= t; x += 0.0f; return x; }
+
+__global__ __launch_bounds__(256) void normalize_sum_kernel(float* v, size_t n, const float* mm, double* csum, int* cbad)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const float cmax = mm[0], cmin = mm[1];
     float t = cmax - cmin;
     if (t == 0.f) t = 1.f; else t = (1.0f - 0.0f) / t;
-    float x = v[i];
-    x -= cmin; x *= t; x += 0.0f;
-    v[i] = x;
+    const int lane = threadIdx.x & 63;
+    const size_t nblk = (n + 1023) / 1024;
+    for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const size_t chunk = blk * 4 + (threadIdx.x >> 6);
+        const size_t base = chunk * 256 + (size_t)lane * 4;
+        if (chunk * 256 >= n) continue;
+        float x[4];
+        if (base + 4 <= n) {
+            const float4 q = *reinterpret_cast<const float4*>(v + base);
+            x[0] = normalize_one(q.x, cmin, t); x[1] = normalize_one(q.y, cmin, t); x[2] = normalize_one(q.z, cmin, t); x[3] = normalize_one(q.w, cmin, t);
+            *reinterpret_cast<float4*>(v + base) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+            for (int j = 0; j < 4; ++j) { x[j] = 0.f; if (base + j < n) { x[j] = normalize_one(v[base + j], cmin, t); v[base + j] = x[j]; } }
+        }
+        if (!csum) continue;
+        double s = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
+        int bad = 0;
+        for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(x[j]); bad |= (int)(b >> 31) | (int)(((b >> 23) & 255u) == 255u); }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); bad |= __shfl_xor(bad, o); }
+        if (lane == 0) { csum[chunk] = s; cbad[chunk] = bad; }
+    }
 }
 
 // CMatrix::avg: fp32 running sum in index order, then / size (CMatrix.h:1245-1251).  Every addition rounds, so the value
@@ -516,17 +557,20 @@ struct ChunkXd { int e_lo, flags, d0[2], d1[2], pp[2]; };     // flags: bit 0 sl
 
 __global__ __launch_bounds__(256) void avg_chunk_sum_kernel(const float* v, int n, double* csum, int* cbad)
 {
-    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int base = chunk * ACH + lane * 4;
-    if (chunk * ACH >= n) return;
-    float x[4];
-    if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
-    else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }
-    double t = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
-    int bad = 0;
-    for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(x[j]); bad |= (int)(b >> 31) | (int)(((b >> 23) & 255u) == 255u); }
-    for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); bad |= __shfl_xor(bad, o); }
-    if (lane == 0) { csum[chunk] = t; cbad[chunk] = bad; }
+    const int lane = threadIdx.x & 63;
+    for (int blk = blockIdx.x; blk * 4 * ACH < n; blk += gridDim.x) {
+        const int chunk = blk * 4 + (threadIdx.x >> 6);
+        const int base = chunk * ACH + lane * 4;
+        if (chunk * ACH >= n) continue;
+        float x[4];
+        if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
+        else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }
+        double t = ((double)x[0] + (double)x[1]) + ((double)x[2] + (double)x[3]);
+        int bad = 0;
+        for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(x[j]); bad |= (int)(b >> 31) | (int)(((b >> 23) & 255u) == 255u); }
+        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); bad |= __shfl_xor(bad, o); }
+        if (lane == 0) { csum[chunk] = t; cbad[chunk] = bad; }
+    }
 }
 
 __device__ __forceinline__ int f32_exponent_of(double p)     // exponent field of p rounded to fp32 (0 if zero / denormal / not finite)
@@ -541,48 +585,51 @@ __global__ __launch_bounds__(256) void avg_chunk_class_kernel(const float* v, in
     __shared__ double red[4];
     __shared__ double s_pre;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int chunk0 = blockIdx.x * 4;
-    // exclusive prefix of the chunk sums at this block's first chunk (the estimate only steers the choice of exponents)
-    double acc = 0.0;
-    for (int j = t; j < chunk0; j += 256) acc += csum[j];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (t == 0) s_pre = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    const int chunk = chunk0 + wave;
-    if (chunk >= nchunks) return;
-    double P = s_pre;
-    for (int j = 0; j < wave; ++j) P += csum[chunk0 + j];
-    const double T = csum[chunk];
-    const int e_lo = f32_exponent_of(P * 0.96875), e_hi = f32_exponent_of((P + T) * 1.03125);
-    const int base = chunk * ACH + lane * 4;
-    float x[4];
-    if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
-    else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }      // (padding zeros are identity transducers)
-    ChunkXd r; r.e_lo = e_lo; r.flags = cbad[chunk] ? 256 : 0;
-    const int nslots = (e_lo == 0 || cbad[chunk]) ? 0 : (e_hi > e_lo ? 2 : 1);
+    for (int blk = blockIdx.x; blk * 4 < nchunks; blk += gridDim.x) {
+        const int chunk0 = blk * 4;
+        // exclusive prefix of the chunk sums at this block's first chunk (the estimate only steers the choice of exponents)
+        double acc = 0.0;
+        for (int j = t; j < chunk0; j += 256) acc += csum[j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        __syncthreads();                                     // (the previous item's s_pre / red have been read by everyone)
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (t == 0) s_pre = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        const int chunk = chunk0 + wave;
+        if (chunk >= nchunks) continue;
+        double P = s_pre;
+        for (int j = 0; j < wave; ++j) P += csum[chunk0 + j];
+        const double T = csum[chunk];
+        const int e_lo = f32_exponent_of(P * 0.96875), e_hi = f32_exponent_of((P + T) * 1.03125);
+        const int base = chunk * ACH + lane * 4;
+        float x[4];
+        if (base + 4 <= n) { const float4 q = *reinterpret_cast<const float4*>(v + base); x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w; }
+        else { for (int j = 0; j < 4; ++j) x[j] = base + j < n ? v[base + j] : 0.f; }      // (padding zeros are identity transducers)
+        ChunkXd r; r.e_lo = e_lo; r.flags = cbad[chunk] ? 256 : 0;
+        const int nslots = (e_lo == 0 || cbad[chunk]) ? 0 : (e_hi > e_lo ? 2 : 1);
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        r.d0[sl] = 0; r.d1[sl] = 0; r.pp[sl] = 2;
-        if (sl >= nslots) continue;                          // (wave-uniform)
-        const int e = e_lo + sl;
-        int d0 = 0, d1 = 0, p0 = 0, p1 = 1;
+        for (int sl = 0; sl < 2; ++sl) {
+            r.d0[sl] = 0; r.d1[sl] = 0; r.pp[sl] = 2;
+            if (sl >= nslots) continue;                          // (wave-uniform)
+            const int e = e_lo + sl;
+            int d0 = 0, d1 = 0, p0 = 0, p1 = 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int f, g, tie; elem_class(x[j], e, f, g, tie);
-            const int fo = f & 1;
-            const int dl0 = f + g + (tie & (p0 ^ fo)), dl1 = f + g + (tie & (p1 ^ fo));
-            d0 = sat_add(d0, dl0); p0 = (p0 + dl0) & 1;
-            d1 = sat_add(d1, dl1); p1 = (p1 + dl1) & 1;
+            for (int j = 0; j < 4; ++j) {
+                int f, g, tie; elem_class(x[j], e, f, g, tie);
+                const int fo = f & 1;
+                const int dl0 = f + g + (tie & (p0 ^ fo)), dl1 = f + g + (tie & (p1 ^ fo));
+                d0 = sat_add(d0, dl0); p0 = (p0 + dl0) & 1;
+                d1 = sat_add(d1, dl1); p1 = (p1 + dl1) & 1;
+            }
+            Xd inc = {d0, d1, p0 | (p1 << 1)};
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const Xd a = xd_shfl_up(inc, off); if (lane >= off) inc = xd_then(a, inc); }
+            r.d0[sl] = __shfl(inc.d0, 63); r.d1[sl] = __shfl(inc.d1, 63); r.pp[sl] = __shfl(inc.pp, 63);
+            r.flags |= 1 << sl;
         }
-        Xd inc = {d0, d1, p0 | (p1 << 1)};
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const Xd a = xd_shfl_up(inc, off); if (lane >= off) inc = xd_then(a, inc); }
-        r.d0[sl] = __shfl(inc.d0, 63); r.d1[sl] = __shfl(inc.d1, 63); r.pp[sl] = __shfl(inc.pp, 63);
-        r.flags |= 1 << sl;
+        if (lane == 0) out[chunk] = r;
     }
-    if (lane == 0) out[chunk] = r;
 }
 
 __global__ __launch_bounds__(1024) void avg_chunk_scan_kernel(const float* v, int n, const ChunkXd* cx, int nchunks, int* state_out)
@@ -678,22 +725,6 @@ __global__ __launch_bounds__(1024) void avg_chunk_scan_kernel(const float* v, in
     }
 }
 
-// [R][C] (row pitch pin) -> [C][R] (row pitch pout) per plane, 32x32 LDS tiles, both sides coalesced: the Y smoothing pass runs as
-// the same one-lane-per-contiguous-line kernel as the X pass, without changing a single floating-point operation
-__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, size_t plane_stride, int R, int C, int pin, int pout)
-{
-    __shared__ float tl[32][33];
-    const float* ip = in + (size_t)blockIdx.z * plane_stride;
-    float* op = out + (size_t)blockIdx.z * plane_stride;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < C) tl[j][tx] = ip[(size_t)(r0 + j) * pin + c0 + tx];
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * pout + r0 + tx] = tl[tx][j];
-}
-
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -706,26 +737,42 @@ size_t seqsum_workspace_bytes(size_t n)
 }
 
 // the four launches of the sum (see avg_chunk_sum_kernel): short arrays go straight to the one-block kernel
-static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st)
+struct SeqsumPlan { bool multi = false; int nc = 0; int* state = nullptr; double* csum = nullptr; int* cbad = nullptr; ChunkXd* cx = nullptr; };
+
+static SeqsumPlan seqsum_plan(size_t n, void* ws)
 {
     static const bool one_block = getenv("FAV_AVG_ONE_BLOCK") != nullptr;       // (A/B: the round-3 form)
-    // (very long arrays too: avg_chunk_class_kernel re-adds the chunk sums before its chunk in every block -- nc^2 / 2 reads, nothing at
-    //  1280x720 (3 600 chunks) or a 1504^2 VR face (8 836), minutes of L2 traffic at the 2^31 elements fav_sequential_sum_f32 accepts;
-    //  the one-block kernel is linear.  Both produce the same bits: the sequential fp32 sum is what they compute)
-    if (n < 65536 || one_block || !ws || n > (size_t)16384 * ACH) {
+    SeqsumPlan pl;
+    // (very long arrays too: avg_chunk_class_kernel re-adds the chunk sums before its chunk in every block -- nc^2 / 8 reads of 8 bytes:
+    //  nothing at 1280x720 (3 600 chunks) or a 1504^2 VR face (8 836), 1 GB of L2 reads (~0.1 ms) for a 3840x2160 frame (32 400), 4 GB at
+    //  the 65 536 chunks below -- against 1 024 dependent windows of ~14 us for the one-block kernel at that length -- and minutes at the
+    //  2^31 elements fav_sequential_sum_f32 accepts, where the one-block kernel is linear.  Both produce the same bits: the sequential fp32
+    //  sum is what they compute)
+    if (n < 65536 || one_block || !ws || n > (size_t)65536 * ACH) return pl;
+    pl.multi = true;
+    pl.nc = (int)((n + ACH - 1) / ACH);
+    char* w = static_cast<char*>(ws);
+    pl.state = reinterpret_cast<int*>(w);
+    pl.csum = reinterpret_cast<double*>(w + 256);
+    pl.cbad = reinterpret_cast<int*>(w + 256 + align_up((size_t)pl.nc * 8, 256));
+    pl.cx = reinterpret_cast<ChunkXd*>(w + 256 + align_up((size_t)pl.nc * 8, 256) + align_up((size_t)pl.nc * 4, 256));
+    return pl;
+}
+
+// presummed: the chunk sums / flags of step 1 are already in the workspace (normalize_sum_kernel wrote them)
+static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st, int max_blocks = 0, bool presummed = false)
+{
+    auto cap = [&](int g) { return max_blocks > 0 && g > max_blocks ? max_blocks : g; };
+    const SeqsumPlan pl = seqsum_plan(n, ws);
+    if (!pl.multi) {
         hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(nullptr));
         return;
     }
-    const int nc = (int)((n + ACH - 1) / ACH);
-    char* w = static_cast<char*>(ws);
-    int* state = reinterpret_cast<int*>(w);
-    double* csum = reinterpret_cast<double*>(w + 256);
-    int* cbad = reinterpret_cast<int*>(w + 256 + align_up((size_t)nc * 8, 256));
-    ChunkXd* cx = reinterpret_cast<ChunkXd*>(w + 256 + align_up((size_t)nc * 8, 256) + align_up((size_t)nc * 4, 256));
-    hipLaunchKernelGGL(avg_chunk_sum_kernel, dim3((nc + 3) / 4), dim3(256), 0, st, v, (int)n, csum, cbad);
-    hipLaunchKernelGGL(avg_chunk_class_kernel, dim3((nc + 3) / 4), dim3(256), 0, st, v, (int)n, csum, cbad, nc, cx);
-    hipLaunchKernelGGL(avg_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, cx, nc, state);
-    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(state));
+    const int nc = pl.nc;
+    if (!presummed) hipLaunchKernelGGL(avg_chunk_sum_kernel, dim3(cap((nc + 3) / 4)), dim3(256), 0, st, v, (int)n, pl.csum, pl.cbad);
+    hipLaunchKernelGGL(avg_chunk_class_kernel, dim3(cap((nc + 3) / 4)), dim3(256), 0, st, v, (int)n, pl.csum, pl.cbad, nc, pl.cx);
+    hipLaunchKernelGGL(avg_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, pl.cx, nc, pl.state);
+    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(pl.state));
 }
 
 // floats per plane: the larger of the [H][pw] and the transposed [W][ph] layout (row pitches rounded up to 4 floats)
@@ -757,14 +804,17 @@ static void iir_constants(float sigma, IIR& c)
     c.e2 = aExpSqr;
 }
 
+// max_blocks > 0: every wide launch is capped at that many blocks (they walk their items with a grid stride) -- the look-ahead path, where
+// a mask runs next to the network of an earlier frame (fav_stream_prefetch_mask); 0: one block per item
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes, const float** structure_out,
-                     const float** avg_out, hipStream_t st)
+                     const float** avg_out, hipStream_t st, int max_blocks)
 {
     FAV_REQUIRE(ws != nullptr && ws_bytes >= structure_workspace_bytes(W, H), "consistency: workspace too small");
     FAV_REQUIRE(W >= 2 && H >= 2, "consistency: structure mode needs W,H >= 2");
     const size_t n = (size_t)W * H, ps = structure_plane_floats(W, H);
     const int pw = (W + 3) & ~3, ph = (H + 3) & ~3;
     const int nb = (int)((n + NB - 1) / NB);
+    auto cap = [&](long long g) { return (unsigned)(max_blocks > 0 && g > max_blocks ? max_blocks : g); };
     float* planes = static_cast<float*>(ws);          // dxx, dyy, dxy
     float* scratch = planes + 3 * ps;
     float* corners = scratch + 3 * ps;
@@ -774,21 +824,20 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     float* bmin = bpre + align_up((size_t)nb * 4, 256) / 4;
     float* mm = bmin + align_up((size_t)nb * 4, 256) / 4;   // [0]=cmax [1]=cmin [2]=avg
     IIR c; iir_constants(3.0f, c);                          // main(): computeCorners(image, &structure, 3.0f)
-    const dim3 g2((W + 255) / 256, H);
-    hipLaunchKernelGGL(moments_kernel, g2, dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H, pw);
-    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane.  X pass on the rows of the planes,
-    // transpose, Y pass on the rows of the transposed planes, eigenvalue read back through a tile transpose (blocks of ONE wave: a pass is
-    // 34 / 60 waves, each gets a SIMD of its own)
-    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((H + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, H, W, pw, c);
-    hipLaunchKernelGGL(transpose_kernel, dim3((W + 31) / 32, (H + 31) / 32, 3), dim3(256), 0, st, planes, tmp3, ps, H, W, pw, ph);
-    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((W + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, W, H, ph, c);
-    hipLaunchKernelGGL(eigen_t_kernel, dim3((W + 31) / 32, (H + 31) / 32), dim3(256), 0, st, tmp3, ps, corners, H, W, ph);
-    hipLaunchKernelGGL(blockmax_kernel, dim3(nb), dim3(256), 0, st, corners, n, bmax);
+    hipLaunchKernelGGL(moments_kernel, dim3(cap((long long)((W + 255) / 256) * H)), dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H, pw);
+    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane.  X pass on the rows of the planes; its
+    // result leaves transposed ([W][ph] in tmp3), so the Y pass finds the image's columns contiguous; the Y pass writes row-major planes
+    // back (blocks of ONE wave: a pass is 34 / 60 waves, each gets a SIMD of its own).  No transpose launches since round 6.
+    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((H + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, tmp3, ph, H, W, pw, c);
+    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((W + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, planes, pw, W, H, ph, c);
+    hipLaunchKernelGGL(eigen_blockmax_kernel, dim3(cap(nb)), dim3(256), 0, st, planes, ps, pw, corners, H, W, bmax, nb);
     hipLaunchKernelGGL(prefixmax_kernel, dim3(1), dim3(1024), 0, st, bmax, nb, bpre, mm);
-    hipLaunchKernelGGL(quirkmin_kernel, dim3(nb), dim3(256), 0, st, corners, n, bpre, bmin);
+    hipLaunchKernelGGL(quirkmin_kernel, dim3(cap(nb)), dim3(256), 0, st, corners, n, bpre, bmin, nb);
     hipLaunchKernelGGL(minreduce_kernel, dim3(1), dim3(256), 0, st, bmin, nb, mm);
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, corners, n, mm);
-    launch_seqsum(corners, n, reinterpret_cast<char*>(mm) + 256, mm + 2, nullptr, st);
+    void* sum_ws = reinterpret_cast<char*>(mm) + 256;
+    const SeqsumPlan pl = seqsum_plan(n, sum_ws);
+    hipLaunchKernelGGL(normalize_sum_kernel, dim3(cap((long long)nb)), dim3(256), 0, st, corners, n, mm, pl.multi ? pl.csum : nullptr, pl.multi ? pl.cbad : nullptr);
+    launch_seqsum(corners, n, sum_ws, mm + 2, nullptr, st, max_blocks, true);
     FAV_LAUNCH_CHECK("structure kernels");
     *structure_out = corners;
     *avg_out = mm + 2;

@@ -324,6 +324,26 @@ __global__ __launch_bounds__(256) void check_prep_kernel(const uint8_t* frame_hw
     }
 }
 
+// A padding layer inside the network (models_video.lua:12-16,27-31,70-77: padding_type reflect / replicate puts one in front of every
+// convolution): out[y][x][:] = in[map(y - pt)][map(x - pl)][:], NHWC, 16 bytes per lane.  mode 0 = nn.SpatialReflectionPadding (mirror
+// without repeating the edge pixel), mode 1 = nn.SpatialReplicationPadding (repeat the edge pixel) [both `nn`, recalled; the oracle
+// pins them on numpy's 'reflect' / 'edge' modes = torch.nn.functional.pad's].  `ups`: the source is still to be x2 nearest-upsampled
+// (nn.SpatialUpSamplingNearest pending on the tensor): logical pixel (i, j) lives at (i >> 1, j >> 1).
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(const float4* in, int Hl, int Wl, int in_pitch, int C4, int ups, float4* out, int Ho, int Wo, int pl, int pt, int mode)
+{
+    const size_t total = (size_t)Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const size_t px = i / C4;
+        const int x = (int)(px % Wo), y = (int)(px / Wo);
+        int sy = y - pt, sx = x - pl;
+        if (mode == 0) { if (sy < 0) sy = -sy; if (sy >= Hl) sy = 2 * (Hl - 1) - sy; if (sx < 0) sx = -sx; if (sx >= Wl) sx = 2 * (Wl - 1) - sx; }
+        else { sy = sy < 0 ? 0 : (sy >= Hl ? Hl - 1 : sy); sx = sx < 0 ? 0 : (sx >= Wl ? Wl - 1 : sx); }
+        sy >>= ups; sx >>= ups;
+        out[i] = in[((size_t)sy * in_pitch + sx) * C4 + c];
+    }
+}
+
 // test view of the fused input: interior of the padded NHWC8 buffer -> planar [7][H][W] (fav_stream_get_input_f32)
 __global__ __launch_bounds__(256) void unpad_input_kernel(const float* in8, int H, int W, int pad, float* in7)
 {
@@ -457,6 +477,20 @@ int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, i
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
                        prev_rgb, Hs, Ws, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
     FAV_LAUNCH_CHECK("prep_input_kernel");
+    return FAV_OK;
+}
+
+int launch_pad_nhwc(const float* in, int Hp, int Wp, int in_pitch, int C, int ups, float* out, int pl, int pr, int pt, int pb, int mode, hipStream_t st)
+{
+    FAV_REQUIRE(in && out && C > 0 && (C & 3) == 0 && pl >= 0 && pr >= 0 && pt >= 0 && pb >= 0 && (mode == 0 || mode == 1) && (ups == 0 || ups == 1), "padding layer: bad argument");
+    const int Hl = Hp << ups, Wl = Wp << ups;
+    FAV_REQUIRE(mode == 1 || (pl < Wl && pr < Wl && pt < Hl && pb < Hl), "reflection padding must be smaller than the tensor");
+    const int Ho = Hl + pt + pb, Wo = Wl + pl + pr;
+    const size_t total = (size_t)Ho * Wo * (C / 4);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(in), Hl, Wl, in_pitch, C / 4, ups,
+                       reinterpret_cast<float4*>(out), Ho, Wo, pl, pt, mode);
+    FAV_LAUNCH_CHECK("pad_nhwc_kernel");
     return FAV_OK;
 }
 

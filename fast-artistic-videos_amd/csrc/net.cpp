@@ -183,6 +183,7 @@ struct fav_net {
     std::vector<Layer> layers;    // as parsed from the checkpoint (describe / output size / parameter count)
     std::vector<Layer> exec;      // what runs: the same network with channel counts padded to powers of two (pad_channel_counts)
     int pad = 0;                  // leading nn.SpatialReflectionPadding (train_video.lua:319-325)
+    bool pad_folded = false;      // ... folded into the input assembly (layers[0] is then skipped by the executor)
     int in_channels = 0;
     long long params = 0;
     std::vector<DevConvW> convs;  // traversal order
@@ -363,14 +364,15 @@ int fav_net::upload()
 {
     FAV_HIP(hipSetDevice(device));
     if (layers.empty()) { set_error("network: empty model"); return FAV_EFORMAT; }
-    size_t first = 0;
+    // A LEADING symmetric reflection padding (padding_type reflect-start: train_video.lua:319-325; also the pad in front of the first
+    // convolution with padding_type reflect, models_video.lua:70-72) is folded into the input assembly (prep_input / check_prep write the
+    // reflected copies).  Every other padding layer -- replication, asymmetric, or further inside the network (models_video.lua:12-16,27-31:
+    // padding_type reflect / replicate pads in front of EVERY convolution) -- runs as a gather launch (launch_pad_nhwc).
+    pad = 0; pad_folded = false;
     if (layers[0].type == L_PAD) {
         const Layer& P = layers[0];
-        if (P.pl != P.pr || P.pl != P.pt || P.pl != P.pb || P.pl < 0) { set_error("network: asymmetric reflection padding is unsupported"); return FAV_EUNSUPPORTED; }
-        pad = P.pl; first = 1;
+        if (P.pad_mode == 0 && P.pl == P.pr && P.pl == P.pt && P.pl == P.pb) { pad = P.pl; pad_folded = true; }
     }
-    for (size_t i = first; i < layers.size(); ++i)
-        if (layers[i].type == L_PAD) { set_error("network: reflection padding is only supported as the first layer (padding_type reflect-start)"); return FAV_EUNSUPPORTED; }
     in_channels = 0;
     for (const Layer& L : layers) if (L.type == L_CONV) { in_channels = L.cin; break; }
     if (in_channels != 7 && in_channels != 3) {
@@ -496,7 +498,20 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
     for (size_t li = 0; li < ls.size(); ++li) {
         Layer& L = ls[li];
         switch (L.type) {
-        case L_PAD: break;   // folded into the input conversion (leading layer only, checked in upload())
+        case L_PAD: {
+            if (top && li == 0 && pad_folded) break;        // folded into the input assembly (upload())
+            if (cur.data == nullptr || cur.join_skip != nullptr) { set_error("network: misplaced padding layer"); return FAV_EUNSUPPORTED; }
+            // reflection needs pad < size on each axis (nn.SpatialReflectionPadding asserts the same)
+            if (L.pad_mode == 0 && (std::max(L.pl, L.pr) >= cur.W() || std::max(L.pt, L.pb) >= cur.H())) { set_error("network: reflection padding %d %d %d %d of a %dx%d tensor", L.pl, L.pr, L.pt, L.pb, cur.W(), cur.H()); return FAV_EINVAL; }
+            // index map only: a pending per-channel transform (InstanceNorm / ReLU) commutes with it and stays pending
+            Act nxt;
+            nxt.Hp = cur.H() + L.pt + L.pb; nxt.Wp = cur.W() + L.pl + L.pr; nxt.C = cur.C; nxt.pre = cur.pre;
+            if (nxt.pre.acc1 != nullptr) { set_error("internal: accumulator-form InstanceNorm in front of a padding layer"); return FAV_EINVAL; }
+            int rc = alloc((size_t)nxt.Hp * nxt.Wp * nxt.C * sizeof(float), &nxt.data); if (rc) return rc;
+            rc = launch_pad_nhwc(cur.data, cur.Hp, cur.Wp, cur.P(), cur.C, cur.ups, nxt.data, L.pl, L.pr, L.pt, L.pb, L.pad_mode, st); if (rc) return rc;
+            cur = nxt;
+            break;
+        }
         case L_CONV: {
             const DevConvW& d = convs[conv_cursor++];
             if (cur.C != d.cinp) { set_error("internal: channel pitch mismatch (%d vs %d)", cur.C, d.cinp); return FAV_EINVAL; }
@@ -709,7 +724,8 @@ void fav_net::out_size(int H, int W, int* Ho, int* Wo) const
     int h = H + 2 * pad, w = W + 2 * pad;
     std::function<void(const std::vector<Layer>&)> walk = [&](const std::vector<Layer>& ls) {
         for (const Layer& L : ls) {
-            if (L.type == L_CONV && L.transposed) { h = (h - 1) * L.stride - 2 * L.pad + L.k + L.adj; w = (w - 1) * L.stride - 2 * L.pad + L.k + L.adj; }
+            if (L.type == L_PAD) { if (&L == &layers[0] && pad_folded) continue; h += L.pt + L.pb; w += L.pl + L.pr; }
+            else if (L.type == L_CONV && L.transposed) { h = (h - 1) * L.stride - 2 * L.pad + L.k + L.adj; w = (w - 1) * L.stride - 2 * L.pad + L.k + L.adj; }
             else if (L.type == L_CONV) { h = (h + 2 * L.pad - L.k) / L.stride + 1; w = (w + 2 * L.pad - L.k) / L.stride + 1; }
             else if (L.type == L_UP) { h *= L.scale; w *= L.scale; }
             else if (L.type == L_RES) walk(L.block);
@@ -1087,9 +1103,17 @@ static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FA
 // one side queue carries every look-ahead since round 4 (a mask is 0.6 ms of short kernels, two in flight fit a 1.8 ms frame back to
 // back; two queues measured 541-543 frames/s against 546-548: profiles/r04c_4arg_knobs_ab.log)
 static const int NSIDE_USED = getenv("FAV_SIDE_QUEUES") ? std::max(1, std::min(2, atoi(getenv("FAV_SIDE_QUEUES")))) : 1;
+// the look-ahead mask's wide kernels are capped at this many blocks (they walk their items with a grid stride; 0: one block per item)
+static const int SIDE_BLOCKS = getenv("FAV_SIDE_BLOCKS") ? std::max(0, atoi(getenv("FAV_SIDE_BLOCKS"))) : 0;
 static hipError_t create_side_stream(hipStream_t* st)
 {
-    // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free)
+    // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free, rounds 2-3)
+    // FAV_SIDE_CU_MASK=<comma-separated bit numbers>: experiment, round 6
+    if (const char* m = getenv("FAV_SIDE_CU_MASK")) {
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (const char* p = m; *p;) { const int b = atoi(p); if (b >= 0 && b < 256) words[b / 32] |= 1u << (b % 32); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        return hipExtStreamCreateWithCUMask(st, 8, words);
+    }
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
@@ -1303,7 +1327,7 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     }
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
-        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd); if (rc) return rc;
+        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd, SIDE_BLOCKS); if (rc) return rc;
     }
     // mask + certainty of the frame (mask options, fix_occlusions warp of ones, erosion): depends on the flows and the stream's options only
     int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, pf.mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,

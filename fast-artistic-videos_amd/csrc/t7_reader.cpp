@@ -263,10 +263,12 @@ int module_to_layers(const Val* m, std::vector<Layer>& out, int depth)
         }
         return extract(m, out, depth + 1);
     }
-    if (c == "nn.SpatialReflectionPadding") {
+    if (c == "nn.SpatialReflectionPadding" || c == "nn.SpatialReplicationPadding") {
+        // (both keep pad_l / pad_r / pad_t / pad_b: SpatialReflectionPadding.lua / SpatialReplicationPadding.lua of `nn` [recalled])
         if (!num_field(m, "pad_l", a) || !num_field(m, "pad_r", b) || !num_field(m, "pad_t", cc) || !num_field(m, "pad_b", d)) {
-            set_error(".t7: SpatialReflectionPadding without pad_* fields"); return FAV_EFORMAT; }
-        L.type = L_PAD; L.pl = (int)a; L.pr = (int)b; L.pt = (int)cc; L.pb = (int)d;
+            set_error(".t7: %s without pad_* fields", c.c_str()); return FAV_EFORMAT; }
+        if (a < 0 || b < 0 || cc < 0 || d < 0 || a > 4096 || b > 4096 || cc > 4096 || d > 4096) { set_error(".t7: %s with a negative (cropping) or absurd pad", c.c_str()); return FAV_EUNSUPPORTED; }
+        L.type = L_PAD; L.pl = (int)a; L.pr = (int)b; L.pt = (int)cc; L.pb = (int)d; L.pad_mode = c == "nn.SpatialReplicationPadding" ? 1 : 0;
     } else if (c == "nn.SpatialConvolution" || c == "cudnn.SpatialConvolution" || c == "nn.SpatialConvolutionMM") {
         double cin, cout, kw, kh, dw = 1, dh = 1, pw = 0, ph = 0;
         if (!num_field(m, "nInputPlane", cin) || !num_field(m, "nOutputPlane", cout) || !num_field(m, "kW", kw) || !num_field(m, "kH", kh)) {
@@ -358,7 +360,7 @@ void pack_layers(const std::vector<Layer>& ls, W& w)
     w.i32((int)ls.size());
     for (const Layer& L : ls) {
         w.i32((int)L.type);
-        w.i32(L.pl); w.i32(L.pr); w.i32(L.pt); w.i32(L.pb);
+        w.i32(L.pl); w.i32(L.pr); w.i32(L.pt); w.i32(L.pb); w.i32(L.pad_mode);
         w.i32(L.cin); w.i32(L.cout); w.i32(L.k); w.i32(L.stride); w.i32(L.pad);
         w.i32(L.scale); w.i32(L.shave); w.f32(L.mul); w.f32(L.eps); w.i32(L.transposed); w.i32(L.adj);
         w.vec(L.w); w.vec(L.b); w.vec(L.gamma); w.vec(L.beta); w.vec(L.mean); w.vec(L.var);
@@ -384,7 +386,7 @@ void unpack_layers(R& r, std::vector<Layer>& ls, int depth)
     ls.resize((size_t)cnt);
     for (Layer& L : ls) {
         L.type = (LayerType)r.i32();
-        L.pl = r.i32(); L.pr = r.i32(); L.pt = r.i32(); L.pb = r.i32();
+        L.pl = r.i32(); L.pr = r.i32(); L.pt = r.i32(); L.pb = r.i32(); L.pad_mode = r.i32();
         L.cin = r.i32(); L.cout = r.i32(); L.k = r.i32(); L.stride = r.i32(); L.pad = r.i32();
         L.scale = r.i32(); L.shave = r.i32(); L.mul = r.f32(); L.eps = r.f32(); L.transposed = r.i32(); L.adj = r.i32();
         r.vec(L.w); r.vec(L.b); r.vec(L.gamma); r.vec(L.beta); r.vec(L.mean); r.vec(L.var);
@@ -421,7 +423,7 @@ int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob)
     blob.clear();
     W w{blob};
     w.i32(0x42564146);   // "FAVB"
-    w.i32(2);
+    w.i32(3);            // 3: padding layers carry their mode (round 6)
     pack_layers(layers, w);
     return FAV_OK;
 }
@@ -429,7 +431,7 @@ int blob_pack(const std::vector<Layer>& layers, std::vector<uint8_t>& blob)
 int blob_unpack(const void* blob, size_t bytes, std::vector<Layer>& out)
 {
     R r{static_cast<const uint8_t*>(blob), bytes};
-    if (r.i32() != 0x42564146 || r.i32() != 2) { set_error("weight blob: bad magic/version"); return FAV_EFORMAT; }
+    if (r.i32() != 0x42564146 || r.i32() != 3) { set_error("weight blob: bad magic/version"); return FAV_EFORMAT; }
     unpack_layers(r, out, 0);
     if (!r.ok) { set_error("weight blob: truncated or corrupt"); return FAV_EFORMAT; }
     return FAV_OK;
@@ -442,7 +444,7 @@ std::string describe_layers(const std::vector<Layer>& layers, int indent)
     const std::string pad((size_t)indent * 2, ' ');
     for (const Layer& L : layers) {
         switch (L.type) {
-        case L_PAD: snprintf(buf, sizeof buf, "pad %d %d %d %d", L.pl, L.pr, L.pt, L.pb); break;
+        case L_PAD: snprintf(buf, sizeof buf, "%s %d %d %d %d", L.pad_mode ? "replicate-pad" : "pad", L.pl, L.pr, L.pt, L.pb); break;
         case L_CONV:
             if (L.transposed) snprintf(buf, sizeof buf, "fullconv %d %d %d %d %d adj=%d bias=%d", L.cin, L.cout, L.k, L.stride, L.pad, L.adj, L.b.empty() ? 0 : 1);
             else snprintf(buf, sizeof buf, "conv %d %d %d %d %d bias=%d", L.cin, L.cout, L.k, L.stride, L.pad, L.b.empty() ? 0 : 1);

@@ -22,9 +22,15 @@
 // without a request (default 120) and removes its socket.  FAV_CC_DAEMON=0 switches all of this off (every call computes in its own
 // process, as in round 4).  The socket lives in a directory only the calling user can enter (mode 0700, ownership checked):
 // $XDG_RUNTIME_DIR/fav-cc or /tmp/fav-cc-<uid>; one helper per GPU (FAV_GPU).  FAV_CC_TIMING=1 prints where a call's time goes.
+// Round 6: every request carries the caller's BUILD ID (this executable + the libfav.so it loaded + the FAV_* settings in its environment,
+// which the library reads once per process): a helper left behind by an older build, or started under other FAV_* settings, answers
+// "stale" and leaves instead of serving the call with the old code; the caller computes in its own process and the next call starts a
+// fresh helper.  A request the helper took but never answered (FAV_CC_REPLY_S) is an ERROR (exit code 3), not a second computation of
+// the same output next to it; outputs are written through a per-process temporary name and renamed.
 #include <hip/hip_runtime.h>
 
 #include <cerrno>
+#include <dlfcn.h>
 #include <chrono>
 #include <csignal>
 #include <fcntl.h>
@@ -186,7 +192,34 @@ bool read_all(int fd, void* p, size_t n)
     while (n) { const ssize_t k = recv(fd, c, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= (size_t)k; }
     return true;
 }
-constexpr uint32_t CC_MAGIC = 0x31434346u;      // "FCC1"
+constexpr uint32_t CC_MAGIC = 0x32434346u;      // "FCC2": the request carries the caller's build id
+constexpr int32_t CC_STALE = -1000;             // reply: "I am another build / was started under other settings -- I am leaving"
+
+// What a helper IS: this executable, the libfav.so it loaded and the FAV_* settings it was started under (the library reads its
+// switches once per process).  A caller that differs in any of them -- a rebuilt bin/consistencyChecker, an upgraded library, another
+// FAV_* environment -- must not be served by the old helper: the id travels in every request, a helper that sees a foreign one answers
+// CC_STALE and leaves (the caller computes in its own process, the next call starts a fresh helper).
+uint64_t build_id()
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    auto mix_file = [&](const char* path) {
+        struct stat st;
+        if (stat(path, &st) == 0) { mix(&st.st_dev, sizeof st.st_dev); mix(&st.st_ino, sizeof st.st_ino); mix(&st.st_size, sizeof st.st_size); mix(&st.st_mtim, sizeof st.st_mtim); }
+        else mix(path, strlen(path));
+    };
+    mix_file("/proc/self/exe");
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void*>(&fav_version), &di) && di.dli_fname) mix_file(di.dli_fname);
+    const int v = fav_version(); mix(&v, sizeof v);
+    // FAV_* settings, sorted (the order of `environ` is the caller's business); the helper's own knobs and FAV_GPU (part of the socket's name) excepted
+    std::vector<std::string> env;
+    for (char** e = environ; e && *e; ++e)
+        if (strncmp(*e, "FAV_", 4) == 0 && strncmp(*e, "FAV_CC_", 7) != 0 && strncmp(*e, "FAV_GPU=", 8) != 0) env.push_back(*e);
+    for (size_t i = 1; i < env.size(); ++i) for (size_t j = i; j > 0 && env[j] < env[j - 1]; --j) std::swap(env[j], env[j - 1]);
+    for (const std::string& e : env) mix(e.c_str(), e.size() + 1);
+    return h;
+}
 
 int connect_helper(const std::string& sock)
 {
@@ -197,16 +230,21 @@ int connect_helper(const std::string& sock)
     return fd;
 }
 
-// client: 0 = served (status in *rc), -1 = no answer (the caller computes in-process)
+// client: 0 = served (status in *rc); -1 = not served and nothing of this request is under way in the helper (the caller computes in its own
+// process: the request could not be sent, the helper is another build, or it rejected the request as malformed); -2 = the request WAS
+// handed over and no answer came back (time-out, connection lost): the helper may still be working on it, so the caller reports the
+// failure instead of computing the same output a second time next to it
 int ask_helper(int fd, const std::vector<std::string>& a, int* rc)
 {
-    uint32_t hd[2] = {CC_MAGIC, (uint32_t)a.size()};
+    const uint64_t id = build_id();
+    uint32_t hd[4] = {CC_MAGIC, (uint32_t)a.size(), (uint32_t)id, (uint32_t)(id >> 32)};
     if (!write_all(fd, hd, sizeof hd)) return -1;
     for (const std::string& s : a) { const uint32_t n = (uint32_t)s.size(); if (!write_all(fd, &n, 4) || !write_all(fd, s.data(), n)) return -1; }
     int32_t status; uint32_t mlen;
-    if (!read_all(fd, &status, 4) || !read_all(fd, &mlen, 4) || mlen > (1u << 20)) return -1;
+    if (!read_all(fd, &status, 4) || !read_all(fd, &mlen, 4) || mlen > (1u << 20)) return -2;
     std::string msg(mlen, '\0');
-    if (mlen && !read_all(fd, &msg[0], mlen)) return -1;
+    if (mlen && !read_all(fd, &msg[0], mlen)) return -2;
+    if (status == CC_STALE || status == 2) return -1;      // another build (it is leaving) / a request it would not take: compute here
     if (!msg.empty()) fputs(msg.c_str(), stderr);
     *rc = status;
     return 0;
@@ -243,6 +281,7 @@ void on_term(int) { g_stop = 1; }
     const char* idle_s = getenv("FAV_CC_IDLE_S");
     const int idle_ms = (idle_s && atoi(idle_s) > 0 ? atoi(idle_s) : 120) * 1000;
     Batch b;
+    const uint64_t my_id = build_id();
     while (!g_stop) {
         pollfd pf{ls, POLLIN, 0};
         const int pr = poll(&pf, 1, idle_ms);
@@ -251,16 +290,18 @@ void on_term(int) { g_stop = 1; }
         const int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
         if (c < 0) continue;
         timeval tv{10, 0}; setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);       // (a caller that dies mid-request does not hang the helper)
-        uint32_t hd[2];
+        uint32_t hd[4];
         std::vector<std::string> a;
         bool ok = read_all(c, hd, sizeof hd) && hd[0] == CC_MAGIC && hd[1] >= 3 && hd[1] <= 4;
+        const bool stale = ok && (((uint64_t)hd[3] << 32) | hd[2]) != my_id;
         for (uint32_t i = 0; ok && i < hd[1]; ++i) {
             uint32_t n;
             ok = read_all(c, &n, 4) && n > 0 && n < 65536;
             if (ok) { std::string s(n, '\0'); ok = read_all(c, &s[0], n) && s[0] == '/'; a.push_back(s); }
         }
         int32_t status = 2; std::string msg = "consistencyChecker: malformed request to the resident helper\n";
-        if (ok) { status = b.run(a); msg = b.err; }
+        if (stale) { status = CC_STALE; msg.clear(); g_stop = 1; unlink(sock.c_str()); }      // the caller is another build: make room for its helper
+        else if (ok) { status = b.run(a); msg = b.err; }
         const uint32_t mlen = (uint32_t)msg.size();
         (void)(write_all(c, &status, 4) && write_all(c, &mlen, 4) && (mlen == 0 || write_all(c, msg.data(), mlen)));
         close(c);
@@ -278,7 +319,7 @@ std::string absolute(const char* path)
     return std::string(cwd) + "/" + path;
 }
 
-// the single call through the helper: 0 = done (exit status in *rc), -1 = not available (compute here)
+// the single call through the helper: 0 = done (exit status in *rc), -1 = not available (compute here), -2 = handed over, no answer
 int via_helper(int argc, char** argv, int* rc)
 {
     const char* off = getenv("FAV_CC_DAEMON");
@@ -333,10 +374,16 @@ int main(int argc, char** argv)
     if (argc >= 4) {
         int rc = 0;
         const double t0 = now_s();
-        if (via_helper(argc, argv, &rc) == 0) {
+        const int via = via_helper(argc, argv, &rc);
+        if (via == 0) {
             if (rc == 0) printf("%s", argv[3]);      // :166
             if (getenv("FAV_CC_TIMING")) fprintf(stderr, "consistencyChecker timing: through the resident helper %.1f ms\n", (now_s() - t0) * 1e3);
             return rc;
+        }
+        if (via == -2) {
+            fprintf(stderr, "consistencyChecker: the resident helper took the request and did not answer (FAV_CC_REPLY_S); not computing %s a second time next to it.\n"
+                            "  FAV_CC_DAEMON=0 computes in the calling process; `kill $(cat <runtime dir>/fav-cc/gpu*.lock)` ends the helper.\n", argv[3]);
+            return 3;
         }
     }
     if (argc < 4) {

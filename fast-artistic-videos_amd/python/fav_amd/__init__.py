@@ -237,7 +237,7 @@ def describe_layers(layers, indent: int = 0) -> str:
     pad = "  " * indent
     for L in layers:
         t = L["type"]
-        if t == "pad": out.append(f"{pad}pad {L['l']} {L['r']} {L['t']} {L['b']}")
+        if t == "pad": out.append(f"{pad}{'replicate-pad' if L.get('mode') == 'replicate' else 'pad'} {L['l']} {L['r']} {L['t']} {L['b']}")
         elif t == "fullconv":
             ci, co, k, _ = L["w"].shape
             out.append(f"{pad}fullconv {ci} {co} {k} {L['stride']} {L['pad']} adj={L['adj']} bias={0 if L['b'] is None else 1}")

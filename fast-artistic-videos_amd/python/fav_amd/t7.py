@@ -198,9 +198,10 @@ def extract_layers(module) -> List[dict]:
                 out.append({"type": "res", "block": extract_layers(branches[0]), "shave": shave})
             else:
                 out.extend(extract_layers(m))
-        elif c == "nn.SpatialReflectionPadding":
+        elif c in ("nn.SpatialReflectionPadding", "nn.SpatialReplicationPadding"):
             out.append({"type": "pad", "l": int(m["pad_l"]), "r": int(m["pad_r"]),
-                        "t": int(m["pad_t"]), "b": int(m["pad_b"])})
+                        "t": int(m["pad_t"]), "b": int(m["pad_b"]),
+                        "mode": "replicate" if c == "nn.SpatialReplicationPadding" else "reflect"})
         elif c == "nn.SpatialConvolution":
             cin, cout, kw, kh = int(m["nInputPlane"]), int(m["nOutputPlane"]), int(m["kW"]), int(m["kH"])
             w = np.asarray(m["weight"], np.float32).reshape(cout, cin, kh, kw)
@@ -294,15 +295,33 @@ def _sequential(mods):
 IMAGE_ARCH = "c9s1-32,d64,d128,R128,R128,R128,R128,R128,u64,u32,c9s1-3"        # train_video.lua:21 (fast-neural-style image models)
 
 
+PADDING_TYPES = ("reflect-start", "none", "reflect", "replicate", "zero")          # train_video.lua:25
+
+
+def _padlayer(padding_type, p):
+    cls = "nn.SpatialReflectionPadding" if padding_type == "reflect" else "nn.SpatialReplicationPadding"
+    return TorchObject(cls, {"pad_l": p, "pad_r": p, "pad_t": p, "pad_b": p, "_type": "torch.FloatTensor", "train": False})
+
+
 def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
                 tanh_constant: float = 150.0, insert_pad: bool = True, use_instance_norm: bool = True,
-                recurrent_gain: float = 1.0) -> TorchObject:
-    """Mirror of models_video.lua:55-140 for padding_type='reflect-start', use_instance_norm=1.
+                recurrent_gain: float = 1.0, padding_type: str = "reflect-start") -> TorchObject:
+    """Mirror of models_video.lua:55-140 for every padding_type of train_video.lua:25 (default 'reflect-start', use_instance_norm=1).
+
+    padding_type (models_video.lua:10-53,65-80):
+      'reflect-start' / 'none'  residual blocks unpadded with nn.ShaveImage(2) on the skip; 'reflect-start' additionally gets ONE
+                                nn.SpatialReflectionPadding at the front (train_video.lua:319-325).  The c-layers keep their zero padding
+                                in both (the `elseif padding_type == 'none'` of :76 tests an undefined global and never fires);
+      'reflect' / 'replicate'   a padding layer of (f-1)/2 in front of every c-convolution (which then has padW = 0) and of 1 in front of
+                                both convolutions of every residual block; nn.Identity on the skip;
+      'zero'                    residual-block convolutions with padW = 1, nn.Identity on the skip.
+    The d / u layers always carry their own zero padding (:90-93,99-102).
 
     recurrent_gain scales the first convolution's weights on input channels 4-7 (1-based: the warped, masked previous output and the
     certainty plane, fast_artistic_video_core.lua:166-171).  Random-init weights make frame -> frame an expanding map (any perturbation
     of the previous output grows ~3x per frame), which no trained model with the temporal-consistency loss does; a gain well below 1
     gives a CONTRACTIVE synthetic checkpoint on which free-running whole-clip parity is a meaningful gate."""
+    assert padding_type in PADDING_TYPES, padding_type
     rng = np.random.default_rng(seed)
     mods = []
     prev = in_channels
@@ -313,7 +332,10 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
         c0 = v[0]
         if c0 == "c":
             f, s, nxt = int(v[1]), int(v[3]), int(v[5:])
-            mods.append(_conv(rng, prev, nxt, f, s, (f - 1) // 2))          # :65-80 (zero pad stays)
+            p = (f - 1) // 2
+            if padding_type in ("reflect", "replicate"):                    # :70-75
+                mods.append(_padlayer(padding_type, p)); p = 0
+            mods.append(_conv(rng, prev, nxt, f, s, p))                     # :65-80 (otherwise the zero pad stays)
             if i == 0 and recurrent_gain != 1.0 and prev == 7:
                 mods[-1].fields["weight"][:, 3:7] *= np.float32(recurrent_gain)
         elif c0 == "d":
@@ -325,9 +347,12 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
         elif c0 == "R":
             nxt = int(v[1:]); n_res += 1; res_down = down
             norm = _inorm if use_instance_norm else _bnorm
-            block = _sequential([_conv(rng, nxt, nxt, 3, 1, 0), norm(rng, nxt), _simple("nn.ReLU", inplace=True),
-                                 _conv(rng, nxt, nxt, 3, 1, 0), norm(rng, nxt)])                # :10-39
-            concat = TorchObject("nn.ConcatTable", {"modules": [block, _simple("nn.ShaveImage", size=2)]})
+            padded = padding_type in ("reflect", "replicate")
+            pc = 1 if padding_type == "zero" else 0
+            block = ([_padlayer(padding_type, 1)] if padded else []) + [_conv(rng, nxt, nxt, 3, 1, pc), norm(rng, nxt), _simple("nn.ReLU", inplace=True)] + \
+                    ([_padlayer(padding_type, 1)] if padded else []) + [_conv(rng, nxt, nxt, 3, 1, pc), norm(rng, nxt)]       # :10-39
+            skip = _simple("nn.ShaveImage", size=2) if padding_type in ("none", "reflect-start") else _simple("nn.Identity")      # :45-49
+            concat = TorchObject("nn.ConcatTable", {"modules": [_sequential(block), skip]})
             mods.append(_sequential([concat, _simple("nn.CAddTable", inplace=False)]))            # :41-53
             needs_bn = needs_relu = False
         else:
@@ -340,7 +365,7 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
     mods.append(_simple("nn.Tanh"))
     mods.append(_simple("nn.MulConstant", constant_scalar=float(tanh_constant), inplace=False))
     mods.append(_simple("nn.TotalVariation", strength=1e-6))
-    if insert_pad and n_res:
+    if insert_pad and n_res and padding_type == "reflect-start":
         p = 2 * n_res * res_down  # train_video.lua:319-325: 2 px/side/block at 1/res_down res (40 for 5 blocks at 1/4)
         mods.insert(0, TorchObject("nn.SpatialReflectionPadding",
                                    {"pad_l": p, "pad_r": p, "pad_t": p, "pad_b": p,
@@ -350,7 +375,7 @@ def build_model(arch: str = CANONICAL_ARCH, seed: int = 0, in_channels: int = 7,
 
 def make_synthetic_checkpoint(path: str, arch: str = CANONICAL_ARCH, seed: int = 0, **kw) -> None:
     model = build_model(arch, seed, **kw)
-    ckpt = {"opt": {"arch": arch, "padding_type": "reflect-start", "use_instance_norm": 1,
+    ckpt = {"opt": {"arch": arch, "padding_type": kw.get("padding_type", "reflect-start"), "use_instance_norm": 1,
                     "tanh_constant": kw.get("tanh_constant", 150.0)},
             "train_loss_history": {}, "val_loss_history": {}, "iter": 0, "model": model}
     write_checkpoint(path, ckpt)

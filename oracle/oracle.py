@@ -297,7 +297,10 @@ def net_forward(layers: List[dict], x: np.ndarray, trace: Optional[list] = None,
     while i < len(layers):
         L = layers[i]; t = L["type"]
         if t == "pad":
-            x = reflect_pad(x, L["l"], L["r"], L["t"], L["b"])
+            if L.get("mode", "reflect") == "replicate":     # nn.SpatialReplicationPadding (models_video.lua:14-16,29-31,73-75): the edge pixel repeated
+                x = np.ascontiguousarray(np.pad(x, ((0, 0), (L["t"], L["b"]), (L["l"], L["r"])), mode="edge"))
+            else:                                           # nn.SpatialReflectionPadding
+                x = reflect_pad(x, L["l"], L["r"], L["t"], L["b"])
         elif t == "conv":
             if bf16_ops and _bf16_conv(L):      # FAV_PRECISION_BF16_OPERANDS: both operands rounded, wide accumulation
                 x = conv2d(bf16_round(x), bf16_round(L["w"]), L["b"], L["stride"], L["pad"])

@@ -281,6 +281,56 @@ def test_oracle_image_model_layers_vs_torch(oracle):
     assert np.abs(oracle.batchnorm_eval_(x.copy(), mean, var, g, bt, 1e-5) - ref).max() < 1e-5
 
 
+def _torch_forward(layers, x):
+    """the layer list in torch, double precision: what Torch7's modules compute [recalled semantics, SURVEY.md Appendix C]"""
+    import torch
+    import torch.nn.functional as F
+    T = lambda a: torch.from_numpy(np.asarray(a)).double()
+    for L in layers:
+        t = L["type"]
+        if t == "pad": x = F.pad(x, (L["l"], L["r"], L["t"], L["b"]), mode="replicate" if L["mode"] == "replicate" else "reflect")
+        elif t == "conv": x = F.conv2d(x, T(L["w"]), None if L["b"] is None else T(L["b"]), L["stride"], L["pad"])
+        elif t == "in": x = F.instance_norm(x, weight=T(L["gamma"]), bias=T(L["beta"]), eps=L["eps"])
+        elif t == "relu": x = F.relu(x)
+        elif t == "up": x = F.interpolate(x, scale_factor=L["s"], mode="nearest")
+        elif t == "res":
+            y = _torch_forward(L["block"], x); s = L["shave"]
+            x = y + (x[:, :, s:-s, s:-s] if s else x)
+        elif t == "tanh": x = torch.tanh(x)
+        elif t == "mul": x = x * L["k"]
+        elif t == "identity": pass
+        else: raise ValueError(t)
+    return x
+
+
+@pytest.mark.parametrize("ptype", ["reflect-start", "none", "reflect", "replicate", "zero"])
+def test_every_padding_type_oracle_vs_torch_and_both_readers(oracle, favlib, tmp_path, ptype):
+    """train_video.lua:25 -padding_type: the five forms models_video.lua:10-53,65-80 builds (padding modules in front of every convolution
+    for reflect / replicate, zero-padded block convolutions for zero, shaved skips for none / reflect-start).  The emitter mirrors the
+    builder, both readers agree on the layer list, and the oracle's forward matches a torch (double) restatement."""
+    import torch
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch="c9s1-8,d16,R16,R16,U2,c3s1-8,c9s1-3", seed=5, padding_type=ptype)
+    layers = t7.extract_layers(t7.load(p)["model"])
+    assert favlib.describe_t7(p) == favlib.describe_layers(layers)
+    kinds = [L["type"] for L in layers]
+    if ptype in ("reflect", "replicate"):
+        assert kinds[0] == "pad" and layers[0]["l"] == 4 and layers[0]["mode"] == ptype and kinds.count("pad") == 3
+        blk = [L for L in layers if L["type"] == "res"][0]
+        assert [b["type"] for b in blk["block"]] == ["pad", "conv", "in", "relu", "pad", "conv", "in"] and blk["shave"] == 0 and blk["block"][1]["pad"] == 0
+    elif ptype == "zero":
+        blk = [L for L in layers if L["type"] == "res"][0]
+        assert "pad" not in kinds and blk["shave"] == 0 and blk["block"][0]["pad"] == 1
+    else:
+        assert (kinds[0] == "pad") == (ptype == "reflect-start") and [L for L in layers if L["type"] == "res"][0]["shave"] == 2
+        if ptype == "reflect-start": assert layers[0]["l"] == 8                     # 2 blocks x 2 px at 1/2 resolution
+    x = np.random.default_rng(2).standard_normal((7, 28, 36)).astype(np.float32)
+    y = oracle.net_forward(layers, x)
+    ref = _torch_forward(layers, torch.from_numpy(x)[None].double())[0].numpy()
+    assert y.shape == ref.shape == ((3, 28, 36) if ptype not in ("none",) else ref.shape)
+    assert np.abs(y - ref).max() < 2e-3, float(np.abs(y - ref).max())
+
+
 def _convs(ls):
     for L in ls:
         if L["type"] == "conv": yield L
@@ -297,7 +347,7 @@ def test_canonical_architecture_shapes(tmp_path):
     p = str(tmp_path / "m.t7")
     t7.make_synthetic_checkpoint(p, seed=1)
     layers = t7.extract_layers(t7.load(p)["model"])
-    assert layers[0] == {"type": "pad", "l": 40, "r": 40, "t": 40, "b": 40}        # train_video.lua:319-325
+    assert layers[0] == {"type": "pad", "l": 40, "r": 40, "t": 40, "b": 40, "mode": "reflect"}        # train_video.lua:319-325
     n = sum(L["w"].size + L["b"].size for L in _convs(layers)) + sum(2 * len(L["gamma"]) for L in _ins(layers))
     assert n == 1679235                                                              # 6.72 MB
 

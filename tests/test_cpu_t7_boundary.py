@@ -159,7 +159,7 @@ def emit_layers(e, layers, prefix=""):
                     e.i32(4); e.i32(relu_index[0])
         elif t == "pad":
             def th(L=L):
-                e.module("nn.SpatialReflectionPadding", [(k, (lambda v=L["p"]: e.number(v))) for k in ("pad_l", "pad_r", "pad_t", "pad_b")])
+                e.module(L.get("cls", "nn.SpatialReflectionPadding"), [(k, (lambda v=L["p"]: e.number(v))) for k in ("pad_l", "pad_r", "pad_t", "pad_b")])
         elif t == "up":
             def th(L=L):
                 e.module("nn.SpatialUpSamplingNearest", [("scale_factor", lambda: e.number(2)), ("inputSize", lambda: e.nil())])
@@ -226,12 +226,12 @@ def parse_blob(blob):
     def f32(): v = struct.unpack_from("<f", blob, pos[0])[0]; pos[0] += 4; return v
     def vec():
         n = i32(); a = np.frombuffer(blob, np.float32, n, pos[0]).copy(); pos[0] += 4 * n; return a
-    assert i32() == 0x42564146 and i32() == 2
+    assert i32() == 0x42564146 and i32() == 3
     def layers():
         out = []
         for _ in range(i32()):
             L = {"type": i32()}
-            L["pads"] = [i32() for _ in range(4)]
+            L["pads"] = [i32() for _ in range(4)]; L["pad_mode"] = i32()
             L["cin"], L["cout"], L["k"], L["stride"], L["pad"] = (i32() for _ in range(5))
             L["scale"], L["shave"] = i32(), i32(); L["mul"], L["eps"] = f32(), f32(); L["transposed"], L["adj"] = i32(), i32()
             for k in ("w", "b", "gamma", "beta", "mean", "var"): L[k] = vec()
@@ -260,7 +260,7 @@ def check(parsed, layers, arrays, dtype, prefix=""):
             assert P["type"] == L_BN and np.array_equal(P["mean"], cast(arrays[key + "m"])) and np.array_equal(P["var"], cast(arrays[key + "v"]))
             assert np.array_equal(P["gamma"], cast(arrays[key + "g"])) and np.array_equal(P["beta"], cast(arrays[key + "be"]))
         elif t == "relu": assert P["type"] == L_RELU
-        elif t == "pad": assert P["type"] == L_PAD and P["pads"] == [L["p"]] * 4
+        elif t == "pad": assert P["type"] == L_PAD and P["pads"] == [L["p"]] * 4 and P["pad_mode"] == (1 if L.get("cls") == "nn.SpatialReplicationPadding" else 0)
         elif t == "up": assert P["type"] == L_UP and P["scale"] == 2
         elif t == "tanh": assert P["type"] == L_TANH
         elif t == "mul": assert P["type"] == L_MUL and abs(P["mul"] - L["v"]) < 1e-6
@@ -298,6 +298,30 @@ def test_reader_on_independent_emitter(favlib, tmp_path, legacy, double, cuda, c
     check(parse_blob(favlib.pack_checkpoint(p)), spec, arrays, np.float64 if double else np.float32)
 
 
+@pytest.mark.parametrize("ptype", ["reflect", "replicate", "zero"])
+def test_reader_on_the_other_padding_types(favlib, tmp_path, ptype):
+    """train_video.lua:25 -padding_type reflect | replicate | zero (models_video.lua:10-53,65-80): a padding MODULE in front of every
+    c-convolution and of both convolutions of a residual block (nn.SpatialReflectionPadding / nn.SpatialReplicationPadding, the
+    convolutions then carry padW = 0) or zero-padded block convolutions, nn.Identity on the skip -- read back with the right mode"""
+    rng = np.random.default_rng(3)
+    conv = lambda cin, cout, k, s, p: {"t": "conv", "cls": "nn.SpatialConvolution", "cin": cin, "cout": cout, "k": k, "s": s, "p": p, "bias": True}
+    IN = lambda c: {"t": "in", "c": c, "eps": 1e-5}
+    R = {"t": "relu", "cls": "nn.ReLU"}
+    cls = {"reflect": "nn.SpatialReflectionPadding", "replicate": "nn.SpatialReplicationPadding"}.get(ptype)
+    P = (lambda p: [{"t": "pad", "p": p, "cls": cls}]) if cls else (lambda p: [])
+    pc = 1 if ptype == "zero" else 0
+    block = {"t": "res", "shave": 0, "block": P(1) + [conv(16, 16, 3, 1, pc), IN(16), R] + P(1) + [conv(16, 16, 3, 1, pc), IN(16)]}
+    spec = P(4) + [conv(7, 8, 9, 1, 0 if cls else 4), IN(8), R, conv(8, 16, 3, 2, 1), IN(16), R, block, {"t": "up"}, IN(16), R] + P(1) + \
+           [conv(16, 8, 3, 1, 0 if cls else 1), IN(8), R] + P(4) + [conv(8, 3, 9, 1, 0 if cls else 4), {"t": "tanh", "cls": "nn.Tanh"}, {"t": "mul", "v": 150.0}, {"t": "tv"}]
+    p = str(tmp_path / "m.t7")
+    arrays = write_checkpoint(p, spec, rng)
+    text = favlib.describe_t7(p)
+    want_first = {"reflect": "pad 4 4 4 4", "replicate": "replicate-pad 4 4 4 4", "zero": "conv 7 8 9 1 4 bias=1"}[ptype]
+    assert text.splitlines()[0] == want_first and "res shave=0" in text
+    assert text.count("replicate-pad 1 1 1 1") == (3 if ptype == "replicate" else 0)
+    check(parse_blob(favlib.pack_checkpoint(p)), spec, arrays, np.float32)
+
+
 layer_st = st.deferred(lambda: st.one_of(
     st.builds(lambda cin, cout, k, s, p, cls, bias: {"t": "conv", "cls": cls, "cin": cin, "cout": cout, "k": k, "s": s, "p": p, "bias": bias},
               st.integers(1, 6), st.integers(1, 6), st.sampled_from([1, 3, 5]), st.integers(1, 2), st.integers(0, 2),
@@ -307,7 +331,7 @@ layer_st = st.deferred(lambda: st.one_of(
     st.builds(lambda c, eps: {"t": "in", "c": c, "eps": eps}, st.integers(1, 7), st.sampled_from([1e-5, 1e-3])),
     st.builds(lambda c, cls: {"t": "bn", "c": c, "eps": 1e-5, "cls": cls}, st.integers(1, 7), st.sampled_from(["nn.SpatialBatchNormalization", "cudnn.SpatialBatchNormalization"])),
     st.sampled_from([{"t": "relu", "cls": "nn.ReLU"}, {"t": "relu", "cls": "cudnn.ReLU"}, {"t": "up"}, {"t": "tanh", "cls": "nn.Tanh"}, {"t": "tv"},
-                     {"t": "mul", "v": 150.0}, {"t": "pad", "p": 3}]),
+                     {"t": "mul", "v": 150.0}, {"t": "pad", "p": 3}, {"t": "pad", "p": 1, "cls": "nn.SpatialReplicationPadding"}]),
     st.builds(lambda block, shave: {"t": "res", "shave": shave, "block": block}, st.lists(layer_st, min_size=1, max_size=3), st.sampled_from([0, 2]))))
 
 

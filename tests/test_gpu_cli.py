@@ -100,6 +100,29 @@ def test_consistency_checker_resident_helper(oracle, favlib, tmp_path):
         assert r.returncode == 0 and open(d / "o2.pgm", "rb").read() == b"P5\n%d %d\n255\n" % (w, h) + oracle.consistency(bw, fw, img).tobytes()
         r = subprocess.run([exe, "a.flo", "b.flo", "o3.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=env)
         assert r.returncode == 0 and open(d / "o3.pgm", "rb").read() == open(d / "o2.pgm", "rb").read()
+        # a caller that is ANOTHER BUILD -- here: other FAV_* settings, which the library reads once per process; the same happens after a
+        # rebuild of the executable or the library (the build id in every request: executable + libfav.so + FAV_* environment) -- is not served
+        # by the old helper: it computes in its own process, the old helper leaves, and the next such call starts a fresh one
+        lock = list((run / "fav-cc").glob("gpu0*.lock"))[0]
+        old_pid = int(lock.read_text().split()[0])
+        env2 = dict(env, FAV_TEST_BUILD_TAG="another-build")
+        r = subprocess.run([exe, "a.flo", "b.flo", "o4.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=env2)
+        assert r.returncode == 0 and r.stdout == "o4.pgm" and open(d / "o4.pgm", "rb").read() == open(d / "o2.pgm", "rb").read(), (r.stdout, r.stderr)
+        for _ in range(100):
+            try:
+                os.kill(old_pid, 0); time.sleep(0.05)
+            except ProcessLookupError:
+                break
+        else:
+            raise AssertionError("the helper of the other build is still there")
+        r = subprocess.run([exe, "a.flo", "b.flo", "o5.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=env2)      # starts the new build's helper
+        assert r.returncode == 0 and open(d / "o5.pgm", "rb").read() == open(d / "o2.pgm", "rb").read()
+        new_pid = int(lock.read_text().split()[0])
+        assert new_pid != old_pid
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "a.flo", "b.flo", "o6.pgm", "i.ppm"], capture_output=True, text=True, cwd=str(d), env=env2)      # ... and is served by it
+        assert r.returncode == 0 and open(d / "o6.pgm", "rb").read() == open(d / "o2.pgm", "rb").read() and int(lock.read_text().split()[0]) == new_pid
+        assert not list(d.glob("*.tmp*"))                                   # per-process temporary names are renamed or removed
     finally:
         pid = _stop_helper(str(run))
     assert pid is not None

@@ -445,6 +445,43 @@ def test_image_model_vs_oracle(favlib, oracle, cuda, tmp_path, golden_dir, inorm
     assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
 
 
+@pytest.mark.parametrize("ptype", ["reflect", "replicate", "zero", "none"])
+@pytest.mark.parametrize("arch", ["c9s1-8,d16,d32,R32,R32,R32,U2,c3s1-16,U2,c9s1-3", "c9s1-32,d64,d128,R128,R128,R128,U2,c3s1-64,U2,c9s1-3"])
+def test_padding_types_vs_oracle(favlib, oracle, cuda, tmp_path, ptype, arch):
+    """train_video.lua:25 -padding_type reflect | replicate | zero | none (reflect-start is every other test): three residual blocks per type.
+    reflect / replicate put a padding MODULE in front of every convolution (models_video.lua:12-16,27-31,70-75): the leading symmetric
+    reflection is folded into the input assembly like reflect-start's, every other one is a gather launch (pad_nhwc_kernel) through which
+    the pending InstanceNorm / ReLU passes unchanged -- also behind an upsampling; with the canonical filter counts the block convolutions
+    stay on the F(4x4) kernel (they see a padded input with padW = 0).  Net forward and two recurrent frames against the oracle."""
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=21, padding_type=ptype)
+    layers = _layers(p)
+    net = favlib.Net(p, 0)
+    assert net.describe() == favlib.describe_layers(layers)
+    h, w = 56, 72
+    x = (np.random.default_rng(4).standard_normal((7, h, w)) * 40).astype(np.float32)
+    got = net.forward(T(x, cuda)).cpu().numpy()
+    ref = oracle.net_forward(layers, x)
+    assert got.shape == ref.shape
+    assert ptype == "none" or got.shape == (3, h, w)
+    assert np.abs(got - ref).max() <= 5e-2, float(np.abs(got - ref).max())
+    if ptype == "none":
+        return                       # (frames shrink: fast_artistic_video.lua cannot warp such outputs either)
+    frames, bws, fws = _clip(h, w, 3, 90)
+    st = favlib.Stream(net, h, w)
+    ref_s = oracle.Stylizer(layers)
+    o, _ = st.first_frame(T(frames[0], cuda))
+    assert np.abs(o.cpu().numpy() - ref_s.first(_f01(frames[0]))).max() <= 2e-4
+    for i in (1, 2):
+        ref_s.last = o.cpu().numpy()                                   # teacher-forced
+        o, _ = st.next_frame_flow(T(frames[i], cuda), T(bws[i], cuda), T(fws[i], cuda))
+        m = oracle.consistency(bws[i], fws[i])
+        assert np.array_equal(st.last_mask().cpu().numpy(), m)
+        r = ref_s.next(_f01(frames[i]), bws[i], m.astype(np.float32) / np.float32(255))
+        assert np.abs(o.cpu().numpy() - r).max() <= 2e-4, (i, float(np.abs(o.cpu().numpy() - r).max()))
+    net.check()
+
+
 def test_unsupported_models_fail_with_status(favlib, cuda, tmp_path):
     p = str(tmp_path / "odd.t7")
     t7.make_synthetic_checkpoint(p, arch="c9s1-8,d16,R16,U2,c9s1-3", seed=2, in_channels=5)
