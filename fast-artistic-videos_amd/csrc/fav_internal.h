@@ -245,7 +245,7 @@ int launch_cert_prepare(const uint8_t* mask, const float* backward_flo, int inve
 // fused A2+A6+A7+reflection pad: writes the padded NHWC8 network input
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo,
                       const float* cert, int border, int H, int W, int pad, float* in8, hipStream_t st,
-                      int fill_random = 0, unsigned seed = 0, unsigned index = 0);
+                      int fill_random = 0, unsigned seed = 0, unsigned index = 0, int* q0_out = nullptr);
 int launch_quantize_rgb8(const float* rgb_planar, uint8_t* out_hwc, int H, int W, hipStream_t st);
 // Huffman codes of the PNG encoder (png_tables.cpp): PNG_NTABLES model codes with their dynamic-block headers + the fixed code
 constexpr int PNG_NSYM = 277;            // literals 0..255, end of block 256, length symbols 257..276 (runs of 3..66)
@@ -275,7 +275,7 @@ int launch_temporal_loss(const float* prev_rgb, const float* cur_rgb, const floa
 
 size_t structure_workspace_bytes(int W, int H);
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes,
-                     const float** structure_out, const float** avg_out, hipStream_t st, int max_blocks = 0);
+                     const float** structure_out, const float** avg_out, hipStream_t st, int pack_cus = 0, const int* q0_main = nullptr);
 int launch_sequential_sum(const float* x, size_t n, float* sum_out, hipStream_t st);
 int launch_consistency(const float* f1_flo, const float* f2_flo, const float* structure, const float* avg,
                        uint8_t* out, int W, int H, hipStream_t st);

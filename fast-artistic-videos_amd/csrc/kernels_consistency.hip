@@ -23,6 +23,28 @@
 namespace fav {
 namespace {
 
+// WHERE a long-lived block of the look-ahead mask may run (round 6; measured with scripts/cu_probe2.hip, profiles/r8_xcd_dispatch_probe.log).
+// The hardware deals the blocks of a launch to the eight XCDs round-robin by block index, starting -- for every launch of a queue -- at an
+// XCD that belongs to the QUEUE (block i -> XCD (q0 + i) mod 8; q0 differs between queues and may change when the runtime re-maps them).
+// The network's persistent grids are 252 blocks for 256 CUs (fav_net::reserve_cus = 4): the XCDs q0_main .. q0_main + 3 are FULL (32 blocks
+// on 32 CUs), the four free CUs sit in the XCDs q0_main + 4 .. q0_main + 7, one each.  A block of a side-queue kernel that lands on a full
+// XCD waits for a CU, takes the first that frees up and holds it against the block the next network kernel has dealt there (one CU
+// missing = that kernel's slowest block starts a whole round late: first layer 190 -> 298 us, d128 91 -> 155 us, F(4x4) launches 70 -> 78 us
+// depending on which kernel the pass happened to overlap).  So the mask's long-lived kernels (the two recursive passes, the one-block
+// scans) are launched as EIGHT blocks -- one per XCD whatever the queue's q0 -- and every block looks up where it is (XCC_ID) and
+// where the network's queue starts (a word its first kernel of the frame writes, prep_input_kernel): the blocks on the four free XCDs
+// share the work, the others leave at once.  At most ONE mask block sits on a free XCD at any time -- next to 31 network blocks on 32 CUs.
+__device__ __forceinline__ int xcd_share(const int* q0_main, int shares)
+{
+    // this block's share of the work in [0, shares), or -1: not on one of the XCDs the network leaves a CU free on (shares <= 4)
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int rel = ((int)(xcc & 7u) - *q0_main) & 7;
+    return rel >= 4 && rel - 4 < shares ? rel - 4 : -1;
+}
+
+constexpr int MAX_DEVICES = 64;
+inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+
 __global__ __launch_bounds__(256) void consistency_kernel(const float2* f1, const float2* f2, const float* structure,
                                                           const float* avg_ptr, uint8_t* out, int W, int H)
 {
@@ -39,171 +61,251 @@ struct IIR { float k, pm, pp, e2, a2; };
 // gradient [-0.5,0,0.5] with edge-repeating mirror (CFilter.h:600-611,1499-1578), second-moment sums
 // over the 3 colour planes in plane order (consistencyChecker.cpp:54-60)
 // (the three planes are written with a row pitch `pw` that is a multiple of 4 floats: the smoothing passes read 16 bytes per lane)
-// Every wide kernel of the structure map walks its work items with a grid stride: launched with one block per item it is the plain
-// data-parallel form; launched with a CAPPED grid (the look-ahead path: launch_structure's max_blocks) a mask occupies a few CUs' worth
-// of waves for longer instead of flooding the chip next to the network's persistent grids.  Same items, same arithmetic, same bits.
-__global__ __launch_bounds__(256) void moments_kernel(const uint8_t* rgb_hwc, float* dxx, float* dyy, float* dxy, int W, int H, int pw)
+// (the three planes leave TRANSPOSED -- [W][ph], ph a multiple of 4 floats -- through a 32x32 LDS tile: the X smoothing pass wants the
+//  image's rows as lines with the line index fastest, see iir_col.  Wide kernels walk their items with a grid stride.)
+__global__ __launch_bounds__(256) void moments_t_kernel(const uint8_t* rgb_hwc, float* dxxT, float* dyyT, float* dxyT, int W, int H, int ph)
 {
-    const int xb = (W + 255) / 256;
-    for (int it = blockIdx.x; it < H * xb; it += gridDim.x) {
-        const int y = it / xb, x = (it - y * xb) * 256 + threadIdx.x;
-        if (x >= W) continue;
-        const int xm = x - 1 < 0 ? 0 : x - 1, xp = x + 1 >= W ? W - 1 : x + 1;
-        const int ym = y - 1 < 0 ? 0 : y - 1, yp = y + 1 >= H ? H - 1 : y + 1;
-        float sxx = 0.f, syy = 0.f, sxy = 0.f;
-        for (int c = 0; c < 3; ++c) {
-            const float l = (float)rgb_hwc[((size_t)y * W + xm) * 3 + c], r = (float)rgb_hwc[((size_t)y * W + xp) * 3 + c];
-            const float up = (float)rgb_hwc[((size_t)ym * W + x) * 3 + c], dn = (float)rgb_hwc[((size_t)yp * W + x) * 3 + c];
-            const float mid = (float)rgb_hwc[((size_t)y * W + x) * 3 + c];
-            float dx = 0.f; dx += -0.5f * l; dx += 0.0f * mid; dx += 0.5f * r;
-            float dy = 0.f; dy += -0.5f * up; dy += 0.0f * mid; dy += 0.5f * dn;
-            sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+    __shared__ float tl[3][32][33];
+    const int ntx = (W + 31) / 32, nty = (H + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int it = blockIdx.x; it < ntx * nty; it += gridDim.x) {
+        const int x0 = (it % ntx) * 32, y0 = (it / ntx) * 32;
+        for (int j = ty; j < 32; j += 8) {
+            const int y = y0 + j, x = x0 + tx;
+            if (y >= H || x >= W) continue;
+            const int xm = x - 1 < 0 ? 0 : x - 1, xp = x + 1 >= W ? W - 1 : x + 1;
+            const int ym = y - 1 < 0 ? 0 : y - 1, yp = y + 1 >= H ? H - 1 : y + 1;
+            float sxx = 0.f, syy = 0.f, sxy = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const float l = (float)rgb_hwc[((size_t)y * W + xm) * 3 + c], r = (float)rgb_hwc[((size_t)y * W + xp) * 3 + c];
+                const float up = (float)rgb_hwc[((size_t)ym * W + x) * 3 + c], dn = (float)rgb_hwc[((size_t)yp * W + x) * 3 + c];
+                const float mid = (float)rgb_hwc[((size_t)y * W + x) * 3 + c];
+                float dx = 0.f; dx += -0.5f * l; dx += 0.0f * mid; dx += 0.5f * r;
+                float dy = 0.f; dy += -0.5f * up; dy += 0.0f * mid; dy += 0.5f * dn;
+                sxx += dx * dx; syy += dy * dy; sxy += dx * dy;
+            }
+            tl[0][j][tx] = sxx; tl[1][j][tx] = syy; tl[2][j][tx] = sxy;
         }
-        const size_t i = (size_t)y * pw + x;
-        dxx[i] = sxx; dyy[i] = syy; dxy[i] = sxy;
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int x = x0 + j, y = y0 + tx;
+            if (x < W && y < H) { const size_t o = (size_t)x * ph + y; dxxT[o] = tl[0][tx][j]; dyyT[o] = tl[1][tx][j]; dxyT[o] = tl[2][tx][j]; }
+        }
+        __syncthreads();
     }
 }
 
 // recursiveSmoothX / recursiveSmoothY (CFilter.h:1416-1464): one LANE per line, the recurrences of :1426-1437 / :1451-1462 in their
-// exact order (they round at every step: nothing along a line can be re-associated), lines are independent.  Round 4: the line lies
-// CONTIGUOUS in memory (rows of the [H][pw] planes for the X pass, rows of the transposed [W][ph] planes for the Y pass) and travels
-// as 16-byte pieces per lane through a ring of NG register groups of 16 samples, requested NG-1 groups ahead.  Why: a pass is 34 / 60
-// waves, each alone on its SIMD -- a step is ~30 cycles of arithmetic, a memory round trip ~2000, and a wave may have at most 63
-// memory operations in flight (vmcnt).  With one dword per lane and step (the round-1..3 form, lanes side by side in the transposed
-// plane) that budget covers 63 steps; the compiler additionally consumed every group right behind its own loads (s_waitcnt
-// vmcnt(31), (30), ... in the ISA), so each group of 32 steps paid a full round trip: 130-240 us per pass where the arithmetic
-// needs ~40.  With four samples per operation the same budget reaches 250 steps ahead.  v1 (the causal half) goes to `scratch`.
-// Round 6: the smoothed line leaves TRANSPOSED -- sample x of line l goes to out[x * opitch + l]: the 64 lanes of a wave are 64 neighbouring
-// lines, so one store instruction writes 256 contiguous bytes of the transposed plane.  The X pass (lines = image rows) thereby hands the
-// Y pass its lines (image columns) contiguous, and the Y pass hands the eigenvalue kernel row-major planes back: the two tile-transpose
-// launches of rounds 4-5 (22 MB + 15 MB of wide-kernel traffic next to the network) are gone; `m` is only read.
-template <int NGF, int NGB>
-__global__ __launch_bounds__(64) void iir_rows_kernel(const float* plane0, size_t plane_stride, float* scratch0, float* out0, int opitch, int nlines, int n, int pitch, IIR c)
+// exact order (they round at every step: nothing along a line can be re-associated); lines are independent.
+//
+// Round 6 form.  The 64 lanes of a wave are 64 NEIGHBOURING lines and the array is stored with the line index fastest: sample x of line
+// l lives at a[x * pitch + l], so every step of a wave is one 256-byte load (and store) -- the X pass therefore runs on the TRANSPOSED
+// planes (moments_t_kernel writes them that way), a tile transpose follows, and the Y pass runs on the row-major planes.  Loads run D steps
+// ahead through a register ring; the result overwrites the input (the anti-causal sweep needs m(x+1), m(x+2) of the ORIGINAL line: two
+// registers), the causal half v1 goes to `scratch`.
+// Why not a contiguous line per lane (rounds 4-5: 16-byte pieces through a ring of register groups): a wave's load then touches 64 cache
+// lines for 16 bytes each and the pass is bound by the CU's address / tag pipe (~70 cycles per step where the arithmetic needs ~30), which
+// is tolerable only with ONE wave per CU -- and that footprint is what the look-ahead mode cannot afford:
+// what a pass costs the network next to it is not its arithmetic but the CUs it touches.  The network's persistent kernels (252 blocks
+// that need a CU's whole register file: 8 waves x 250 VGPRs for the first layer, 8 x 256 for the F(4x4) stage) cannot start a block on a
+// CU that holds even ONE foreign wave, and a pass lives ~100 us: 36 / 60 one-wave blocks spread over as many CUs kept that many of the
+// first layer's blocks waiting (first layer 190 -> 233 us, d64 100 -> 140 us; attribution: profiles/r8e_4arg_attribution.log -- without
+// the two passes the 4-argument mode runs at 632 frames/s instead of 595, without the mask's WIDE kernels at all only at 636).
+// Work unit = one wave = 64 lines of one plane (a "task"); a wave walks tasks blockIdx.x * waves-per-block + wave, + gridDim.x *
+// waves-per-block, ...: launched as `pack_cus` blocks of sixteen waves a pass occupies at most that many CUs (the ones the network
+// leaves free, fav_net::reserve_cus) and hides its memory latency behind its own waves; launched as one block per task it is the widest
+// form (the stand-alone mask), with a deeper ring instead.
+// The ring is fed by hand and lives in LDS: `global_load_lds` (the DMA form of a load: wave-uniform LDS base + lane x 4 bytes) lands the
+// sample D - 1 steps before its step reads it back, and every read waits with an EXACT `s_waitcnt vmcnt(N)`.  Left to the compiler
+// the same loop with a register ring waits for (nearly) everything in flight at the top of every round (`s_waitcnt vmcnt(2)`,
+// `vmcnt(1)`: its bookkeeping does not carry a partly drained counter across the loop's back edge), i.e. the ring reaches one round
+// ahead whatever its depth, and a step costs ~350 cycles instead of the ~40 its arithmetic needs (372 us per pass packed on four CUs,
+// profiles/r8h_*); a register ring fed through inline assembly is not an option either -- the register allocator copies a slot
+// between the peeled round and the loop while its load is still in flight (seen in the ISA; the copy reads stale bits).
+// Vector memory operations of a wave complete in issue order, so "the sample has landed" is a count of what was issued since: the
+// sample of step s is requested in step s - D + 1 (the slot read in step s - D is refilled one step LATER, when its value has long been
+// consumed), behind it that step's store and D - 2 steps of one request + one store each (causal sweep: 2 D - 3 younger operations) or
+// two requests + one store (anti-causal sweep, which streams m and v1: 3 D - 5).  The first round waits for the prologue's requests.
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+
+template <int N>
+__device__ __forceinline__ void vm_wait_mem()
 {
-    const int line = blockIdx.x * 64 + threadIdx.x;
-    if (line >= nlines || n < 2) return;
-    const float* __restrict__ m = plane0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
-    float* __restrict__ v1 = scratch0 + (size_t)blockIdx.y * plane_stride + (size_t)line * pitch;
-    float* __restrict__ outT = out0 + (size_t)blockIdx.y * plane_stride + line;
-    constexpr int G = 16;
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// A LANE carries FOUR neighbouring lines (one 16-byte piece per step: a wave = 256 lines) as two packed pairs: v_pk_mul_f32 / v_pk_add_f32
+// round each component exactly like the scalar instruction, so a line's arithmetic is unchanged while a wave-instruction does the work
+// of two.  Why four: a CU's address pipe takes ~16 cycles per wave-wide memory instruction whatever its width -- with one dword per
+// lane the packed pass was bound by exactly that (9 waves x (1 request + 1 store) per step = 288 cycles per step, 360 us per pass,
+// profiles/r8j_*), with 16 bytes per lane the same traffic is a quarter of the instructions and the pass is bound by its arithmetic.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct F4 { f2 lo, hi; };
+__device__ __forceinline__ F4 f4_from(const float4& q) { F4 r; r.lo = f2{q.x, q.y}; r.hi = f2{q.z, q.w}; return r; }
+__device__ __forceinline__ F4 operator*(float s, const F4& v) { F4 r; r.lo = f2{s, s} * v.lo; r.hi = f2{s, s} * v.hi; return r; }
+__device__ __forceinline__ F4 operator+(const F4& a, const F4& b) { F4 r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; }
+__device__ __forceinline__ F4 operator-(const F4& a, const F4& b) { F4 r; r.lo = a.lo - b.lo; r.hi = a.hi - b.hi; return r; }
+
+// The ring is READ by hand as well (ds_read_b128 through inline assembly, one step ahead, with its own lgkmcnt wait): the compiler does
+// not know which DMA a read of LDS depends on and puts `s_waitcnt vmcnt(0)` in front of every LDS read it emits itself -- a full drain
+// of the ring per step (seen in the ISA).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F4 f4_from(const v4f& q) { F4 r; r.lo = f2{q.x, q.y}; r.hi = f2{q.z, q.w}; return r; }
+template <int OFF>
+__device__ __forceinline__ void lds_read_issue(v4f& q, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(OFF) : "memory"); }
+__device__ __forceinline__ void lds_read_wait(v4f& q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q) : : "memory"); }
+
+template <int D>
+__device__ __forceinline__ void iir_col(float* mb, float* vb, int lane, size_t pitch, int n, const IIR& c, float4* ring /* [2][D][64], this wave's */)
+{
+    // mb, vb: sample 0 of the wave's first line in the plane / in the scratch plane (wave-uniform); this lane's four lines are 4 * lane floats further on
+    static_assert(D >= 4 && 3 * D - 8 <= 63 && 2 * D * 1024 <= 65536, "ring depth against the 6-bit vmcnt / the 16-bit ds offset");
     const float c0f = 0.5f - c.k * c.pm, cd = c.a2 - c.e2;
+    float4* ringm = ring; float4* ringv = ring + D * 64;
+    const unsigned la = (unsigned)(unsigned long)(lds_vptr_t)ring + 16u * (unsigned)lane;      // LDS byte address of this lane's piece of slot 0 (m ring; the v ring is D KB further on)
+    constexpr int VO = D * 1024;
+    const F4 zero = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+    auto request = [&](const float* src, float4* slot) {         // one DMA: 64 lanes x 16 bytes -> slot[0..63]
+        __builtin_amdgcn_global_load_lds(src + 4 * lane, (lds_vptr_t)slot, 16, 0, 0);
+    };
+    auto put = [&](float* dst, const F4& v) {
+        v4f t = {v.lo.x, v.lo.y, v.hi.x, v.hi.y};
+        *reinterpret_cast<v4f*>(dst) = t;
+    };
+    // Step s: [sample s + 1 has landed?] [read it from LDS, asynchronously] [request sample s - 1 + D into the slot step s - 1 read] [the
+    // arithmetic of step s] [store] [the LDS read has arrived].  The sample of step s + 1 was requested in step s - D + 2: behind it that
+    // step's store and D - 3 steps of (one request + one store) or (two requests + one store): 2 D - 5 / 3 D - 8 younger operations.
     // ---------------------------------------------------------------- causal sweep, x = 0 .. n-1
     {
-        const int ng = n / G;                                  // full groups [16 g, 16 g + 15]; the rest (< 16 samples) is the tail
-        float R[NGF][G];
-        float tl[G - 1];
 #pragma unroll
-        for (int j = 0; j < G - 1; ++j) { const int x = ng * G + j; tl[j] = x < n ? m[x] : 0.f; }     // the tail, requested first
-        auto loadg = [&](float (&r)[G], int g) {
-            const float4* p = reinterpret_cast<const float4*>(m + (size_t)g * G);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float4 q = p[j]; r[4 * j] = q.x; r[4 * j + 1] = q.y; r[4 * j + 2] = q.z; r[4 * j + 3] = q.w; }
-        };
-#pragma unroll
-        for (int k = 0; k < NGF; ++k) if (k < ng) loadg(R[k], k);
-        float a0 = 0.f, a1 = 0.f, mp = 0.f;
+        for (int k = 0; k < D - 1; ++k) request(mb + (size_t)min(k, n - 1) * pitch, ringm + k * 64);
+        F4 a0 = zero, a1 = zero, mp = zero;
         // x = 0: v1 = (0.5 - k pm) m0;  x = 1: v1 = k (m1 + pm m0) + (a2 - e2) v1(0);  then the three-term recurrence
-        auto step = [&](float mx) {
-            const float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+        auto step = [&](const F4& mx, int x, bool may_be_first) {
+            F4 a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
+            if (may_be_first && x < 2) a = x == 0 ? c0f * mx : c.k * (mx + c.pm * mp) + cd * a1;
             a0 = a1; a1 = a; mp = mx;
-            return a;
+            put(vb + (size_t)x * pitch + 4 * lane, a);
         };
-        auto step01 = [&](float mx, int x) {                   // positions that may be the line's first two
-            float a = c.k * (mx + c.pm * mp) + c.a2 * a1 - c.e2 * a0;
-            if (x < 2) a = x == 0 ? c0f * mx : c.k * (mx + c.pm * mp) + cd * a1;
-            a0 = a1; a1 = a; mp = mx;
-            return a;
-        };
-        auto chain = [&](const float (&r)[G], int g) {
-            float4* o = reinterpret_cast<float4*>(v1 + (size_t)g * G);
+        v4f q, qn;
+        vm_wait_mem<D - 2>(); lds_read_issue<0>(q, la); lds_read_wait(q);                 // sample 0
+        int x = 0;
+        auto round = [&](bool first) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 w;
-                w.x = j ? step(r[4 * j]) : step01(r[0], g * G); w.y = j ? step(r[4 * j + 1]) : step01(r[1], g * G + 1);
-                w.z = step(r[4 * j + 2]); w.w = step(r[4 * j + 3]);
-                o[j] = w;
+            for (int k = 0; k < D; ++k) {
+                if (first) vm_wait_mem<D - 3>(); else vm_wait_mem<2 * D - 5>();
+                switch ((k + 1) % D) {                                                       // the slot of sample x + k + 1 (compile-time after unrolling)
+#define FAV_RD(j) case j: lds_read_issue<(j) * 1024>(qn, la); break;
+                    FAV_RD(0) FAV_RD(1) FAV_RD(2) FAV_RD(3) FAV_RD(4) FAV_RD(5) FAV_RD(6) FAV_RD(7) FAV_RD(8) FAV_RD(9) FAV_RD(10) FAV_RD(11) FAV_RD(12) FAV_RD(13) FAV_RD(14) FAV_RD(15)
+                    FAV_RD(16) FAV_RD(17) FAV_RD(18) FAV_RD(19) FAV_RD(20) FAV_RD(21) FAV_RD(22) FAV_RD(23)
+#undef FAV_RD
+                }
+                request(mb + (size_t)min(x + k - 1 + D, n - 1) * pitch, ringm + ((k + D - 1) % D) * 64);      // (clamped: always issued, the counts stay exact)
+                step(f4_from(q), x + k, first);
+                lds_read_wait(qn); q = qn;
             }
-            // the sample the next group's first step needs must not LIVE in the ring: the slot is refilled right behind this chain, and a
-            // value left there is rescued by the compiler only after the refill -- behind a wait for the load just issued
-            asm volatile("v_mov_b32 %0, %1" : "=v"(mp) : "v"(r[G - 1]));
+            x += D;
         };
-        // whole rounds: the slot just consumed takes the group NGF further on -- UNCONDITIONALLY (the index is clamped; the last round
-        // re-requests the last group): a conditional refill makes the slot's registers a phi of "loaded" and "stale", which the
-        // compiler resolves with a copy behind the load, i.e. a wait for the load it has just issued (s_waitcnt vmcnt(3) in the ISA)
-        int gb = 0;
-        for (; gb + NGF <= ng; gb += NGF) {
+        if (n >= D) round(true);
+        while (x + D <= n) round(false);
+        // the tail: fewer than D samples; sample x is in q already, the others are read in order (everything has landed)
+        vm_wait_mem<0>();
 #pragma unroll
-            for (int k = 0; k < NGF; ++k) {
-                // (fences: left alone, the scheduler hoists the recurrence-free products of ALL slots to the top of the round -- and
-                //  with them a wait for the slot requested a moment ago)
-                __builtin_amdgcn_sched_barrier(0);
-                chain(R[k], gb + k);
-                __builtin_amdgcn_sched_barrier(0);
-                loadg(R[k], min(gb + k + NGF, ng - 1));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NGF; ++k) if (gb + k < ng) chain(R[k], gb + k);
-#pragma unroll
-        for (int j = 0; j < G - 1; ++j) { const int x = ng * G + j; if (x < n) v1[x] = step01(tl[j], x); }
+        for (int k = 0; k < D; ++k) if (x + k < n) { if (k) { const float4 t = ringm[k * 64 + lane]; step(f4_from(t), x + k, true); } else step(f4_from(q), x + k, true); }
     }
     // ---------------------------------------------------------------- anti-causal sweep, x = n-1 .. 0; m is overwritten with v1 + v2
     {
-        const int ng = (n - 2) / G;                            // full groups below the head; the head [16 ng, n) has 2 .. 17 samples
-        constexpr int HN = G + 2;
-        float hm[HN], hv[HN];
+        vm_wait_mem<0>();                                      // every v1 of the causal sweep has left, every slot has been read
 #pragma unroll
-        for (int j = 0; j < HN; ++j) { const int x = n - 1 - j; const bool in = x >= ng * G; hm[j] = in ? m[x] : 0.f; hv[j] = in ? v1[x] : 0.f; }
-        float Rm[NGB][G], Rv[NGB][G];
-        auto loadg = [&](float (&rm)[G], float (&rv)[G], int g) {
-            const float4* p = reinterpret_cast<const float4*>(m + (size_t)g * G);
-            const float4* pv = reinterpret_cast<const float4*>(v1 + (size_t)g * G);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 q = p[j], u = pv[j];
-                rm[4 * j] = q.x; rm[4 * j + 1] = q.y; rm[4 * j + 2] = q.z; rm[4 * j + 3] = q.w;
-                rv[4 * j] = u.x; rv[4 * j + 1] = u.y; rv[4 * j + 2] = u.z; rv[4 * j + 3] = u.w;
-            }
-        };
-#pragma unroll
-        for (int k = 0; k < NGB; ++k) if (ng - 1 - k >= 0) loadg(Rm[k], Rv[k], ng - 1 - k);
+        for (int k = 0; k < D - 1; ++k) { const size_t o = (size_t)max(n - 1 - k, 0) * pitch; request(mb + o, ringm + k * 64); request(vb + o, ringv + k * 64); }
         // v2(n-1) = (0.5 + k pm) m(n-1);  v2(n-2) = k ((pp - e2) m(n-1)) + (a2 - e2) v2(n-1);  then the recurrence on the ORIGINAL m
-        float b0 = 0.f, b1 = 0.f, mo1 = 0.f, mo2 = 0.f;          // b0 = v2(x+1), b1 = v2(x+2), mo1 = m(x+1), mo2 = m(x+2)
+        F4 b0 = zero, b1 = zero, mo1 = zero, mo2 = zero;         // b0 = v2(x+1), b1 = v2(x+2), mo1 = m(x+1), mo2 = m(x+2)
         const float c1f = 0.5f + c.k * c.pm, cpe = c.pp - c.e2;
-#pragma unroll
-        for (int j = 0; j < HN; ++j) {
-            const int x = n - 1 - j;
-            if (x >= ng * G) {
-                float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-                if (j == 0) bv = c1f * hm[0];
-                if (j == 1) bv = c.k * (cpe * mo1) + cd * b0;
-                outT[(size_t)x * opitch] = hv[j] + bv;
-                b1 = b0; b0 = bv; mo2 = mo1; mo1 = hm[j];
-            }
-        }
-        auto chain = [&](const float (&rm)[G], const float (&rv)[G], int g) {
-            float* o = outT + (size_t)g * G * opitch;
-#pragma unroll
-            for (int q = G - 1; q >= 0; --q) {
-                const float bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
-                o[(size_t)q * opitch] = rv[q] + bv;
-                b1 = b0; b0 = bv; mo2 = mo1; mo1 = rm[q];
-            }
-            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(mo1), "=&v"(mo2) : "v"(rm[0]), "v"(rm[1]));      // (as above)
+        auto step = [&](const F4& mx, const F4& vx, int x, bool may_be_last) {
+            F4 bv = c.k * (c.pp * mo1 - c.e2 * mo2) + c.a2 * b0 - c.e2 * b1;
+            if (may_be_last && x == n - 1) bv = c1f * mx;
+            if (may_be_last && x == n - 2) bv = c.k * (cpe * mo1) + cd * b0;
+            put(mb + (size_t)x * pitch + 4 * lane, vx + bv);
+            b1 = b0; b0 = bv; mo2 = mo1; mo1 = mx;
         };
-        int gb = 0;
-        for (; gb + NGB <= ng; gb += NGB) {
+        v4f qm, qv, qmn, qvn;
+        vm_wait_mem<2 * (D - 2)>(); lds_read_issue<0>(qm, la); lds_read_issue<VO>(qv, la); lds_read_wait(qm); lds_read_wait(qv);      // sample n - 1
+        int x = n - 1;
+        auto round = [&](bool first) {
 #pragma unroll
-            for (int k = 0; k < NGB; ++k) {
-                const int g = ng - 1 - (gb + k);
-                __builtin_amdgcn_sched_barrier(0);
-                chain(Rm[k], Rv[k], g);
-                __builtin_amdgcn_sched_barrier(0);
-                loadg(Rm[k], Rv[k], max(g - NGB, 0));
+            for (int k = 0; k < D; ++k) {
+                if (first) vm_wait_mem<2 * (D - 3)>(); else vm_wait_mem<3 * D - 8>();
+                switch ((k + 1) % D) {
+#define FAV_RD(j) case j: lds_read_issue<(j) * 1024>(qmn, la); lds_read_issue<VO + (j) * 1024>(qvn, la); break;
+                    FAV_RD(0) FAV_RD(1) FAV_RD(2) FAV_RD(3) FAV_RD(4) FAV_RD(5) FAV_RD(6) FAV_RD(7) FAV_RD(8) FAV_RD(9) FAV_RD(10) FAV_RD(11) FAV_RD(12) FAV_RD(13) FAV_RD(14) FAV_RD(15)
+                    FAV_RD(16) FAV_RD(17) FAV_RD(18) FAV_RD(19) FAV_RD(20) FAV_RD(21) FAV_RD(22) FAV_RD(23)
+#undef FAV_RD
+                }
+                const size_t o = (size_t)max(x - k + 1 - D, 0) * pitch;
+                request(mb + o, ringm + ((k + D - 1) % D) * 64); request(vb + o, ringv + ((k + D - 1) % D) * 64);
+                step(f4_from(qm), f4_from(qv), x - k, first);
+                lds_read_wait(qmn); lds_read_wait(qvn); qm = qmn; qv = qvn;
             }
-        }
+            x -= D;
+        };
+        if (n >= D) round(true);
+        while (x - (D - 1) >= 0) round(false);
+        vm_wait_mem<0>();
 #pragma unroll
-        for (int k = 0; k < NGB; ++k) if (ng - 1 - (gb + k) >= 0) chain(Rm[k], Rv[k], ng - 1 - (gb + k));
+        for (int k = 0; k < D; ++k) if (x - k >= 0) {
+            if (k) { const float4 tm = ringm[k * 64 + lane], tv = ringv[k * 64 + lane]; step(f4_from(tm), f4_from(tv), x - k, true); }
+            else step(f4_from(qm), f4_from(qv), x - k, true);
+        }
+        vm_wait_mem<0>();
+    }
+}
+
+// (lines beyond nlines inside a lane's group of four are the row pitch's padding -- a multiple of 4 floats: computed and stored like the
+//  others, read by nobody)
+// Packed form (look-ahead path): eight blocks, of which the `nwork` (<= 4) on the free XCDs work (xcd_share), each with `nw` working waves.
+// The blocks are 1024 threads: the waves beyond nw wait at the closing barrier (a wave at a barrier holds its registers and issues
+// nothing) -- a block that fills a CU's register file can only be placed on a CU that is completely idle, and nothing joins it there.
+// With four-wave blocks the same placement measured first layer 190 -> 270-310 us (profiles/r8p_4arg_packed_xcd_ab.log, FAV_IIR_FILL=0):
+// a small block is placed at once on ANY CU of its XCD that has room, next to whatever light kernel of the network runs there.
+// Wide form: one block (one wave) per task.
+template <int D, int MAXT>
+__global__ __launch_bounds__(MAXT) void iir_cols_kernel(float* plane0, size_t plane_stride, float* scratch0, int nlines, int n, int pitch, int groups, int nwork, int nw, const int* q0_main, IIR c)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 iir_lds[];      // [nw][2][D][64]
+    if (n < 2) return;
+    const int wb = q0_main ? xcd_share(q0_main, nwork) : (int)blockIdx.x;      // (look-ahead path: eight blocks, those on the free XCDs work -- see xcd_share)
+    if (wb < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform by construction; says so to the compiler: bases stay in scalar registers)
+    if (wave < nw) {
+        float4* ring = iir_lds + (size_t)wave * 2 * D * 64;
+        for (int task = wb * nw + wave; task < 3 * groups; task += nwork * nw) {      // groups: of 256 lines
+            const int plane = task / groups, line0 = (task - plane * groups) * 256;
+            if (line0 + 4 * lane >= nlines) continue;                 // (the wave's other lanes go on; a DMA of an inactive lane writes nothing)
+            iir_col<D>(plane0 + (size_t)plane * plane_stride + line0, scratch0 + (size_t)plane * plane_stride + line0, lane, (size_t)pitch, n, c, ring);
+        }
+    }
+    if ((int)blockDim.x > 64 * nw) __syncthreads();      // (a CU-filling launch: the idle waves keep their registers until the working ones are through; a wave at a barrier issues nothing)
+}
+
+// [R][C] (row pitch pin) -> [C][R] (row pitch pout) per plane, 32x32 LDS tiles, both sides coalesced (between the two smoothing passes)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, size_t plane_stride, int R, int C, int pin, int pout, int planes)
+{
+    __shared__ float tl[32][33];
+    const int ntx = (C + 31) / 32, nty = (R + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int it = blockIdx.x; it < ntx * nty * planes; it += gridDim.x) {
+        const int pl = it / (ntx * nty), rem = it - pl * ntx * nty;
+        const float* ip = in + (size_t)pl * plane_stride;
+        float* op = out + (size_t)pl * plane_stride;
+        const int c0 = (rem % ntx) * 32, r0 = (rem / ntx) * 32;
+        for (int j = ty; j < 32; j += 8)
+            if (r0 + j < R && c0 + tx < C) tl[j][tx] = ip[(size_t)(r0 + j) * pin + c0 + tx];
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8)
+            if (c0 + j < C && r0 + tx < R) op[(size_t)(c0 + j) * pout + r0 + tx] = tl[tx][j];
+        __syncthreads();
     }
 }
 
@@ -260,8 +362,9 @@ __global__ __launch_bounds__(256) void eigen_blockmax_kernel(const float* p3, si
 // pass 1: per-block maxima (eigen_blockmax_kernel above); pass 2: exclusive prefix max over blocks (single block) then, per block,
 // an in-block exclusive running max and the min over non-record elements.
 // single block: exclusive prefix max of bmax (seeded with -30000) -> bpre; total max -> mm[0]
-__global__ __launch_bounds__(1024) void prefixmax_kernel(const float* bmax, int nb, float* bpre, float* mm)
+__global__ __launch_bounds__(1024) void prefixmax_kernel(const float* bmax, int nb, float* bpre, float* mm, const int* q0_main)
 {
+    if (q0_main && xcd_share(q0_main, 1) != 0) return;      // (look-ahead path: eight blocks, the one on the first free XCD works -- see xcd_share)
     __shared__ float sh[1024];
     float carry = -30000.0f;
     for (int base = 0; base < nb; base += 1024) {
@@ -322,8 +425,9 @@ __global__ __launch_bounds__(256) void quirkmin_kernel(const float* v, size_t n,
     }
 }
 
-__global__ __launch_bounds__(256) void minreduce_kernel(const float* bmin, int nb, float* mm)
+__global__ __launch_bounds__(256) void minreduce_kernel(const float* bmin, int nb, float* mm, const int* q0_main)
 {
+    if (q0_main && xcd_share(q0_main, 1) != 0) return;      // (look-ahead path: eight blocks, the one on the first free XCD works -- see xcd_share)
     __shared__ float red[4];
     float mn = 30000.0f;
     for (int j = threadIdx.x; j < nb; j += 256) mn = fminf(mn, bmin[j]);
@@ -423,8 +527,9 @@ __device__ __forceinline__ Xd xd_shfl_up(const Xd& v, int off)
 
 // (`start`: optional {index, sum bits} left by avg_chunk_scan_kernel below -- this kernel then finishes from there; with the whole
 //  array behind it only the final store is left)
-__global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, float* avg_out, float* sum_out, const int* start)
+__global__ __launch_bounds__(1024) void avg_scan_kernel(const float* v, int n, float* avg_out, float* sum_out, const int* start, const int* q0_main)
 {
+    if (q0_main && xcd_share(q0_main, 1) != 0) return;      // (look-ahead path: eight blocks, the one on the first free XCD works -- see xcd_share)
     constexpr int NT = 1024, E = 16, WIN = NT * E, NW = NT / 64;
     __shared__ int wD[2][NW], wPP[NW];                       // per-wave totals, then their exclusive scan
     __shared__ __attribute__((aligned(16))) float sX[WIN];
@@ -632,8 +737,9 @@ __global__ __launch_bounds__(256) void avg_chunk_class_kernel(const float* v, in
     }
 }
 
-__global__ __launch_bounds__(1024) void avg_chunk_scan_kernel(const float* v, int n, const ChunkXd* cx, int nchunks, int* state_out)
+__global__ __launch_bounds__(1024) void avg_chunk_scan_kernel(const float* v, int n, const ChunkXd* cx, int nchunks, int* state_out, const int* q0_main)
 {
+    if (q0_main && xcd_share(q0_main, 1) != 0) return;      // (look-ahead path: eight blocks, the one on the first free XCD works -- see xcd_share)
     constexpr int NT = 1024, NW = NT / 64;
     __shared__ int wD[2][NW], wPP[NW];
     __shared__ __attribute__((aligned(16))) float sX[ACH];
@@ -760,19 +866,20 @@ static SeqsumPlan seqsum_plan(size_t n, void* ws)
 }
 
 // presummed: the chunk sums / flags of step 1 are already in the workspace (normalize_sum_kernel wrote them)
-static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st, int max_blocks = 0, bool presummed = false)
+static void launch_seqsum(const float* v, size_t n, void* ws, float* avg_out, float* sum_out, hipStream_t st, const int* q0_main = nullptr, bool presummed = false)
 {
-    auto cap = [&](int g) { return max_blocks > 0 && g > max_blocks ? max_blocks : g; };
+    auto cap = [&](int g) { return g; };
+    const dim3 one(q0_main ? 8 : 1);
     const SeqsumPlan pl = seqsum_plan(n, ws);
     if (!pl.multi) {
-        hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(nullptr));
+        hipLaunchKernelGGL(avg_scan_kernel, one, dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(nullptr), q0_main);
         return;
     }
     const int nc = pl.nc;
     if (!presummed) hipLaunchKernelGGL(avg_chunk_sum_kernel, dim3(cap((nc + 3) / 4)), dim3(256), 0, st, v, (int)n, pl.csum, pl.cbad);
     hipLaunchKernelGGL(avg_chunk_class_kernel, dim3(cap((nc + 3) / 4)), dim3(256), 0, st, v, (int)n, pl.csum, pl.cbad, nc, pl.cx);
-    hipLaunchKernelGGL(avg_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, pl.cx, nc, pl.state);
-    hipLaunchKernelGGL(avg_scan_kernel, dim3(1), dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(pl.state));
+    hipLaunchKernelGGL(avg_chunk_scan_kernel, one, dim3(1024), 0, st, v, (int)n, pl.cx, nc, pl.state, q0_main);
+    hipLaunchKernelGGL(avg_scan_kernel, one, dim3(1024), 0, st, v, (int)n, avg_out, sum_out, static_cast<const int*>(pl.state), q0_main);
 }
 
 // floats per plane: the larger of the [H][pw] and the transposed [W][ph] layout (row pitches rounded up to 4 floats)
@@ -804,17 +911,19 @@ static void iir_constants(float sigma, IIR& c)
     c.e2 = aExpSqr;
 }
 
-// max_blocks > 0: every wide launch is capped at that many blocks (they walk their items with a grid stride) -- the look-ahead path, where
-// a mask runs next to the network of an earlier frame (fav_stream_prefetch_mask); 0: one block per item
+// pack_cus > 0 (the look-ahead path, fav_stream_prefetch_mask: the mask runs next to the network of an earlier frame): the two recursive
+// passes run as pack_cus blocks of eight waves instead of one block per wave (see iir_rows_kernel) -- together with the one-block scans
+// they are the mask's only long-lived blocks, and they then hold at most pack_cus CUs at any time.  The wide kernels stay wide: their
+// blocks live for microseconds (measured: all of them together cost the network 4 us per frame).  0: the widest form (stand-alone mask).
 int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_bytes, const float** structure_out,
-                     const float** avg_out, hipStream_t st, int max_blocks)
+                     const float** avg_out, hipStream_t st, int pack_cus, const int* q0_main)
 {
+    if (!q0_main) pack_cus = 0;
     FAV_REQUIRE(ws != nullptr && ws_bytes >= structure_workspace_bytes(W, H), "consistency: workspace too small");
     FAV_REQUIRE(W >= 2 && H >= 2, "consistency: structure mode needs W,H >= 2");
     const size_t n = (size_t)W * H, ps = structure_plane_floats(W, H);
     const int pw = (W + 3) & ~3, ph = (H + 3) & ~3;
     const int nb = (int)((n + NB - 1) / NB);
-    auto cap = [&](long long g) { return (unsigned)(max_blocks > 0 && g > max_blocks ? max_blocks : g); };
     float* planes = static_cast<float*>(ws);          // dxx, dyy, dxy
     float* scratch = planes + 3 * ps;
     float* corners = scratch + 3 * ps;
@@ -824,20 +933,40 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     float* bmin = bpre + align_up((size_t)nb * 4, 256) / 4;
     float* mm = bmin + align_up((size_t)nb * 4, 256) / 4;   // [0]=cmax [1]=cmin [2]=avg
     IIR c; iir_constants(3.0f, c);                          // main(): computeCorners(image, &structure, 3.0f)
-    hipLaunchKernelGGL(moments_kernel, dim3(cap((long long)((W + 255) / 256) * H)), dim3(256), 0, st, rgb_hwc, planes, planes + ps, planes + 2 * ps, W, H, pw);
-    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67); planes are independent => blockIdx.y = plane.  X pass on the rows of the planes; its
-    // result leaves transposed ([W][ph] in tmp3), so the Y pass finds the image's columns contiguous; the Y pass writes row-major planes
-    // back (blocks of ONE wave: a pass is 34 / 60 waves, each gets a SIMD of its own).  No transpose launches since round 6.
-    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((H + 63) / 64, 3), dim3(64), 0, st, planes, ps, scratch, tmp3, ph, H, W, pw, c);
-    hipLaunchKernelGGL((iir_rows_kernel<6, 4>), dim3((W + 63) / 64, 3), dim3(64), 0, st, tmp3, ps, scratch, planes, pw, W, H, ph, c);
-    hipLaunchKernelGGL(eigen_blockmax_kernel, dim3(cap(nb)), dim3(256), 0, st, planes, ps, pw, corners, H, W, bmax, nb);
-    hipLaunchKernelGGL(prefixmax_kernel, dim3(1), dim3(1024), 0, st, bmax, nb, bpre, mm);
-    hipLaunchKernelGGL(quirkmin_kernel, dim3(cap(nb)), dim3(256), 0, st, corners, n, bpre, bmin, nb);
-    hipLaunchKernelGGL(minreduce_kernel, dim3(1), dim3(256), 0, st, bmin, nb, mm);
+    const unsigned tiles = (unsigned)(((W + 31) / 32) * ((H + 31) / 32));
+    hipLaunchKernelGGL(moments_t_kernel, dim3(tiles), dim3(256), 0, st, rgb_hwc, tmp3, tmp3 + ps, tmp3 + 2 * ps, W, H, ph);
+    // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67): X pass in place on the transposed planes (lines = image rows, [W][ph]), tile
+    // transpose, Y pass in place on the row-major planes (lines = image columns, [H][pw]); see iir_col for the packed / wide launch forms
+    constexpr int DP = 12, DW = 22;      // ring depths of the packed form (1024-thread blocks: 128 registers per lane) / the wide form (3 D - 8 <= 63, D <= 24: the read switch)
+    const int gx = (H + 255) / 256, gy = (W + 255) / 256;      // tasks (waves) per plane: 256 lines each
+    if (pack_cus > 0) {
+        // packed: eight CU-filling blocks (1024 threads), the pack_cus (<= 4) on the free XCDs work (xcd_share) with as many WORKING waves
+        // each as the tasks need (<= 4: one per SIMD); a working wave's ring = 2 x DP x 1 KB
+        const int shares = std::min(pack_cus, 4);
+        auto launch = [&](float* pl, int nlines, int n, int pitch, int g) {
+            const int nwv = std::min(4, (3 * g + shares - 1) / shares);
+            hipLaunchKernelGGL((iir_cols_kernel<DP, 1024>), dim3(8), dim3(1024), (size_t)nwv * 2 * DP * 1024, st, pl, ps, scratch, nlines, n, pitch, g, shares, nwv, q0_main, c);
+        };
+        static bool attr_done[MAX_DEVICES] = {};
+        { const int dv = cur_dev();
+          if (!attr_done[dv]) { FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(iir_cols_kernel<DP, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * DP * 1024)); attr_done[dv] = true; } }
+        launch(tmp3, H, W, ph, gx);
+        hipLaunchKernelGGL(transpose_kernel, dim3(tiles * 3), dim3(256), 0, st, tmp3, planes, ps, W, H, ph, pw, 3);
+        launch(planes, W, H, pw, gy);
+    } else {
+        const size_t lds = (size_t)2 * DW * 1024;
+        hipLaunchKernelGGL((iir_cols_kernel<DW, 64>), dim3(3 * gx), dim3(64), lds, st, tmp3, ps, scratch, H, W, ph, gx, 3 * gx, 1, static_cast<const int*>(nullptr), c);
+        hipLaunchKernelGGL(transpose_kernel, dim3(tiles * 3), dim3(256), 0, st, tmp3, planes, ps, W, H, ph, pw, 3);
+        hipLaunchKernelGGL((iir_cols_kernel<DW, 64>), dim3(3 * gy), dim3(64), lds, st, planes, ps, scratch, W, H, pw, gy, 3 * gy, 1, static_cast<const int*>(nullptr), c);
+    }
+    hipLaunchKernelGGL(eigen_blockmax_kernel, dim3(nb), dim3(256), 0, st, planes, ps, pw, corners, H, W, bmax, nb);
+    hipLaunchKernelGGL(prefixmax_kernel, dim3(q0_main ? 8 : 1), dim3(1024), 0, st, bmax, nb, bpre, mm, q0_main);
+    hipLaunchKernelGGL(quirkmin_kernel, dim3(nb), dim3(256), 0, st, corners, n, bpre, bmin, nb);
+    hipLaunchKernelGGL(minreduce_kernel, dim3(q0_main ? 8 : 1), dim3(256), 0, st, bmin, nb, mm, q0_main);
     void* sum_ws = reinterpret_cast<char*>(mm) + 256;
     const SeqsumPlan pl = seqsum_plan(n, sum_ws);
-    hipLaunchKernelGGL(normalize_sum_kernel, dim3(cap((long long)nb)), dim3(256), 0, st, corners, n, mm, pl.multi ? pl.csum : nullptr, pl.multi ? pl.cbad : nullptr);
-    launch_seqsum(corners, n, sum_ws, mm + 2, nullptr, st, max_blocks, true);
+    hipLaunchKernelGGL(normalize_sum_kernel, dim3(nb), dim3(256), 0, st, corners, n, mm, pl.multi ? pl.csum : nullptr, pl.multi ? pl.cbad : nullptr);
+    launch_seqsum(corners, n, sum_ws, mm + 2, nullptr, st, q0_main, true);
     FAV_LAUNCH_CHECK("structure kernels");
     *structure_out = corners;
     *avg_out = mm + 2;

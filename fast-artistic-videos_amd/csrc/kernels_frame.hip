@@ -247,8 +247,13 @@ __device__ __forceinline__ void prep_pixel(const uint8_t* frame_hwc, const float
 
 __global__ __launch_bounds__(256) void prep_input_kernel(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws,
                                                          const float2* bw_flo, const float* cert, int border, int H,
-                                                         int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index)
+                                                         int W, int pad, float* in8, int fill_random, unsigned seed, unsigned index, int* q0_out)
 {
+    // (the XCD this queue deals block 0 of a launch to: the look-ahead mask's long-lived blocks place themselves by it, kernels_consistency.hip)
+    if (q0_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        *q0_out = (int)(xcc & 7u);
+    }
     // image.load: byte / 255 -- a correctly rounded division (a dozen instructions); the 256 possible quotients are formed once per block
     __shared__ float byte01[256];
     byte01[threadIdx.x] = (float)threadIdx.x / 255.f;
@@ -472,10 +477,10 @@ int launch_check_prep(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, i
 }
 
 int launch_prep_input(const uint8_t* frame_hwc, const float* prev_rgb, int Hs, int Ws, const float* backward_flo, const float* cert,
-                      int border, int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index)
+                      int border, int H, int W, int pad, float* in8, hipStream_t st, int fill_random, unsigned seed, unsigned index, int* q0_out)
 {
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 2 * pad + 255) / 256, H + 2 * pad), dim3(256), 0, st, frame_hwc,
-                       prev_rgb, Hs, Ws, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index);
+                       prev_rgb, Hs, Ws, reinterpret_cast<const float2*>(backward_flo), cert, border, H, W, pad, in8, fill_random, seed, index, q0_out);
     FAV_LAUNCH_CHECK("prep_input_kernel");
     return FAV_OK;
 }

@@ -332,12 +332,12 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
     }
     const int ngrp = WIDE ? a.groups : 1;
     const int tiles = a.tiles_x * a.tiles_y * ngrp;
-    // Next to the look-ahead side queues (reserve_cus > 0) a layer of many short tiles is launched one tile per block: a persistent
-    // block that shares its CU with a side-queue kernel falls behind and its statically assigned tiles become the launch's tail
-    // (d64 at 1280x720, 9 tiles per block: 175 us against 100 us alone and 154 us for the data-parallel kernel it replaced --
-    // profiles/r02zg_4arg_s2w_ab.log); the hardware scheduler hands single tiles to whichever CU is free.  Same tiles, same partials.
+    // (Rounds 2-5 launched a layer of many short tiles one tile per block next to the look-ahead queue: a persistent block that shared its
+    //  CU with a side-queue kernel fell behind and its statically assigned tiles became the launch's tail.  Since round 6 the mask's
+    //  long-lived kernels sit on the CUs this grid leaves free (kernels_consistency.hip, xcd_share) and the persistent form is the
+    //  faster one again: d64 100 us against 137 us, profiles/r8l_4arg_cu_filling_ab.log.  FAV_S2W_TILE_GRID restores the old form.)
     const int slots = std::max(1, cus[dv] - reserve_cus);
-    static const bool tile_grid = !getenv("FAV_S2W_PERSISTENT");      // (A/B, round 4: the mask pipeline is 0.6 ms of short kernels now)
+    static const bool tile_grid = getenv("FAV_S2W_TILE_GRID") != nullptr;      // (tuning: read once)
     int grid = (tile_grid && reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
     if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block stays with one group
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SwGeo<NTC, TR>::NTH), lds, st, a);

@@ -1029,6 +1029,7 @@ struct fav_stream {
     float* in8 = nullptr;        // padded NHWC8 network input
     float* cert_tmp = nullptr; float* cert = nullptr;
     uint8_t* mask = nullptr;     // certainty as the checker writes it (u8 {0,255})
+    int* q0_main = nullptr;      // the XCD the caller's queue deals block 0 of a launch to (written by prep_input_kernel, read by the look-ahead mask's long-lived kernels)
     void* ws = nullptr; size_t ws_bytes = 0;
     void* png_ws = nullptr; size_t png_ws_bytes = 0;      // workspace of fav_stream_encode_png (allocated on first use)
     // fav_stream_encode_png_async: the encoder's kernels run on a queue of their own, next to the NEXT frame's network (they fill the
@@ -1074,7 +1075,7 @@ struct fav_stream {
         if (done_host) (void)hipHostFree(done_host);       // (retired_host lives in the same allocation)
         for (auto& pf : pref) { if (pf.done) (void)hipEventDestroy(pf.done); (void)hipFree(pf.mask); (void)hipFree(pf.cert); }
         for (int i = 0; i < NSIDE; ++i) (void)hipFree(side_cert_tmp[i]);
-        (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws); (void)hipFree(png_ws);
+        (void)hipFree(q0_main); (void)hipFree(state); (void)hipFree(in8); (void)hipFree(cert_tmp); (void)hipFree(cert); (void)hipFree(mask); (void)hipFree(ws); (void)hipFree(png_ws);
     }
 };
 
@@ -1103,8 +1104,9 @@ static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FA
 // one side queue carries every look-ahead since round 4 (a mask is 0.6 ms of short kernels, two in flight fit a 1.8 ms frame back to
 // back; two queues measured 541-543 frames/s against 546-548: profiles/r04c_4arg_knobs_ab.log)
 static const int NSIDE_USED = getenv("FAV_SIDE_QUEUES") ? std::max(1, std::min(2, atoi(getenv("FAV_SIDE_QUEUES")))) : 1;
-// the look-ahead mask's wide kernels are capped at this many blocks (they walk their items with a grid stride; 0: one block per item)
-static const int SIDE_BLOCKS = getenv("FAV_SIDE_BLOCKS") ? std::max(0, atoi(getenv("FAV_SIDE_BLOCKS"))) : 0;
+// the look-ahead mask's long-lived kernels (the recursive-filter passes) are packed onto the reserved CUs (launch_structure's pack_cus;
+// FAV_SIDE_PACK=0: one block per wave, the form of rounds 4-5)
+static const int SIDE_PACK = getenv("FAV_SIDE_PACK") ? std::max(0, atoi(getenv("FAV_SIDE_PACK"))) : -1;
 static hipError_t create_side_stream(hipStream_t* st)
 {
     // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free, rounds 2-3)
@@ -1135,6 +1137,7 @@ extern "C" int fav_stream_create(fav_net* net, int H, int W, const fav_stream_op
         hipMalloc(reinterpret_cast<void**>(&s->cert_tmp), n * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->cert), n * 4) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->mask), n) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->q0_main), 64) != hipSuccess || hipMemset(s->q0_main, 0, 64) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipMalloc(&s->ws, s->ws_bytes) != hipSuccess) { delete s; return hip_fail(hipErrorOutOfMemory, "hipMalloc(stream buffers)"); }
     for (auto& pf : s->pref)
@@ -1227,7 +1230,7 @@ static int stream_next(fav_stream* s, const uint8_t* frame, const float* bw, con
         if (rc) return rc;
         ++s->frame_counter;
         rc = launch_prep_input(frame, s->state, s->Ho, s->Wo, bw, s->cert, s->opts.border_mode, s->H, s->W, s->net->pad, s->in8, st,
-                               s->opts.fill_random, s->opts.seed, s->frame_counter);
+                               s->opts.fill_random, s->opts.seed, s->frame_counter, s->q0_main);
         if (rc) return rc;
     }
     s->last_st = st; s->ran = true;
@@ -1327,7 +1330,7 @@ extern "C" int fav_stream_prefetch_mask(fav_stream* s, const uint8_t* frame_rgb_
     }
     const float* structure = nullptr; const float* avg = nullptr;
     if (use_structure) {
-        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd, SIDE_BLOCKS); if (rc) return rc;
+        int rc = launch_structure(frame_rgb_hwc, s->W, s->H, s->side_ws[q], s->ws_bytes, &structure, &avg, sd, SIDE_PACK >= 0 ? SIDE_PACK : SIDE_CUS, s->q0_main); if (rc) return rc;
     }
     // mask + certainty of the frame (mask options, fix_occlusions warp of ones, erosion): depends on the flows and the stream's options only
     int rc = launch_check_cert(backward_flo, forward_flo, structure, avg, pf.mask, s->opts.invert_occlusion, s->opts.fix_occlusions, s->opts.border_mode,
