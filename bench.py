@@ -241,9 +241,10 @@ def _cli_leg(base, extra_args, out_dirs, timeout=900, taskset=None, verify=None,
     return res
 
 
-def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames=3000, quick=False):
+def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_frames=3000, quick=False, structure=1):
     """File -> PNG rate of the drop-in CLI (fast_artistic_video.lua:93-97,160-170) -- BASELINE.json's "end-to-end": bin/fav_stylize
-    over RAM-backed 1280x720 P6 frames + backward/forward .flo, fused on-GPU 3-argument check, PNG files written back to RAM.
+    over RAM-backed 1280x720 P6 frames + backward/forward .flo, on-GPU consistency check in the headline mode (`structure`: 1 = the
+    checker's 4-argument form, the CLI's default and what makeOptFlow_deepflow.sh:59-60 runs; 0 = 3-argument), PNG files written back to RAM.
     Everything the in-HBM `value` leaves out is inside: file reads, decode, H2D, D2H, file writes.  world > 1: the product's own
     launcher (`-streams s0,.. -gpus N`: one worker process per GPU, RCCL broadcast of the weights), one clip per GPU.
     EVERY leg's output is content-checked: each PNG byte for byte against the in-process fav_stream_* run of the same inputs
@@ -272,7 +273,8 @@ def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_f
         outp = lambda tag: ["-output_prefix", f"{d}/{pat}/o_{tag}/out"]
         outd = lambda tag: [f"{d}/{nm}/o_{tag}" for nm in names]
         out = {"frames_per_stream": nframes, "streams": world, "host_threads": os.cpu_count(), "usable_cpus": effective_cpus(),
-               "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> fused 3-arg check + warp + net + PNG encode (GPU) -> D2H (exact size) -> write() to /dev/shm",
+               "pipeline": "P6 + 2 x .flo from /dev/shm -> H2D -> %s check + warp + net + PNG encode (GPU) -> D2H (exact size) -> write() to /dev/shm" % ("4-arg (look-ahead)" if structure else "fused 3-arg"),
+               "checker_mode_of_the_headline_legs": "4-argument (-structure 1)" if structure else "3-argument (-structure 0)",
                "h2d_bytes_per_frame": H * W * (3 + 8 + 8),
                "content_check": "every PNG of every leg byte for byte against the in-process fav_stream_* run of the same inputs (bit-deterministic GPU path); "
                                 "png_mismatch_frames / png_missing_frames must be 0"}
@@ -280,25 +282,27 @@ def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_f
         n_long = sustained_frames if (sustained_frames and world == 1 and not quick) else nframes
         every10 = list(range(10, nframes + 1, 10)) + ([nframes] if nframes % 10 else [])
         t_ref = time.perf_counter()
-        ref3 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, max(n_long, nframes), "3arg", keep=every10)
-        out["reference_run_s"] = {"3arg_%d_frames" % max(n_long, nframes): round(time.perf_counter() - t_ref, 2)}
+        hm, om = ("4arg", "3arg") if structure else ("3arg", "4arg")      # headline / other checker mode
+        HS, OS = ["-structure", "1" if structure else "0"], ["-structure", "0" if structure else "1"]
+        ref3 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, max(n_long, nframes), hm, keep=every10)      # (the HEADLINE mode's reference, whatever its name says)
+        out["reference_run_s"] = {"%s_%d_frames" % (hm, max(n_long, nframes)): round(time.perf_counter() - t_ref, 2)}
         # the headline leg: the defaults of the CLI (-png_encoder gpu), 3-argument check = the workload of `value`
         # (at --gpus N a launcher that cannot bring its RCCL communicator up must not hold the bench line back: 4 minutes)
-        out["gpu_png"] = _cli_leg(base, ["-structure", "0"] + outp("gpu"), outd("gpu"), timeout=900 if world == 1 else 240, verify=(ref3, nframes, None))
+        out["gpu_png"] = _cli_leg(base, HS + outp("gpu"), outd("gpu"), timeout=900 if world == 1 else 240, verify=(ref3, nframes, None))
         if quick:
             return out
         if world == 1:
             # the SAME job through the product's multi-GPU launcher (-streams s0 -gpus 1 -force_dist 1: worker process, RCCL communicator
             # of one rank, ncclBroadcast of the packed weights): the exact command line the N > 1 runs issue, driver-run at N = 1
             lb = [exe] + flow_args("%S") + ["-forward_flow_pattern", f"{d}/%S/flow/forward_{{%d}}_[%d].flo"] + tail + ["-streams", names[0], "-gpus", "1", "-force_dist", "1"]
-            out["gpu_png_via_launcher_rccl_world_1"] = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/%S/o_ln/out"], outd("ln"), timeout=300, verify=(ref3, nframes, None))
+            out["gpu_png_via_launcher_rccl_world_1"] = _cli_leg(lb, HS + ["-output_prefix", f"{d}/%S/o_ln/out"], outd("ln"), timeout=300, verify=(ref3, nframes, None))
             # what the same job costs when the host deflates (round 2's path) and with the 4-argument (image-structure) check of
             # makeOptFlow_deepflow.sh:59; then the per-GPU share of a 16-CPU quota on an 8-GPU node: two cores
-            out["host_zlib_png_level_1"] = _cli_leg(base, ["-structure", "0", "-png_encoder", "host", "-png_level", "1"] + outp("zl"), outd("zl"), verify=(ref3, nframes, every10))
+            out["host_zlib_png_level_1"] = _cli_leg(base, HS + ["-png_encoder", "host", "-png_level", "1"] + outp("zl"), outd("zl"), verify=(ref3, nframes, every10))
             t_ref = time.perf_counter()
-            ref4 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, nframes, "4arg")
-            out["reference_run_s"]["4arg_%d_frames" % nframes] = round(time.perf_counter() - t_ref, 2)
-            out["gpu_png_4arg_check"] = _cli_leg(base, ["-structure", "1"] + outp("g4"), outd("g4"), verify=(ref4, nframes, None))
+            ref4 = EC.reference_run(fav_amd, net, frames_h, bw_h, fw_h, nframes, om)
+            out["reference_run_s"]["%s_%d_frames" % (om, nframes)] = round(time.perf_counter() - t_ref, 2)
+            out["gpu_png_%s_check" % om] = _cli_leg(base, OS + outp("g4"), outd("g4"), verify=(ref4, nframes, None))
             del ref4
             if have_ref_checker:
                 # the certainty path exactly as stylizeVideo_deepflow.sh:87-96 calls it -- through the `th` shim, .pgm files written by the
@@ -309,19 +313,19 @@ def e2e_block(ckpt, net, frames_h, bw_h, fw_h, nframes=300, world=1, sustained_f
                       "-backend", "cuda", "-use_cudnn", "1"] + tail
                 out["gpu_png_cert_path_via_th_shim"] = _cli_leg(th, outp("ct"), outd("ct"), verify=(refc, nframes, None))
                 del refc
-            out["host_zlib_two_cores"] = _cli_leg(base, ["-structure", "0", "-png_encoder", "host", "-png_level", "1", "-num_frames", "100"] + outp("z2"), outd("z2"), taskset="0-1",
+            out["host_zlib_two_cores"] = _cli_leg(base, HS + ["-png_encoder", "host", "-png_level", "1", "-num_frames", "100"] + outp("z2"), outd("z2"), taskset="0-1",
                                                   verify=(ref3, 100, list(range(10, 101, 10))))
         # sustained leg: >= 3000 frames (same ring of inputs), shader clock sampled while it runs
         if sustained_frames and world == 1:
             EC.make_clip_dir(d, "long", frames_h, bw_h, fw_h, sustained_frames, O)
             lb = [a.replace(f"{d}/{names[0]}/", f"{d}/long/") for a in base]
             with ClockSampler() as cs:
-                leg = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/long/o/out"], [f"{d}/long/o"], timeout=1200, verify=(ref3, sustained_frames, None))
+                leg = _cli_leg(lb, HS + ["-output_prefix", f"{d}/long/o/out"], [f"{d}/long/o"], timeout=1200, verify=(ref3, sustained_frames, None))
             leg["shader_clock"] = cs.summary()
             out["sustained"] = leg
             # the per-GPU share of a 16-CPU quota on an 8-GPU node: the whole process (loaders, submission, file writes, the HIP
             # runtime's own threads) confined to two CPUs
-            leg2 = _cli_leg(lb, ["-structure", "0", "-output_prefix", f"{d}/long/o2/out"], [f"{d}/long/o2"], timeout=1200, taskset="0-1", verify=(ref3, sustained_frames, None))
+            leg2 = _cli_leg(lb, HS + ["-output_prefix", f"{d}/long/o2/out"], [f"{d}/long/o2"], timeout=1200, taskset="0-1", verify=(ref3, sustained_frames, None))
             leg2["note"] = "taskset -c 0-1 on the %d-frame clip" % sustained_frames
             out["sustained_two_cores"] = leg2
         legs = [v for v in out.values() if isinstance(v, dict) and "png_written" in v]
@@ -405,7 +409,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--structure", type=int, default=0, help="1 = 4-argument (image-structure) checker mode")
+    ap.add_argument("--structure", type=int, default=1, help="1 (default since round 6) = the checker's 4-argument, image-structure form: what makeOptFlow_deepflow.sh:59-60 "
+                    "runs in production and what bin/fav_stylize defaults to; 0 = the 3-argument form (the headline of rounds 1-5, now `config.value_in_3arg_mode`)")
     ap.add_argument("--no-profile", action="store_true", help="no per-convolution HIP events in the timed region (A/B of their cost; the roofline block is then empty)")
     ap.add_argument("--profile-every", type=int, default=4, help="HIP events around the convolutions on every n-th step of the timed region")
     ap.add_argument("--lookahead", type=int, default=-1, help="1 = compute the masks of the next two frames on the side queues "
@@ -545,23 +550,38 @@ def main():
             step_other(i)
         torch.cuda.synchronize()
         extra["frames_per_s_png_encode_on_the_compute_queue" if args.png_async else "frames_per_s_png_encode_on_the_streams_encoder_queue"] = round(n0 / (time.perf_counter() - t1), 3)
-    if world == 1 and not args.structure and not args.no_extra:
-        def step4(i):
-            k2 = (i + 2) % ring
-            stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)
-            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=True, want_f32=False, want_u8=False)
-            if not args.png_async: stream.encode_png_into(png_out, png_n)        # (the timed step's own ending: the two rates compare like with like)
-            else: stream.encode_png_async_into(png_out, png_n)
-        stream.prefetch_mask(frames[0], bws[0], fws[0], use_structure=True)
-        stream.prefetch_mask(frames[1], bws[1], fws[1], use_structure=True)
+    if world == 1 and not args.no_extra:
+        # the same loop in the OTHER checker mode (like for like: the timed step's own ending).  4-argument: masks two frames ahead on the
+        # side queue; 3-argument: the check is part of the frame's first kernel
+        other = not bool(args.structure)
+        # (a network that has served look-ahead masks keeps its persistent grids at 252 blocks: the 3-argument sibling of a 4-argument run
+        #  gets a network and a stream of its own, so that it is the plain 3-argument configuration)
+        net_o = net if other else fav_amd.Net(blob=blob, device=local)
+        stream_o = stream if other else fav_amd.Stream(net_o, H, W)
+        png_o, png_no = (png_out, png_n) if other else stream_o.png_buffers()
+        if not other:
+            stream_o.first_frame(frames[0], want_f32=False, out_u8=out8)
+        def step_o(i):
+            if other:
+                k2 = (i + 2) % ring
+                stream_o.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=True)
+            stream_o.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=other, want_f32=False, want_u8=False)
+            if not args.png_async: stream_o.encode_png_into(png_o, png_no)
+            else: stream_o.encode_png_async_into(png_o, png_no)
+        if other:
+            stream_o.prefetch_mask(frames[0], bws[0], fws[0], use_structure=True)
+            stream_o.prefetch_mask(frames[1], bws[1], fws[1], use_structure=True)
         for i in range(4):
-            step4(i)
+            step_o(i)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         n4 = max(8, args.steps // 2)
         for i in range(4, 4 + n4):
-            step4(i)
+            step_o(i)
         torch.cuda.synchronize()
-        extra["frames_per_s_4arg_structure_mode_lookahead"] = round(n4 / (time.perf_counter() - t1), 3)
+        extra["frames_per_s_4arg_structure_mode_lookahead" if other else "frames_per_s_3arg_mode"] = round(n4 / (time.perf_counter() - t1), 3)
+        if not other:
+            net_o.check(); del stream_o, net_o
+    if world == 1 and not args.no_extra:
         # informational, NOT the parity mode and not `value`: the optional fast mode with bf16 operands in the halo-resident 3x3
         # convolutions (fav_net_set_precision; tests gate it at >= 45 dB PSNR against the fp32 oracle)
         net.profile_enable(False)
@@ -578,7 +598,7 @@ def main():
     # not part of `value` either: the same step on checkpoints with MORE FILTERS (README.md:141: the published VR models; the reference
     # builds any architecture string) -- every filter count doubled / x1.5; scripts/wide_bench.py.  Their layers must stay on the
     # minimal-filtering kernels (`fallback_layers` empty) at a conv-stack rate close to the canonical network's
-    if world == 1 and not args.no_extra and not args.structure:
+    if world == 1 and not args.no_extra:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import wide_bench
         try:
@@ -684,6 +704,9 @@ def main():
         if "frames_per_s_4arg_structure_mode_lookahead" in extra:      # `value`'s sibling: the checker mode makeOptFlow_deepflow.sh:59-60 runs
             line["config"]["value_in_4arg_structure_mode"] = extra["frames_per_s_4arg_structure_mode_lookahead"]
             line["config"]["value_in_4arg_structure_mode_over_value"] = round(extra["frames_per_s_4arg_structure_mode_lookahead"] / fps, 4)
+        if "frames_per_s_3arg_mode" in extra:                           # `value` is the 4-argument mode: its 3-argument sibling (the headline of rounds 1-5)
+            line["config"]["value_in_3arg_mode"] = extra["frames_per_s_3arg_mode"]
+            line["config"]["value_over_value_in_3arg_mode"] = round(fps / extra["frames_per_s_3arg_mode"], 4)
         # the launch path is not the limiter: host enqueue time per frame vs GPU time per frame (why a HIP graph would not help:
         # kernel boundaries cost the same GPU-side in a replayed graph, MI355X_MICROARCH.md "boundary" row)
         line["extra"]["host_enqueue_ms_per_frame"] = round(t_enq / args.steps * 1e3, 4)
@@ -712,7 +735,7 @@ def main():
         line["extra"]["png_bytes_per_frame_in_timed_region"] = int(png_n.item())
         if not args.no_e2e:
             del stream; torch.cuda.synchronize()
-            line["e2e"] = e2e_block(ckpt, net, frames_h, bw_h, fw_h, world=world, sustained_frames=args.sustained_frames, quick=args.quick_e2e)
+            line["e2e"] = e2e_block(ckpt, net, frames_h, bw_h, fw_h, world=world, sustained_frames=args.sustained_frames, quick=args.quick_e2e, structure=int(bool(args.structure)))
             head = line["e2e"].get("gpu_png", {}) if isinstance(line["e2e"], dict) else {}
             line["end_to_end_fps"] = head.get("fps")
             # the bytes behind the end-to-end numbers: PNGs of ALL e2e legs that differ from (or are missing against) the in-process run

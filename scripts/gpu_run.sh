@@ -7,13 +7,13 @@
 #   testfile:<file>[:<k>]            one test file
 #   smoke                            __graft_entry__.smoke()
 #   bench[:<extra bench.py flags>]   the driver's default command line (+ flags, '+' for spaces)
-#   quick                            in-HBM rate only (no CPU baseline, no e2e, no extras)
-#   prof                             rocprofv3 --kernel-trace --stats of the timed configuration -> <tag>_kernel_stats.csv
-#   prof4                            the same with --structure 1 (4-argument checker mode)
+#   quick                            in-HBM rate only (no CPU baseline, no e2e, no extras); quick3: the 3-argument checker mode (--structure 0)
+#   prof                             rocprofv3 --kernel-trace --stats of the timed configuration (4-argument mode since round 6) -> <tag>_kernel_stats.csv
+#   prof4 / prof3                    the same with --structure 1 / --structure 0
 #   pmc                              scripts/gpu_pmc.sh <tag>  (separate --pmc passes)
 #   gaps                             scripts/gaps.sh
 #   ab:<env=val>[,<env=val>...][;<env=val>...]   quick bench alternating default / each ';'-separated set of environment settings, two rounds
-#   ab4:...                          the same in the 4-argument checker mode (--structure 1)
+#   ab4:... / ab3:...                the same with --structure 1 / --structure 0 spelled out
 #   ablib:<lib.so>[,<lib.so>...]     scripts/ab_lib.sh (alternating library builds)
 #   e2e[:<frames>]                   scripts/e2e.py (the CLI's own timing breakdown)
 #   c3dump                           GPU side of the 300-frame config-3 free-running parity run (contractive checkpoint)
@@ -44,9 +44,10 @@ for STEP in "$@"; do
               timeout 3000 python -m pytest tests/$F -m gpu -x -q -s --timeout 900 ${KX:+-k "$KX"} 2>&1 | tee $O/test_${TAG}_${F%.py}.log | tail -25 ;;
     smoke)    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tee $O/smoke_${TAG}.log | tail -3 ;;
     bench)    timeout 1500 python bench.py $A > $O/bench_${TAG}.log 2> $O/bench_${TAG}.err; summ bench < $O/bench_${TAG}.log; tail -3 $O/bench_${TAG}.err ;;
-    quick)    for i in 1 2; do timeout 300 $QUICK $A 2>/dev/null | tee -a $O/quick_${TAG}.log | summ quick; done ;;
-    prof|prof4)
-              X=""; [ $K = prof4 ] && X="--structure 1"
+    quick|quick3) X=""; [ $K = quick3 ] && X="--structure 0"
+              for i in 1 2; do timeout 300 $QUICK $X $A 2>/dev/null | tee -a $O/${K}_${TAG}.log | summ $K; done ;;
+    prof|prof4|prof3)
+              X=""; [ $K = prof4 ] && X="--structure 1"; [ $K = prof3 ] && X="--structure 0"
               (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_$K -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-e2e $X > $O/prof_${TAG}_$K.log 2>&1)
               cp $(ls $O/prof_${TAG}_$K/*kernel_stats.csv | head -1) $O/${TAG}_${K}_kernel_stats.csv 2>/dev/null
               python - <<PY
@@ -58,7 +59,7 @@ PY
               ;;
     pmc)      bash scripts/gpu_pmc.sh $TAG 2>&1 | tail -40 ;;
     gaps)     bash scripts/gaps.sh 2>&1 | tail -70 ;;
-    ab|ab4)   X=""; [ $K = ab4 ] && X="--structure 1"
+    ab|ab4|ab3) X=""; [ $K = ab4 ] && X="--structure 1"; [ $K = ab3 ] && X="--structure 0"
               for rep in 1 2; do
                 timeout 300 $QUICK $X 2>/dev/null | summ "default "
                 for V in ${A//;/ }; do (export ${V//,/ }; timeout 300 $QUICK $X 2>/dev/null | summ "$V "); done
