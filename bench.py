@@ -530,23 +530,29 @@ def main():
     extra = {}
     if world == 1 and not args.no_extra:
         # continuity with rounds 1-2, whose step ended at the de-processed frame (A9 was a host job then): the same loop without the PNG encode
-        for i in range(4):
+        def frame_only(i):
+            if args.lookahead:
+                k2 = (i + 2) % ring
+                stream.prefetch_mask(frames[k2], bws[k2], fws[k2], use_structure=bool(args.structure))
             stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+        for i in range(args.steps, args.steps + 4):
+            frame_only(i)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         n0 = max(8, args.steps // 2)
-        for i in range(4, 4 + n0):
-            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+        for i in range(args.steps + 4, args.steps + 4 + n0):
+            frame_only(i)
         torch.cuda.synchronize()
         extra["frames_per_s_without_png_encode"] = round(n0 / (time.perf_counter() - t1), 3)
         # ... and with the encode on the other queue (informational: the form `value` does not use)
         def step_other(i):
-            stream.next_frame_flow(frames[i % ring], bws[i % ring], fws[i % ring], use_structure=bool(args.structure), want_f32=False, want_u8=False)
+            frame_only(i)
             if args.png_async: stream.encode_png_into(png_out, png_n)
             else: stream.encode_png_async_into(png_out, png_n)
-        for i in range(4):
+        b0 = args.steps + 4 + n0
+        for i in range(b0, b0 + 4):
             step_other(i)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        for i in range(4, 4 + n0):
+        for i in range(b0 + 4, b0 + 4 + n0):
             step_other(i)
         torch.cuda.synchronize()
         extra["frames_per_s_png_encode_on_the_compute_queue" if args.png_async else "frames_per_s_png_encode_on_the_streams_encoder_queue"] = round(n0 / (time.perf_counter() - t1), 3)

@@ -11,6 +11,22 @@
 
 #include "../../include/fav.h"
 
+// Environment variables.  A RELEASE build of the library (the default `make`: libfav.so) reads only the documented ones -- FAV_SIDE_CUS,
+// FAV_SIDE_QUEUES, FAV_ROCTX in the library; FAV_GPU, FAV_CC_*, FAV_RCCL_TIMEOUT_S, FAV_TEST_WORKER_FAIL in the executables.  Every
+// kernel-selection, tuning and debug switch (FAV_NO_*, FAV_WINO_F2, FAV_W4_*, FAV_*_DBG, ...) goes through diag_env() and exists in the
+// DIAGNOSTIC build only (`make diag`: libfav_diag.so, -DFAV_DIAG; what the cross-check tests and the A/B scripts load): a stray FAV_NO_WINO
+// in a user's environment cannot silently halve the rate of the library that ships.
+#include <cstdlib>
+inline const char* diag_env(const char* name)
+{
+#ifdef FAV_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 namespace fav {
 
 void set_error(const char* fmt, ...);
@@ -100,6 +116,15 @@ struct Affine {            // pending per-channel transform t(x) = relu?(x*scale
 // accumulator layout of one InstanceNorm: [parity 2][copy STAT_COPIES][channel C][4 words: sum lo, sum hi, squares lo, squares hi]
 constexpr int STAT_COPIES = 8;       // one copy per XCD (blockIdx & 7): 8x shallower chains of atomics on one address
 inline size_t stat_acc_words(int C) { return (size_t)STAT_COPIES * C * 4; }      // per parity
+// A unit whose statistics are not finite (a diverged clip, a damaged checkpoint: NaN / Inf activations) cannot be written as fixed point
+// (the double -> integer conversion would be undefined): its producer adds STAT_NONFINITE to the HIGH words instead, and a consumer that
+// finds a high word beyond STAT_NONFINITE / 2 in magnitude forms NaN scale / shift -- what in_finalize_kernel gives for the same input.
+// (legitimate high words stay below 2^45 for any activation range the fp32 network can produce; 300 units x 2^53 still fits 63 bits)
+constexpr long long STAT_NONFINITE = 1ll << 53;
+__host__ __device__ inline bool stat_acc_poisoned(long long hi_sum, long long hi_squares)
+{
+    return hi_sum >= STAT_NONFINITE / 2 || hi_sum <= -(STAT_NONFINITE / 2) || hi_squares >= STAT_NONFINITE / 2 || hi_squares <= -(STAT_NONFINITE / 2);
+}
 
 struct ConvLaunch {
     const float* in = nullptr;      // NHWC physical [IHp][IWp][CIN]

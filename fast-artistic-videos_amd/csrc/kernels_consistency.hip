@@ -847,7 +847,7 @@ struct SeqsumPlan { bool multi = false; int nc = 0; int* state = nullptr; double
 
 static SeqsumPlan seqsum_plan(size_t n, void* ws)
 {
-    static const bool one_block = getenv("FAV_AVG_ONE_BLOCK") != nullptr;       // (A/B: the round-3 form)
+    static const bool one_block = diag_env("FAV_AVG_ONE_BLOCK") != nullptr;       // (A/B: the round-3 form)
     SeqsumPlan pl;
     // (very long arrays too: avg_chunk_class_kernel re-adds the chunk sums before its chunk in every block -- nc^2 / 8 reads of 8 bytes:
     //  nothing at 1280x720 (3 600 chunks) or a 1504^2 VR face (8 836), 1 GB of L2 reads (~0.1 ms) for a 3840x2160 frame (32 400), 4 GB at

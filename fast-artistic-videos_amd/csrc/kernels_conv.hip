@@ -1583,7 +1583,7 @@ static int launch_h3_t(const H3Args& a0, int cin, int reserve_cus, bool no_sk, h
     const bool one_per_cu = tiles <= nres && tiles * 100 >= nres * 94;
     const int grid = (no_sk || one_per_cu) ? tiles : (tiles * (cin / 32) * 3 < nres ? 1 : nres);      // (stream-K units: tap rows)
     H3Args a = a0; a.dbg = nullptr;
-    static int dbg_n = getenv("FAV_H3_DBG") ? atoi(getenv("FAV_H3_DBG")) : 0;
+    static int dbg_n = diag_env("FAV_H3_DBG") ? atoi(diag_env("FAV_H3_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && BN == 128 && !BF && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), SK_GRID * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, SK_GRID * 24 * 8, st)); a.dbg = dbuf; }
@@ -2402,7 +2402,7 @@ int launch_fold_up2_t(FoldArgs a, int reserve_cus, hipStream_t st)
     a.tiles_x = (a.OW + XO - 1) / XO; a.tiles_y = (a.OH + FOLD_R - 1) / FOLD_R;
     const int tiles = a.tiles_x * a.tiles_y;
     const int nres = std::max(1, cus[dv] - reserve_cus);
-    static int dbg_n = getenv("FAV_FOLD_DBG") ? atoi(getenv("FAV_FOLD_DBG")) : 0;      // print the in-kernel timeline of the n-th launch
+    static int dbg_n = diag_env("FAV_FOLD_DBG") ? atoi(diag_env("FAV_FOLD_DBG")) : 0;      // print the in-kernel timeline of the n-th launch
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
     static long long* dbuf = nullptr;
     a.dbg = nullptr;
@@ -2457,7 +2457,7 @@ bool conv_fold_eligible(int cin_pitch, int cout, int k, int stride)
 // every architecture string of the reference ends that way); anything else with that many channels takes the generic kernel
 bool conv_fold_launchable(int cin_pitch, int k, int pad, int ups, int IH, int IW)
 {
-    static const bool no_up2 = getenv("FAV_NO_FOLD_UP2") != nullptr;
+    static const bool no_up2 = diag_env("FAV_NO_FOLD_UP2") != nullptr;
     if (cin_pitch <= 64) return true;
     return ups == 1 && !no_up2 && (pad & 1) == 0 && (k & 1) == 1 && (IH & 1) == 0 && (IW & 1) == 0 && k + 1 <= 10;
 }
@@ -2474,7 +2474,7 @@ int launch_conv_fold(const ConvLaunch& c, const float* wfold, hipStream_t st)
     a.IH = c.IH; a.IW = c.IW; a.IWp = c.IWp; a.ups = c.ups; a.COUT = c.COUT; a.KH = c.KH; a.KW = c.KW; a.pad = c.pad;
     a.OH = c.OH; a.OW = c.OW; a.tanh_mul = c.tanh_mul;
     // x2 nearest-upsampled input: physical columns, merged ky slices (wfold carries them after the plain slices)
-    static const bool no_up2 = getenv("FAV_NO_FOLD_UP2") != nullptr;
+    static const bool no_up2 = diag_env("FAV_NO_FOLD_UP2") != nullptr;
     if (c.ups == 1 && !no_up2 && (c.pad & 1) == 0 && (c.KW & 1) == 1 && (c.IH & 1) == 0 && (c.IW & 1) == 0 && c.KH + 1 <= 10) {
         if (c.CIN == 256) return launch_fold_up2_t<64, 4>(a, c.reserve_cus, st);
         if (c.CIN == 128) return launch_fold_up2_t<64, 2>(a, c.reserve_cus, st);
@@ -2677,7 +2677,7 @@ __global__ __launch_bounds__(256) void res_add_kernel(const float* y, const floa
             const double mean = s1 / (double)br.count1;
             double var = s2 / (double)br.count1 - mean * mean;
             var = var > 0.0 ? var : 0.0;
-            const double sc = (double)br.gamma1[i] / sqrt(var + (double)br.eps1);
+            const double sc = stat_acc_poisoned(w1, w3) ? (double)NAN : (double)br.gamma1[i] / sqrt(var + (double)br.eps1);
             ss[i] = (float)sc; ss[C + i] = (float)((double)br.beta1[i] - mean * sc);
             if (blockIdx.x == 0) {      // the other parity's accumulators: zero for the next frame
 #pragma unroll

@@ -507,7 +507,7 @@ int launch_first2d_t(const FirstArgs& a, int reserve_cus, hipStream_t st)
     grid = std::min(grid, tiles * ngrp);
     if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block keeps one group's weights
 #ifdef FAV_DIAG
-    static int dbg_n = getenv("FAV_FIRST_DBG") ? atoi(getenv("FAV_FIRST_DBG")) : 0;
+    static int dbg_n = diag_env("FAV_FIRST_DBG") ? atoi(diag_env("FAV_FIRST_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
     FirstArgs ad = a;

@@ -337,7 +337,7 @@ int launch_s2w_t(const S2wArgs& a, int reserve_cus, hipStream_t st)
     //  long-lived kernels sit on the CUs this grid leaves free (kernels_consistency.hip, xcd_share) and the persistent form is the
     //  faster one again: d64 100 us against 137 us, profiles/r8l_4arg_cu_filling_ab.log.  FAV_S2W_TILE_GRID restores the old form.)
     const int slots = std::max(1, cus[dv] - reserve_cus);
-    static const bool tile_grid = getenv("FAV_S2W_TILE_GRID") != nullptr;      // (tuning: read once)
+    static const bool tile_grid = diag_env("FAV_S2W_TILE_GRID") != nullptr;      // (tuning: read once)
     int grid = (tile_grid && reserve_cus > 0 && tiles > 4 * slots) ? tiles : std::min(tiles, slots);
     if (WIDE) grid = std::max(ngrp, grid / ngrp * ngrp);      // a block stays with one group
     hipLaunchKernelGGL(kern, dim3(grid), dim3(SwGeo<NTC, TR>::NTH), lds, st, a);
@@ -354,7 +354,7 @@ bool conv3s2w_eligible(int cin_pitch, int cout, int coutp, int k, int stride, in
 }
 // tile rows: d64 4 (8 waves); d128 3 (12 waves: 737 tiles = 3 rounds on 256 CUs at 1280x720; with 2 rows 1100 tiles = 5 rounds where 4.3 would do)
 // (measured and not kept: d64 with 6 rows on 12 waves -- 104 us against 98.8 us with 4 rows on 8: profiles/r02y_s2w_rows_ab.log)
-static int s2w_rows(int coutp) { static const int r128 = getenv("FAV_S2W_ROWS128") ? atoi(getenv("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 && coutp == 128 ? 2 : 3); }      // (tuning: read once)
+static int s2w_rows(int coutp) { static const int r128 = diag_env("FAV_S2W_ROWS128") ? atoi(diag_env("FAV_S2W_ROWS128")) : 3; return coutp == 64 ? 4 : (r128 == 2 && coutp == 128 ? 2 : 3); }      // (tuning: read once)
 int conv3s2w_tiles(int OH, int OW, int coutp) { const int tr = s2w_rows(coutp); return ((OH + tr - 1) / tr) * ((OW + 31) / 32); }
 
 int launch_conv3s2w(const ConvLaunch& c, const float* wpk, int* counts, hipStream_t st)

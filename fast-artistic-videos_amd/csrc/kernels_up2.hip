@@ -455,7 +455,7 @@ __global__ __launch_bounds__(768) void conv3_up2w_kernel(const Up2Args p)
 
 }  // namespace
 
-static bool up2_winograd() { static const bool w = getenv("FAV_UP2_PHASES") == nullptr; return w; }      // (tuning: read once)
+static bool up2_winograd() { static const bool w = diag_env("FAV_UP2_PHASES") == nullptr; return w; }      // (tuning: read once)
 bool conv3_up2_eligible(int cin_pitch, int cout, int coutp, int k, int stride, int pad, int stages, int ups)
 {
     return k == 3 && stride == 1 && pad == 1 && ups == 1 && stages == 1 && cin_pitch % 32 == 0 && cin_pitch >= 32 && cin_pitch <= 256 &&

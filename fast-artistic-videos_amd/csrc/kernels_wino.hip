@@ -468,10 +468,10 @@ int launch_wino_t(const WinoArgs& a0, int reserve_cus, hipStream_t st)
     // unit time.  When the last round has at most grid / 4 units (the first three residual layers at 1280x720: 550, 525, 525 units
     // on 256 CUs) its units are cut into quarters of 32 output channels: four times as many CUs work on that round and it takes
     // roughly a third of a unit time instead of a whole one.
-    static const bool no_quarters = getenv("FAV_WINO_NO_QUARTERS") != nullptr;
+    static const bool no_quarters = diag_env("FAV_WINO_NO_QUARTERS") != nullptr;
     const int rounds = (units + grid - 1) / grid, rem = units - (rounds - 1) * grid;
     a.nfull = (rounds >= 2 && rem * 4 <= grid && !no_quarters) ? (rounds - 1) * grid : units;
-    static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
+    static int dbg_n = diag_env("FAV_WINO_DBG") ? atoi(diag_env("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 24 * 8, st)); a.dbg = dbuf; }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const double mean = s1 / (double)p.count1;
             double var = s2 / (double)p.count1 - mean * mean;
             var = var > 0.0 ? var : 0.0;
-            const double sc = (double)p.gamma1[i] / sqrt(var + (double)p.eps1);
+            const double sc = stat_acc_poisoned(w1, w3) ? (double)NAN : (double)p.gamma1[i] / sqrt(var + (double)p.eps1);
             aff[i] = (float)sc; aff[CIN + i] = (float)((double)p.beta1[i] - mean * sc);
             if (blockIdx.x == 0) {      // the other parity's accumulators were last read a frame ago: zero for the next frame
 #pragma unroll
@@ -546,7 +546,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const double v = (g & 2) ? (double)m2 + nd * mud * mud : nd * mud;
                 const double tt = v * 1099511627776.0;
                 const double hi = floor(tt * (1.0 / 4294967296.0));
-                const long long word = (g & 1) ? (long long)hi : (long long)(tt - hi * 4294967296.0);
+                const bool fin = fabs(tt) < 9.0e18;                          // (false for NaN / Inf too: STAT_NONFINITE, fav_internal.h)
+                const long long word = !fin ? ((g & 1) ? STAT_NONFINITE : 0ll) : (g & 1) ? (long long)hi : (long long)(tt - hi * 4294967296.0);
                 long long* const dst = p.stat_acc + ((size_t)(blockIdx.x & (STAT_COPIES - 1)) * (WIDE ? p.COUT : 128) + cb) * 4 + g;
                 __hip_atomic_fetch_add(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (g == 0) p.partials[(size_t)u * (WIDE ? p.COUT : 128) + cb] = make_float2(mu, m2);
@@ -600,7 +601,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
 {
 #ifdef FAV_DIAG
     // timing experiments (make DIAG=1 only): these instantiations skip parts of the kernel and produce garbage
-    static const int var = getenv("FAV_W4_VAR") ? atoi(getenv("FAV_W4_VAR")) : 0;
+    static const int var = diag_env("FAV_W4_VAR") ? atoi(diag_env("FAV_W4_VAR")) : 0;
     const auto kern = (!WIDE && MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (!WIDE && MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (!WIDE && MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
                       (!WIDE && MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (!WIDE && MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
                       (!WIDE && MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> : conv3_wino4_kernel<MODE, 0, WIDE>;
@@ -632,15 +633,15 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     // queues) -- not a function of the device's CU count or of reserve_cus: which units are cut, and at which slice, decides the order
     // the channels of a cut unit are summed in, i.e. the fp32 bits of the output.  Every device, partition mode and side-queue
     // setting (FAV_SIDE_CUS) therefore produces the same bits; with fewer blocks than shares a block simply takes several shares
-    static const bool no_stream = getenv("FAV_W4_NO_STREAM") != nullptr;
-    static const int grid_cap = getenv("FAV_W4_GRID") ? atoi(getenv("FAV_W4_GRID")) : 0;
+    static const bool no_stream = diag_env("FAV_W4_NO_STREAM") != nullptr;
+    static const int grid_cap = diag_env("FAV_W4_GRID") ? atoi(diag_env("FAV_W4_GRID")) : 0;
     if (grid_cap > 0) grid = std::min(grid, std::max(1, grid_cap));
     const int shares = grid_cap > 0 ? std::max(1, std::min(W4_SHARES, grid_cap)) : W4_SHARES;
     const int rounds = (units + shares - 1) / shares, rem = units - (rounds - 1) * shares;
     a.stream = (rounds >= 2 && rem * 5 <= shares * 3 && shares <= W4_MEET_MAX && a0.ks_ws && a0.ks_cnt && !no_stream) ? 1 : 0;
     a.shares = shares;
     if (a.stream) grid = std::min(grid, shares);
-    static int dbg_n = getenv("FAV_WINO_DBG") ? atoi(getenv("FAV_WINO_DBG")) : 0;
+    static int dbg_n = diag_env("FAV_WINO_DBG") ? atoi(diag_env("FAV_WINO_DBG")) : 0;
     static long long* dbuf = nullptr;
     const bool dbg = dbg_n > 0 && --dbg_n == 0;
     if (dbg) { FAV_HIP(hipMalloc(reinterpret_cast<void**>(&dbuf), 512 * 24 * 8)); FAV_HIP(hipMemsetAsync(dbuf, 0, 512 * 24 * 8, st)); a.dbg = dbuf; }

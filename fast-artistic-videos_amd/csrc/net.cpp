@@ -93,9 +93,9 @@ void repack_weights(const Layer& L, int cinp, int coutp, int kpad, std::vector<f
 struct Tuning { bool no_fold, no_c8, no_h3, no_s2, no_c8d, no_wino, no_up2, no_first, no_s2w, wino_f2, no_acc_stats; };
 const Tuning& tuning()
 {
-    static const Tuning t = {getenv("FAV_NO_FOLD") != nullptr, getenv("FAV_NO_C8") != nullptr, getenv("FAV_NO_H3") != nullptr, getenv("FAV_NO_S2") != nullptr, getenv("FAV_NO_C8D") != nullptr, getenv("FAV_NO_WINO") != nullptr, getenv("FAV_NO_UP2") != nullptr, getenv("FAV_NO_FIRST") != nullptr, getenv("FAV_NO_S2W") != nullptr,
-                             getenv("FAV_WINO_F2") != nullptr,       // FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (rounds 2-3) instead of F(4x4,3x3)
-                             getenv("FAV_NO_ACC_STATS") != nullptr}; // FAV_NO_ACC_STATS: every InstanceNorm through partials + an in_finalize launch (rounds 1-4)
+    static const Tuning t = {diag_env("FAV_NO_FOLD") != nullptr, diag_env("FAV_NO_C8") != nullptr, diag_env("FAV_NO_H3") != nullptr, diag_env("FAV_NO_S2") != nullptr, diag_env("FAV_NO_C8D") != nullptr, diag_env("FAV_NO_WINO") != nullptr, diag_env("FAV_NO_UP2") != nullptr, diag_env("FAV_NO_FIRST") != nullptr, diag_env("FAV_NO_S2W") != nullptr,
+                             diag_env("FAV_WINO_F2") != nullptr,       // FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (rounds 2-3) instead of F(4x4,3x3)
+                             diag_env("FAV_NO_ACC_STATS") != nullptr}; // FAV_NO_ACC_STATS: every InstanceNorm through partials + an in_finalize launch (rounds 1-4)
     return t;
 }
 
@@ -438,7 +438,7 @@ int fav_net::timed_conv(const ConvLaunch& c, int conv_index, const Layer& L)
     // profiles/r02p_4arg_kernel_stats.csv).  Data-parallel grids do not wait for anybody.  The halo-resident 3x3 kernel (bf16 fast
     // mode, FAV_NO_WINO) hands tiles over the same way and takes the same descriptor.
     ConvLaunch cg = cs;
-    static const int side_sk_mode = getenv("FAV_SIDE_SK") ? atoi(getenv("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
+    static const int side_sk_mode = diag_env("FAV_SIDE_SK") ? atoi(diag_env("FAV_SIDE_SK")) : 0;      // (tuning: read once) 1: keep stream-K next to the side queues, 2: for the stride-2 halo kernel only
     if (reserve_cus > 0 && side_sk_mode != 1) cg.no_sk = 1;
     auto go = [&]() { return use_first ? (use_first2d ? launch_conv_first2d(cs, L.cin, convs[conv_index].wfirst2d, c8_counts, st) : launch_conv_first(cs, L.cin, convs[conv_index].wfirst, c8_counts, st)) : use_s2w ? launch_conv3s2w(cs, convs[conv_index].ws2w, c8_counts, st) : use_up2 ? launch_conv3_up2(cs, convs[conv_index].wup2, c8_counts, st) : use_wino ? (use_wino4 ? launch_conv3_wino4(cs, convs[conv_index].wwino4, c8_counts, st) : launch_conv3_wino(cs, convs[conv_index].wwino, c8_counts, st)) : wfold ? launch_conv_fold(cs, wfold, st) : (use_c8 ? (c8d_w ? launch_conv_c8d(cs, L.cin, c8d_w, c8_counts, st) : launch_conv_c8(cs, c8_counts, st)) : (use_h3 ? launch_conv3_halo(cg, c8_counts, st) : (use_s2 ? launch_conv3s2(side_sk_mode == 2 ? cs : cg, c8_counts, st) : launch_conv(cg, st)))); };
     char tag[96] = "";
@@ -567,7 +567,7 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
                              conv3s2w_eligible(d.cinp, L.cout, d.coutp, L.k, L.stride, L.pad, cur.pre.stages, cur.ups);
             const bool h3 = !wino && !up2 && !s2w && !L.transposed && conv3_halo_eligible(d.cinp, d.coutp, L.k, L.stride) && !tuning().no_h3;
             const bool s2 = !L.transposed && !s2w && !h3 && !c8 && conv3s2_eligible(d.cinp, d.coutp, L.k, L.stride, cur.pre.stages, cur.ups) && !tuning().no_s2;
-            static const bool first_1d = getenv("FAV_FIRST_1D") != nullptr;      // (tuning: read once) the 1-D form of the first layer
+            static const bool first_1d = diag_env("FAV_FIRST_1D") != nullptr;      // (tuning: read once) the 1-D form of the first layer
             const bool first2d = first_wide || (first && d.wfirst2d != nullptr && !first_1d);
             nxt.mblocks = first ? (first2d ? conv_first2d_tiles(c.OH, c.OW) : conv_first_tiles(c.OH, c.OW)) : s2w ? conv3s2w_tiles(c.OH, c.OW, d.coutp) : up2 ? conv3_up2_tiles(c.OH, c.OW) : wino ? (wino4 ? conv3_wino4_tiles(c.OH, c.OW) : conv3_wino_tiles(c.OH, c.OW)) : c8 ? conv_c8_tiles(c.OH, c.OW) : (h3 ? conv3_halo_tiles(c.OH, c.OW, precision == 0) : (s2 ? conv3s2_tiles(c.OH, c.OW) : conv_mblocks(c.OH, c.OW))); nxt.ppitch = d.coutp;
             const bool acc = wino4 && want_stats && !pitched_out && cur.join_skip == nullptr &&
@@ -663,8 +663,8 @@ int fav_net::run(std::vector<Layer>& ls, Act& cur, bool top, float* out_planar, 
             // 16 us launch they replace (639 against 634 frames/s, profiles/r4s_stream_k_and_joins_ab.log).  (The F(4x4) kernel's pending-join
             // instantiation is kept for FAV_LAZY_JOIN and the tests that pin its bits against the launched joins; since the row requests carry
             // their own offsets it spills inside its K loop -- nobody tuned it further)
-            static const bool no_lazy = getenv("FAV_NO_LAZY_JOIN") != nullptr;      // (tuning: read once)
-            static const bool want_lazy = getenv("FAV_LAZY_JOIN") != nullptr;
+            static const bool no_lazy = diag_env("FAV_NO_LAZY_JOIN") != nullptr;      // (tuning: read once)
+            static const bool want_lazy = diag_env("FAV_LAZY_JOIN") != nullptr;
             const int nconv = count_convs(L.block);
             const bool lazy_out = !no_lazy && (tuning().wino_f2 || want_lazy) && precision == 0 && li + 1 < ls.size() && ls[li + 1].type == L_RES && skip.pre.stages == 0 && skip.ups == 0 &&
                                   res_block_is_winograd(L, conv_cursor) && res_block_is_winograd(ls[li + 1], conv_cursor + (size_t)nconv);
@@ -1106,12 +1106,12 @@ static const int SIDE_CUS = getenv("FAV_SIDE_CUS") ? std::max(0, atoi(getenv("FA
 static const int NSIDE_USED = getenv("FAV_SIDE_QUEUES") ? std::max(1, std::min(2, atoi(getenv("FAV_SIDE_QUEUES")))) : 1;
 // the look-ahead mask's long-lived kernels (the recursive-filter passes) are packed onto the reserved CUs (launch_structure's pack_cus;
 // FAV_SIDE_PACK=0: one block per wave, the form of rounds 4-5)
-static const int SIDE_PACK = getenv("FAV_SIDE_PACK") ? std::max(0, atoi(getenv("FAV_SIDE_PACK"))) : -1;
+static const int SIDE_PACK = diag_env("FAV_SIDE_PACK") ? std::max(0, atoi(diag_env("FAV_SIDE_PACK"))) : -1;
 static hipError_t create_side_stream(hipStream_t* st)
 {
     // (confining the side queues with a CU mask -- hipExtStreamCreateWithCUMask -- measured slower than leaving the CUs free, rounds 2-3)
     // FAV_SIDE_CU_MASK=<comma-separated bit numbers>: experiment, round 6
-    if (const char* m = getenv("FAV_SIDE_CU_MASK")) {
+    if (const char* m = diag_env("FAV_SIDE_CU_MASK")) {
         uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (const char* p = m; *p;) { const int b = atoi(p); if (b >= 0 && b < 256) words[b / 32] |= 1u << (b % 32); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
         return hipExtStreamCreateWithCUMask(st, 8, words);
@@ -1288,7 +1288,7 @@ extern "C" int fav_stream_next_frame_flow(fav_stream* s, const uint8_t* frame_rg
     }
     // check + certainty options + erosion + input assembly in ONE tile kernel (round 5; the mask byte and the eroded certainty of every pixel
     // are still written: fav_stream_last_mask); FAV_NO_CHECK_PREP: the check and the assembly as two launches (rounds 3-4)
-    static const bool fused_prep = getenv("FAV_NO_CHECK_PREP") == nullptr;      // (tuning: read once)
+    static const bool fused_prep = diag_env("FAV_NO_CHECK_PREP") == nullptr;      // (tuning: read once)
     if (fused_prep && s->has_state) {
         ++s->frame_counter;
         int rcp = launch_check_prep(frame_rgb_hwc, s->state, s->Ho, s->Wo, backward_flo, forward_flo, structure, avg, s->mask, s->cert,

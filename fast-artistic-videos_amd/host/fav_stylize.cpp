@@ -75,6 +75,17 @@ struct Opt {
 
 using favl::die;
 
+// diagnostic switches exist in -DFAV_DIAG builds of this executable only (csrc/fav_internal.h says why)
+const char* diag_env(const char* name)
+{
+#ifdef FAV_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 void check(int rc, const char* what)
 {
     if (rc) die(std::string(what) + ": " + fav_last_error());
@@ -580,7 +591,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         } else if (cur.W != W || cur.H != H) die("frame size changed inside the sequence");
         issue();                                         // keep DEPTH loads in flight
         const auto t0 = std::chrono::steady_clock::now();
-        static const bool loop_trace = getenv("FAV_LOOP_TRACE") != nullptr;      // where a loop iteration's host time goes (frames 100-111)
+        static const bool loop_trace = diag_env("FAV_LOOP_TRACE") != nullptr;      // where a loop iteration's host time goes (frames 100-111)
         double tr_ms[6] = {0, 0, 0, 0, 0, 0};
         auto tr_mark = [&](int k) { if (loop_trace) tr_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         // frames i+1 (i+2): wait for the loader, upload, and start the consistency mask on the side queues so the (sequential, 1.5 ms)
@@ -649,7 +660,7 @@ void run_stream(const Opt& o, fav_net* net, fav_net* net_img, int nwriters, Stre
         finish(pend);                                    // frame i-1: wait, report, hand to the PNG pool -- frame i's kernels are already queued
         t_gpu += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
         tr_mark(3);
-        static const bool loop_trace_start = loop_trace && atoi(getenv("FAV_LOOP_TRACE")) == 2;       // 2: the first 48 frames instead (start-up)
+        static const bool loop_trace_start = loop_trace && atoi(diag_env("FAV_LOOP_TRACE")) == 2;       // 2: the first 48 frames instead (start-up)
         if (loop_trace_start && done < 48)
             fprintf(stderr, "loop trace frame %d: at %.3f ms since start: look-ahead %.3f  frame enqueued %.3f  encode enqueued %.3f  previous frame finished %.3f ms\n", i,
                     std::chrono::duration<double, std::milli>(t0 - t_begin).count(), tr_ms[0], tr_ms[1], tr_ms[2], tr_ms[3]);

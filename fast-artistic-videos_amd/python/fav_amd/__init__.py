@@ -14,7 +14,10 @@ from typing import Optional, Tuple
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # fast-artistic-videos_amd/
-LIB_PATH = os.path.join(_PKG, "libfav.so")
+# FAV_AMD_LIB: another build of the library for THIS binding (tests / A-B scripts load libfav_diag.so, the build whose kernel-selection
+# switches are live; the release library reads none of them)
+LIB_PATH = os.environ.get("FAV_AMD_LIB") or os.path.join(_PKG, "libfav.so")
+DIAG_LIB_PATH = os.path.join(_PKG, "libfav_diag.so")
 BORDER_STN, BORDER_CPU = 0, 1
 
 _lib = None

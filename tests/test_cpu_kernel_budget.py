@@ -14,7 +14,8 @@ CSRC = os.path.join(ROOT, "fast-artistic-videos_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize",
          "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include")]
-FILES = ["kernels_s2.hip", "kernels_up2.hip", "kernels_wino.hip", "kernels_png.hip"]
+FILES = ["kernels_s2.hip", "kernels_up2.hip", "kernels_wino.hip", "kernels_png.hip", "kernels_wino4.hip", "kernels_first.hip", "kernels_consistency.hip"]
+EXTRA = {"kernels_consistency.hip": ["-ffp-contract=off"]}          # (as in the Makefile)
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 
@@ -23,7 +24,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 def usage(tmp_path_factory):
     """{kernel symbol: {VGPRs, ScratchSize, Occupancy}} for the three files, compiled concurrently"""
     d = tmp_path_factory.mktemp("kres")
-    procs = [(f, subprocess.Popen([HIPCC] + FLAGS + [os.path.join(CSRC, f), "-o", str(d / (f + ".o"))], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True))
+    procs = [(f, subprocess.Popen([HIPCC] + FLAGS + EXTRA.get(f, []) + [os.path.join(CSRC, f), "-o", str(d / (f + ".o"))], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True))
              for f in FILES]
     out = {}
     for f, p in procs:
@@ -75,3 +76,54 @@ def test_png_encoder_kernels_keep_everything_in_registers_and_lds(usage):
     for name in ("png_rows_kernelILb1E", "png_rows_kernelILb0E", "png_pack_kernel", "png_finish_kernel"):
         u = _one(usage, name)
         assert u["ScratchSize"] == 0 and u["VGPRs"] <= 96, (name, u)
+
+
+def _loops_with_matrix_instructions(asm, symbol_part):
+    """(first, last, mfma count, scratch count) of every loop (backward branch) of the kernel whose symbol contains symbol_part"""
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S+:", l) and symbol_part in l)
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    out = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)|s_branch (\.LBB\d+_\d+)", l)
+        if m:
+            tgt = m.group(1) or m.group(2)
+            if tgt in labels and labels[tgt] < i:
+                seg = body[labels[tgt]:i]
+                out.append((labels[tgt], i, sum("v_mfma" in x for x in seg), sum("scratch_" in x for x in seg)))
+    return out
+
+
+def test_f4x4_and_first_layer_kernels_budget(usage, tmp_path):
+    """the two files that hold 58 % of a frame (round-5 review): the F(4x4) residual kernel and the first layer.  Both are written for 256
+    registers at two waves per SIMD.  The first layer must not spill at all; the F(4x4) kernel's canonical instantiations spill a few
+    loop-invariant words AROUND the slice loop (the accumulators take 144 of the 256 registers) -- never inside it: the innermost loops
+    that hold its matrix instructions must be free of scratch accesses (what scripts/isa_loops.py prints), and the total stays bounded."""
+    for inst in ("ILi7ELb0E", "ILi3ELb0E", "ILi7ELb1E", "ILi3ELb1E"):
+        u = _one(usage, "conv_first2d_kernel", inst)
+        assert u["ScratchSize"] == 0 and u["Occupancy"] == 2 and u["VGPRs"] <= 256, (inst, u)
+    for inst, cap in (("ILi0ELi0ELb0E", 32), ("ILi1ELi0ELb0E", 56), ("ILi0ELi0ELb1E", 16), ("ILi1ELi0ELb1E", 16)):
+        u = _one(usage, "conv3_wino4_kernel", inst)
+        assert u["Occupancy"] == 2 and u["VGPRs"] <= 256 and u["ScratchSize"] <= cap, (inst, u)
+    s = str(tmp_path / "w4.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "kernels_wino4.hip"), "-o", s], stderr=subprocess.DEVNULL)
+    asm = open(s).read()
+    for inst in ("conv3_wino4_kernelILi0ELi0ELb0E", "conv3_wino4_kernelILi1ELi0ELb0E"):
+        loops = [l for l in _loops_with_matrix_instructions(asm, inst) if l[2] > 0]
+        assert loops, inst
+        inner = [l for l in loops if not any(o is not l and l[0] <= o[0] and o[1] <= l[1] for o in loops)]      # loops that contain no other matrix loop
+        assert inner and all(l[3] == 0 for l in inner), (inst, inner)
+        # whatever encloses them (the unit loop: prologue, slices, output transform) touches scratch a handful of times per UNIT at most
+        assert max(l[3] for l in loops) <= 4, (inst, loops)
+
+
+def test_recursive_filter_kernels_budget(usage):
+    """the mask's recursive smoothing passes (round 6): the packed form is launched as CU-filling 1024-thread blocks (<= 128 registers per
+    lane, and more than 104 -- registers are allocated in granules of 8 -- so that its four waves per SIMD take at least 448 of the 512 registers: that is what keeps the network's blocks off the CU); neither form spills"""
+    p = _one(usage, "iir_cols_kernel", "ILi12ELi1024E")
+    assert p["ScratchSize"] == 0 and 104 < p["VGPRs"] <= 128, p
+    w = _one(usage, "iir_cols_kernel", "ILi22ELi64E")
+    assert w["ScratchSize"] == 0 and w["VGPRs"] <= 256, w

@@ -365,6 +365,24 @@ def test_c_abi_exports_every_declared_symbol(favlib):
     assert declared == set(favlib.EXPORTS)
 
 
+def test_release_library_reads_only_the_documented_environment_variables(favlib):
+    """the library that ships must not change its kernels because of a stray FAV_NO_WINO in somebody's environment (round-5 review): every
+    kernel-selection / tuning / debug switch goes through diag_env() (csrc/fav_internal.h) and exists in libfav_diag.so only.  The names
+    a binary can pass to getenv are in its string table: the release library's are exactly the documented ones."""
+    import re
+    pkg = os.path.join(ROOT, "fast-artistic-videos_amd")
+    names = lambda f: set(m.decode() for m in re.findall(rb"FAV_[A-Z0-9_]{2,}", open(os.path.join(pkg, f), "rb").read()))
+    documented = {"FAV_SIDE_CUS", "FAV_SIDE_QUEUES", "FAV_ROCTX"}
+    constants = {"FAV_PRECISION_BF16_OPERANDS", "FAV_PRECISION_FP32"}                 # (enumerators quoted in error messages)
+    assert names("libfav.so") - constants == documented, names("libfav.so")
+    if os.path.exists(os.path.join(pkg, "libfav_diag.so")):
+        diag = names("libfav_diag.so")
+        assert {"FAV_NO_WINO", "FAV_WINO_F2", "FAV_W4_GRID", "FAV_NO_CHECK_PREP"} <= diag and documented <= diag
+    for exe, allowed in (("bin/fav_stylize", {"FAV_RCCL_TIMEOUT_S", "FAV_TEST_WORKER_FAIL"}), ("bin/fav_stylize_vr", {"FAV_RCCL_TIMEOUT_S", "FAV_TEST_WORKER_FAIL"}),
+                         ("bin/consistencyChecker", {"FAV_CC_", "FAV_CC_DAEMON", "FAV_CC_IDLE_S", "FAV_CC_REPLY_S", "FAV_CC_TIMING", "FAV_GPU"})):
+        assert names(exe) <= allowed, (exe, names(exe))
+
+
 def test_no_gpu_means_loud_failure(favlib):
     import torch
     if torch.cuda.is_available():

@@ -18,6 +18,10 @@ import pytest
 from fav_amd import synth, t7
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# kernel-selection switches (FAV_NO_*, FAV_WINO_F2, FAV_W4_*, ...) exist in the DIAGNOSTIC build of the library only (make diag:
+# libfav_diag.so, csrc/fav_internal.h diag_env): the child processes of the cross-check tests load that one; the release library ignores them
+DIAG_LIB = os.path.join(ROOT, "fast-artistic-videos_amd", "libfav_diag.so")
+DIAG_ENV = dict(os.environ, FAV_AMD_LIB=DIAG_LIB)
 
 pytestmark = pytest.mark.gpu
 
@@ -283,7 +287,7 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
              "x = np.load(%r); net = fav_amd.Net(%r, 0)\n"
              "np.save(%r, net.forward(torch.from_numpy(x).cuda()).cpu().numpy())\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical, str(tmp_path / "direct.npy")))
-    env = dict(os.environ, FAV_NO_WINO="1", FAV_NO_UP2="1", FAV_NO_FOLD_UP2="1", FAV_NO_FIRST="1", FAV_NO_S2W="1")
+    env = dict(DIAG_ENV, FAV_NO_WINO="1", FAV_NO_UP2="1", FAV_NO_FOLD_UP2="1", FAV_NO_FIRST="1", FAV_NO_S2W="1")
     subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
     direct = np.load(tmp_path / "direct.npy")
     ref = oracle.net_forward(_layers(canonical), x)
@@ -291,12 +295,12 @@ def test_direct_form_kernels_behind_the_switches_match_the_minimal_filtering_one
     assert np.abs(direct - ref).max() <= 5e-2 and np.abs(got - ref).max() <= 5e-2
     assert np.abs(got - direct).max() <= 2e-2, np.abs(got - direct).max()
     # FAV_UP2_PHASES: U2 + c3s1-64 as four phase-wise 2x2 convolutions (conv3_up2_kernel) instead of the nine-position form
-    env = dict(os.environ, FAV_UP2_PHASES="1")
+    env = dict(DIAG_ENV, FAV_UP2_PHASES="1")
     subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
     phases = np.load(tmp_path / "direct.npy")
     assert np.abs(phases - ref).max() <= 5e-2 and np.abs(got - phases).max() <= 2e-2, (np.abs(phases - ref).max(), np.abs(got - phases).max())
     # FAV_WINO_F2: the residual convolutions as F(2x2,3x3) (conv3_wino_kernel, the reference-accuracy form) instead of F(4x4,3x3)
-    env = dict(os.environ, FAV_WINO_F2="1")
+    env = dict(DIAG_ENV, FAV_WINO_F2="1")
     subprocess.check_call([sys.executable, "-c", child], env=env, timeout=300)
     f2 = np.load(tmp_path / "direct.npy")
     e2, e4 = np.abs(f2 - ref).max(), np.abs(got - ref).max()
@@ -323,7 +327,7 @@ def test_accumulator_statistics_match_the_partials_form(favlib, oracle, cuda, ca
              "    x = torch.from_numpy(np.load(%r %% k)).cuda()\n"
              "    np.save(%r %% k, net.forward(x).cpu().numpy())\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), canonical, str(tmp_path / "x%d.npy"), str(tmp_path / "p%d.npy")))
-    subprocess.check_call([sys.executable, "-c", child], env=dict(os.environ, FAV_NO_ACC_STATS="1"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child], env=dict(DIAG_ENV, FAV_NO_ACC_STATS="1"), timeout=300)
     net = favlib.Net(canonical, 0)
     first = {}
     for rep in range(3):                                  # frames alternate sizes: parity flips every forward
@@ -370,8 +374,8 @@ def test_stream_k_shares_of_the_winograd_layers(favlib, cuda, canonical, tmp_pat
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), canonical))
     envg = {"FAV_W4_GRID": str(grid)} if grid else {}
     if lazy: envg["FAV_LAZY_JOIN"] = "1"           # residual joins pending in the next convolution (conv3_wino4_kernel<2>) instead of launched
-    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(os.environ, FAV_W4_NO_STREAM="1", **envg), timeout=300)
-    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(os.environ, **envg), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(DIAG_ENV, FAV_W4_NO_STREAM="1", **envg), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(DIAG_ENV, **envg), timeout=300)
     whole, stream = np.load(tmp_path / "whole.npy"), np.load(tmp_path / "stream.npy")
     assert np.isfinite(stream).all()
     d = np.abs(stream - whole).max()
@@ -402,7 +406,7 @@ def test_pending_residual_joins_give_the_bits_of_the_launched_ones(favlib, cuda,
     assert np.isfinite(eager).all()
     assert np.array_equal(eager, net.forward(T(x, cuda)).cpu().numpy())
     for extra in ({"FAV_LAZY_JOIN": "1"}, {"FAV_WINO_F2": "1"}):
-        ref_env = dict(os.environ, **extra)
+        ref_env = dict(DIAG_ENV, **extra)
         subprocess.check_call([sys.executable, "-c", child], env=ref_env, timeout=300)
         pending = np.load(tmp_path / "eager.npy")
         if "FAV_WINO_F2" in extra:      # the F(2x2) kernels: pending (their default) against launched, both in children
@@ -479,6 +483,26 @@ def test_padding_types_vs_oracle(favlib, oracle, cuda, tmp_path, ptype, arch):
         assert np.array_equal(st.last_mask().cpu().numpy(), m)
         r = ref_s.next(_f01(frames[i]), bws[i], m.astype(np.float32) / np.float32(255))
         assert np.abs(o.cpu().numpy() - r).max() <= 2e-4, (i, float(np.abs(o.cpu().numpy() - r).max()))
+    net.check()
+
+
+def test_non_finite_activations_come_out_as_nan_and_leave_nothing_behind(favlib, cuda, canonical):
+    """a NaN / Inf in the input (a diverged free-running clip, a damaged checkpoint) must reach the output as NaN on EVERY path of the
+    InstanceNorm statistics: the accumulator form (exact fixed point, round 5) cannot hold a non-finite sum -- its producer poisons the high
+    words instead (STAT_NONFINITE, csrc/fav_internal.h) and the consumer forms NaN scale / shift, like in_finalize_kernel does for the
+    partials form.  The frames after it are clean again (the accumulators' halves alternate and are zeroed by their consumers)."""
+    net = favlib.Net(canonical, 0)
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((7, 96, 128)) * 60).astype(np.float32)
+    clean = net.forward(T(x, cuda)).cpu().numpy()
+    assert np.isfinite(clean).all()
+    for bad in (np.nan, np.inf):
+        xb = x.copy(); xb[2, 40, 50] = bad
+        out = net.forward(T(xb, cuda)).cpu().numpy()
+        assert np.isnan(out).all(), float(np.isfinite(out).mean())        # InstanceNorm spreads it over every channel of every layer
+        for _ in range(2):                                                   # both parities of the accumulators
+            again = net.forward(T(x, cuda)).cpu().numpy()
+            assert np.array_equal(again, clean)
     net.check()
 
 
@@ -681,7 +705,7 @@ def test_fused_check_and_input_assembly_gives_the_bytes_of_the_two_launches(favl
              "o2, _ = st.next_frame_flow(T(d['f2']), T(d['b2']), T(d['w2'])); m2 = st.last_mask().cpu().numpy()\n"
              "np.savez(sys.argv[1], o1=o1.cpu().numpy(), o2=o2.cpu().numpy(), i1=i1, m1=m1, m2=m2)\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "clip.npz"), canonical, h, w, opts))
-    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "two.npz")], env=dict(os.environ, FAV_NO_CHECK_PREP="1"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "two.npz")], env=dict(DIAG_ENV, FAV_NO_CHECK_PREP="1"), timeout=300)
     subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "one.npz")], env=os.environ.copy(), timeout=300)
     a, b = np.load(tmp_path / "two.npz"), np.load(tmp_path / "one.npz")
     for k in ("m1", "m2", "i1", "o1", "o2"):
@@ -1234,8 +1258,8 @@ def test_stream_k_shares_with_more_filters(favlib, cuda, tmp_path):
              "assert np.array_equal(a, b)\n"
              "np.save(sys.argv[1], a)\n"
              % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), str(tmp_path / "x.npy"), p))
-    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(os.environ, FAV_W4_NO_STREAM="1", FAV_W4_GRID="7"), timeout=300)
-    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(os.environ, FAV_W4_GRID="7"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "whole.npy")], env=dict(DIAG_ENV, FAV_W4_NO_STREAM="1", FAV_W4_GRID="7"), timeout=300)
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(DIAG_ENV, FAV_W4_GRID="7"), timeout=300)
     whole, stream = np.load(tmp_path / "whole.npy"), np.load(tmp_path / "stream.npy")
     assert np.isfinite(stream).all()
     d = np.abs(stream - whole).max()
