@@ -42,6 +42,13 @@ __device__ __forceinline__ int xcd_share(const int* q0_main, int shares)
     return rel >= 4 && rel - 4 < shares ? rel - 4 : -1;
 }
 
+// one block per XCD?  (what xcd_share relies on: eight consecutive blocks of a launch land on eight different XCDs)
+__global__ void xcd_probe_kernel(int* out)
+{
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(xcc & 15u);
+}
+
 constexpr int MAX_DEVICES = 64;
 inline int cur_dev() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
 
@@ -919,6 +926,28 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
                      const float** avg_out, hipStream_t st, int pack_cus, const int* q0_main)
 {
     if (!q0_main) pack_cus = 0;
+    if (pack_cus > 0) {
+        // The placement scheme is written for a device that presents EIGHT XCDs and deals consecutive blocks to consecutive XCDs (MI355X /
+        // MI300X in SPX mode).  On anything else -- a partitioned device, another XCD count -- no block would find itself on a "free" XCD and
+        // the mask would never be computed: asked ONCE per device (eight blocks report their XCC_ID; one stream synchronisation), and the
+        // wide form is used when the answer is not a permutation of 0..7.
+        static int xcd8[MAX_DEVICES] = {};      // 0: not asked yet, 1: yes, -1: no
+        const int dv = cur_dev();
+        if (!xcd8[dv]) {
+            int* d = nullptr; int h[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+            bool ok = hipMalloc(reinterpret_cast<void**>(&d), sizeof h) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(xcd_probe_kernel, dim3(8), dim3(64), 0, st, d);
+                ok = hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+                (void)hipFree(d);
+            }
+            unsigned seen = 0;
+            for (int i = 0; i < 8; ++i) if (h[i] >= 0 && h[i] < 8) seen |= 1u << h[i];
+            xcd8[dv] = ok && seen == 0xffu ? 1 : -1;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (xcd8[dv] < 0) { pack_cus = 0; q0_main = nullptr; }
+    }
     FAV_REQUIRE(ws != nullptr && ws_bytes >= structure_workspace_bytes(W, H), "consistency: workspace too small");
     FAV_REQUIRE(W >= 2 && H >= 2, "consistency: structure mode needs W,H >= 2");
     const size_t n = (size_t)W * H, ps = structure_plane_floats(W, H);
@@ -937,7 +966,7 @@ int launch_structure(const uint8_t* rgb_hwc, int W, int H, void* ws, size_t ws_b
     hipLaunchKernelGGL(moments_t_kernel, dim3(tiles), dim3(256), 0, st, rgb_hwc, tmp3, tmp3 + ps, tmp3 + 2 * ps, W, H, ph);
     // recursiveSmoothX then Y on dxx, dyy, dxy (:62-67): X pass in place on the transposed planes (lines = image rows, [W][ph]), tile
     // transpose, Y pass in place on the row-major planes (lines = image columns, [H][pw]); see iir_col for the packed / wide launch forms
-    constexpr int DP = 12, DW = 22;      // ring depths of the packed form (1024-thread blocks: 128 registers per lane) / the wide form (3 D - 8 <= 63, D <= 24: the read switch)
+    constexpr int DP = 14, DW = 22;      // ring depths of the packed form (1024-thread blocks: 128 registers per lane) / the wide form (3 D - 8 <= 63, D <= 24: the read switch)
     const int gx = (H + 255) / 256, gy = (W + 255) / 256;      // tasks (waves) per plane: 256 lines each
     if (pack_cus > 0) {
         // packed: eight CU-filling blocks (1024 threads), the pack_cus (<= 4) on the free XCDs work (xcd_share) with as many WORKING waves

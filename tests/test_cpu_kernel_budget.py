@@ -123,7 +123,7 @@ def test_f4x4_and_first_layer_kernels_budget(usage, tmp_path):
 def test_recursive_filter_kernels_budget(usage):
     """the mask's recursive smoothing passes (round 6): the packed form is launched as CU-filling 1024-thread blocks (<= 128 registers per
     lane, and more than 104 -- registers are allocated in granules of 8 -- so that its four waves per SIMD take at least 448 of the 512 registers: that is what keeps the network's blocks off the CU); neither form spills"""
-    p = _one(usage, "iir_cols_kernel", "ILi12ELi1024E")
+    p = _one(usage, "iir_cols_kernel", "ILi14ELi1024E")
     assert p["ScratchSize"] == 0 and 104 < p["VGPRs"] <= 128, p
     w = _one(usage, "iir_cols_kernel", "ILi22ELi64E")
     assert w["ScratchSize"] == 0 and w["VGPRs"] <= 256, w
