@@ -52,7 +52,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out_u8, gpu_mask):
+def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out_u8, gpu_mask, structure=1):
     """The oracle (a port of the reference's CPU path, fast_artistic_video_core.lua:161-180) timed on this host's cores on ONE
     1280x720 recurrent step (min of 3 runs), and -- since that frame is computed anyway -- compared with what the GPU path
     produced from the same inputs (teacher-forced: both start from the GPU's previous stylised frame).  Outside the timed
@@ -70,12 +70,12 @@ def cpu_baseline_and_parity(layers, frame1, bw, fw, prev_state, gpu_out, gpu_out
         st = O.Stylizer(layers)
         st.last = prev_state
         t0 = time.perf_counter()
-        mask = O.consistency(b, f)
+        mask = O.consistency(b, f, np.ascontiguousarray(frame1) if structure else None)      # (the timed configuration's checker mode)
         r1 = st.next(f1, b, mask.astype(np.float32) / np.float32(255))
         times.append(time.perf_counter() - t0)
     dt = min(times)
     base = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame of 1280x720 (3-arg mask + min-filter + warp + assemble + net + deprocess) through oracle/ "
+            "sample": f"1 frame of 1280x720 ({'4' if structure else '3'}-arg mask + min-filter + warp + assemble + net + deprocess) through oracle/ "
                       f"(C, fp64 accumulation, OpenMP) on {cores} threads (= usable CPUs: {len(os.sched_getaffinity(0))} visible, cgroup quota applied), min of 3 runs ({', '.join('%.2f' % t for t in times)} s)"}
     ref_u8 = O.to_u8_hwc(r1)
     mse = float(np.mean((ref_u8.astype(np.float64) - gpu_out_u8.astype(np.float64)) ** 2))
@@ -723,10 +723,10 @@ def main():
             layers = t7.extract_layers(t7.load(ckpt)["model"])
             pst = fav_amd.Stream(net, H, W)
             o0, _ = pst.first_frame(frames[0])
-            o1, u1 = pst.next_frame_flow(frames[1], bws[1], fws[1], use_structure=False, want_u8=True)
+            o1, u1 = pst.next_frame_flow(frames[1], bws[1], fws[1], use_structure=bool(args.structure), want_u8=True)
             torch.cuda.synchronize(); net.check()
             base, parity = cpu_baseline_and_parity(layers, frames_h[1], bw_h[1], fw_h[1], o0.cpu().numpy(), o1.cpu().numpy(), u1.cpu().numpy(),
-                                                   pst.last_mask().cpu().numpy())
+                                                   pst.last_mask().cpu().numpy(), structure=int(bool(args.structure)))
             ref = reference_checker_baseline(bw_h[1], fw_h[1], frames_h[1])
             if ref is not None:
                 base["reference_consistency_checker"] = ref
