@@ -144,7 +144,7 @@ def test_mask_bit_exact_vs_reference_golden(favlib, cuda, golden_dir, name):
     assert np.array_equal(m4, g["mask4"]), f"{(m4 != g['mask4']).sum()} bytes differ from the reference binary (4-arg)"
 
 
-@pytest.mark.parametrize("size", [(360, 640), (720, 1280), (5, 3), (130, 1029), (2, 2), (17, 18), (98, 33), (53, 71), (480, 854)])
+@pytest.mark.parametrize("size", [(360, 640), (720, 1280), (5, 3), (130, 1029), (2, 2), (17, 18), (98, 33), (53, 71), (480, 854), (9, 300), (2160, 3840)])
 def test_mask_bit_exact_vs_oracle(favlib, oracle, cuda, size):
     h, w = size
     bw = synth.backward_flow(h, w, 5) if h > 8 else synth.random_flow(h, w, 5, 0.5)
@@ -624,14 +624,18 @@ def test_stream_vs_oracle_recurrent(favlib, oracle, cuda, golden_dir, mode):
     assert np.array_equal(st.state().cpu().numpy(), outs[-1])
 
 
+@pytest.mark.parametrize("size", [(48, 72), (130, 1029), (301, 258)])
 @pytest.mark.parametrize("host_ordered", [False, True])
-def test_stream_mask_lookahead(favlib, oracle, cuda, golden_dir, host_ordered):
+def test_stream_mask_lookahead(favlib, oracle, cuda, golden_dir, host_ordered, size):
     """fav_stream_prefetch_mask: the next frame's mask computed on the side stream gives identical frames -- event-ordered (default)
     and host-ordered (fav_stream_set_host_ordered: no event in any queue, the caller has seen the inputs complete, the consumer waits on
-    the host for a sequence number in host-mapped memory)"""
+    the host for a sequence number in host-mapped memory).  In the 4-argument mode this is the PACKED form of the mask pipeline (round 6:
+    eight blocks per long-lived kernel, the ones on the XCDs the network leaves a CU free on work -- xcd_share; four lines per lane, LDS
+    ring): sizes with one and with several groups of 256 lines, line counts that are not multiples of 4 or 256, lines shorter and longer
+    than the ring"""
     import torch
     path = os.path.join(golden_dir, "tiny_model.t7")
-    h, w, n = 48, 72, 4
+    (h, w), n = size, 4
     frames, bws, fws = _clip(h, w, n, 60)
     net = favlib.Net(path, 0)
     fr = [T(f, cuda) for f in frames]; bw = [None] + [T(b, cuda) for b in bws[1:]]; fw = [None] + [T(f, cuda) for f in fws[1:]]
