@@ -16,8 +16,8 @@
 //     16 w .. 16 w + 15 (wave = 2 w' + nt in wino4_pack.h's (w', nt) numbering) for ALL 36 transform positions and all 16 tiles:
 //     acc[36] x 4 = 144 accumulator registers.  Every (tile, output channel) has its 36 position values in ONE lane, so the output
 //     transform A^T M A never leaves the lane -- no exchange between waves, no LDS pass (the F(2x2) kernel spends 4.9 of 39 us per unit there)
-//   * input: per 16-channel slice the 18 x 18 pixel halo arrives as raw rows by `buffer_load ... lds` (requested a slice ahead, 64 contiguous
-//     bytes per four adjacent lanes), the producing layer's pending InstanceNorm / ReLU (or pending residual join) is applied, and
+//   * input: per 16-channel slice the 18 x 18 pixel halo arrives as raw rows by `buffer_load ... lds` (requested a slice or two ahead: two
+//     slices per request since round 6, 128 contiguous bytes per eight adjacent lanes), the producing layer's pending InstanceNorm / ReLU (or pending residual join) is applied, and
 //     B^T d B is formed in TWO passes through LDS between the matrix instructions: rows (288 items of 6 -> 6: threads 0..287, i.e.
 //     waves 0-3 and half of wave 4) into L, columns (384 items: waves 2..7, one transform line each) into V[position][chunk][tile].
 //     An A fragment is then ONE conflict-free ds_read_b128 per position and 16 channels
@@ -65,8 +65,9 @@ constexpr int W4_LTY = 113 * 4;                // 452: the six lines of a tile r
 constexpr int W4_LKQ = 464 * 4;                // 1856: the four tile rows of a chunk plane (452 slots) padded to 464
 constexpr int W4_LBUF = 4 * W4_LKQ;            // 7424 words
 constexpr int W4_RBUF = 6 * 288 * 4;           // landing area of the raw rows (buffer_load ... lds): [row][thread < 288] 16 bytes each: 6912 words
-constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF + W4_RBUF;      // 32768 words = 131 072 B (+ a second landing area for the skip rows of a
-                                                              //  pending join, + 2 CIN words of pending scale / shift: 159 744 B)
+constexpr int W4_SMEM = 2 * W4_VBUF + W4_LBUF + W4_RBUF;      // 32768 words = 131 072 B (+ a second landing area -- the second slice of a
+                                                              //  paired request, or the skip rows of a pending join --, + 2 CIN words of
+                                                              //  pending scale / shift: 159 744 B)
 static_assert((W4_LTY / 4) % 16 == 1 && (W4_LKQ / 4) % 16 == 0 && W4_LTY >= 6 * W4_LLINE && W4_LKQ >= 4 * W4_LTY, "pitches of L");
 
 struct Wino4Args {
@@ -102,25 +103,34 @@ __device__ __forceinline__ void w4_store16_wt(void* ptr, v4f v)
 // B^T d and A^T m (wino4_pack.h) with every multiply-add WRITTEN as one: the three instantiations of the kernel (plain input, pending
 // normalisation, pending join) must round alike -- a network computes the same bits whether a residual join is launched or left pending
 // (test_pending_residual_joins_give_the_bits_of_the_launched_ones) -- and the compiler's own choice of contractions differs with context
-__device__ __forceinline__ v4f w4_fma(float a, v4f b, v4f c)
+// (round 6: the same operations on PAIRS of values -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, each component rounded exactly like
+//  the single-value instruction; four-wide vectors are legalised to single-value instructions, two-wide ones to the packed forms)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f w4_fma(float a, v2f b, v2f c) { return __builtin_elementwise_fma(v2f{a, a}, b, c); }
+__device__ __forceinline__ void w4_bt2(const v2f d[6], v2f v[6])
 {
-    return v4f{__builtin_fmaf(a, b.x, c.x), __builtin_fmaf(a, b.y, c.y), __builtin_fmaf(a, b.z, c.z), __builtin_fmaf(a, b.w, c.w)};
-}
-__device__ __forceinline__ void w4_bt(const v4f d[6], v4f v[6])
-{
-    const v4f e1 = w4_fma(-2.25f, d[2], d[4]), o1 = w4_fma(-1.6875f, d[1], 0.75f * d[3]);
-    const v4f e2 = w4_fma(-0.5625f, d[2], d[4]), o2 = w4_fma(-0.84375f, d[1], 1.5f * d[3]);
+    const v2f e1 = w4_fma(-2.25f, d[2], d[4]), o1 = w4_fma(-1.6875f, d[1], 0.75f * d[3]);
+    const v2f e2 = w4_fma(-0.5625f, d[2], d[4]), o2 = w4_fma(-0.84375f, d[1], 1.5f * d[3]);
     v[0] = w4_fma(1.265625f, d[0], w4_fma(-2.8125f, d[2], d[4]));
     v[1] = e1 + o1; v[2] = e1 - o1; v[3] = e2 + o2; v[4] = e2 - o2;
     v[5] = w4_fma(1.265625f, d[1], w4_fma(-2.8125f, d[3], d[5]));
 }
-__device__ __forceinline__ void w4_at(const float m[6], float y[4])
+__device__ __forceinline__ void w4_bt(const v4f d[6], v4f v[6])
 {
-    const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    v2f dl[6], dh[6], vl[6], vh[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { dl[i] = d[i].xy; dh[i] = d[i].zw; }
+    w4_bt2(dl, vl); w4_bt2(dh, vh);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = v4f{vl[i].x, vl[i].y, vh[i].x, vh[i].y};
+}
+__device__ __forceinline__ void w4_at(const v2f m[6], v2f y[4])
+{
+    const v2f s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
     y[0] = (m[0] + s1) + s2;
-    y[1] = __builtin_fmaf(1.5f, d2, 0.75f * d1);
-    y[2] = __builtin_fmaf(2.25f, s2, 0.5625f * s1);
-    y[3] = __builtin_fmaf(3.375f, d2, __builtin_fmaf(0.421875f, d1, m[5]));
+    y[1] = w4_fma(1.5f, d2, 0.75f * d1);
+    y[2] = w4_fma(2.25f, s2, 0.5625f * s1);
+    y[3] = w4_fma(3.375f, d2, w4_fma(0.421875f, d1, m[5]));
 }
 
 // MODE 0: plain input; MODE 1: pending per-channel scale / shift (+ ReLU) of the producing convolution's InstanceNorm; MODE 2: pending
@@ -134,13 +144,17 @@ template <int MODE, int VAR = 0, bool WIDE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_wino4_kernel(const Wino4Args p)
 {
     constexpr bool AFF = MODE != 0, JOIN = MODE == 2;
+    // PAIR (round 6; not with a pending join, whose skip rows have the room): the raw rows are requested for TWO slices at a time -- the
+    // 128 contiguous bytes of a pixel's slices (a, a + 1), a even, by eight adjacent lanes, every other slice -- into a landing area of
+    // twice the size.  70.8 -> 69.3 us per launch (profiles/r9a_w4_two_slices_per_request_ab.log); VAR bit 3 = one slice per request
+    constexpr bool PAIR = (VAR & 8) == 0 && MODE != 2;
     constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Vs = smem;                        // [2][W4_VBUF]
     float* const Ls = smem + 2 * W4_VBUF;          // [W4_LBUF]
     float* const Rs = Ls + W4_LBUF;                // landing area of the raw rows
     float* const Ss = Rs + W4_RBUF;                // MODE 2: landing area of the skip rows (same shape)
-    float* const aff = Ss + (MODE == 2 ? W4_RBUF : 0);      // [2][CIN]
+    float* const aff = Ss + ((MODE == 2 || PAIR) ? W4_RBUF : 0);      // [2][CIN]
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -278,6 +292,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
               __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land + a * RROW), 16, hd_(a), (slice_) * 64, 0, 0); }
 #define W4_TAKE_RAW(q_)                                                                             \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rread + a * RROW); }
+        // PAIR: slot d of the landing area = (pixel d >> 3, 16-byte piece d & 7 of the pair's 128 bytes: slice a for pieces 0..3, a + 1 for
+        // 4..7); wave w < 4 requests slots 128 w .. 128 w + 127 (two instructions per row), wave 4 slots 512 .. 575 -- the slots its OWN row-pass
+        // threads read (pixels 16 w .. 16 w + 15), so that, as above, the wave's own s_waitcnt orders request and read.  The per-lane offsets are
+        // formed where they are used (every other slice; the opaque copy of the lane keeps them out of the loop's live registers)
+        constexpr int RROW2 = 576 * 4;
+        const float* const rread2 = Rs + (pix1 * 8 + cq) * 4;
+        float* const land2 = Rs + wave * 512;
+#define W4_REQ_PAIR(a_)                                                                             \
+        { asm volatile("" ::: "memory");                                                            \
+          int ln_ = lane; asm volatile("" : "+v"(ln_));                                             \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) { if (j == 0 || wave < 4) {                 \
+              const int dp_ = 16 * wave + 8 * j + (ln_ >> 3), dy_ = (dp_ * 3641) >> 16, dx_ = dp_ - 18 * dy_;                     \
+              const int b_ = ((min(oy0 + 4 * dy_, p.IH - 1) * p.IWp + min(ox0 + dx_, p.IW - 1)) * CIN + (ln_ & 7) * 4) * 4;       \
+              const int mx_ = max(p.IH - 1 - (oy0 + 4 * dy_), 0);                                   \
+              _Pragma("unroll") for (int a = 0; a < 6; ++a)                                         \
+                  __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (lds_ptr_t)(land2 + j * 256 + a * RROW2), 16, b_ + min(a, mx_) * hrow, (a_) * 64, 0, 0); } } }
+        // (tried, profiles/r9b_*: the pair's 54 request instructions dealt out over ALL eight waves behind the slice's first barrier -- seven
+        //  per wave instead of twelve on four -- 634 against 637 frames/s: the requests' place in the waves' queues is not what costs)
+#define W4_TAKE_PAIR(q_, slice_)                                                                    \
+        { const float* const rr_ = rread2 + ((slice_) & 1) * 16;                                     \
+          _Pragma("unroll") for (int a = 0; a < 6; ++a) q_[a] = *reinterpret_cast<const v4f*>(rr_ + a * RROW2); }
         // (the skip rows of a pending join are read one at a time where they are added: six more live rows would not fit the registers)
 #define W4_SKIP_LDS(a_) (*reinterpret_cast<const v4f*>(rread + SKO + (a_) * RROW))
 #define W4_AFF(slice_)                                                                              \
@@ -286,8 +321,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // out of the buffer's range and the hardware drops the store)
 #define W4_PEND(q_, xs_, slice_)                                                                    \
         { _Pragma("unroll") for (int a = 0; a < 6; ++a) {                                           \
-            if (MODE == 1) { q_[a].x = fmaxf(fmaf(q_[a].x, sc.x, sh.x), lo1); q_[a].y = fmaxf(fmaf(q_[a].y, sc.y, sh.y), lo1);  \
-                             q_[a].z = fmaxf(fmaf(q_[a].z, sc.z, sh.z), lo1); q_[a].w = fmaxf(fmaf(q_[a].w, sc.w, sh.w), lo1); } \
+            if (MODE == 1) { const v2f fl_ = __builtin_elementwise_fma(q_[a].xy, sc.xy, sh.xy), fh_ = __builtin_elementwise_fma(q_[a].zw, sc.zw, sh.zw); \
+                             q_[a].x = fmaxf(fl_.x, lo1); q_[a].y = fmaxf(fl_.y, lo1); q_[a].z = fmaxf(fh_.x, lo1); q_[a].w = fmaxf(fh_.y, lo1); } \
             if (JOIN) { const v4f x1_ = xs_(a);                                                     \
                         q_[a].x = fmaf(q_[a].x, sc.x, sh.x) + x1_.x; q_[a].y = fmaf(q_[a].y, sc.y, sh.y) + x1_.y;                \
                         q_[a].z = fmaf(q_[a].z, sc.z, sh.z) + x1_.z; q_[a].w = fmaf(q_[a].w, sc.w, sh.w) + x1_.w;                \
@@ -321,8 +356,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define W4_SKIP_REG(a_) xa[a_]
                 W4_PEND(qa, W4_SKIP_REG, s0); W4_COMMIT1(qa);
 #undef W4_SKIP_REG
-                W4_REQ_RAW(min(s0 + 1, s1 - 1));
+                if (!PAIR) W4_REQ_RAW(min(s0 + 1, s1 - 1));
             }
+            if (PAIR && wave < 5) W4_REQ_PAIR((s0 + 1) & ~1);        // (the pair that holds slice s0 + 1)
             __syncthreads();
             if (has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, 0); }
         }
@@ -364,9 +400,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int sn2 = min(s + 2, s1 - 1);
             W4_POSITIONS(0, 6);
             if (sl == 0) {      // the rows requested in the prologue (by other waves): landed, and everybody knows
-                if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if (PAIR ? wave < 5 : has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 __syncthreads();
             }
+            if (PAIR) {
+                // slice sn = s + 1 is one half of a pair that landed a slice or two ago; behind an even slice's take both halves of the
+                // area's pair are used up and the next pair (s + 2, s + 3) is requested into it
+                if (has1) { v4f qa[6]; W4_TAKE_PAIR(qa, sn); W4_AFF(sn); W4_PEND(qa, W4_SKIP_LDS, sn); W4_COMMIT1(qa); }
+                if (wave < 5 && !(s & 1) && s + 2 < s1) W4_REQ_PAIR(s + 2);
+            } else
             if (!(VAR & 2) && has1) {
                 // slice sn's rows were requested a slice ago (in the prologue for s = 0: six weight loads have followed): read back, pending
                 // transform, rows of B^T d, into L -- in one piece (nothing is held across matrix instructions: the registers are the
@@ -381,7 +423,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             W4_POSITIONS(12, 14);
             if (!(VAR & 2) && has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
             W4_POSITIONS(14, 36);
-            if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this slice's row requests (30 weight loads ago) have landed: the barrier tells the readers
+            if (PAIR ? wave < 5 : has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this slice's row requests (30 weight loads ago) have landed: the barrier tells the readers
             if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
         }
@@ -395,6 +437,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef W4_LOAD_RAW
 #undef W4_REQ_RAW
 #undef W4_TAKE_RAW
+#undef W4_REQ_PAIR
+#undef W4_TAKE_PAIR
 #undef W4_SKIP_LDS
 #undef W4_S2_READ
 #undef W4_S2_DONE
@@ -422,20 +466,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float y[4][4][4];                      // [row a][column b][tile column r]
         {
             const float bv = whole ? p.bias[cb] : 0.f;
+            const v2f bv2 = v2f{bv, bv};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float Q[4][6];
+            for (int r = 0; r < 4; r += 2) {       // tile columns r, r + 1 as one pair of values
+                v2f Q[4][6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float mcol[6] = {acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r]};
-                    float o[4]; w4_at(mcol, o);
+                    const v2f mcol[6] = {r ? acc[j].zw : acc[j].xy, r ? acc[6 + j].zw : acc[6 + j].xy, r ? acc[12 + j].zw : acc[12 + j].xy,
+                                         r ? acc[18 + j].zw : acc[18 + j].xy, r ? acc[24 + j].zw : acc[24 + j].xy, r ? acc[30 + j].zw : acc[30 + j].xy};
+                    v2f o[4]; w4_at(mcol, o);
                     Q[0][j] = o[0]; Q[1][j] = o[1]; Q[2][j] = o[2]; Q[3][j] = o[3];
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    float o[4]; w4_at(Q[a], o);
+                    v2f o[4]; w4_at(Q[a], o);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) y[a][b][r] = o[b] + bv;
+                    for (int b = 0; b < 4; ++b) { const v2f ob = o[b] + bv2; y[a][b][r] = ob.x; y[a][b][r + 1] = ob.y; }
                 }
             }
         }
@@ -604,11 +650,14 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     static const int var = diag_env("FAV_W4_VAR") ? atoi(diag_env("FAV_W4_VAR")) : 0;
     const auto kern = (!WIDE && MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (!WIDE && MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (!WIDE && MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
                       (!WIDE && MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (!WIDE && MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
-                      (!WIDE && MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> : conv3_wino4_kernel<MODE, 0, WIDE>;
+                      (!WIDE && MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> :
+                      (MODE != 2 && var == 8) ? conv3_wino4_kernel<MODE, MODE != 2 ? 8 : 0, WIDE> : conv3_wino4_kernel<MODE, 0, WIDE>;
+    const bool pair = MODE != 2 && !(var & 8);
 #else
     const auto kern = conv3_wino4_kernel<MODE, 0, WIDE>;
+    const bool pair = MODE != 2;
 #endif
-    const size_t lds = (size_t)(W4_SMEM + (MODE == 2 ? W4_RBUF : 0) + 2 * a0.CIN + 4) * sizeof(float);
+    const size_t lds = (size_t)(W4_SMEM + ((MODE == 2 || pair) ? W4_RBUF : 0) + 2 * a0.CIN + 4) * sizeof(float);
     const int dv = cur_dev();
     static int cus[MAX_DEVICES] = {};
     if (!cus[dv]) {

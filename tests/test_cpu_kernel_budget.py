@@ -104,7 +104,9 @@ def test_f4x4_and_first_layer_kernels_budget(usage, tmp_path):
     for inst in ("ILi7ELb0E", "ILi3ELb0E", "ILi7ELb1E", "ILi3ELb1E"):
         u = _one(usage, "conv_first2d_kernel", inst)
         assert u["ScratchSize"] == 0 and u["Occupancy"] == 2 and u["VGPRs"] <= 256, (inst, u)
-    for inst, cap in (("ILi0ELi0ELb0E", 32), ("ILi1ELi0ELb0E", 56), ("ILi0ELi0ELb1E", 16), ("ILi1ELi0ELb1E", 16)):
+    # (round 6: with two slices per row request the request offsets are formed where they are used -- 52 -> 12 bytes per lane in the
+    #  most-launched instantiation, none in the others; the review asked for <= 24)
+    for inst, cap in (("ILi0ELi0ELb0E", 8), ("ILi1ELi0ELb0E", 24), ("ILi0ELi0ELb1E", 8), ("ILi1ELi0ELb1E", 8)):
         u = _one(usage, "conv3_wino4_kernel", inst)
         assert u["Occupancy"] == 2 and u["VGPRs"] <= 256 and u["ScratchSize"] <= cap, (inst, u)
     s = str(tmp_path / "w4.s")
