@@ -87,6 +87,20 @@ __device__ __forceinline__ float sample(const float* plane, const Taps& t)
     return t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
 }
 
+// the same four values with the two taps of a row fetched as ONE 8-byte load when they are neighbours in memory (everywhere but at a
+// clamped border): half the gather instructions of the fused input assembly, whose three planes share the taps (round 6)
+__device__ __forceinline__ float sample_pairs(const float* plane, const Taps& t)
+{
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    float v00, v01, v10, v11;
+    if (t.o01 == t.o00 + 1) { const f2u a = *reinterpret_cast<const f2u*>(plane + t.o00); v00 = a.x; v01 = a.y; }
+    else { v00 = plane[t.o00]; v01 = plane[t.o01]; }
+    if (t.o11 == t.o10 + 1) { const f2u b = *reinterpret_cast<const f2u*>(plane + t.o10); v10 = b.x; v11 = b.y; }
+    else { v10 = plane[t.o10]; v11 = plane[t.o11]; }
+    v00 = (t.in & 1u) ? v00 : 0.f; v01 = (t.in & 2u) ? v01 : 0.f; v10 = (t.in & 4u) ? v10 : 0.f; v11 = (t.in & 8u) ? v11 : 0.f;
+    return t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
+}
+
 __global__ __launch_bounds__(256) void warp_kernel(const float* img, const float* flow, float* out, int C, int H, int W,
                                                    int Ho, int Wo, int border)
 {
@@ -234,7 +248,7 @@ __device__ __forceinline__ void prep_pixel(const uint8_t* frame_hwc, const float
         const float2 f = bw_flo[i];                                     // .flo payload: (u, v) = (dx, dy)
         const Taps t = make_taps(border, f.y + (float)y, f.x + (float)x, Hs, Ws);
         const size_t ns = (size_t)Hs * Ws;
-        const float wr = sample(prev_rgb, t), wg = sample(prev_rgb + ns, t), wb = sample(prev_rgb + 2 * ns, t);
+        const float wr = sample_pairs(prev_rgb, t), wg = sample_pairs(prev_rgb + ns, t), wb = sample_pairs(prev_rgb + 2 * ns, t);
         lo.w = fb + (wb * 255.f - 103.939f) * cv;                       // torch.add(fill, prev_warped_masked), core:169
         hi.x = fg + (wg * 255.f - 116.779f) * cv;
         hi.y = fr + (wr * 255.f - 123.68f) * cv;

@@ -88,7 +88,7 @@ __host__ __device__ inline int png_row_stride(int W)
     return ((n + 5 + 3) & ~3) + 8;      // a row never takes more than its STORED form (5 + n bytes): see the kernel; + 8 for the 2-word OR
 }
 
-constexpr int PNG_ROW_WAVES = 4;                // waves per row block; wave w takes the 64-position steps w, w + 4, ...
+constexpr int PNG_ROW_WAVES = 8;                // waves per row block; wave w takes the 64-position steps w, w + 8, ... (four until round 6)
 constexpr int PNG_HIST = 288;                   // histogram bins per wave: 277 symbols, [280] extra bits of the matches, [281] matches
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -200,12 +200,17 @@ __global__ __launch_bounds__(64 * PNG_ROW_WAVES) void png_rows_kernel(const uint
         if (d) atomicAdd(&hist[wave][d & 511u], 1u);
     }
     __syncthreads();
-    for (int i = tid; i < PNG_HIST; i += NT) hist[0][i] = hist[0][i] + hist[1][i] + hist[2][i] + hist[3][i];
+    for (int i = tid; i < PNG_HIST; i += NT) {
+        uint32_t h = hist[0][i];
+#pragma unroll
+        for (int w = 1; w < PNG_ROW_WAVES; ++w) h += hist[w][i];
+        hist[0][i] = h;
+    }
     __syncthreads();
-    // the row's exact size under every code (wave w: codes w, w + 4, w + 8, w + 12; the last one is the fixed code), and stored.
+    // the row's exact size under every code (wave w: codes w, w + 8; code 12 is the fixed code), and stored.
     // All code lengths a lane needs (5 symbols x up to 4 codes) are requested in one batch: one memory latency, not one per code.
     {
-        constexpr int KPW = (PNG_NTABLES + PNG_ROW_WAVES) / PNG_ROW_WAVES;      // codes per wave: 4
+        constexpr int KPW = (PNG_NTABLES + PNG_ROW_WAVES) / PNG_ROW_WAVES;      // codes per wave: 2
         uint32_t len[KPW][5], hs[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) { const int sy = lane + 64 * i; hs[i] = sy < PNG_NSYM ? hist[0][sy] : 0u; }
@@ -572,8 +577,16 @@ int launch_png_encode(const uint8_t* rgb_hwc, const float* rgb_planar, int W, in
         bool have = false;
         for (int d : done) have |= d == device;
         if (!have) {
-            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            // (160 KB minus the kernel's static arrays -- the per-wave histograms: 10.6 KB with eight waves per row; the widest row, 9000
+            //  pixels, needs 137 KB)
+            hipFuncAttributes fa;
+            FAV_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(png_rows_kernel<true>)));
+            const int dyn_t = (160 * 1024 - (int)fa.sharedSizeBytes) & ~255;
+            FAV_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(png_rows_kernel<false>)));
+            const int dyn_f = (160 * 1024 - (int)fa.sharedSizeBytes) & ~255;
+            FAV_REQUIRE((size_t)std::min(dyn_t, dyn_f) >= lds1, "png: a row of %d pixels needs %zu bytes of LDS, %d are there", W, lds1, std::min(dyn_t, dyn_f));
+            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_t));
+            FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_f));
             FAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(png_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
             done.push_back(device);
         }
