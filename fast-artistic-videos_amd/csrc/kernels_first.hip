@@ -25,6 +25,7 @@ namespace fav {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -404,36 +405,63 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
         // ---- output transform (A^T M A, in registers) + epilogue.  Register r of an accumulator = tile column 4 g + r, lane & 15 =
         // output channel inside the half nt
         const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-        const int oy0 = ty * G_TH + 2 * wave, ox0 = tx * G_TW;
+        const int oy0 = ty * G_TH + 2 * __builtin_amdgcn_readfirstlane(wave), ox0 = tx * G_TW;
+        // nine tiles in ten lie wholly inside the image (wave-uniform): no per-pixel test, one per-lane base pointer and uniform offsets
+        // (round 6: the per-pixel form spent 64 64-bit address computations and 72 divergent branches per tile on its 32 stores)
+        const bool inside = oy0 + 2 <= p.OH && ox0 + G_TW <= p.OW && grp * 32 + 32 <= p.COUT;
+        float* const pb = p.out + ((size_t)oy0 * p.OW + ox0 + 8 * g) * p.COUT + grp * 32 + txl;
         float y[2][4][2][2];               // [nt][r][row a][column b]
         float sm[2] = {0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int ch = grp * 32 + nt * 16 + txl;
             const float bv = p.bias[ch];
+            const v2f bv2 = v2f{bv, bv};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float Q[4][2];
+            for (int rp = 0; rp < 4; rp += 2) {      // tile columns rp, rp + 1 as one pair of values (packed adds, rounded like the single ones)
+                v2f Q[4][2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float m0 = acc[4 * i][nt][r], m1 = acc[4 * i + 1][nt][r], m2 = acc[4 * i + 2][nt][r], m3 = acc[4 * i + 3][nt][r];
+                    const v2f m0 = rp ? acc[4 * i][nt].zw : acc[4 * i][nt].xy, m1 = rp ? acc[4 * i + 1][nt].zw : acc[4 * i + 1][nt].xy;
+                    const v2f m2 = rp ? acc[4 * i + 2][nt].zw : acc[4 * i + 2][nt].xy, m3 = rp ? acc[4 * i + 3][nt].zw : acc[4 * i + 3][nt].xy;
                     Q[i][0] = (m0 + m1) + m2; Q[i][1] = (m1 - m2) - m3;
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    y[nt][r][0][b] = (Q[0][b] + Q[1][b]) + Q[2][b] + bv;
-                    y[nt][r][1][b] = (Q[1][b] - Q[2][b]) - Q[3][b] + bv;
+                    const v2f y0 = (Q[0][b] + Q[1][b]) + Q[2][b] + bv2, y1 = (Q[1][b] - Q[2][b]) - Q[3][b] + bv2;
+                    y[nt][rp][0][b] = y0.x; y[nt][rp + 1][0][b] = y0.y;
+                    y[nt][rp][1][b] = y1.x; y[nt][rp + 1][1][b] = y1.y;
                 }
+            }
+        }
+        if (inside) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
-                        if (oy < p.OH && ox < p.OW) {
-                            if (ch < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + ch] = y[nt][r][a][b];
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            pb[((size_t)a * p.OW + 2 * r + b) * p.COUT + nt * 16] = y[nt][r][a][b];
                             sm[nt] += y[nt][r][a][b];
                         }
-                    }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int ch = grp * 32 + nt * 16 + txl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
+                            if (oy < p.OH && ox < p.OW) {
+                                if (ch < p.COUT) p.out[((size_t)oy * p.OW + ox) * p.COUT + ch] = y[nt][r][a][b];
+                                sm[nt] += y[nt][r][a][b];
+                            }
+                        }
             }
         }
         G_DBG(3);      /* output transform + stores */
@@ -448,16 +476,25 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
                 s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
                 const float mu = nw ? s / (float)nw : 0.f;
                 float qv = 0.f;
+                if (inside) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
-                            const float d = y[nt][r][a][b] - mu;
-                            if (oy < p.OH && ox < p.OW) qv = fmaf(d, d, qv);
-                        }
+                            for (int b = 0; b < 2; ++b) { const float d = y[nt][r][a][b] - mu; qv = fmaf(d, d, qv); }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                const int oy = oy0 + a, ox = ox0 + 2 * (4 * g + r) + b;
+                                const float d = y[nt][r][a][b] - mu;
+                                if (oy < p.OH && ox < p.OW) qv = fmaf(d, d, qv);
+                            }
+                }
                 qv += __shfl_xor(qv, 16); qv += __shfl_xor(qv, 32);
                 if (lane < 16) st[wave * 32 + nt * 16 + lane] = make_float2(mu, qv);
             }
