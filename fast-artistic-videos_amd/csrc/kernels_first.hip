@@ -409,7 +409,6 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
         // nine tiles in ten lie wholly inside the image (wave-uniform): no per-pixel test, one per-lane base pointer and uniform offsets
         // (round 6: the per-pixel form spent 64 64-bit address computations and 72 divergent branches per tile on its 32 stores)
         const bool inside = oy0 + 2 <= p.OH && ox0 + G_TW <= p.OW && grp * 32 + 32 <= p.COUT;
-        float* const pb = p.out + ((size_t)oy0 * p.OW + ox0 + 8 * g) * p.COUT + grp * 32 + txl;
         float y[2][4][2][2];               // [nt][r][row a][column b]
         float sm[2] = {0.f, 0.f};
 #pragma unroll
@@ -435,6 +434,9 @@ __global__ __launch_bounds__(512, 2) void conv_first2d_kernel(const FirstArgs p)
             }
         }
         if (inside) {
+            int gq = g, tq = txl;
+            asm volatile("" : "+v"(gq), "+v"(tq));   // (the lane's part of the address is formed here, per tile: hoisted out of the tile loop it costs the WIDE form a spill)
+            float* const pb = p.out + ((size_t)oy0 * p.OW + ox0 + 8 * gq) * p.COUT + grp * 32 + tq;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
