@@ -10,6 +10,7 @@ Tolerances (fp32 path, stated once):
     <= 2e-4 after de-processing to [0,1]; 8-bit PSNR >= 50 dB.
 """
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -447,6 +448,33 @@ def test_image_model_vs_oracle(favlib, oracle, cuda, tmp_path, golden_dir, inorm
     m = oracle.consistency(bws[1], fws[1])
     r1 = ref_s.next(_f01(frames[1]), bws[1], m.astype(np.float32) / np.float32(255))
     assert np.abs(o1.cpu().numpy() - r1).max() <= 2e-4
+
+
+@pytest.mark.parametrize("cin", [16, 48, 80, 64])
+def test_f4x4_kernel_on_an_odd_number_of_channel_slices(favlib, oracle, cuda, tmp_path, cin):
+    """With -padding_type reflect a c3s1-128 layer is a padding module + a 3x3 convolution with padW = 0 (models_video.lua:70-75): it runs
+    on the F(4x4) kernel with however many input channels the layer before it left -- 16, 48, 80 channels are 1, 3, 5 slices of 16.  The
+    kernel requests its raw rows two slices at a time (round 6): with an odd count the last request's second half lies past the pixel's
+    channels and is never taken.  Whole-unit launches and (FAV_W4_GRID, diagnostic library, in a child process) a stream-K dealing."""
+    arch = "c3s1-%d,c3s1-128,c9s1-3" % cin
+    p = str(tmp_path / "m.t7")
+    t7.make_synthetic_checkpoint(p, arch=arch, seed=77, padding_type="reflect")
+    layers = _layers(p)
+    h, w = 37, 70
+    x = (np.random.default_rng(31).standard_normal((7, h, w)) * 50).astype(np.float32)
+    ref = oracle.net_forward(layers, x)
+    net, got, kids = _wide_forward(favlib, cuda, p, x)
+    assert kids[1] in (728, 729), kids                # the F(4x4) kernel (fav_internal.h: conv kernel ids)
+    assert got.shape == ref.shape == (3, h, w)
+    err = np.abs(got - ref).max()
+    assert err <= 2e-2 and np.abs(ref).std() > 5, err
+    np.save(tmp_path / "x.npy", x)
+    child = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import fav_amd\n"
+             "net = fav_amd.Net(%r, 0); x = torch.from_numpy(np.load(%r)).cuda()\n"
+             "np.save(sys.argv[1], net.forward(x).cpu().numpy()); net.check()\n" % (os.path.join(ROOT, "fast-artistic-videos_amd", "python"), p, str(tmp_path / "x.npy")))
+    subprocess.check_call([sys.executable, "-c", child, str(tmp_path / "stream.npy")], env=dict(DIAG_ENV, FAV_W4_GRID="5"), timeout=300)
+    stream = np.load(tmp_path / "stream.npy")
+    assert np.abs(stream - ref).max() <= 2e-2, float(np.abs(stream - ref).max())
 
 
 @pytest.mark.parametrize("ptype", ["reflect", "replicate", "zero", "none"])
