@@ -209,12 +209,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // stage 2 (columns): item = (tile m, line i, channel chunk kq) -> columns 4 tx .. 4 tx + 5 of line i, six positions out.
     // 16 x 6 x 4 = 384 items = waves 2..7 (line i = wave - 2; waves 0, 1 carry the row pass only, waves 5..7 this pass only);
     // lane = (kq = lane >> 4, m = lane & 15), as the matrix operand
-    // RS (VAR bit 6, experiment): the two waves of a SIMD (w and w + 4) never stage at the same time -- the column pass's six lines on waves
-    // 4, 5, 6 (position 14) and 7, 0, 1 (position 22) instead of waves 2..7 at position 14, where SIMDs 2 and 3 have both their waves in it
-    constexpr bool RS = (VAR & 64) != 0;
-    const bool has2 = RS ? (wave != 2 && wave != 3) : wave >= 2;
-    const int i2 = RS ? (wave >= 4 ? wave - 4 : (wave < 2 ? wave + 4 : 0)) : max(wave - 2, 0);
-    const bool col_early = !RS || (wave >= 4 && wave <= 6);
+    const bool has2 = wave >= 2;
+    const int i2 = max(wave - 2, 0);
     const int m2 = lane & 15, kq2 = lane >> 4;
     const float* const l2 = Ls + kq2 * W4_LKQ + (m2 >> 2) * W4_LTY + 4 * (m2 & 3) * 4 + i2 * W4_LLINE;
     float* const v2 = Vs + lane * 4 + 6 * i2 * W4_VPOS;
@@ -425,14 +421,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             W4_POSITIONS(6, 12);
             if (!(VAR & 4)) __syncthreads();
             W4_POSITIONS(12, 14);
-            if (!(VAR & 2) && has2 && col_early) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
-            if (RS) {
-                W4_POSITIONS(14, 22);
-                if (has2 && !col_early) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
-                W4_POSITIONS(22, 36);
-            } else {
+            if (!(VAR & 2) && has2) { v4f c2[6]; W4_S2_READ(c2); W4_S2_DONE(c2, par ^ 1); }
             W4_POSITIONS(14, 36);
-            }
             if (PAIR ? wave < 5 : has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this slice's row requests (30 weight loads ago) have landed: the barrier tells the readers
             if (!(VAR & 4)) __syncthreads();
             W4_READ_A(0, par ^ 1, 0); W4_READ_A(1, par ^ 1, 1);
@@ -661,8 +651,7 @@ int launch_wino4_t(const Wino4Args& a0, int reserve_cus, hipStream_t st)
     const auto kern = (!WIDE && MODE == 1 && var == 1) ? conv3_wino4_kernel<1, 1> : (!WIDE && MODE == 1 && var == 2) ? conv3_wino4_kernel<1, 2> : (!WIDE && MODE == 1 && var == 3) ? conv3_wino4_kernel<1, 3> :
                       (!WIDE && MODE == 1 && var == 7) ? conv3_wino4_kernel<1, 7> : (!WIDE && MODE == 1 && var == 6) ? conv3_wino4_kernel<1, 6> :
                       (!WIDE && MODE == 2 && var == 16) ? conv3_wino4_kernel<2, 16> :
-                      (MODE != 2 && var == 8) ? conv3_wino4_kernel<MODE, MODE != 2 ? 8 : 0, WIDE> :
-                      (MODE != 2 && !WIDE && var == 64) ? conv3_wino4_kernel<MODE, (MODE != 2 && !WIDE) ? 64 : 0, WIDE> : conv3_wino4_kernel<MODE, 0, WIDE>;
+                      (MODE != 2 && var == 8) ? conv3_wino4_kernel<MODE, MODE != 2 ? 8 : 0, WIDE> : conv3_wino4_kernel<MODE, 0, WIDE>;
     const bool pair = MODE != 2 && !(var & 8);
 #else
     const auto kern = conv3_wino4_kernel<MODE, 0, WIDE>;
